@@ -1,0 +1,335 @@
+"""ctypes binding of libhesaff_amd.so (C ABI in include/hesaff_amd.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class HesaffError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("hesaff_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    """hesaff_params (include/hesaff_amd.h): reference defaults + capacity knobs."""
+    _fields_ = [
+        ("threshold", C.c_float),
+        ("edgeEigenValueRatio", C.c_float),
+        ("initialSigma", C.c_float),
+        ("maxIterations", C.c_int),
+        ("convergenceThreshold", C.c_float),
+        ("mrSize", C.c_float),
+        ("maxBinValue", C.c_float),
+        ("max_batch", C.c_int),
+        ("max_kpts_per_mpx", C.c_int),
+    ]
+
+
+class _Result(C.Structure):
+    _fields_ = [("count_hessian", C.c_int32), ("count_desc", C.c_int32), ("keys", C.c_void_p)]
+
+
+class Timings(C.Structure):
+    _fields_ = [
+        ("pyramid_ms", C.c_float), ("detect_ms", C.c_float), ("affine_ms", C.c_float), ("patch_ms", C.c_float),
+        ("sift_ms", C.c_float), ("total_ms", C.c_float), ("blur_hess_ms", C.c_float), ("blur_hess_launches", C.c_int32),
+        ("blur_hess_bytes", C.c_double), ("pyramid_bytes", C.c_double),
+    ]
+
+
+# struct Keypoint of hesaff.cpp:41-48 == hesaff_keypoint, 164 bytes
+KEYPOINT_DTYPE = np.dtype([
+    ("x", "<f4"), ("y", "<f4"), ("s", "<f4"), ("a11", "<f4"), ("a12", "<f4"), ("a21", "<f4"), ("a22", "<f4"),
+    ("response", "<f4"), ("type", "<i4"), ("desc", "u1", (128,)),
+])
+assert KEYPOINT_DTYPE.itemsize == 164
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+_lib = None
+
+
+def lib_path():
+    return os.path.join(_HERE, "libhesaff_amd.so")
+
+
+def load_library():
+    """Load libhesaff_amd.so; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise HesaffError(-1, "%s not built: run `make -C hesaff_amd/csrc` (or __graft_entry__.build())" % p)
+    L = C.CDLL(p)
+    vp = C.c_void_p
+    L.hesaff_version.restype = C.c_char_p
+    L.hesaff_default_params.argtypes = [C.POINTER(Params)]
+    L.hesaff_create.argtypes = [C.POINTER(vp), C.POINTER(Params), C.c_int]
+    L.hesaff_destroy.argtypes = [vp]; L.hesaff_destroy.restype = None
+    L.hesaff_last_error.argtypes = [vp]; L.hesaff_last_error.restype = C.c_char_p
+    L.hesaff_detect_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_Result)]
+    L.hesaff_detect_batch_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, _i32p, _i32p, C.POINTER(vp), C.POINTER(C.c_int64)]
+    L.hesaff_set_profiling.argtypes = [vp, C.c_int]
+    L.hesaff_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.hesaff_ellipse.argtypes = [vp, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.hesaff_ellipse.restype = None
+    L.hesaff_write_sift.argtypes = [C.c_char_p, vp, C.c_int, C.c_float]
+    L.hesaff_format_sift.argtypes = [vp, C.c_int, C.c_float, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.hesaff_free.argtypes = [vp]; L.hesaff_free.restype = None
+    L.hesaff_read_pnm.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.hesaff_stage_gaussian_blur.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_float, _f32p]
+    L.hesaff_stage_hessian_response.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_float, _f32p]
+    L.hesaff_stage_half_image.argtypes = [vp, _f32p, C.c_int, C.c_int, _f32p]
+    L.hesaff_stage_pyramid.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+    L.hesaff_stage_hessian_keypoints.argtypes = [vp, _u8p, C.c_int, C.c_int, C.c_int, _f32p, _i32p, C.POINTER(C.c_int)]
+    L.hesaff_stage_find_affine_shape.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _i32p, _f32p, _i32p]
+    L.hesaff_stage_rectify.argtypes = [vp, C.c_int, _f32p]
+    L.hesaff_stage_normalize_affine.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _i32p, _f32p]
+    L.hesaff_stage_sift.argtypes = [vp, C.c_int, _f32p, _u8p]
+    L.hesaff_stage_math.argtypes = [vp, C.c_int, _f32p, _f32p, _f32p, _f32p]
+    L.hesaff_table_gauss_mask.argtypes = [C.c_int, _f32p]
+    L.hesaff_table_circ_gauss_mask.argtypes = [C.c_int, _f32p]
+    L.hesaff_table_sift_bins.argtypes = [_i32p, _i32p, _f32p, _f32p]
+    L.hesaff_table_gauss_kernel.argtypes = [C.c_float, C.c_int, vp, C.POINTER(C.c_int)]
+    _lib = L
+    return L
+
+
+# every symbol include/hesaff_amd.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "hesaff_version", "hesaff_default_params", "hesaff_create", "hesaff_destroy", "hesaff_last_error",
+    "hesaff_detect_batch", "hesaff_detect_batch_device", "hesaff_set_profiling", "hesaff_get_timings", "hesaff_ellipse",
+    "hesaff_write_sift", "hesaff_format_sift", "hesaff_free", "hesaff_read_pnm", "hesaff_stage_gaussian_blur",
+    "hesaff_stage_hessian_response", "hesaff_stage_half_image", "hesaff_stage_pyramid", "hesaff_stage_hessian_keypoints",
+    "hesaff_stage_find_affine_shape", "hesaff_stage_rectify", "hesaff_stage_normalize_affine", "hesaff_stage_sift",
+    "hesaff_stage_math", "hesaff_table_gauss_mask", "hesaff_table_circ_gauss_mask", "hesaff_table_sift_bins",
+    "hesaff_table_gauss_kernel",
+]
+
+
+def default_params():
+    p = Params()
+    load_library().hesaff_default_params(C.byref(p))
+    return p
+
+
+def table_gauss_mask(size):
+    m = np.zeros((size, size), np.float32)
+    load_library().hesaff_table_gauss_mask(size, m)
+    return m
+
+
+def table_circ_gauss_mask(size):
+    m = np.zeros((size, size), np.float32)
+    load_library().hesaff_table_circ_gauss_mask(size, m)
+    return m
+
+
+def table_sift_bins():
+    b0 = np.zeros(41, np.int32); b1 = np.zeros(41, np.int32); w0 = np.zeros(41, np.float32); w1 = np.zeros(41, np.float32)
+    load_library().hesaff_table_sift_bins(b0, b1, w0, w1)
+    return b0, b1, w0, w1
+
+
+def table_gauss_kernel(sigma):
+    L = load_library()
+    k = C.c_int()
+    L.hesaff_table_gauss_kernel(sigma, 0, None, C.byref(k))
+    taps = np.zeros(k.value, np.float32)
+    L.hesaff_table_gauss_kernel(sigma, k.value, taps.ctypes.data, C.byref(k))
+    return taps
+
+
+def ellipse(keys, mr_size):
+    """(a,b,c) of each record, hesaff.cpp:115-123 in closed form."""
+    L = load_library()
+    keys = np.ascontiguousarray(keys, dtype=KEYPOINT_DTYPE)
+    out = np.zeros((len(keys), 3), np.float32)
+    a = C.c_float(); b = C.c_float(); c = C.c_float()
+    base = keys.ctypes.data
+    for i in range(len(keys)):
+        L.hesaff_ellipse(base + i * 164, mr_size, C.byref(a), C.byref(b), C.byref(c))
+        out[i] = (a.value, b.value, c.value)
+    return out
+
+
+def format_sift(keys, mr_size):
+    """exportKeypoints hesaff.cpp:107-130 -> bytes of the .hesaff.sift file."""
+    L = load_library()
+    keys = np.ascontiguousarray(keys, dtype=KEYPOINT_DTYPE)
+    buf = C.c_void_p(); n = C.c_size_t()
+    rc = L.hesaff_format_sift(keys.ctypes.data, len(keys), mr_size, C.byref(buf), C.byref(n))
+    if rc != 0:
+        raise HesaffError(rc, "hesaff_format_sift")
+    try:
+        return C.string_at(buf.value, n.value)
+    finally:
+        L.hesaff_free(buf)
+
+
+def write_sift(path, keys, mr_size):
+    keys = np.ascontiguousarray(keys, dtype=KEYPOINT_DTYPE)
+    rc = load_library().hesaff_write_sift(os.fsencode(path), keys.ctypes.data, len(keys), mr_size)
+    if rc != 0:
+        raise HesaffError(rc, "hesaff_write_sift(%s)" % path)
+
+
+def read_pnm(path):
+    L = load_library()
+    data = C.c_void_p(); w = C.c_int(); h = C.c_int(); ch = C.c_int()
+    rc = L.hesaff_read_pnm(os.fsencode(path), C.byref(data), C.byref(w), C.byref(h), C.byref(ch))
+    if rc != 0:
+        raise HesaffError(rc, "hesaff_read_pnm(%s)" % path)
+    try:
+        n = w.value * h.value * ch.value
+        arr = np.frombuffer(C.string_at(data.value, n), dtype=np.uint8).copy()
+    finally:
+        L.hesaff_free(data)
+    return arr.reshape((h.value, w.value) if ch.value == 1 else (h.value, w.value, 3))
+
+
+class HesaffContext:
+    """One device context (hesaff_create / hesaff_destroy)."""
+
+    def __init__(self, params=None, device=0):
+        self.L = load_library()
+        self.params = params if params is not None else default_params()
+        self.h = C.c_void_p()
+        rc = self.L.hesaff_create(C.byref(self.h), C.byref(self.params), device)
+        if rc != 0:
+            raise HesaffError(rc, self.L.hesaff_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.L.hesaff_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise HesaffError(rc, self.L.hesaff_last_error(self.h).decode())
+
+    # ---- whole path ----
+    def detect_batch(self, images):
+        """images: list of uint8 arrays HxW (grey) or HxWx3.  -> list of (count_hessian, keys[KEYPOINT_DTYPE])."""
+        n = len(images)
+        imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        ws = (C.c_int * n)(*[im.shape[1] for im in imgs])
+        hs = (C.c_int * n)(*[im.shape[0] for im in imgs])
+        chs = (C.c_int * n)(*[1 if im.ndim == 2 else 3 for im in imgs])
+        st = (C.c_int * n)(*[im.shape[1] * (1 if im.ndim == 2 else 3) for im in imgs])
+        res = (_Result * n)()
+        self._check(self.L.hesaff_detect_batch(self.h, n, ptrs, ws, hs, st, chs, res))
+        out = []
+        for r in res:
+            if r.count_desc > 0:
+                keys = np.frombuffer(C.string_at(r.keys, r.count_desc * 164), dtype=KEYPOINT_DTYPE).copy()
+            else:
+                keys = np.zeros(0, KEYPOINT_DTYPE)
+            out.append((r.count_hessian, keys))
+        return out
+
+    def detect_batch_device(self, d_ptr, n, width, height):
+        """Inputs resident in HBM (uint8 [n,H,W], raw device pointer).  -> (count_hessian[n], count_desc[n], d_keys, total)."""
+        ch = np.zeros(n, np.int32); cd = np.zeros(n, np.int32)
+        dk = C.c_void_p(); tot = C.c_int64()
+        self._check(self.L.hesaff_detect_batch_device(self.h, n, C.c_void_p(d_ptr), width, height, ch, cd, C.byref(dk), C.byref(tot)))
+        return ch, cd, dk.value, tot.value
+
+    def set_profiling(self, level):
+        self._check(self.L.hesaff_set_profiling(self.h, level))
+
+    def timings(self):
+        t = Timings()
+        self._check(self.L.hesaff_get_timings(self.h, C.byref(t)))
+        return t
+
+    # ---- stage entry points (one reference operator each) ----
+    def gaussian_blur(self, img, sigma):
+        img = np.ascontiguousarray(img, np.float32); out = np.empty_like(img)
+        self._check(self.L.hesaff_stage_gaussian_blur(self.h, img, img.shape[0], img.shape[1], sigma, out))
+        return out
+
+    def hessian_response(self, img, norm):
+        img = np.ascontiguousarray(img, np.float32); out = np.empty_like(img)
+        self._check(self.L.hesaff_stage_hessian_response(self.h, img, img.shape[0], img.shape[1], norm, out))
+        return out
+
+    def half_image(self, img):
+        img = np.ascontiguousarray(img, np.float32)
+        out = np.empty((img.shape[0] // 2, img.shape[1] // 2), np.float32)
+        self._check(self.L.hesaff_stage_half_image(self.h, img, img.shape[0], img.shape[1], out))
+        return out
+
+    def pyramid(self, gray_u8):
+        """-> list over octaves of (L[5,rows,cols], R[5,rows,cols])."""
+        g = np.ascontiguousarray(gray_u8, np.uint8)
+        no = C.c_int(); nf = C.c_size_t()
+        self._check(self.L.hesaff_stage_pyramid(self.h, None, g.shape[0], g.shape[1], None, C.byref(no), C.byref(nf)))
+        buf = np.empty(max(nf.value, 1), np.float32)
+        self._check(self.L.hesaff_stage_pyramid(self.h, g.ctypes.data, g.shape[0], g.shape[1], buf.ctypes.data, C.byref(no), C.byref(nf)))
+        out = []; off = 0; r, c = g.shape
+        for _ in range(no.value):
+            n = r * c
+            Ls = buf[off:off + 5 * n].reshape(5, r, c); off += 5 * n
+            Rs = buf[off:off + 5 * n].reshape(5, r, c); off += 5 * n
+            out.append((Ls, Rs))
+            r //= 2; c //= 2
+        return out
+
+    def hessian_keypoints(self, gray_u8, cap=None):
+        """-> f[n,5] = x,y,s,pd,response ; i[n,5] = type,octave,level,r0,c0 (reference order)."""
+        g = np.ascontiguousarray(gray_u8, np.uint8)
+        if cap is None:
+            cap = max(4096, int(g.size * 0.05))
+        f = np.zeros((cap, 5), np.float32); i = np.zeros((cap, 5), np.int32); cnt = C.c_int()
+        self._check(self.L.hesaff_stage_hessian_keypoints(self.h, g, g.shape[0], g.shape[1], cap, f, i, C.byref(cnt)))
+        n = min(cnt.value, cap)
+        return f[:n].copy(), i[:n].copy(), cnt.value
+
+    def find_affine_shape(self, blur, kp):
+        blur = np.ascontiguousarray(blur, np.float32); kp = np.ascontiguousarray(kp, np.float32).reshape(-1, 4)
+        n = len(kp)
+        conv = np.zeros(n, np.int32); U = np.zeros((n, 4), np.float32); it = np.zeros(n, np.int32)
+        self._check(self.L.hesaff_stage_find_affine_shape(self.h, blur, blur.shape[0], blur.shape[1], n, kp, conv, U, it))
+        return conv, U, it
+
+    def rectify(self, A):
+        A = np.ascontiguousarray(A, np.float32).reshape(-1, 4).copy()
+        self._check(self.L.hesaff_stage_rectify(self.h, len(A), A))
+        return A
+
+    def normalize_affine(self, img, kp, A):
+        img = np.ascontiguousarray(img, np.float32); kp = np.ascontiguousarray(kp, np.float32).reshape(-1, 3)
+        A = np.ascontiguousarray(A, np.float32).reshape(-1, 4)
+        n = len(kp)
+        rej = np.zeros(n, np.int32); patches = np.zeros((n, 41 * 41), np.float32)
+        self._check(self.L.hesaff_stage_normalize_affine(self.h, img, img.shape[0], img.shape[1], n, kp, A, rej, patches))
+        return rej, patches.reshape(n, 41, 41)
+
+    def sift(self, patches):
+        p = np.ascontiguousarray(patches, np.float32).reshape(-1, 41 * 41)
+        d = np.zeros((len(p), 128), np.uint8)
+        self._check(self.L.hesaff_stage_sift(self.h, len(p), p, d))
+        return d
+
+    def math(self, a, b):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        at = np.zeros_like(a); pw = np.zeros_like(a)
+        self._check(self.L.hesaff_stage_math(self.h, a.size, a.reshape(-1), b.reshape(-1), at.reshape(-1), pw.reshape(-1)))
+        return at, pw

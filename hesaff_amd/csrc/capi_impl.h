@@ -1,0 +1,467 @@
+// capi_impl.h -- the extern "C" entry points of include/hesaff_amd.h.
+// Included at the end of pipeline.hip (same translation unit: needs hesaff_ctx and the
+// batch runner).  No exception crosses the ABI: everything is caught and turned into a
+// negative return code + hesaff_last_error().
+#pragma once
+
+namespace {
+
+int fail(hesaff_ctx *c, const HsError &e)
+{
+   if (c) c->err = e.msg; else g_create_error = e.msg;
+   return e.code;
+}
+
+#define HS_API_BEGIN try {
+#define HS_API_END(ctx)                                              \
+   }                                                                 \
+   catch (const HsError &e) { return fail(ctx, e); }                 \
+   catch (const std::exception &e) { return fail(ctx, HsError(HESAFF_ERR_NOMEM, e.what())); } \
+   return HESAFF_OK;
+
+void bind_device(hesaff_ctx *c) { HIP_TRY(hipSetDevice(c->device)); }
+
+// one-image float plane on the device for the stage API
+DPlane stage_plane(DevBuf &buf, int rows, int cols)
+{
+   buf.ensure(std::max<size_t>((size_t)rows * cols * 4, 16));
+   return make_plane(buf.as<float>(), 1, rows, cols, cols);
+}
+
+} // namespace
+
+extern "C" {
+
+const char *hesaff_version(void) { return "hesaff_amd 0.1 (gfx950)"; }
+
+int hesaff_default_params(hesaff_params *p)
+{
+   if (!p) return HESAFF_ERR_ARG;
+   p->threshold = 16.0f / 3.0f;
+   p->edgeEigenValueRatio = 10.0f;
+   p->initialSigma = 1.6f;
+   p->maxIterations = 16;
+   p->convergenceThreshold = 0.05f;
+   p->mrSize = 3.0f * sqrtf(3.0f);
+   p->maxBinValue = 0.2f;
+   p->max_batch = 16;
+   p->max_kpts_per_mpx = 40000;
+   return HESAFF_OK;
+}
+
+int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
+{
+   if (!out) return HESAFF_ERR_ARG;
+   *out = nullptr;
+   hesaff_ctx *c = nullptr;
+   try {
+      int ndev = 0;
+      if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+         throw HsError(HESAFF_ERR_DEVICE, "no HIP device visible: libhesaff_amd has no CPU fallback");
+      if (device < 0 || device >= ndev) throw HsError(HESAFF_ERR_ARG, "device ordinal out of range");
+      c = new hesaff_ctx();
+      if (p) c->par = *p; else hesaff_default_params(&c->par);
+      if (c->par.max_batch < 1) c->par.max_batch = 1;
+      if (c->par.max_kpts_per_mpx < 1000) c->par.max_kpts_per_mpx = 1000;
+      if (c->par.maxIterations < 1 || c->par.maxIterations > 1000) throw HsError(HESAFF_ERR_ARG, "maxIterations out of range");
+      c->device = device;
+      bind_device(c);
+      hipDeviceProp_t prop;
+      HIP_TRY(hipGetDeviceProperties(&prop, device));
+      if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+         std::string m = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+         throw HsError(HESAFF_ERR_DEVICE, m);
+      }
+      HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+      build_tables(c);
+      refresh_tables_struct(c);
+      memset(&c->tm, 0, sizeof c->tm);
+   } catch (const HsError &e) {
+      delete c;
+      return fail(nullptr, e);
+   } catch (const std::exception &e) {
+      delete c;
+      return fail(nullptr, HsError(HESAFF_ERR_NOMEM, e.what()));
+   }
+   *out = c;
+   return HESAFF_OK;
+}
+
+void hesaff_destroy(hesaff_ctx *c)
+{
+   if (!c) return;
+   (void)hipSetDevice(c->device);
+   if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+   DevBuf *bufs[] = {&c->t_smm, &c->t_sift, &c->t_bin0, &c->t_bin1, &c->t_w0, &c->t_w1, &c->t_pyr_taps, &c->t_patch_taps,
+                     &c->t_patch_off, &c->t_patch_k, &c->b_gray, &c->b_L, &c->b_L3, &c->b_R, &c->b_map, &c->b_bitmask, &c->b_prefix,
+                     &c->b_blocksums, &c->b_counters, &c->b_cand, &c->b_rec_f, &c->b_rec_i, &c->b_rec_w, &c->b_hess_f, &c->b_hess_i,
+                     &c->b_aff, &c->b_pw, &c->b_bins, &c->b_rank, &c->b_desc, &c->b_out, &c->b_starts, &c->b_scratch, &c->b_patches,
+                     &c->b_stage, &c->b_input};
+   for (DevBuf *b : bufs) b->release();
+   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+   if (c->stream) (void)hipStreamDestroy(c->stream);
+   delete c;
+}
+
+const char *hesaff_last_error(const hesaff_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int hesaff_set_profiling(hesaff_ctx *c, int level)
+{
+   if (!c) return HESAFF_ERR_ARG;
+   c->profiling = level;
+   return HESAFF_OK;
+}
+
+int hesaff_get_timings(const hesaff_ctx *c, hesaff_timings *t)
+{
+   if (!c || !t) return HESAFF_ERR_ARG;
+   *t = c->tm;
+   return HESAFF_OK;
+}
+
+int hesaff_detect_batch_device(hesaff_ctx *c, int n, const void *d_gray, int width, int height, int32_t *count_hessian,
+                               int32_t *count_desc, const void **d_keys_out, int64_t *total_out)
+{
+   if (!c || n < 1 || !d_gray) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   bind_device(c);
+   if (n > c->par.max_batch) throw HsError(HESAFF_ERR_ARG, "n exceeds hesaff_params.max_batch for the device-resident entry point");
+   plan(c, c->par.max_batch, height, width);
+   run_batch(c, (const uint8_t *)d_gray, 1, (long long)width * height, width, n, height, width);
+   const int32_t *hs = c->h_starts.data(), *ds = c->h_starts.data() + (n + 1);
+   for (int b = 0; b < n; b++) {
+      if (count_hessian) count_hessian[b] = hs[b + 1] - hs[b];
+      if (count_desc) count_desc[b] = ds[b + 1] - ds[b];
+   }
+   if (d_keys_out) *d_keys_out = c->b_out.p;
+   if (total_out) *total_out = ds[n];
+   HS_API_END(c)
+}
+
+int hesaff_detect_batch(hesaff_ctx *c, int n, const uint8_t *const *images, const int *widths, const int *heights,
+                        const int *strides, const int *channels, hesaff_result *results)
+{
+   if (!c || n < 0 || (n > 0 && (!images || !widths || !heights || !results))) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   bind_device(c);
+   c->host_keys.clear();
+   std::vector<size_t> key_off(n, 0);
+   std::vector<char> done(n, 0);
+   // group by (width, height, channels); each group runs in chunks of max_batch
+   for (int i = 0; i < n; i++) {
+      if (done[i]) continue;
+      const int W = widths[i], H = heights[i], ch = channels ? channels[i] : 1;
+      if (ch != 1 && ch != 3) throw HsError(HESAFF_ERR_ARG, "channels must be 1 or 3");
+      if (!images[i] || W < 1 || H < 1) throw HsError(HESAFF_ERR_ARG, "bad image");
+      std::vector<int> grp;
+      for (int j = i; j < n; j++)
+         if (!done[j] && widths[j] == W && heights[j] == H && (channels ? channels[j] : 1) == ch) grp.push_back(j);
+      const size_t row_bytes = (size_t)W * ch, img_bytes = row_bytes * H;
+      for (size_t g0 = 0; g0 < grp.size(); g0 += c->par.max_batch) {
+         const int B = (int)std::min<size_t>(c->par.max_batch, grp.size() - g0);
+         c->b_input.ensure(img_bytes * B);
+         for (int b = 0; b < B; b++) {
+            const int j = grp[g0 + b];
+            const int stride = strides ? strides[j] : (int)row_bytes;
+            HIP_TRY(hipMemcpy2DAsync((uint8_t *)c->b_input.p + img_bytes * b, row_bytes, images[j], (size_t)stride, row_bytes, H,
+                                     hipMemcpyHostToDevice, c->stream));
+         }
+         plan(c, std::min<int>(c->par.max_batch, (int)grp.size()), H, W);
+         run_batch(c, (const uint8_t *)c->b_input.p, ch, (long long)img_bytes, (int)row_bytes, B, H, W);
+         const int32_t *hs = c->h_starts.data(), *ds = c->h_starts.data() + (B + 1);
+         const size_t base = c->host_keys.size();
+         const int total = ds[B];
+         c->host_keys.resize(base + (size_t)total);
+         if (total > 0) HIP_TRY(hipMemcpy(c->host_keys.data() + base, c->b_out.p, (size_t)total * sizeof(hesaff_keypoint), hipMemcpyDeviceToHost));
+         for (int b = 0; b < B; b++) {
+            const int j = grp[g0 + b];
+            results[j].count_hessian = hs[b + 1] - hs[b];
+            results[j].count_desc = ds[b + 1] - ds[b];
+            key_off[j] = base + (size_t)ds[b];
+            done[j] = 1;
+         }
+      }
+   }
+   for (int i = 0; i < n; i++) results[i].keys = c->host_keys.data() + key_off[i];
+   HS_API_END(c)
+}
+
+// ---------------------------------- stage entry points ----------------------------------
+
+int hesaff_stage_gaussian_blur(hesaff_ctx *c, const float *in, int rows, int cols, float sigma, float *out)
+{
+   if (!c || !in || !out || rows < 1 || cols < 1) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   bind_device(c);
+   const int K = hesaff::gauss_ksize(sigma);
+   const size_t n = (size_t)rows * cols;
+   c->b_stage.ensure(n * 4 * 3 + (size_t)(K + 16) * 4);
+   float *d_in = c->b_stage.as<float>(), *d_tmp = d_in + n, *d_out = d_tmp + n, *d_taps = d_out + n;
+   std::vector<float> taps(K, 1.0f);
+   if (K > 1) hesaff::gauss_taps(K, sigma, taps.data());
+   HIP_TRY(hipMemcpyAsync(d_in, in, n * 4, hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(hipMemcpyAsync(d_taps, taps.data(), (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
+   if (K == 1) {
+      HIP_TRY(hipMemcpyAsync(d_out, d_in, n * 4, hipMemcpyDeviceToDevice, c->stream));
+   } else {
+      DPlane pi = make_plane(d_in, 1, rows, cols, cols), pt = make_plane(d_tmp, 1, rows, cols, cols), po = make_plane(d_out, 1, rows, cols, cols);
+      const dim3 grid((cols + 255) / 256, rows, 1);
+      hipLaunchKernelGGL(k_blur_rows_generic, grid, dim3(256), 0, c->stream, pi, pt, (const float *)d_taps, K);
+      hipLaunchKernelGGL(k_blur_cols_generic, grid, dim3(256), 0, c->stream, pt, po, (const float *)d_taps, K);
+   }
+   HIP_TRY(hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipStreamSynchronize(c->stream));
+   HIP_TRY(hipGetLastError());
+   HS_API_END(c)
+}
+
+int hesaff_stage_hessian_response(hesaff_ctx *c, const float *in, int rows, int cols, float norm, float *out)
+{
+   if (!c || !in || !out || rows < 1 || cols < 1) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   bind_device(c);
+   const size_t n = (size_t)rows * cols;
+   c->b_stage.ensure(n * 4 * 2);
+   float *d_in = c->b_stage.as<float>(), *d_out = d_in + n;
+   HIP_TRY(hipMemcpyAsync(d_in, in, n * 4, hipMemcpyHostToDevice, c->stream));
+   DPlane pi = make_plane(d_in, 1, rows, cols, cols), po = make_plane(d_out, 1, rows, cols, cols);
+   hipLaunchKernelGGL(k_hess, dim3((cols + 255) / 256, rows, 1), dim3(256), 0, c->stream, pi, po, norm * norm);
+   HIP_TRY(hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipStreamSynchronize(c->stream));
+   HIP_TRY(hipGetLastError());
+   HS_API_END(c)
+}
+
+int hesaff_stage_half_image(hesaff_ctx *c, const float *in, int rows, int cols, float *out)
+{
+   if (!c || !in || !out || rows < 2 || cols < 2) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   bind_device(c);
+   const size_t n = (size_t)rows * cols;
+   const int r2 = rows / 2, c2 = cols / 2;
+   c->b_stage.ensure(n * 4 * 2);
+   float *d_in = c->b_stage.as<float>(), *d_out = d_in + n;
+   HIP_TRY(hipMemcpyAsync(d_in, in, n * 4, hipMemcpyHostToDevice, c->stream));
+   DPlane pi = make_plane(d_in, 1, rows, cols, cols), po = make_plane(d_out, 1, r2, c2, c2);
+   hipLaunchKernelGGL(k_half, dim3((c2 + 255) / 256, r2, 1), dim3(256), 0, c->stream, pi, po);
+   HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)r2 * c2 * 4, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipStreamSynchronize(c->stream));
+   HIP_TRY(hipGetLastError());
+   HS_API_END(c)
+}
+
+int hesaff_stage_pyramid(hesaff_ctx *c, const uint8_t *gray, int rows, int cols, float *planes, int *n_octaves, size_t *n_floats)
+{
+   if (!c || rows < 1 || cols < 1) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   bind_device(c);
+   plan(c, 1, rows, cols);
+   size_t nf = 0;
+   for (const OctGeom &g : c->oct) nf += (size_t)10 * g.rows * g.cols;
+   if (n_octaves) *n_octaves = (int)c->oct.size();
+   if (n_floats) *n_floats = nf;
+   if (planes) {
+      if (!gray) throw HsError(HESAFF_ERR_ARG, "gray is NULL");
+      c->b_input.ensure((size_t)rows * cols);
+      c->b_stage.ensure((size_t)rows * round_up(cols, 64) * 4);
+      HIP_TRY(hipMemcpyAsync(c->b_input.p, gray, (size_t)rows * cols, hipMemcpyHostToDevice, c->stream));
+      c->ev_used = 0;
+      StageTimer tm(c);
+      Lists s = make_lists(c);
+      run_detection(c, (const uint8_t *)c->b_input.p, 1, (long long)rows * cols, cols, 1, s, tm, true, planes);
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(hipGetLastError());
+   }
+   HS_API_END(c)
+}
+
+int hesaff_stage_hessian_keypoints(hesaff_ctx *c, const uint8_t *gray, int rows, int cols, int cap, float *f, int32_t *iv, int *count)
+{
+   if (!c || !gray || rows < 1 || cols < 1 || !count) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   bind_device(c);
+   plan(c, 1, rows, cols);
+   c->b_input.ensure((size_t)rows * cols);
+   HIP_TRY(hipMemcpyAsync(c->b_input.p, gray, (size_t)rows * cols, hipMemcpyHostToDevice, c->stream));
+   c->ev_used = 0;
+   StageTimer tm(c);
+   Lists s = make_lists(c);
+   run_detection(c, (const uint8_t *)c->b_input.p, 1, (long long)rows * cols, cols, 1, s, tm, false, nullptr);
+   uint32_t cn[8];
+   HIP_TRY(hipMemcpyAsync(cn, s.counters, sizeof cn, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipStreamSynchronize(c->stream));
+   HIP_TRY(hipGetLastError());
+   if (cn[2] != 0 || cn[1] > c->cap) throw HsError(HESAFF_ERR_CAPACITY, "keypoint capacity exceeded");
+   const int n = (int)cn[3];
+   *count = n;
+   const int m = std::min(n, cap);
+   if (m > 0 && f && iv) {
+      std::vector<float> x(m), y(m), sc(m), resp(m);
+      std::vector<int32_t> meta(m), key(m);
+      HIP_TRY(hipMemcpy(x.data(), s.hl.x, (size_t)m * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(y.data(), s.hl.y, (size_t)m * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(sc.data(), s.hl.s, (size_t)m * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(resp.data(), s.hl.response, (size_t)m * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(meta.data(), s.hl.meta, (size_t)m * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(key.data(), s.hl.r0c0, (size_t)m * 4, hipMemcpyDeviceToHost));
+      for (int i = 0; i < m; i++) {
+         const int octave = (meta[i] >> 4) & 15, level = (meta[i] >> 2) & 3, type = meta[i] & 3;
+         const OctGeom &g = c->oct[octave];
+         const uint32_t pix = (uint32_t)key[i] % (uint32_t)(g.rows * g.cols);
+         f[5 * i] = x[i]; f[5 * i + 1] = y[i]; f[5 * i + 2] = sc[i]; f[5 * i + 3] = (float)(1 << octave); f[5 * i + 4] = resp[i];
+         iv[5 * i] = type; iv[5 * i + 1] = octave; iv[5 * i + 2] = level; iv[5 * i + 3] = (int32_t)(pix / g.cols); iv[5 * i + 4] = (int32_t)(pix % g.cols);
+      }
+   }
+   HS_API_END(c)
+}
+
+int hesaff_stage_find_affine_shape(hesaff_ctx *c, const float *blur, int rows, int cols, int n, const float *kp, int32_t *converged,
+                                   float *U, int32_t *iters)
+{
+   if (!c || !blur || !kp || rows < 2 || cols < 2 || n < 0) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   bind_device(c);
+   if (n == 0) return HESAFF_OK;
+   const size_t np = (size_t)rows * cols;
+   c->b_stage.ensure(np * 4 + (size_t)n * (4 + 6) * 4 + 64);
+   float *d_plane = c->b_stage.as<float>();
+   float *d_kp = d_plane + np;
+   int32_t *d_conv = (int32_t *)(d_kp + (size_t)4 * n), *d_iters = d_conv + n;
+   float *d_U = (float *)(d_iters + n);
+   HIP_TRY(hipMemcpyAsync(d_plane, blur, np * 4, hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(hipMemcpyAsync(d_kp, kp, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+   AffineOut ao; ao.converged = d_conv; ao.iters = d_iters; ao.U = d_U;
+   DPlane P = make_plane(d_plane, 1, rows, cols, cols);
+   hipLaunchKernelGGL(k_affine_stage, dim3(std::min(n, 8192)), dim3(64), 0, c->stream, P, (const float *)d_kp, n, c->tables, c->consts, ao);
+   if (converged) HIP_TRY(hipMemcpyAsync(converged, d_conv, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+   if (iters) HIP_TRY(hipMemcpyAsync(iters, d_iters, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+   if (U) HIP_TRY(hipMemcpyAsync(U, d_U, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipStreamSynchronize(c->stream));
+   HIP_TRY(hipGetLastError());
+   HS_API_END(c)
+}
+
+int hesaff_stage_rectify(hesaff_ctx *c, int n, float *A)
+{
+   if (!c || !A || n < 0) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   bind_device(c);
+   if (n == 0) return HESAFF_OK;
+   c->b_stage.ensure((size_t)n * 16);
+   HIP_TRY(hipMemcpyAsync(c->b_stage.p, A, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+   hipLaunchKernelGGL(k_rectify_stage, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->b_stage.as<float>());
+   HIP_TRY(hipMemcpyAsync(A, c->b_stage.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipStreamSynchronize(c->stream));
+   HIP_TRY(hipGetLastError());
+   HS_API_END(c)
+}
+
+// normalizeAffine for caller-supplied keypoints: reuses the batch kernels through a
+// one-image plan whose Hessian list is filled from the arguments.
+int hesaff_stage_normalize_affine(hesaff_ctx *c, const float *img, int rows, int cols, int n, const float *kp, const float *A,
+                                  int32_t *rejected, float *patches)
+{
+   if (!c || !img || !kp || !A || rows < 2 || cols < 2 || n < 0) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   bind_device(c);
+   if (n == 0) return HESAFF_OK;
+   plan(c, 1, rows, cols);
+   if ((uint32_t)n > c->cap) throw HsError(HESAFF_ERR_CAPACITY, "too many keypoints for this image size");
+   Lists s = make_lists(c);
+   hipStream_t st = c->stream;
+   HIP_TRY(hipMemcpy2DAsync(c->gray.p, (size_t)c->gray.pitch * 4, img, (size_t)cols * 4, (size_t)cols * 4, rows, hipMemcpyHostToDevice, st));
+   std::vector<float> x(n), y(n), sc(n);
+   std::vector<int32_t> meta(n, 0), P0(n), alive(n);
+   std::vector<uint32_t> bins((size_t)HS_NBINS * n), bcount(HS_NBINS, 0);
+   for (int i = 0; i < n; i++) { x[i] = kp[3 * i]; y[i] = kp[3 * i + 1]; sc[i] = kp[3 * i + 2]; }
+   HIP_TRY(hipMemcpyAsync(s.hl.x, x.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+   HIP_TRY(hipMemcpyAsync(s.hl.y, y.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+   HIP_TRY(hipMemcpyAsync(s.hl.s, sc.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+   HIP_TRY(hipMemcpyAsync(s.hl.meta, meta.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+   // feed A through the affine-output slot as an already rectified matrix: k_prepare_patch
+   // would rectify again, so do its arithmetic (mrScale, P0, border test) via a dedicated kernel
+   HIP_TRY(hipMemcpyAsync(s.pw.A, A, (size_t)n * 16, hipMemcpyHostToDevice, st));
+   HIP_TRY(hipMemsetAsync(s.counters, 0, 64 * 4, st));
+   uint32_t nn = (uint32_t)n;
+   HIP_TRY(hipMemcpyAsync(s.counters + 3, &nn, 4, hipMemcpyHostToDevice, st));
+   hipLaunchKernelGGL(k_prepare_patch_given_A, dim3((n + 255) / 256), dim3(256), 0, st, s.hl, (const uint32_t *)(s.counters + 3), rows, cols,
+                      c->consts, c->tables, s.pw);
+   c->b_patches.ensure((size_t)n * HS_PATCH_PIX * 4);
+   HIP_TRY(hipMemsetAsync(c->b_patches.p, 0, (size_t)n * HS_PATCH_PIX * 4, st));
+   run_patch_stage(c, s, c->gray, c->b_patches.as<float>(), 0);
+   HIP_TRY(hipMemcpyAsync(alive.data(), s.pw.alive, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+   if (patches) HIP_TRY(hipMemcpyAsync(patches, c->b_patches.p, (size_t)n * HS_PATCH_PIX * 4, hipMemcpyDeviceToHost, st));
+   HIP_TRY(hipStreamSynchronize(st));
+   HIP_TRY(hipGetLastError());
+   if (rejected) for (int i = 0; i < n; i++) rejected[i] = alive[i] ? 0 : 1;
+   HS_API_END(c)
+}
+
+int hesaff_stage_sift(hesaff_ctx *c, int n, const float *patches, uint8_t *desc)
+{
+   if (!c || !patches || !desc || n < 0) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   bind_device(c);
+   if (n == 0) return HESAFF_OK;
+   c->b_stage.ensure((size_t)n * (HS_PATCH_PIX * 4 + 128));
+   float *d_p = c->b_stage.as<float>();
+   uint8_t *d_d = (uint8_t *)(d_p + (size_t)n * HS_PATCH_PIX);
+   HIP_TRY(hipMemcpyAsync(d_p, patches, (size_t)n * HS_PATCH_PIX * 4, hipMemcpyHostToDevice, c->stream));
+   hipLaunchKernelGGL(k_sift_stage, dim3(std::min(n, 4096)), dim3(256), 0, c->stream, (const float *)d_p, n, c->tables, c->consts, d_d);
+   HIP_TRY(hipMemcpyAsync(desc, d_d, (size_t)n * 128, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipStreamSynchronize(c->stream));
+   HIP_TRY(hipGetLastError());
+   HS_API_END(c)
+}
+
+int hesaff_stage_math(hesaff_ctx *c, int n, const float *a, const float *b, float *atan2_out, float *pow2_out)
+{
+   if (!c || !a || !b || n < 0) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   bind_device(c);
+   if (n == 0) return HESAFF_OK;
+   c->b_stage.ensure((size_t)n * 16);
+   float *d_a = c->b_stage.as<float>(), *d_b = d_a + n, *d_at = d_b + n, *d_pw = d_at + n;
+   HIP_TRY(hipMemcpyAsync(d_a, a, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(hipMemcpyAsync(d_b, b, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+   hipLaunchKernelGGL(k_math, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, (const float *)d_a, (const float *)d_b, d_at, d_pw);
+   if (atan2_out) HIP_TRY(hipMemcpyAsync(atan2_out, d_at, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+   if (pow2_out) HIP_TRY(hipMemcpyAsync(pow2_out, d_pw, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipStreamSynchronize(c->stream));
+   HIP_TRY(hipGetLastError());
+   HS_API_END(c)
+}
+
+// ---------------------------------- host tables ----------------------------------
+
+int hesaff_table_gauss_mask(int size, float *mask)
+{
+   if (size < 1 || !(size & 1) || !mask) return HESAFF_ERR_ARG;
+   hesaff::gauss_mask(size, mask);
+   return HESAFF_OK;
+}
+int hesaff_table_circ_gauss_mask(int size, float *mask)
+{
+   if (size < 1 || !(size & 1) || !mask) return HESAFF_ERR_ARG;
+   hesaff::circ_gauss_mask(size, mask);
+   return HESAFF_OK;
+}
+int hesaff_table_sift_bins(int32_t *bin0, int32_t *bin1, float *w0, float *w1)
+{
+   if (!bin0 || !bin1 || !w0 || !w1) return HESAFF_ERR_ARG;
+   hesaff::sift_bins(bin0, bin1, w0, w1);
+   return HESAFF_OK;
+}
+int hesaff_table_gauss_kernel(float sigma, int cap, float *taps, int *ksize)
+{
+   if (!ksize) return HESAFF_ERR_ARG;
+   const int K = hesaff::gauss_ksize(sigma);
+   *ksize = K;
+   if (taps) {
+      if (cap < K) return HESAFF_ERR_ARG;
+      if (K == 1) taps[0] = 1.0f; else hesaff::gauss_taps(K, sigma, taps);
+   }
+   return HESAFF_OK;
+}
+
+} // extern "C"

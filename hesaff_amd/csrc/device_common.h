@@ -1,0 +1,163 @@
+// device_common.h -- scalar device helpers of the hesaff hot path (gfx950).
+//
+// Each function states the reference expression it evaluates (file:line under the
+// reference tree) and keeps its float operation ORDER: this translation unit is compiled
+// with -ffp-contract=off, IEEE division/sqrt and denormals on, so a given expression
+// tree rounds exactly like the reference's scalar x86-64 build.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hmath.h"
+
+#define HS_PATCH 41                 // patchSize, affine.h:42 / siftdesc.h:30
+#define HS_PATCH_PIX (41 * 41)
+#define HS_SMM 19                   // smmWindowSize, affine.h:43
+#define HS_SMM_PIX (19 * 19)
+#define HS_BORDER 5                 // PyramidParams::border, pyramid.h:39
+#define HS_NSCALES 3                // numberOfScales, pyramid.h:35
+#define HS_MAX_OCTAVES 16
+
+// A batch of equally sized float planes: [img][rows][pitch]
+struct DPlane {
+   float *p;
+   int rows, cols, pitch;
+   long long img_stride;   // floats between consecutive images
+   __host__ __device__ float *img(int b) const { return p + (long long)b * img_stride; }
+};
+
+// constants of one context, uploaded once (tables) / per call (thresholds)
+struct DConsts {
+   float edgeScoreThreshold, finalThreshold, positiveThreshold, negativeThreshold;  // pyramid.h:60-64
+   float convergenceThreshold;  // affine.h:41
+   float affInitialSigma;       // affine.h:40
+   float mrSize;                // affine.h:44
+   float maxBinValue;           // siftdesc.h:29
+   int maxIterations;           // affine.h:39
+};
+
+// ---- helpers.cpp:227-240 : one bilinear tap; `outside` is OR-ed like `ret` ----
+// (int)floor(w) of the reference is cvttss2si (INT_MIN on NaN/overflow -> "outside");
+// comparing the floored float gives the same classification without the cast.
+__device__ __forceinline__ float hs_bilinear(const float *__restrict__ im, int pitch, int width, int height,
+                                             float wx, float wy, bool &outside)
+{
+   const float fx = floorf(wx), fy = floorf(wy);
+   if (!(fx >= 0.0f && fy >= 0.0f && fx < (float)width && fy < (float)height)) {
+      outside = true;
+      return 0.0f;
+   }
+   const int x = (int)fx, y = (int)fy;
+   wx -= fx;
+   wy -= fy;
+   const float *p = im + (long long)y * pitch + x;
+   const float p00 = p[0], p01 = p[1], p10 = p[pitch], p11 = p[pitch + 1];
+   return (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + (wy) * ((1.0f - wx) * p10 + wx * p11);
+}
+
+// ---- helpers.cpp:46-88 solveLinear3x3 (value swaps, partial pivoting) ----
+__device__ __forceinline__ void hs_swap(float &a, float &b) { const float t = a; a = b; b = t; }
+__device__ inline void hs_solve3x3(float *A, float *b)
+{
+   int i = 0;
+   float vp = fabsf(A[0]);
+   const float tmp = fabsf(A[3]);
+   if (tmp > vp) { i = 1; vp = tmp; }
+   if (fabsf(A[6]) > vp) { i = 2; }
+   if (i == 1) { hs_swap(A[3], A[0]); hs_swap(A[4], A[1]); hs_swap(A[5], A[2]); hs_swap(b[1], b[0]); }
+   if (i == 2) { hs_swap(A[6], A[0]); hs_swap(A[7], A[1]); hs_swap(A[8], A[2]); hs_swap(b[2], b[0]); }
+   vp = A[3] / A[0]; A[4] -= vp * A[1]; A[5] -= vp * A[2]; b[1] -= vp * b[0];
+   vp = A[6] / A[0]; A[7] -= vp * A[1]; A[8] -= vp * A[2]; b[2] -= vp * b[0];
+   if (fabsf(A[4]) < fabsf(A[7])) { hs_swap(A[7], A[4]); hs_swap(A[8], A[5]); hs_swap(b[2], b[1]); }
+   vp = A[7] / A[4];
+   A[8] -= vp * A[5];
+   b[2] -= vp * b[1];
+   b[2] = (b[2]) / A[8];
+   b[1] = (b[1] - A[5] * b[2]) / A[4];
+   b[0] = (b[0] - A[2] * b[2] - A[1] * b[1]) / A[0];
+}
+
+// ---- helpers.cpp:149-175 invSqrt (double inside) ----
+__device__ inline void hs_inv_sqrt(float &a, float &b, float &c, float &l1, float &l2)
+{
+   double t, r;
+   if (b != 0) {
+      r = double(c - a) / (2 * b);
+      if (r >= 0) t = 1.0 / (r + sqrt(1 + r * r));
+      else t = -1.0 / (-r + sqrt(1 + r * r));
+      r = 1.0 / sqrt(1 + t * t);
+      t = t * r;
+   } else {
+      r = 1;
+      t = 0;
+   }
+   double x = 1.0 / sqrt(r * r * a - 2 * r * t * b + t * t * c);
+   double z = 1.0 / sqrt(t * t * a + 2 * r * t * b + r * r * c);
+   const double d = sqrt(x * z);
+   x /= d;
+   z /= d;
+   if (x < z) { l1 = float(z); l2 = float(x); } else { l1 = float(x); l2 = float(z); }
+   a = float(r * r * x + t * t * z);
+   b = float(-r * t * x + t * r * z);
+   c = float(t * t * x + r * r * z);
+}
+
+// ---- helpers.cpp:177-188 getEigenvalues ----
+__device__ __forceinline__ bool hs_eigenvalues(float a, float b, float c, float d, float &l1, float &l2)
+{
+   const float trace = a + d;
+   const float delta1 = (trace * trace - 4 * (a * d - b * c));
+   if (delta1 < 0) return false;
+   const float delta = sqrtf(delta1);
+   l1 = (trace + delta) / 2.0f;
+   l2 = (trace - delta) / 2.0f;
+   return true;
+}
+
+// ---- helpers.cpp:90-97 rectifyAffineTransformationUpIsUp (double inside) ----
+__device__ inline void hs_rectify(float &a11, float &a12, float &a21, float &a22)
+{
+   const double a = a11, b = a12, c = a21, d = a22;
+   const double det = sqrt(fabs(a * d - b * c));
+   const double b2a2 = sqrt(b * b + a * a);
+   a11 = (float)(b2a2 / det);
+   a12 = 0;
+   a21 = (float)((d * b + c * a) / (b2a2 * det));
+   a22 = (float)(det / b2a2);
+}
+
+// ---- helpers.cpp:191-207 interpolateCheckBorders for a 41x41 result ----
+__device__ inline bool hs_check_borders(int imRows, int imCols, float ofsx, float ofsy, float a11, float a12,
+                                        float a21, float a22)
+{
+   const int width = imCols - 2, height = imRows - 2;
+   const float h = (float)(HS_PATCH >> 1);
+   const float xs[4] = {-h, -h, h, h};
+   const float ys[4] = {-h, h, -h, h};
+   for (int i = 0; i < 4; i++) {
+      const float imx = ofsx + xs[i] * a11 + ys[i] * a12;
+      const float imy = ofsy + xs[i] * a21 + ys[i] * a22;
+      if (floorf(imx) <= 0 || floorf(imy) <= 0 || ceilf(imx) >= width || ceilf(imy) >= height) return true;
+   }
+   return false;
+}
+
+// ---- affine.cpp:14-33 / siftdesc.cpp:123-134 gradient stencil on a size x size tile ----
+__device__ __forceinline__ void hs_grad(const float *img, int size, int r, int c, float &gx, float &gy)
+{
+   if (c == 0) gx = img[r * size + c + 1] - img[r * size + c];
+   else if (c == size - 1) gx = img[r * size + c] - img[r * size + c - 1];
+   else gx = img[r * size + c + 1] - img[r * size + c - 1];
+   if (r == 0) gy = img[(r + 1) * size + c] - img[r * size + c];
+   else if (r == size - 1) gy = img[r * size + c] - img[(r - 1) * size + c];
+   else gy = img[(r + 1) * size + c] - img[(r - 1) * size + c];
+}
+
+// ---- pyramid.cpp:95-100 det-of-Hessian at the centre of a 3x3 neighbourhood ----
+__device__ __forceinline__ float hs_hessian(float v11, float v12, float v13, float v21, float v22, float v23,
+                                            float v31, float v32, float v33, float norm2)
+{
+   const float Lxx = (v21 - 2 * v22 + v23);
+   const float Lyy = (v12 - 2 * v22 + v32);
+   const float Lxy = (v13 - v11 + v31 - v33) / 4.0f;
+   return (Lxx * Lyy - Lxy * Lxy) * norm2;
+}

@@ -1,0 +1,474 @@
+// kernels_pyramid.h -- scale-space kernels: grey conversion, separable Gaussian with the
+// fused det-of-Hessian response and 2x decimation, extrema scan, localisation, ordering.
+// Reference: pyramid.cpp, helpers.cpp:283-295,331-339, hesaff.cpp:138-148.
+#pragma once
+#include "device_common.h"
+
+// ---------------------------------------------------------------------------------------
+// k_gray: 8-bit (1 or 3 interleaved channels) -> float32 grey, hesaff.cpp:145
+//   out = ((float(c0) + c1) + c2) / 3.0f   (channels == 1: c0 = c1 = c2, like cv::imread)
+// grid (ceil(cols/256), rows, B)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gray(const uint8_t *__restrict__ src, int channels, long long src_img_stride,
+                                              int src_row_stride, DPlane dst)
+{
+   const int c = blockIdx.x * 256 + threadIdx.x;
+   const int r = blockIdx.y, b = blockIdx.z;
+   if (c >= dst.cols) return;
+   const uint8_t *p = src + (long long)b * src_img_stride + (long long)r * src_row_stride + (long long)c * channels;
+   const float c0 = (float)p[0];
+   const float c1 = (float)(channels == 3 ? p[1] : p[0]);
+   const float c2 = (float)(channels == 3 ? p[2] : p[0]);
+   dst.img(b)[(long long)r * dst.pitch + c] = (c0 + c1 + c2) / 3.0f;
+}
+
+// ---------------------------------------------------------------------------------------
+// k_blur_hess_tile (v1, LDS tile): separable Gaussian (pinned cv::GaussianBlur order, see
+// DESIGN.md) of one 64x16 tile + 1-pixel halo, then the det-of-Hessian response of the
+// blurred tile (pyramid.cpp:63-114) and optionally the 2x decimated copy
+// (helpers.cpp:331-339).
+//   row pass   : t = k[0]*S[x-r]; t += k[j]*S[x-r+j], j = 1..K-1            (RowFilter)
+//   column pass: d = k[r]*T[y];  d += k[r+j]*(T[y+j] + T[y-j]), j = 1..r     (SymmColumnFilter)
+// K <= 15 (pyramid sigmas give 9..15).  grid (ceil(cols/64), ceil(rows/16), B), block 256.
+// ---------------------------------------------------------------------------------------
+#define BH_TW 64
+#define BH_TH 16
+#define BH_RMAX 7
+#define BH_INW (BH_TW + 2 + 2 * BH_RMAX)   // 80
+#define BH_INH (BH_TH + 2 + 2 * BH_RMAX)   // 32
+
+template <bool WRITE_L, bool WRITE_R, bool WRITE_HALF>
+__global__ __launch_bounds__(256) void k_blur_hess_tile(DPlane in, DPlane outL, DPlane outR, DPlane outHalf,
+                                                         const float *__restrict__ taps, int K, float norm2)
+{
+   __shared__ float s_in[BH_INH][BH_INW + 1];
+   __shared__ float s_row[BH_INH][BH_TW + 2 + 1];
+   __shared__ float s_blur[BH_TH + 2][BH_TW + 2 + 1];
+   __shared__ float s_k[2 * BH_RMAX + 1];
+
+   const int tid = threadIdx.x;
+   const int b = blockIdx.z;
+   const int x0 = blockIdx.x * BH_TW, y0 = blockIdx.y * BH_TH;
+   const int r = K >> 1;
+   const int rows = in.rows, cols = in.cols;
+   const float *src = in.img(b);
+
+   if (tid < K) s_k[tid] = taps[tid];
+   const int inW = BH_TW + 2 + 2 * r, inH = BH_TH + 2 + 2 * r;
+   for (int idx = tid; idx < inW * inH; idx += 256) {
+      const int ly = idx / inW, lx = idx - ly * inW;
+      int gy = y0 - 1 - r + ly, gx = x0 - 1 - r + lx;
+      gy = min(max(gy, 0), rows - 1);
+      gx = min(max(gx, 0), cols - 1);
+      s_in[ly][lx] = src[(long long)gy * in.pitch + gx];
+   }
+   __syncthreads();
+   // row pass over inH rows x (TW+2) columns
+   for (int idx = tid; idx < inH * (BH_TW + 2); idx += 256) {
+      const int ly = idx / (BH_TW + 2), ox = idx - ly * (BH_TW + 2);
+      float t = s_k[0] * s_in[ly][ox];
+      for (int j = 1; j < K; j++) t += s_k[j] * s_in[ly][ox + j];
+      s_row[ly][ox] = t;
+   }
+   __syncthreads();
+   // column pass over (TH+2) x (TW+2)
+   for (int idx = tid; idx < (BH_TH + 2) * (BH_TW + 2); idx += 256) {
+      const int oy = idx / (BH_TW + 2), ox = idx - oy * (BH_TW + 2);
+      float d = s_k[r] * s_row[oy + r][ox];
+      for (int j = 1; j <= r; j++) d += s_k[r + j] * (s_row[oy + r + j][ox] + s_row[oy + r - j][ox]);
+      s_blur[oy][ox] = d;
+   }
+   __syncthreads();
+   // outputs: 64x16 interior
+   for (int idx = tid; idx < BH_TH * BH_TW; idx += 256) {
+      const int ty = idx / BH_TW, tx = idx - ty * BH_TW;
+      const int y = y0 + ty, x = x0 + tx;
+      if (y >= rows || x >= cols) continue;
+      const int oy = ty + 1, ox = tx + 1;
+      const float v22 = s_blur[oy][ox];
+      if (WRITE_L) outL.img(b)[(long long)y * outL.pitch + x] = v22;
+      if (WRITE_HALF) {
+         if (((y | x) & 1) == 0 && (y >> 1) < outHalf.rows && (x >> 1) < outHalf.cols)
+            outHalf.img(b)[(long long)(y >> 1) * outHalf.pitch + (x >> 1)] = v22;
+      }
+      if (WRITE_R) {
+         float resp = 0.0f;
+         if (y > 0 && y < rows - 1 && x > 0 && x < cols - 1)
+            resp = hs_hessian(s_blur[oy - 1][ox - 1], s_blur[oy - 1][ox], s_blur[oy - 1][ox + 1], s_blur[oy][ox - 1], v22,
+                              s_blur[oy][ox + 1], s_blur[oy + 1][ox - 1], s_blur[oy + 1][ox], s_blur[oy + 1][ox + 1], norm2);
+         outR.img(b)[(long long)y * outR.pitch + x] = resp;
+      }
+   }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_hess: det-of-Hessian of a plane (R0 of every octave, pyramid.cpp:230), frame = 0.
+// grid (ceil(cols/256), rows, B)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hess(DPlane in, DPlane out, float norm2)
+{
+   const int x = blockIdx.x * 256 + threadIdx.x;
+   const int y = blockIdx.y, b = blockIdx.z;
+   if (x >= in.cols) return;
+   float resp = 0.0f;
+   if (y > 0 && y < in.rows - 1 && x > 0 && x < in.cols - 1) {
+      const float *p = in.img(b) + (long long)y * in.pitch + x;
+      const int s = in.pitch;
+      resp = hs_hessian(p[-s - 1], p[-s], p[-s + 1], p[-1], p[0], p[1], p[s - 1], p[s], p[s + 1], norm2);
+   }
+   out.img(b)[(long long)y * out.pitch + x] = resp;
+}
+
+// k_half: halfImage helpers.cpp:331-339 ; grid (ceil(outcols/256), outrows, B)
+__global__ __launch_bounds__(256) void k_half(DPlane in, DPlane out)
+{
+   const int x = blockIdx.x * 256 + threadIdx.x;
+   const int y = blockIdx.y, b = blockIdx.z;
+   if (x >= out.cols) return;
+   out.img(b)[(long long)y * out.pitch + x] = in.img(b)[(long long)(2 * y) * in.pitch + 2 * x];
+}
+
+// ---------------------------------------------------------------------------------------
+// Generic two-pass Gaussian for arbitrary K (stage API gaussianBlur; not on the batch path).
+// K <= 5 uses the SymmRowSmallFilter order (see kernels_patch.h for the same rule).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blur_rows_generic(DPlane in, DPlane tmp, const float *__restrict__ taps, int K)
+{
+   const int x = blockIdx.x * 256 + threadIdx.x;
+   const int y = blockIdx.y, b = blockIdx.z;
+   if (x >= in.cols) return;
+   const float *S = in.img(b) + (long long)y * in.pitch;
+   const int r = K >> 1, cm = in.cols - 1;
+   float t;
+   if (K <= 5) {
+      t = S[x] * taps[r] + (S[max(x - 1, 0)] + S[min(x + 1, cm)]) * taps[r + 1];
+      if (K == 5) t = t + (S[max(x - 2, 0)] + S[min(x + 2, cm)]) * taps[r + 2];
+   } else {
+      t = taps[0] * S[min(max(x - r, 0), cm)];
+      for (int j = 1; j < K; j++) t += taps[j] * S[min(max(x - r + j, 0), cm)];
+   }
+   tmp.img(b)[(long long)y * tmp.pitch + x] = t;
+}
+__global__ __launch_bounds__(256) void k_blur_cols_generic(DPlane tmp, DPlane out, const float *__restrict__ taps, int K)
+{
+   const int x = blockIdx.x * 256 + threadIdx.x;
+   const int y = blockIdx.y, b = blockIdx.z;
+   if (x >= tmp.cols) return;
+   const float *T = tmp.img(b);
+   const int r = K >> 1, rm = tmp.rows - 1;
+   float d = taps[r] * T[(long long)y * tmp.pitch + x];
+   for (int j = 1; j <= r; j++)
+      d += taps[r + j] * (T[(long long)min(y + j, rm) * tmp.pitch + x] + T[(long long)max(y - j, 0) * tmp.pitch + x]);
+   out.img(b)[(long long)y * out.pitch + x] = d;
+}
+
+// ---------------------------------------------------------------------------------------
+// k_extrema: findLevelKeypoints pyramid.cpp:206-222 + isMax/isMin :39-61 for one level.
+// A candidate passes when val > positiveThreshold and no neighbour in the 3x3x3 block is
+// strictly greater (resp. < negativeThreshold and none strictly smaller).  Appends
+// (img,level,r,c) to the octave's candidate list (unordered; order is restored by the
+// bitmask ranks in k_scatter_ordered).  grid (ceil(cols/64), ceil(rows/4), B), block (64,4)
+// ---------------------------------------------------------------------------------------
+struct CandList {
+   uint32_t *count;   // device counter
+   uint2 *items;      // x = img<<2 | level, y = r<<16 | c
+   uint32_t cap;
+   uint32_t *overflow;   // set to 1 when a list ran out of capacity
+};
+
+__device__ __forceinline__ bool hs_is_ext(const float *__restrict__ p, int s, float val, bool wantMax)
+{
+   bool ok = true;
+#pragma unroll
+   for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+      for (int dx = -1; dx <= 1; dx++) {
+         const float v = p[dy * s + dx];
+         ok = ok && (wantMax ? !(v > val) : !(v < val));
+      }
+   return ok;
+}
+
+__global__ __launch_bounds__(256) void k_extrema(DPlane low, DPlane cur, DPlane high, int level, float posThr, float negThr,
+                                                 CandList cl)
+{
+   const int c = blockIdx.x * 64 + threadIdx.x;
+   const int r = blockIdx.y * 4 + threadIdx.y;
+   const int b = blockIdx.z;
+   const int rows = cur.rows, cols = cur.cols;
+   if (r < HS_BORDER || r >= rows - HS_BORDER || c < HS_BORDER || c >= cols - HS_BORDER) return;
+   const long long off = (long long)r * cur.pitch + c;
+   const float *pc = cur.img(b) + off;
+   const float val = *pc;
+   const bool isPos = val > posThr, isNeg = val < negThr;
+   if (!(isPos || isNeg)) return;
+   const float *pl = low.img(b) + off, *ph = high.img(b) + off;
+   const int s = cur.pitch;
+   if (!(hs_is_ext(pc, s, val, isPos) && hs_is_ext(pl, s, val, isPos) && hs_is_ext(ph, s, val, isPos))) return;
+   const uint32_t idx = atomicAdd(cl.count, 1u);
+   if (idx < cl.cap) cl.items[idx] = make_uint2(((uint32_t)b << 2) | (uint32_t)level, ((uint32_t)r << 16) | (uint32_t)c);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_localize: localizeKeypoint pyramid.cpp:122-204 (without the order-dependent octaveMap
+// test, which k_dedupe applies afterwards) + getHessianPointType pyramid.cpp:24-37.
+// Grid-stride over the octave's candidates.  A surviving candidate becomes a record and
+// bids for its final pixel with atomicMin(map[r,c], order key): the reference's
+// first-come-first-kept octaveMap rule (pyramid.cpp:189-193) == lowest (level,r0,c0) wins.
+// ---------------------------------------------------------------------------------------
+struct OctaveCtx {
+   DPlane R[HS_NSCALES + 2];   // responses R0..R4
+   DPlane L[HS_NSCALES + 2];   // blurs L0..L3 (L[4] unused)
+   float sigma[HS_NSCALES + 2];   // curSigma of each level (sigma[1..3] used as curScale)
+   float pixelDistance;
+   int octave;
+   uint32_t *map;                 // [B][rows][cols] order keys, 0xFFFFFFFF = free
+   long long word_base;           // first bitmask word of this octave inside one image
+   long long words_per_image;     // bitmask words of a whole image (all octaves)
+   int words_per_row;
+};
+
+struct RecList {   // surviving localisations of the whole batch (unordered)
+   uint32_t *count;
+   uint32_t cap;
+   float *x, *y, *s, *response;
+   int32_t *meta;       // img<<8 | octave<<4 | level<<2 | type
+   uint32_t *cell;      // final pixel index rf*cols+cf inside the octave plane (for the map)
+   uint32_t *key;       // level*N + r0*cols + c0
+   long long *word;     // bitmask word index of (img,octave,level,r0,c0>>6)
+   uint32_t *bit;       // c0 & 63
+};
+
+__global__ __launch_bounds__(256) void k_localize(OctaveCtx oc, CandList cl, RecList rl, DConsts k)
+{
+   const uint32_t n = min(*cl.count, cl.cap);
+   if (blockIdx.x == 0 && threadIdx.x == 0 && *cl.count > cl.cap) *cl.overflow = 1u;
+   const int rows = oc.R[0].rows, cols = oc.R[0].cols, pitch = oc.R[0].pitch;
+   for (uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x; ci < n; ci += gridDim.x * blockDim.x) {
+      const uint2 it = cl.items[ci];
+      const int b = (int)(it.x >> 2), level = (int)(it.x & 3u);
+      const int r0 = (int)(it.y >> 16), c0 = (int)(it.y & 0xffffu);
+      // level = i-2 : low = R[level], cur = R[level+1], high = R[level+2]
+      const float *low = oc.R[level].img(b), *cur = oc.R[level + 1].img(b), *high = oc.R[level + 2].img(b);
+      float bb[3] = {0.0f, 0.0f, 0.0f};
+      float val = 0.0f;
+      int r = r0, c = c0, nr = r0, nc = c0;
+      bool dead = false;
+      for (int iter = 0; iter < 5; iter++) {
+         r = nr; c = nc;
+         const float *pc = cur + (long long)r * pitch + c;
+         const float *pl = low + (long long)r * pitch + c;
+         const float *ph = high + (long long)r * pitch + c;
+         const float c00 = pc[0];
+         const float dxx = pc[-1] - 2.0f * c00 + pc[1];
+         const float dyy = pc[-pitch] - 2.0f * c00 + pc[pitch];
+         const float dss = pl[0] - 2.0f * c00 + ph[0];
+         const float dxy = 0.25f * (pc[pitch + 1] - pc[pitch - 1] - pc[-pitch + 1] + pc[-pitch - 1]);
+         if (iter == 0) {
+            const float edgeScore = (dxx + dyy) * (dxx + dyy) / (dxx * dyy - dxy * dxy);
+            if (edgeScore >= k.edgeScoreThreshold || edgeScore < 0) { dead = true; break; }
+         }
+         const float dxs = 0.25f * (ph[1] - ph[-1] - pl[1] + pl[-1]);
+         const float dys = 0.25f * (ph[pitch] - ph[-pitch] - pl[pitch] + pl[-pitch]);
+         float A[9] = {dxx, dxy, dxs, dxy, dyy, dys, dxs, dys, dss};
+         const float dx = 0.5f * (pc[1] - pc[-1]);
+         const float dy = 0.5f * (pc[pitch] - pc[-pitch]);
+         const float ds = 0.5f * (ph[0] - pl[0]);
+         bb[0] = -dx; bb[1] = -dy; bb[2] = -ds;
+         hs_solve3x3(A, bb);
+         if (bb[0] != bb[0] || bb[1] != bb[1] || bb[2] != bb[2]) { dead = true; break; }
+         val = c00 + 0.5f * (dx * bb[0] + dy * bb[1] + ds * bb[2]);
+         // MAX_SUBPIXEL_SHIFT is the double 0.6 (pyramid.cpp:117): compare in double
+         if ((double)bb[0] > 0.6) { if (c < cols - 3) nc++; else { dead = true; break; } }
+         if ((double)bb[1] > 0.6) { if (r < rows - 3) nr++; else { dead = true; break; } }
+         if ((double)bb[0] < -0.6) { if (c > 3) nc--; else { dead = true; break; } }
+         if ((double)bb[1] < -0.6) { if (r > 3) nr--; else { dead = true; break; } }
+         if (nr == r && nc == c) break;
+      }
+      if (dead) continue;
+      if (fabsf(bb[0]) > 1.5f || fabsf(bb[1]) > 1.5f || fabsf(bb[2]) > 1.5f || fabsf(val) < k.finalThreshold) continue;
+      const float curScale = oc.sigma[level + 1];
+      const float scale = curScale * hm_pow2f(bb[2] / (float)HS_NSCALES);
+      int type;
+      if (val < 0) type = 2;
+      else {
+         const float *p = oc.L[level + 1].img(b) + (long long)r * oc.L[level + 1].pitch + c;
+         const float Lxx = (p[-1] - 2 * p[0] + p[1]);
+         type = (Lxx < 0) ? 0 : 1;
+      }
+      const uint32_t slot = atomicAdd(rl.count, 1u);
+      if (slot >= rl.cap) { *cl.overflow = 1u; continue; }
+      const float pd = oc.pixelDistance;
+      rl.x[slot] = pd * ((float)c + bb[0]);
+      rl.y[slot] = pd * ((float)r + bb[1]);
+      rl.s[slot] = pd * scale;
+      rl.response[slot] = val;
+      rl.meta[slot] = (b << 8) | (oc.octave << 4) | (level << 2) | type;
+      const uint32_t cell = (uint32_t)(r * cols + c);
+      const uint32_t key = (uint32_t)level * (uint32_t)(rows * cols) + (uint32_t)(r0 * cols + c0);
+      rl.cell[slot] = cell;
+      rl.key[slot] = key;
+      rl.word[slot] = (long long)b * oc.words_per_image + oc.word_base +
+                      ((long long)level * rows + r0) * oc.words_per_row + (c0 >> 6);
+      rl.bit[slot] = (uint32_t)(c0 & 63);
+      atomicMin(oc.map + (long long)b * rows * cols + cell, key);
+   }
+}
+
+// k_dedupe: records [start, count) of this octave; the map winner sets its bitmask bit.
+__global__ __launch_bounds__(256) void k_dedupe(OctaveCtx oc, RecList rl, const uint32_t *__restrict__ start_ptr,
+                                                unsigned long long *__restrict__ bitmask)
+{
+   const uint32_t start = *start_ptr;
+   const uint32_t n = min(*rl.count, rl.cap);
+   const long long N = (long long)oc.R[0].rows * oc.R[0].cols;
+   for (uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const int b = rl.meta[i] >> 8;
+      if (oc.map[(long long)b * N + rl.cell[i]] == rl.key[i]) atomicOr(bitmask + rl.word[i], 1ull << rl.bit[i]);
+      else rl.word[i] = -1;   // lost the octaveMap race
+   }
+}
+
+// ---------------------------------------------------------------------------------------
+// Exclusive scan of 32-bit counts (three phases, 4096 items per block).  LOAD turns the
+// i-th source element into its count (popcount of a bitmask word, or a flag).
+// ---------------------------------------------------------------------------------------
+#define SCAN_ITEMS 16
+#define SCAN_BLOCK (256 * SCAN_ITEMS)
+
+struct LoadPopc {
+   const unsigned long long *p;
+   __device__ uint32_t operator()(long long i) const { return (uint32_t)__popcll(p[i]); }
+};
+struct LoadU32 {
+   const uint32_t *p;
+   __device__ uint32_t operator()(long long i) const { return p[i]; }
+};
+struct LoadFlagI32 {
+   const int32_t *p;
+   __device__ uint32_t operator()(long long i) const { return p[i] != 0 ? 1u : 0u; }
+};
+
+__device__ __forceinline__ uint32_t hs_block_exclusive_scan(uint32_t v, uint32_t *s_wave /*4*/, uint32_t &block_total)
+{
+   // inclusive scan inside the wave (integers: order-free)
+   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+   uint32_t inc = v;
+#pragma unroll
+   for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += t;
+   }
+   if (lane == 63) s_wave[w] = inc;
+   __syncthreads();
+   uint32_t base = 0, tot = 0;
+#pragma unroll
+   for (int i = 0; i < 4; i++) {
+      const uint32_t t = s_wave[i];
+      if (i < w) base += t;
+      tot += t;
+   }
+   block_total = tot;
+   __syncthreads();
+   return base + inc - v;
+}
+
+template <class LOAD>
+__global__ __launch_bounds__(256) void k_scan_reduce(LOAD load, long long n, uint32_t *__restrict__ block_sums)
+{
+   __shared__ uint32_t s_wave[4];
+   const long long base = (long long)blockIdx.x * SCAN_BLOCK;
+   uint32_t v = 0;
+#pragma unroll
+   for (int i = 0; i < SCAN_ITEMS; i++) {
+      const long long idx = base + (long long)i * 256 + threadIdx.x;
+      if (idx < n) v += load(idx);
+   }
+   uint32_t tot;
+   hs_block_exclusive_scan(v, s_wave, tot);
+   if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of block_sums in place; total -> *total_out
+__global__ __launch_bounds__(256) void k_scan_sums(uint32_t *__restrict__ block_sums, int nblocks, uint32_t *__restrict__ total_out)
+{
+   __shared__ uint32_t s_wave[4];
+   uint32_t carry = 0;
+   for (int base = 0; base < nblocks; base += 256) {
+      const int i = base + threadIdx.x;
+      const uint32_t v = (i < nblocks) ? block_sums[i] : 0u;
+      uint32_t tot;
+      const uint32_t ex = hs_block_exclusive_scan(v, s_wave, tot);
+      if (i < nblocks) block_sums[i] = carry + ex;
+      carry += tot;
+   }
+   if (threadIdx.x == 0) *total_out = carry;
+}
+
+template <class LOAD>
+__global__ __launch_bounds__(256) void k_scan_down(LOAD load, long long n, const uint32_t *__restrict__ block_sums,
+                                                   uint32_t *__restrict__ out)
+{
+   __shared__ uint32_t s_wave[4];
+   // thread owns SCAN_ITEMS consecutive items so that the scan is in index order
+   const long long base = (long long)blockIdx.x * SCAN_BLOCK + (long long)threadIdx.x * SCAN_ITEMS;
+   uint32_t vals[SCAN_ITEMS];
+   uint32_t sum = 0;
+#pragma unroll
+   for (int i = 0; i < SCAN_ITEMS; i++) {
+      const long long idx = base + i;
+      vals[i] = (idx < n) ? load(idx) : 0u;
+      sum += vals[i];
+   }
+   uint32_t tot;
+   uint32_t ex = hs_block_exclusive_scan(sum, s_wave, tot) + block_sums[blockIdx.x];
+#pragma unroll
+   for (int i = 0; i < SCAN_ITEMS; i++) {
+      const long long idx = base + i;
+      if (idx < n) out[idx] = ex;
+      ex += vals[i];
+   }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_scatter_ordered: rank = prefix[word] + popcount(bits below) puts every surviving record
+// at its position in the reference's detection order (image, octave, level, raster of the
+// initial extremum).
+// ---------------------------------------------------------------------------------------
+struct HessList {   // ordered Hessian keypoints of the batch = onHessianKeypointDetected calls
+   float *x, *y, *s, *response;
+   int32_t *meta;    // img<<8 | octave<<4 | level<<2 | type
+   int32_t *r0c0;    // r0<<16 | c0 (provenance, for the stage API)
+   uint32_t cap;
+};
+
+__global__ __launch_bounds__(256) void k_scatter_ordered(RecList rl, const unsigned long long *__restrict__ bitmask,
+                                                         const uint32_t *__restrict__ prefix, HessList hl)
+{
+   const uint32_t n = min(*rl.count, rl.cap);
+   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const long long w = rl.word[i];
+      if (w < 0) continue;
+      const uint32_t bit = rl.bit[i];
+      const unsigned long long below = bitmask[w] & ((1ull << bit) - 1ull);
+      const uint32_t rank = prefix[w] + (uint32_t)__popcll(below);
+      if (rank >= hl.cap) continue;
+      hl.x[rank] = rl.x[i];
+      hl.y[rank] = rl.y[i];
+      hl.s[rank] = rl.s[i];
+      hl.response[rank] = rl.response[i];
+      hl.meta[rank] = rl.meta[i];
+      // recover r0,c0 from the key is not needed on the batch path; kept for the stage API
+      hl.r0c0[rank] = (int32_t)rl.key[i];
+   }
+}
+
+// per-image counts from an exclusive prefix sampled at image boundaries:
+// counts[b] = prefix_at(b+1) - prefix_at(b), the last boundary being *total.
+__global__ void k_image_counts(const uint32_t *__restrict__ prefix, long long stride, int nimg, const uint32_t *__restrict__ total,
+                               int32_t *__restrict__ starts /*nimg+1*/)
+{
+   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+   if (b > nimg) return;
+   starts[b] = (b == nimg) ? (int32_t)*total : (int32_t)prefix[(long long)b * stride];
+}

@@ -1,0 +1,606 @@
+// pipeline.hip -- host side of libhesaff_amd.so: context, HBM buffer plan, kernel
+// orchestration of one batch, and the C ABI of include/hesaff_amd.h.
+//
+// The reference chains its stages depth-first through virtual callbacks, one keypoint at
+// a time (hesaff.cpp:66-105).  Here a batch of B equally sized images runs breadth-first:
+//   pyramid (per octave: R0, 4x blur+response, decimate)  ->  extrema + localise per octave
+//   -> order by bitmask rank -> affine iteration -> rectify/bin -> patch+SIFT -> pack.
+// The reference's output order (octave, level, raster of the initial extremum) is
+// reproduced by ranking survivors through a bitmask laid out in exactly that order.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hesaff_amd.h"
+#include "host_tables.h"
+#include "kernels_keypoint.h"
+#include "kernels_pyramid.h"
+
+namespace hesaff {
+OctaveSchedule make_schedule(float initialSigma)
+{
+   OctaveSchedule s;
+   // pyramid.cpp:227 : powf(2, 1/numberOfScales) ; hm_pow2f == glibc powf(2,.) bit for bit
+   const float sigmaStep = hm_pow2f(1.0f / (float)HS_NSCALES);
+   float curSigma = initialSigma;
+   s.init_sigma = sqrtf(initialSigma * initialSigma - 0.5f * 0.5f);
+   s.level_sigma[0] = curSigma;
+   s.blur_sigma[0] = 0.0f;
+   {
+      const float n = curSigma * curSigma;
+      s.norm2[0] = n * n;
+   }
+   for (int i = 1; i < HS_NSCALES + 2; i++) {
+      s.blur_sigma[i] = curSigma * sqrtf(sigmaStep * sigmaStep - 1.0f);
+      const float sigma = curSigma * sigmaStep;
+      s.level_sigma[i] = sigma;
+      const float n = sigma * sigma;
+      s.norm2[i] = n * n;
+      curSigma *= sigmaStep;
+   }
+   return s;
+}
+} // namespace hesaff
+
+static std::string g_create_error;
+
+#define HIP_TRY(expr)                                                                         \
+   do {                                                                                       \
+      hipError_t e_ = (expr);                                                                 \
+      if (e_ != hipSuccess) {                                                                 \
+         char buf_[512];                                                                      \
+         snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+         throw HsError(HESAFF_ERR_DEVICE, buf_);                                              \
+      }                                                                                       \
+   } while (0)
+
+struct HsError {
+   int code;
+   std::string msg;
+   HsError(int c, const std::string &m) : code(c), msg(m) {}
+};
+
+struct DevBuf {
+   void *p = nullptr;
+   size_t bytes = 0;
+   void ensure(size_t need)
+   {
+      if (need <= bytes) return;
+      if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+      hipError_t e = hipMalloc(&p, need);
+      if (e != hipSuccess) {
+         char buf[256];
+         snprintf(buf, sizeof buf, "hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(e));
+         throw HsError(HESAFF_ERR_NOMEM, buf);
+      }
+      bytes = need;
+   }
+   void release()
+   {
+      if (p) (void)hipFree(p);
+      p = nullptr;
+      bytes = 0;
+   }
+   template <class T> T *as() const { return (T *)p; }
+};
+
+struct OctGeom {
+   int rows, cols, pitch;
+   long long word_base;   // first bitmask word of this octave inside one image
+   int words_per_row;
+};
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct hesaff_ctx {
+   hesaff_params par;
+   int device = 0;
+   hipStream_t stream = nullptr;
+   std::string err;
+   hesaff::OctaveSchedule sched;
+   DConsts consts;
+
+   // tables
+   DevBuf t_smm, t_sift, t_bin0, t_bin1, t_w0, t_w1, t_pyr_taps, t_patch_taps, t_patch_off, t_patch_k;
+   int pyr_K[5];          // [0] initial blur, [1..4] octave blurs
+   int pyr_tap_off[5];
+   int max_p0 = 0;        // tap table covers odd P0 <= max_p0
+   KpTables tables;
+
+   // geometry of the current buffer plan
+   int B = 0, H = 0, W = 0;
+   std::vector<OctGeom> oct;
+   long long words_per_image = 0;
+   uint32_t cap = 0;      // keypoint / candidate capacity of a batch
+
+   // planes
+   DevBuf b_gray, b_L, b_L3, b_R, b_map, b_bitmask, b_prefix, b_blocksums;
+   std::vector<DPlane> L;   // [octave*3 + level]
+   DPlane gray, L3, R[5];
+   // lists
+   DevBuf b_counters;       // uint32: [0] cand_count [1] rec_count [2] overflow [3] hess_total [4] desc_total
+                            //         [8..11] bin_count, [16..16+HS_MAX_OCTAVES) octave rec starts
+   DevBuf b_cand, b_rec_f, b_rec_i, b_rec_w, b_hess_f, b_hess_i, b_aff, b_pw, b_bins, b_rank, b_desc, b_out, b_starts, b_scratch,
+      b_patches, b_stage;
+   DevBuf b_input;          // staging for host images
+   std::vector<hesaff_keypoint> host_keys;
+   std::vector<int32_t> h_starts;
+   int n_patch_blocks3 = 64;
+
+   hesaff_timings tm;
+   int profiling = 0;
+   std::vector<hipEvent_t> ev_pool;
+   size_t ev_used = 0;
+};
+
+namespace {
+
+struct EvPair { hipEvent_t a, b; int kind; double bytes; };
+
+hipEvent_t get_event(hesaff_ctx *c)
+{
+   if (c->ev_used == c->ev_pool.size()) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      c->ev_pool.push_back(e);
+   }
+   return c->ev_pool[c->ev_used++];
+}
+
+template <class T> void upload(DevBuf &b, const std::vector<T> &v)
+{
+   b.ensure(std::max<size_t>(v.size() * sizeof(T), 16));
+   HIP_TRY(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+}
+
+void build_tables(hesaff_ctx *c)
+{
+   std::vector<float> smm(HS_SMM_PIX), sm(HS_PATCH_PIX), w0(HS_PATCH), w1(HS_PATCH);
+   std::vector<int32_t> b0(HS_PATCH), b1(HS_PATCH);
+   hesaff::gauss_mask(HS_SMM, smm.data());
+   hesaff::circ_gauss_mask(HS_PATCH, sm.data());
+   hesaff::sift_bins(b0.data(), b1.data(), w0.data(), w1.data());
+   upload(c->t_smm, smm); upload(c->t_sift, sm); upload(c->t_bin0, b0); upload(c->t_bin1, b1); upload(c->t_w0, w0); upload(c->t_w1, w1);
+   c->sched = hesaff::make_schedule(c->par.initialSigma);
+   std::vector<float> taps;
+   for (int i = 0; i < 5; i++) {
+      const float sigma = i == 0 ? c->sched.init_sigma : c->sched.blur_sigma[i];
+      const int K = hesaff::gauss_ksize(sigma);
+      if (K > 2 * BH_RMAX + 1) throw HsError(HESAFF_ERR_ARG, "initialSigma too large for the tiled pyramid kernel (K > 15)");
+      c->pyr_K[i] = K;
+      c->pyr_tap_off[i] = (int)taps.size();
+      taps.resize(taps.size() + 16, 0.0f);
+      hesaff::gauss_taps(K, sigma, taps.data() + c->pyr_tap_off[i]);
+   }
+   upload(c->t_pyr_taps, taps);
+   const hesaff_params &p = c->par;
+   DConsts &k = c->consts;
+   // pyramid.h:59-64
+   k.edgeScoreThreshold = (p.edgeEigenValueRatio + 1.0f) * (p.edgeEigenValueRatio + 1.0f) / p.edgeEigenValueRatio;
+   k.finalThreshold = p.threshold * p.threshold;
+   k.positiveThreshold = (float)(0.8 * k.finalThreshold);
+   k.negativeThreshold = -k.positiveThreshold;
+   k.convergenceThreshold = p.convergenceThreshold;
+   k.affInitialSigma = 1.6f;   // AffineShapeParams::initialSigma affine.h:40 (not overridden by hesaff.cpp)
+   k.mrSize = p.mrSize;
+   k.maxBinValue = p.maxBinValue;
+   k.maxIterations = p.maxIterations;
+}
+
+// taps of the per-keypoint patch blur (affine.cpp:129: sigma = 1.5f * P0/41) for odd P0
+void ensure_patch_taps(hesaff_ctx *c, int max_p0)
+{
+   if (max_p0 <= c->max_p0) return;
+   if ((max_p0 & 1) == 0) max_p0++;
+   std::vector<float> taps;
+   std::vector<int32_t> off((max_p0 + 1) / 2), kk((max_p0 + 1) / 2);
+   for (int P0 = 1; P0 <= max_p0; P0 += 2) {
+      const float scale = (float)P0 / (float)HS_PATCH;
+      const float sigma = 1.5f * scale;
+      const int K = hesaff::gauss_ksize(sigma);
+      off[(P0 - 1) / 2] = (int32_t)taps.size();
+      kk[(P0 - 1) / 2] = K;
+      taps.resize(taps.size() + K);
+      if (K == 1) taps[taps.size() - 1] = 1.0f;
+      else hesaff::gauss_taps(K, sigma, taps.data() + off[(P0 - 1) / 2]);
+   }
+   upload(c->t_patch_taps, taps); upload(c->t_patch_off, off); upload(c->t_patch_k, kk);
+   c->max_p0 = max_p0;
+}
+
+void refresh_tables_struct(hesaff_ctx *c)
+{
+   KpTables &t = c->tables;
+   t.smm_mask = c->t_smm.as<float>(); t.sift_mask = c->t_sift.as<float>();
+   t.bin0 = c->t_bin0.as<int32_t>(); t.bin1 = c->t_bin1.as<int32_t>();
+   t.w0 = c->t_w0.as<float>(); t.w1 = c->t_w1.as<float>();
+   t.patch_taps = c->t_patch_taps.as<float>(); t.patch_tap_off = c->t_patch_off.as<int32_t>(); t.patch_tap_k = c->t_patch_k.as<int32_t>();
+   t.max_p0 = c->max_p0;
+}
+
+DPlane make_plane(float *p, int B, int rows, int cols, int pitch)
+{
+   DPlane d;
+   d.p = p; d.rows = rows; d.cols = cols; d.pitch = pitch; d.img_stride = (long long)rows * pitch;
+   (void)B;
+   return d;
+}
+
+// Buffer plan for a batch of B images of H x W.
+void plan(hesaff_ctx *c, int B, int H, int W)
+{
+   if (B <= c->B && H == c->H && W == c->W) return;
+   if (H < 1 || W < 1 || H > 65535 || W > 65535) throw HsError(HESAFF_ERR_ARG, "image size out of range (1..65535)");
+   c->oct.clear();
+   long long words = 0;
+   size_t L_floats = 0;
+   {
+      int r = H, cc = W;
+      const int minSize = 2 * HS_BORDER + 2;   // pyramid.cpp:283
+      while (r > minSize && cc > minSize) {
+         OctGeom g;
+         g.rows = r; g.cols = cc; g.pitch = round_up(cc, 64);
+         g.words_per_row = (cc + 63) / 64;
+         g.word_base = words;
+         words += (long long)HS_NSCALES * r * g.words_per_row;
+         L_floats += (size_t)3 * B * r * g.pitch;
+         c->oct.push_back(g);
+         r /= 2; cc /= 2;
+         if ((int)c->oct.size() >= HS_MAX_OCTAVES) break;
+      }
+   }
+   c->words_per_image = words;
+   const int pitch0 = round_up(W, 64);
+   const size_t plane0 = (size_t)B * H * pitch0;
+   c->b_gray.ensure(plane0 * 4);
+   c->gray = make_plane(c->b_gray.as<float>(), B, H, W, pitch0);
+   c->b_L.ensure(std::max<size_t>(L_floats * 4, 16));
+   c->L.clear();
+   {
+      float *p = c->b_L.as<float>();
+      for (const OctGeom &g : c->oct)
+         for (int l = 0; l < 3; l++) {
+            c->L.push_back(make_plane(p, B, g.rows, g.cols, g.pitch));
+            p += (size_t)B * g.rows * g.pitch;
+         }
+   }
+   c->b_L3.ensure(plane0 * 4);
+   c->b_R.ensure(plane0 * 4 * 5);
+   c->b_map.ensure(std::max<size_t>((size_t)B * H * W * 4, 16));
+   const long long total_words = (long long)B * words;
+   c->b_bitmask.ensure(std::max<size_t>((size_t)total_words * 8, 16));
+   c->b_prefix.ensure(std::max<size_t>((size_t)(total_words + 1) * 4, 16));
+   double mpx = (double)B * H * W / 1.0e6;
+   double capd = mpx * (double)c->par.max_kpts_per_mpx;
+   if (capd < 4096) capd = 4096;
+   if (capd > 2.0e9) throw HsError(HESAFF_ERR_ARG, "batch too large for 32-bit keypoint indices");
+   c->cap = (uint32_t)capd;
+   const size_t cap = c->cap;
+   const long long scan_items = std::max<long long>(total_words, (long long)cap);
+   c->b_blocksums.ensure((size_t)((scan_items + SCAN_BLOCK - 1) / SCAN_BLOCK + 1) * 4);
+   c->b_counters.ensure(64 * 4);
+   c->b_cand.ensure(cap * sizeof(uint2));
+   c->b_rec_f.ensure(cap * 4 * 4);
+   c->b_rec_i.ensure(cap * 4 * 4);
+   c->b_rec_w.ensure(cap * 8);
+   c->b_hess_f.ensure(cap * 4 * 4);
+   c->b_hess_i.ensure(cap * 2 * 4);
+   c->b_aff.ensure(cap * 6 * 4);
+   c->b_pw.ensure(cap * 6 * 4);
+   c->b_bins.ensure(cap * HS_NBINS * 4);
+   c->b_rank.ensure((cap + 1) * 4);
+   c->b_desc.ensure(cap * 128);
+   c->b_out.ensure(cap * sizeof(KeyRec));
+   c->b_starts.ensure((size_t)(B + 1) * 2 * 4);
+   // patch taps + BIN 3 scratch: P <= sqrt(W*H) + small (the det-1 window must fit)
+   const int max_p0 = (int)std::floor(std::sqrt((double)W * (double)H)) + 3;
+   ensure_patch_taps(c, max_p0);
+   const long long Pm = c->max_p0 + 2;
+   const long long slot = Pm * Pm + Pm * 82 + 82 * 82 + 64;
+   c->b_scratch.ensure((size_t)slot * 4 * c->n_patch_blocks3);
+   refresh_tables_struct(c);
+   c->B = B; c->H = H; c->W = W;
+}
+
+template <class LOAD> void exclusive_scan(hesaff_ctx *c, LOAD load, long long n, uint32_t *out, uint32_t *total)
+{
+   // out[0..n) exclusive prefix, *total = sum (device pointers)
+   if (n <= 0) { HIP_TRY(hipMemsetAsync(total, 0, 4, c->stream)); return; }
+   const int nb = (int)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+   uint32_t *bs = c->b_blocksums.as<uint32_t>();
+   hipLaunchKernelGGL(k_scan_reduce<LOAD>, dim3(nb), dim3(256), 0, c->stream, load, n, bs);
+   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, c->stream, bs, nb, total);
+   hipLaunchKernelGGL(k_scan_down<LOAD>, dim3(nb), dim3(256), 0, c->stream, load, n, bs, out);
+}
+
+struct StageTimer {
+   hesaff_ctx *c;
+   std::vector<EvPair> pairs;
+   explicit StageTimer(hesaff_ctx *ctx) : c(ctx) {}
+   int begin(int kind, double bytes = 0)
+   {
+      if (!c->profiling) return -1;
+      if (kind >= 100 && c->profiling < 2) return -1;
+      EvPair p; p.a = get_event(c); p.b = get_event(c); p.kind = kind; p.bytes = bytes;
+      (void)hipEventRecord(p.a, c->stream);
+      pairs.push_back(p);
+      return (int)pairs.size() - 1;
+   }
+   void end(int id) { if (id >= 0) (void)hipEventRecord(pairs[id].b, c->stream); }
+};
+
+enum { T_PYR = 0, T_DET = 1, T_AFF = 2, T_PATCH = 3, T_SIFT = 4, T_TOTAL = 5, T_BLURHESS = 100 };
+
+template <bool WL, bool WR, bool WH>
+void launch_blur_hess(hesaff_ctx *c, const DPlane &in, const DPlane &outL, const DPlane &outR, const DPlane &outHalf, int tapIdx,
+                      float norm2, int B)
+{
+   const dim3 grid((in.cols + BH_TW - 1) / BH_TW, (in.rows + BH_TH - 1) / BH_TH, B);
+   hipLaunchKernelGGL((k_blur_hess_tile<WL, WR, WH>), grid, dim3(256), 0, c->stream, in, outL, outR, outHalf,
+                      c->t_pyr_taps.as<float>() + c->pyr_tap_off[tapIdx], c->pyr_K[tapIdx], norm2);
+}
+
+struct Lists {
+   CandList cl;
+   RecList rl;
+   HessList hl;
+   AffineOut ao;
+   PatchWork pw;
+   uint32_t *counters;
+};
+
+Lists make_lists(hesaff_ctx *c)
+{
+   Lists s;
+   uint32_t *cnt = c->b_counters.as<uint32_t>();
+   const size_t cap = c->cap;
+   s.counters = cnt;
+   s.cl.count = cnt + 0; s.cl.items = c->b_cand.as<uint2>(); s.cl.cap = c->cap; s.cl.overflow = cnt + 2;
+   s.rl.count = cnt + 1; s.rl.cap = c->cap;
+   float *rf = c->b_rec_f.as<float>();
+   s.rl.x = rf; s.rl.y = rf + cap; s.rl.s = rf + 2 * cap; s.rl.response = rf + 3 * cap;
+   uint32_t *ri = c->b_rec_i.as<uint32_t>();
+   s.rl.meta = (int32_t *)ri; s.rl.cell = ri + cap; s.rl.key = ri + 2 * cap; s.rl.bit = ri + 3 * cap;
+   s.rl.word = c->b_rec_w.as<long long>();
+   float *hf = c->b_hess_f.as<float>();
+   s.hl.x = hf; s.hl.y = hf + cap; s.hl.s = hf + 2 * cap; s.hl.response = hf + 3 * cap;
+   int32_t *hi = c->b_hess_i.as<int32_t>();
+   s.hl.meta = hi; s.hl.r0c0 = hi + cap; s.hl.cap = c->cap;
+   int32_t *ai = c->b_aff.as<int32_t>();
+   s.ao.converged = ai; s.ao.iters = ai + cap; s.ao.U = (float *)(ai + 2 * cap);
+   int32_t *pi = c->b_pw.as<int32_t>();
+   s.pw.P0 = pi; s.pw.alive = pi + cap; s.pw.A = (float *)(pi + 2 * cap);
+   s.pw.bin_count = cnt + 8; s.pw.bin_items = c->b_bins.as<uint32_t>(); s.pw.cap = c->cap;
+   return s;
+}
+
+size_t patch_lds_bytes(int bin)
+{
+   const int PMAX = bin == 0 ? 41 : (bin == 1 ? 64 : (bin == 2 ? 128 : 0));
+   const int WIN = PMAX * PMAX;
+   const int REGION = std::max(2 * WIN, 2 * HS_PATCH_PIX);
+   return (size_t)(REGION + HS_PATCH_PIX + 128 + 8 + 32) * 4;
+}
+
+template <int BIN> void launch_patch(hesaff_ctx *c, const Lists &s, const PatchIO &io, int blocks, int do_sift)
+{
+   const size_t lds = patch_lds_bytes(BIN);
+   static bool attr_set[HS_NBINS] = {false, false, false, false};
+   if (!attr_set[BIN]) {
+      HIP_TRY(hipFuncSetAttribute((const void *)k_patch_sift<BIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set[BIN] = true;
+   }
+   hipLaunchKernelGGL(k_patch_sift<BIN>, dim3(blocks), dim3(256), lds, c->stream, s.hl, s.pw, io, c->tables, c->consts, do_sift);
+}
+
+void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *patches_out, int do_sift)
+{
+   PatchIO io;
+   io.image = image;
+   io.patches = patches_out;
+   io.desc = c->b_desc.as<uint8_t>();
+   io.scratch = c->b_scratch.as<float>();
+   const long long Pm = c->max_p0 + 2;
+   io.scratch_stride = Pm * Pm + Pm * 82 + 82 * 82 + 64;
+   launch_patch<0>(c, s, io, 256 * 8, do_sift);
+   launch_patch<1>(c, s, io, 256 * 4, do_sift);
+   launch_patch<2>(c, s, io, 256 * 2, do_sift);
+   launch_patch<3>(c, s, io, c->n_patch_blocks3, do_sift);
+}
+
+// The scale-space + detection part for the current plan; fills the ordered Hessian list.
+// src: device u8 images ([B][H][row_stride] with `channels` interleaved channels).
+void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_img_stride, int src_row_stride, int B,
+                   const Lists &s, StageTimer &tm, bool keep_all_planes, float *planes_out)
+{
+   const hesaff::OctaveSchedule &sc = c->sched;
+   hipStream_t st = c->stream;
+   uint32_t *cnt = s.counters;
+   HIP_TRY(hipMemsetAsync(cnt, 0, 64 * 4, st));
+   HIP_TRY(hipMemsetAsync(c->b_bitmask.p, 0, std::max<size_t>((size_t)B * c->words_per_image * 8, 8), st));
+
+   int t = tm.begin(T_PYR);
+   {
+      const dim3 grid((c->W + 255) / 256, c->H, B);
+      DPlane g = c->gray;
+      hipLaunchKernelGGL(k_gray, grid, dim3(256), 0, st, d_src, channels, src_img_stride, src_row_stride, g);
+   }
+   DPlane none = make_plane(nullptr, B, 0, 0, 0);
+   if (!c->oct.empty()) {
+      // pyramid.cpp:276-280 initial blur 0.5 -> 1.6
+      DPlane L00 = c->L[0];
+      const int tb = tm.begin(T_BLURHESS, 0);   // initial blur: not counted in the 12N launches (bytes 0)
+      launch_blur_hess<true, false, false>(c, c->gray, L00, none, none, 0, 0.0f, B);
+      tm.end(tb);
+   }
+   tm.end(t);
+   float *pout = planes_out;
+   for (size_t o = 0; o < c->oct.size(); o++) {
+      const OctGeom &g = c->oct[o];
+      const size_t planeF = (size_t)B * g.rows * g.pitch;
+      DPlane Lo[5], Ro[5];
+      for (int l = 0; l < 3; l++) Lo[l] = c->L[o * 3 + l];
+      Lo[3] = make_plane(c->b_L3.as<float>(), B, g.rows, g.cols, g.pitch);
+      Lo[4] = none;
+      if (keep_all_planes) Lo[4] = make_plane(c->b_stage.as<float>(), B, g.rows, g.cols, g.pitch);
+      for (int l = 0; l < 5; l++) Ro[l] = make_plane(c->b_R.as<float>() + l * planeF, B, g.rows, g.cols, g.pitch);
+      t = tm.begin(T_PYR);
+      {
+         const dim3 grid((g.cols + 255) / 256, g.rows, B);
+         hipLaunchKernelGGL(k_hess, grid, dim3(256), 0, st, Lo[0], Ro[0], sc.norm2[0]);
+      }
+      const bool has_next = o + 1 < c->oct.size();
+      for (int i = 1; i <= 4; i++) {
+         const double bytes = 12.0 * (double)B * g.rows * g.cols;
+         const int tb = tm.begin(T_BLURHESS, bytes);
+         if (i < 3) launch_blur_hess<true, true, false>(c, Lo[i - 1], Lo[i], Ro[i], none, i, sc.norm2[i], B);
+         else if (i == 3) {
+            if (has_next) launch_blur_hess<true, true, true>(c, Lo[2], Lo[3], Ro[3], c->L[(o + 1) * 3], 3, sc.norm2[3], B);
+            else launch_blur_hess<true, true, false>(c, Lo[2], Lo[3], Ro[3], none, 3, sc.norm2[3], B);
+         } else {
+            if (keep_all_planes) launch_blur_hess<true, true, false>(c, Lo[3], Lo[4], Ro[4], none, 4, sc.norm2[4], B);
+            else launch_blur_hess<false, true, false>(c, Lo[3], none, Ro[4], none, 4, sc.norm2[4], B);
+         }
+         tm.end(tb);
+      }
+      tm.end(t);
+      if (planes_out) {
+         // stage API (B == 1): copy L0..L4, R0..R4 tightly packed
+         for (int l = 0; l < 5; l++) {
+            HIP_TRY(hipMemcpy2DAsync(pout, (size_t)g.cols * 4, Lo[l].p, (size_t)g.pitch * 4, (size_t)g.cols * 4, g.rows, hipMemcpyDeviceToHost, st));
+            pout += (size_t)g.rows * g.cols;
+         }
+         for (int l = 0; l < 5; l++) {
+            HIP_TRY(hipMemcpy2DAsync(pout, (size_t)g.cols * 4, Ro[l].p, (size_t)g.pitch * 4, (size_t)g.cols * 4, g.rows, hipMemcpyDeviceToHost, st));
+            pout += (size_t)g.rows * g.cols;
+         }
+      }
+      // ---- detection on this octave ----
+      t = tm.begin(T_DET);
+      HIP_TRY(hipMemsetAsync(c->b_map.p, 0xFF, (size_t)B * g.rows * g.cols * 4, st));
+      HIP_TRY(hipMemsetAsync(cnt + 0, 0, 4, st));
+      HIP_TRY(hipMemcpyAsync(cnt + 16 + o, cnt + 1, 4, hipMemcpyDeviceToDevice, st));
+      OctaveCtx oc;
+      for (int l = 0; l < 5; l++) { oc.R[l] = Ro[l]; oc.L[l] = Lo[l]; oc.sigma[l] = sc.level_sigma[l]; }
+      oc.pixelDistance = (float)(1 << o);
+      oc.octave = (int)o;
+      oc.map = c->b_map.as<uint32_t>();
+      oc.word_base = g.word_base;
+      oc.words_per_image = c->words_per_image;
+      oc.words_per_row = g.words_per_row;
+      if (g.rows > 2 * HS_BORDER && g.cols > 2 * HS_BORDER) {
+         const dim3 grid((g.cols + 63) / 64, (g.rows + 3) / 4, B);
+         for (int level = 0; level < 3; level++)
+            hipLaunchKernelGGL(k_extrema, grid, dim3(64, 4), 0, st, Ro[level], Ro[level + 1], Ro[level + 2], level,
+                               c->consts.positiveThreshold, c->consts.negativeThreshold, s.cl);
+         hipLaunchKernelGGL(k_localize, dim3(1024), dim3(256), 0, st, oc, s.cl, s.rl, c->consts);
+         hipLaunchKernelGGL(k_dedupe, dim3(512), dim3(256), 0, st, oc, s.rl, (const uint32_t *)(cnt + 16 + o),
+                            c->b_bitmask.as<unsigned long long>());
+      }
+      tm.end(t);
+   }
+   // ---- ordering ----
+   t = tm.begin(T_DET);
+   const long long total_words = (long long)B * c->words_per_image;
+   LoadPopc lp; lp.p = c->b_bitmask.as<unsigned long long>();
+   exclusive_scan(c, lp, total_words, c->b_prefix.as<uint32_t>(), cnt + 3);
+   hipLaunchKernelGGL(k_scatter_ordered, dim3(1024), dim3(256), 0, st, s.rl, (const unsigned long long *)c->b_bitmask.p,
+                      (const uint32_t *)c->b_prefix.p, s.hl);
+   hipLaunchKernelGGL(k_image_counts, dim3((B + 1 + 63) / 64), dim3(64), 0, st, (const uint32_t *)c->b_prefix.p,
+                      c->words_per_image, B, (const uint32_t *)(cnt + 3), c->b_starts.as<int32_t>());
+   tm.end(t);
+}
+
+__global__ void k_desc_starts(const int32_t *__restrict__ hess_starts, int nimg, const uint32_t *__restrict__ rank,
+                              const uint32_t *__restrict__ n_hess, const uint32_t *__restrict__ total_desc, int32_t *__restrict__ out)
+{
+   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+   if (b > nimg) return;
+   const uint32_t hs = (uint32_t)hess_starts[b];
+   out[b] = (b == nimg || hs >= *n_hess) ? (int32_t)*total_desc : (int32_t)rank[hs];
+}
+
+void collect_timings(hesaff_ctx *c, StageTimer &tm, int B)
+{
+   hesaff_timings &t = c->tm;
+   memset(&t, 0, sizeof t);
+   for (const EvPair &p : tm.pairs) {
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, p.a, p.b);
+      switch (p.kind) {
+         case T_PYR: t.pyramid_ms += ms; break;
+         case T_DET: t.detect_ms += ms; break;
+         case T_AFF: t.affine_ms += ms; break;
+         case T_PATCH: t.patch_ms += ms; break;
+         case T_SIFT: t.sift_ms += ms; break;
+         case T_TOTAL: t.total_ms += ms; break;
+         case T_BLURHESS:
+            if (p.bytes > 0) { t.blur_hess_ms += ms; t.blur_hess_launches++; t.blur_hess_bytes += p.bytes; }
+            break;
+      }
+   }
+   double sumN = 0;
+   for (const OctGeom &g : c->oct) sumN += (double)g.rows * g.cols;
+   t.pyramid_bytes = (double)B * (5.0 * c->H * c->W + 58.0 * sumN);
+}
+
+// Whole hot path on a device-resident batch.  Leaves ordered KeyRec records in b_out and
+// per-image start offsets (hessian: b_starts[0..B], desc: b_starts[B+1..2B+1]).
+void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_img_stride, int src_row_stride, int B, int H, int W)
+{
+   plan(c, B, H, W);
+   c->ev_used = 0;
+   StageTimer tm(c);
+   Lists s = make_lists(c);
+   hipStream_t st = c->stream;
+   uint32_t *cnt = s.counters;
+   const int tt = tm.begin(T_TOTAL);
+   run_detection(c, d_src, channels, src_img_stride, src_row_stride, B, s, tm, false, nullptr);
+
+   int t = tm.begin(T_AFF);
+   PlaneTab pt;
+   memset(&pt, 0, sizeof pt);
+   for (size_t o = 0; o < c->oct.size(); o++)
+      for (int l = 0; l < 3; l++) pt.L[o][l] = c->L[o * 3 + l];
+   hipLaunchKernelGGL(k_affine, dim3(256 * 32), dim3(64), 0, st, pt, s.hl, (const uint32_t *)(cnt + 3), c->tables, c->consts, s.ao);
+   tm.end(t);
+   t = tm.begin(T_PATCH);
+   hipLaunchKernelGGL(k_prepare_patch, dim3(1024), dim3(256), 0, st, s.hl, (const uint32_t *)(cnt + 3), s.ao, H, W, c->consts,
+                      c->tables, s.pw);
+   run_patch_stage(c, s, c->gray, nullptr, 1);
+   tm.end(t);
+   t = tm.begin(T_SIFT);
+   // final stable compaction (hesaff.cpp:87: keys.push_back in detection order)
+   LoadFlagI32 lf; lf.p = s.pw.alive;
+   // scan over cap entries would waste time: scan over n_hess only -> n is on the device, so
+   // scan `cap`-bounded by the host-known upper bound min(cap, candidates) = cap; alive[] of
+   // unused slots must be 0: k_prepare_patch only writes h < n, so clear the tail first.
+   // (cheap: 4 bytes per slot)
+   // NOTE: alive[] is fully rewritten for h < n_hess each batch; slots >= n_hess are zeroed here.
+   hipLaunchKernelGGL(k_clear_tail, dim3(1024), dim3(256), 0, st, s.pw.alive, (const uint32_t *)(cnt + 3), c->cap);
+   exclusive_scan(c, lf, (long long)c->cap, c->b_rank.as<uint32_t>(), cnt + 4);
+   hipLaunchKernelGGL(k_pack, dim3(2048), dim3(256), 0, st, s.hl, (const uint32_t *)(cnt + 3), s.pw, (const uint32_t *)c->b_rank.p,
+                      (const uint8_t *)c->b_desc.p, c->b_out.as<KeyRec>());
+   hipLaunchKernelGGL(k_desc_starts, dim3((B + 1 + 63) / 64), dim3(64), 0, st, (const int32_t *)c->b_starts.p, B,
+                      (const uint32_t *)c->b_rank.p, (const uint32_t *)(cnt + 3), (const uint32_t *)(cnt + 4),
+                      c->b_starts.as<int32_t>() + (B + 1));
+   tm.end(t);
+   tm.end(tt);
+   c->h_starts.resize(2 * (B + 1) + 8);
+   HIP_TRY(hipMemcpyAsync(c->h_starts.data(), c->b_starts.p, (size_t)2 * (B + 1) * 4, hipMemcpyDeviceToHost, st));
+   HIP_TRY(hipMemcpyAsync(c->h_starts.data() + 2 * (B + 1), cnt, 8 * 4, hipMemcpyDeviceToHost, st));
+   HIP_TRY(hipStreamSynchronize(st));
+   HIP_TRY(hipGetLastError());
+   if (c->profiling) collect_timings(c, tm, B);
+   const int32_t *cn = c->h_starts.data() + 2 * (B + 1);
+   if (cn[2] != 0 || (uint32_t)cn[1] > c->cap)
+      throw HsError(HESAFF_ERR_CAPACITY, "keypoint capacity exceeded; raise hesaff_params.max_kpts_per_mpx");
+}
+
+} // namespace
+#include "capi_impl.h"

@@ -1,0 +1,173 @@
+/* hesaff_amd.h -- C ABI of libhesaff_amd.so: MI355X (gfx950) Hessian-Affine + SIFT hot path.
+ *
+ * Drop-in boundary for perdoch/hesaff's detect+describe path.  Plain pointers and sizes
+ * only; no C++/torch types.  Every entry point cites the reference interface it replaces
+ * (file:line under the reference tree).  Return value: 0 = HESAFF_OK, negative = error;
+ * hesaff_last_error() gives the message.  One context per device; a context is not
+ * thread-safe, distinct contexts may be used concurrently.
+ *
+ * The library has NO CPU fallback: every function that computes needs a visible gfx950
+ * device and fails with HESAFF_ERR_DEVICE otherwise.
+ */
+#ifndef HESAFF_AMD_H
+#define HESAFF_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HESAFF_OK 0
+#define HESAFF_ERR_DEVICE (-1)    /* no usable GPU / HIP runtime error            */
+#define HESAFF_ERR_ARG (-2)       /* bad argument                                 */
+#define HESAFF_ERR_CAPACITY (-3)  /* keypoint capacity exceeded (raise max_kpts_per_mpx) */
+#define HESAFF_ERR_IO (-4)        /* file I/O                                     */
+#define HESAFF_ERR_NOMEM (-5)
+
+typedef struct hesaff_ctx hesaff_ctx;
+
+/* Parameters = the reference's compile-time structs flattened.
+ * PyramidParams pyramid.h:18-41, AffineShapeParams affine.h:17-46,
+ * SIFTDescriptorParams siftdesc.h:19-32, HessianAffineParams hesaff.cpp:21-36.
+ * patchSize (41), smmWindowSize (19), spatialBins (4), orientationBins (8),
+ * numberOfScales (3), border (5) and upscaleInputImage (0) are fixed at the reference defaults. */
+typedef struct hesaff_params {
+   float threshold;            /* 16/3  pyramid.h:37, hesaff.cpp:30   */
+   float edgeEigenValueRatio;  /* 10    pyramid.h:38                  */
+   float initialSigma;         /* 1.6   pyramid.h:36 (also affine.h:40) */
+   int maxIterations;          /* 16    affine.h:39, hesaff.cpp:31    */
+   float convergenceThreshold; /* 0.05  affine.h:41                   */
+   float mrSize;               /* 3*sqrt(3) affine.h:44, hesaff.cpp:32 */
+   float maxBinValue;          /* 0.2   siftdesc.h:29                 */
+   /* capacity knobs (no reference counterpart) */
+   int max_batch;              /* images processed together on the device (default 16) */
+   int max_kpts_per_mpx;       /* candidate/keypoint capacity per megapixel (default 40000) */
+} hesaff_params;
+
+/* One detected + described region = the reference's `struct Keypoint` hesaff.cpp:41-48,
+ * same field order and types (164 bytes). */
+typedef struct hesaff_keypoint {
+   float x, y, s;
+   float a11, a12, a21, a22;
+   float response;
+   int32_t type;               /* HESSIAN_DARK 0 / BRIGHT 1 / SADDLE 2, pyramid.h:51-55 */
+   uint8_t desc[128];
+} hesaff_keypoint;
+
+/* Per-image result of hesaff_detect_batch. keys is library-owned host memory, valid until
+ * the next hesaff_detect_batch / hesaff_destroy on the same context.  Order = the
+ * reference's detection order (octave, level, raster of the initial extremum). */
+typedef struct hesaff_result {
+   int32_t count_hessian;      /* g_numberOfPoints,       hesaff.cpp:38,68  */
+   int32_t count_desc;         /* g_numberOfAffinePoints, hesaff.cpp:39,103 */
+   const hesaff_keypoint *keys;
+} hesaff_result;
+
+/* Stage timings of the last device batch, milliseconds (HIP events on the ctx stream). */
+typedef struct hesaff_timings {
+   float pyramid_ms;           /* grey + blur + Hessian + decimation (the roofline kernels) */
+   float detect_ms;            /* extrema + localisation + ordering                          */
+   float affine_ms;            /* Baumberg iteration                                         */
+   float patch_ms;             /* rectify + normalizeAffine                                  */
+   float sift_ms;              /* descriptor + final compaction                              */
+   float total_ms;
+   float blur_hess_ms;         /* sum of the k_blur_hess launches only                       */
+   int32_t blur_hess_launches;
+   double blur_hess_bytes;     /* algorithmic bytes of those launches (12 N each)            */
+   double pyramid_bytes;       /* algorithmic bytes B_pyr = 5 N0 + 58 sum N_k, whole batch   */
+} hesaff_timings;
+
+int hesaff_default_params(hesaff_params *p);
+
+/* replaces: AffineHessianDetector ctor hesaff.cpp:56-64 (+ mask/table setup affine.h:71,
+ * siftdesc.h:47-48).  device = HIP device ordinal. */
+int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device);
+void hesaff_destroy(hesaff_ctx *ctx);
+const char *hesaff_last_error(const hesaff_ctx *ctx);   /* ctx may be NULL: last create error */
+
+/* replaces: main()'s grey conversion hesaff.cpp:138-148 + detectPyramidKeypoints
+ * hesaff.cpp:167 (pyramid.cpp:261) with the whole callback chain hesaff.cpp:66-105,
+ * for n images at once.  images[i]: 8-bit, channels[i] = 1 (grey) or 3 (BGR as cv::imread
+ * delivers; pass RGB bytes of a PPM in any order - the three are summed), row stride in
+ * bytes.  Images of different sizes are allowed (grouped internally). */
+int hesaff_detect_batch(hesaff_ctx *ctx, int n, const uint8_t *const *images, const int *widths,
+                        const int *heights, const int *strides, const int *channels, hesaff_result *results);
+
+/* Same path with inputs already resident in device memory (bench / pipelines that decode
+ * on the GPU): d_gray = n contiguous height x width 8-bit grey planes (device pointer).
+ * Results stay on the device; per-image counts are copied to the two host arrays.
+ * d_keys_out (optional, may be NULL) receives a device pointer to the ordered
+ * hesaff_keypoint array of the whole batch, total_out the number of records. */
+int hesaff_detect_batch_device(hesaff_ctx *ctx, int n, const void *d_gray, int width, int height,
+                               int32_t *count_hessian, int32_t *count_desc, const void **d_keys_out,
+                               int64_t *total_out);
+/* level 0: no events; 1: per-stage HIP events; 2: also one event pair per k_blur_hess launch */
+int hesaff_set_profiling(hesaff_ctx *ctx, int level);
+int hesaff_get_timings(const hesaff_ctx *ctx, hesaff_timings *t);
+
+/* replaces: exportKeypoints hesaff.cpp:107-130 (text format README:27-44).
+ * hesaff_ellipse: (a,b,c) of one region, closed form of the SVD expression hesaff.cpp:115-123. */
+void hesaff_ellipse(const hesaff_keypoint *k, float mrSize, float *a, float *b, float *c);
+int hesaff_write_sift(const char *path, const hesaff_keypoint *keys, int n, float mrSize);
+/* formats into a malloc'ed buffer (*out, *len); caller frees with hesaff_free */
+int hesaff_format_sift(const hesaff_keypoint *keys, int n, float mrSize, char **out, size_t *len);
+void hesaff_free(void *p);
+
+/* replaces: cv::imread(argv[1]) hesaff.cpp:137 for binary PGM/PPM (P5/P6, maxval 255).
+ * *data is malloc'ed (free with hesaff_free), tightly packed, channels 1 or 3. */
+int hesaff_read_pnm(const char *path, uint8_t **data, int *width, int *height, int *channels);
+
+/* ---- stage entry points (host pointers in/out; used by the parity tests and by callers
+ *      that want one operator of the reference at a time) ---- */
+
+/* gaussianBlur helpers.cpp:283-289 (cv::GaussianBlur, BORDER_REPLICATE, ksize from sigma) */
+int hesaff_stage_gaussian_blur(hesaff_ctx *ctx, const float *in, int rows, int cols, float sigma, float *out);
+/* HessianDetector::hessianResponse pyramid.cpp:63-114 (frame written as 0) */
+int hesaff_stage_hessian_response(hesaff_ctx *ctx, const float *in, int rows, int cols, float norm, float *out);
+/* halfImage helpers.cpp:331-339 */
+int hesaff_stage_half_image(hesaff_ctx *ctx, const float *in, int rows, int cols, float *out);
+/* Scale-space of one image: initial blur pyramid.cpp:276-280 + every octave's L0..L4 and
+ * R0..R4 (pyramid.cpp:224-259).  planes receives, octave after octave, 5 blur planes then 5
+ * response planes, each rows_o x cols_o tightly packed; returns the octave count in
+ * *n_octaves.  Call with planes == NULL to get n_octaves and the float count in *n_floats. */
+int hesaff_stage_pyramid(hesaff_ctx *ctx, const uint8_t *gray, int rows, int cols, float *planes,
+                         int *n_octaves, size_t *n_floats);
+/* detectPyramidKeypoints pyramid.cpp:261-292 up to the onHessianKeypointDetected callback
+ * pyramid.h:46: fills f[n][5] = x,y,s,pixelDistance,response and i[n][5] =
+ * type,octave,level,r0,c0 in reference order; returns n in *count (cap = array capacity). */
+int hesaff_stage_hessian_keypoints(hesaff_ctx *ctx, const uint8_t *gray, int rows, int cols, int cap,
+                                   float *f, int32_t *i, int *count);
+/* AffineShape::findAffineShape affine.cpp:35-100 for n keypoints on one blur plane.
+ * kp[n][4] = x,y,s,pixelDistance; out: converged[n], U[n][4] (a11,a12,a21,a22 as passed to
+ * onAffineShapeFound affine.h:50-57), iters[n]. */
+int hesaff_stage_find_affine_shape(hesaff_ctx *ctx, const float *blur, int rows, int cols, int n,
+                                   const float *kp, int32_t *converged, float *U, int32_t *iters);
+/* rectifyAffineTransformationUpIsUp helpers.cpp:90-97 for n matrices (in place, A[n][4]) */
+int hesaff_stage_rectify(hesaff_ctx *ctx, int n, float *A);
+/* AffineShape::normalizeAffine affine.cpp:102-144 for n keypoints on one image.
+ * kp[n][3] = x,y,s; A[n][4] rectified; out: rejected[n] (1 = reference returned true),
+ * patches[n][41*41]. */
+int hesaff_stage_normalize_affine(hesaff_ctx *ctx, const float *img, int rows, int cols, int n,
+                                  const float *kp, const float *A, int32_t *rejected, float *patches);
+/* SIFTDescriptor::computeSiftDescriptor siftdesc.cpp:115-140 for n 41x41 patches;
+ * desc[n][128] = the values of `vec` cast as at hesaff.cpp:91. */
+int hesaff_stage_sift(hesaff_ctx *ctx, int n, const float *patches, uint8_t *desc);
+/* device evaluation of the pinned libm restatements (hmath.h) for testing */
+int hesaff_stage_math(hesaff_ctx *ctx, int n, const float *a, const float *b, float *atan2_out, float *pow2_out);
+
+/* Host-side tables the kernels use (for known-answer tests): computeGaussMask
+ * helpers.cpp:104, computeCircularGaussMask helpers.cpp:131, precomputeBinsAndWeights
+ * siftdesc.cpp:18, OpenCV getGaussianKernel. */
+int hesaff_table_gauss_mask(int size, float *mask);
+int hesaff_table_circ_gauss_mask(int size, float *mask);
+int hesaff_table_sift_bins(int32_t *bin0, int32_t *bin1, float *w0, float *w1);
+int hesaff_table_gauss_kernel(float sigma, int cap, float *taps, int *ksize);
+
+const char *hesaff_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HESAFF_AMD_H */

@@ -1,0 +1,145 @@
+"""GPU parity tests proper: libhesaff_amd (HIP, through the C ABI) against the CPU oracle on
+the same seeded inputs.  Bar: bit-exact for every float plane, keypoint field and
+descriptor byte (the product path and the oracle evaluate the same IEEE expression
+trees); (a,b,c) of the exported ellipse within 1e-4 relative (north_star tolerance).
+"""
+import numpy as np
+import pytest
+
+from hesaff_amd.synth import band_noise_image
+
+pytestmark = pytest.mark.gpu
+
+SMALL_BANDS = ((1.5, 40.0), (3.0, 40.0), (6.0, 50.0))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_bit_equal(a, b, what=""):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    ne = _bits(a) != _bits(b)
+    # +0 / -0 are the same value for every later operation
+    ne &= ~((a == 0) & (b == 0))
+    if ne.any():
+        idx = np.argwhere(ne)[:5]
+        raise AssertionError("%s: %d of %d floats differ, first at %s: %s vs %s" % (
+            what, int(ne.sum()), a.size, idx.tolist(), a[tuple(idx[0])], b[tuple(idx[0])]))
+
+
+def test_device_math_matches_libm(ctx, oracle):
+    rng = np.random.default_rng(5)
+    n = 1 << 20
+    y = (rng.standard_normal(n) * 50).astype(np.float32)
+    x = (rng.standard_normal(n) * 50).astype(np.float32)
+    y[:1000] = 0; x[1000:2000] = 0; x[2000:3000] = 1.0
+    at, _ = ctx.math(y, x)
+    L = oracle.lib()
+    ref = np.array([L.ho_atan2f(float(a), float(b)) for a, b in zip(y[:200000], x[:200000])], np.float32)
+    assert_bit_equal(at[:200000], ref, "atan2f")
+    e = rng.uniform(-0.5, 0.5, 200000).astype(np.float32)
+    _, pw = ctx.math(e, e)
+    refp = np.array([L.ho_pow2f(float(a)) for a in e], np.float32)
+    assert_bit_equal(pw, refp, "powf(2,.)")
+
+
+@pytest.mark.parametrize("shape", [(61, 83), (128, 200), (7, 9)])
+@pytest.mark.parametrize("sigma", [0.62, 0.7, 0.9, 1.2262737, 1.5198685, 2.4525473, 4.3])
+def test_gaussian_blur(ctx, oracle, shape, sigma):
+    rng = np.random.default_rng(11)
+    img = (rng.random(shape) * 255).astype(np.float32)
+    ref = np.empty_like(img)
+    oracle.lib().ho_gaussian_blur(img, shape[0], shape[1], sigma, ref)
+    assert_bit_equal(ctx.gaussian_blur(img, sigma), ref, "blur sigma=%g" % sigma)
+
+
+def test_hessian_and_half(ctx, oracle):
+    rng = np.random.default_rng(12)
+    img = (rng.random((97, 131)) * 255).astype(np.float32)
+    ref = np.empty_like(img)
+    oracle.lib().ho_hessian_response(img, 97, 131, 2.56, ref)
+    assert_bit_equal(ctx.hessian_response(img, 2.56), ref, "hessian")
+    refh = np.empty((48, 65), np.float32)
+    oracle.lib().ho_half_image(img, 97, 131, refh)
+    assert_bit_equal(ctx.half_image(img), refh, "half")
+
+
+@pytest.mark.parametrize("hw,seed", [((131, 77), 7), ((96, 96), 8), ((160, 250), 9), ((480, 640), 1234)])
+def test_pyramid_planes(ctx, oracle, hw, seed):
+    img = band_noise_image(hw[0], hw[1], seed, SMALL_BANDS if hw[0] < 400 else None or SMALL_BANDS)
+    o = oracle.OracleRun(oracle.gray_from_u8(img), keep_planes=True, detect_only=True)
+    pyr = ctx.pyramid(img)
+    assert len(pyr) == o.n_octaves()
+    for oi, (Ls, Rs) in enumerate(pyr):
+        for l in range(5):
+            assert_bit_equal(Ls[l], o.plane(oi, 0, l), "octave %d L%d" % (oi, l))
+            ref = o.plane(oi, 1, l)
+            assert_bit_equal(Rs[l][1:-1, 1:-1], ref[1:-1, 1:-1], "octave %d R%d" % (oi, l))
+
+
+@pytest.mark.parametrize("hw,seed", [((131, 77), 7), ((96, 96), 8), ((240, 320), 10), ((480, 640), 1234)])
+def test_hessian_keypoints(ctx, oracle, hw, seed):
+    img = band_noise_image(hw[0], hw[1], seed, SMALL_BANDS)
+    o = oracle.OracleRun(oracle.gray_from_u8(img), detect_only=True)
+    f, i, n = ctx.hessian_keypoints(img)
+    of, oi = o.hessian()
+    assert n == o.n_hessian
+    assert np.array_equal(i, oi), "type/octave/level/r0/c0 (detection order)"
+    assert_bit_equal(f[:, :5], of[:, :5], "x,y,s,pd,response")
+
+
+def test_affine_shape_stage(ctx, oracle):
+    img = band_noise_image(240, 320, 21, SMALL_BANDS)
+    o = oracle.OracleRun(oracle.gray_from_u8(img), keep_planes=True)
+    f, i = o.hessian()
+    U, ci = o.affine()
+    # keypoints of octave 0, level 1 on their prevBlur plane
+    sel = np.where((i[:, 1] == 0) & (i[:, 2] == 1))[0]
+    assert len(sel) > 50
+    blur = o.plane(0, 0, 1)
+    conv, Ug, it = ctx.find_affine_shape(blur, f[sel][:, :4])
+    assert np.array_equal(conv, ci[sel, 0])
+    ok = conv == 1
+    assert np.array_equal(it[ok], ci[sel, 1][ok])
+    assert_bit_equal(Ug[ok], U[sel][ok], "U")
+
+
+def test_normalize_affine_and_sift_stage(ctx, oracle):
+    img = band_noise_image(300, 400, 22)
+    gray = oracle.gray_from_u8(img)
+    o = oracle.OracleRun(gray)
+    g, t, d = o.keys()
+    assert o.n_keys > 100
+    L = oracle.lib()
+    kp = g[:, :3].copy(); A = g[:, 3:7].copy()
+    rej, patches = ctx.normalize_affine(gray, kp, A)
+    assert not rej.any()
+    ref = np.zeros((len(kp), 41, 41), np.float32)
+    for k in range(len(kp)):
+        r = L.ho_normalize_affine(gray, gray.shape[0], gray.shape[1], float(kp[k, 0]), float(kp[k, 1]), float(kp[k, 2]), A[k], ref[k].reshape(-1))
+        assert r == 0
+    assert_bit_equal(patches, ref, "patches")
+    desc = ctx.sift(ref)
+    assert np.array_equal(desc, d), "descriptors from oracle patches"
+
+
+@pytest.mark.parametrize("hw,seed,bands", [((131, 77), 7, SMALL_BANDS), ((96, 96), 8, SMALL_BANDS), ((480, 640), 1234, None),
+                                           ((20, 15), 1, SMALL_BANDS), ((12, 40), 2, SMALL_BANDS), ((1080, 1920), 1235, None)])
+def test_end_to_end(ctx, oracle, hw, seed, bands):
+    img = band_noise_image(hw[0], hw[1], seed, bands) if bands else band_noise_image(hw[0], hw[1], seed)
+    o = oracle.OracleRun(oracle.gray_from_u8(img))
+    (n_hess, keys), = ctx.detect_batch([img])
+    g, t, d = o.keys()
+    assert n_hess == o.n_hessian
+    assert len(keys) == o.n_keys
+    if len(keys) == 0:
+        return
+    assert np.array_equal(keys["desc"], d), "128-D integer descriptors"
+    assert np.array_equal(keys["type"], t)
+    for j, name in enumerate(["x", "y", "s", "a11", "a12", "a21", "a22", "response"]):
+        assert_bit_equal(keys[name], g[:, j], name)
+    import hesaff_amd
+    txt = hesaff_amd.format_sift(keys, ctx.params.mrSize)
+    assert txt == o.export_text()
