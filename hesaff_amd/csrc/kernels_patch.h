@@ -1,0 +1,487 @@
+// kernels_patch.h -- affine patch normalisation (AffineShape::normalizeAffine,
+// affine.cpp:102-144) fused with the SIFT descriptor (siftdesc.cpp), one 256-thread block
+// per keypoint.  Keypoints are binned by the side P of the warped window:
+//   k_patch_small<0|1>  P <= 41 | 64 : window S and row-pass plane T live in LDS (full blur)
+//   k_patch_mid         P <= 128     : row-streamed; only the 82 blurred columns / rows the
+//                                      41x41 resample reads are evaluated, T' (P x 82) in LDS
+//   k_patch_large_rows + k_patch_large_finish  P > 128 : one wavefront per window ROW writes
+//                                      T' rows to HBM (all rows of all large keypoints run in
+//                                      parallel), then one block per keypoint finishes.
+// Skipping blur outputs nobody reads does not change any value that is read: every
+// evaluated tap sum uses the pinned cv::GaussianBlur order:
+//   row   : t = k[0]*S[x-r]; t += k[j]*S[x-r+j]  (j ascending)       K > 5
+//           S0*k0 + (S-1+S1)*k1 + (S-2+S2)*k2                         K <= 5
+//   column: d = k[r]*T[y];  d += k[r+j]*(T[y+j] + T[y-j])
+#pragma once
+#include "kernels_keypoint.h"
+
+#define HS_SIFT_ARR 1684   // 1681 rounded up to a multiple of 4 floats
+#define HS_SIFT_TAB 232    // 4 x 41 bin/weight entries + 4 x 16 cell weights
+#define HS_NEED 82         // blurred columns (and rows) the 41x41 resample reads: 2 per output
+
+struct PatchIO {
+   DPlane image;         // original float image batch (normalizeAffine samples the ORIGINAL image, hesaff.cpp:82)
+   float *patches;       // optional [n][1681] output (stage API), may be null
+   uint8_t *desc;        // [n][128]
+   float *trows;         // large bin: T' rows, [rows][82]
+   const uint32_t *row_prefix;   // large bin: exclusive prefix of P over the bin's items (+ total)
+   uint32_t item0, item1;        // large bin: item range of this round
+};
+
+__device__ __forceinline__ float hs_serial_sum(const float *__restrict__ v, int n)
+{
+   float acc = 0.0f;
+   const float4 *v4 = reinterpret_cast<const float4 *>(v);
+   const int n4 = n >> 2;
+   for (int i = 0; i < n4; i++) {
+      const float4 q = v4[i];
+      acc += q.x; acc += q.y; acc += q.z; acc += q.w;
+   }
+   for (int i = n4 << 2; i < n; i++) acc += v[i];
+   return acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// SIFT on a 41x41 patch held in LDS: computeSiftDescriptor siftdesc.cpp:115-140.
+//   s_patch[1681] in/out (photometrically normalised in place, helpers.cpp:246-281)
+//   s_va[2*1684]  16-byte aligned scratch: serial-sum operands, then (mask*grad, o) pairs
+//   s_vec[128]    16-byte aligned, s_misc[8], s_tab[HS_SIFT_TAB]
+// Block of 256 threads; all threads must call it (contains __syncthreads()).
+// Sequential float sums stay sequential (one thread adds, in the reference's order); all
+// the work around them is parallel and branch-free:
+//  * masked pixels are gathered into a contiguous array, the serial thread only runs the
+//    dependent chain of additions over float4 LDS reads;
+//  * histogram: thread t owns vec[t] = cell (row bin, col bin, orientation) and walks its
+//    16x16 pixel support in raster order.  Each pixel adds at most one term to a cell
+//    (siftdesc.cpp:75-78); where the reference adds nothing this adds 0.0f (x + 0 == x).
+// flags: profiling ablations only (HESAFF_ABLATE), 0 on every product path.
+// ---------------------------------------------------------------------------------------
+__device__ inline void hs_sift_block(float *s_patch, float *s_va, float *s_vec, float *s_misc, float *s_tab, const KpTables &tb,
+                                     const DConsts &k, uint8_t *__restrict__ desc_out, int flags = 0)
+{
+   const int tid = threadIdx.x;
+   const int nm = (flags & 4) ? 8 : tb.n_masked;
+   int *s_bin0 = reinterpret_cast<int *>(s_tab), *s_bin1 = s_bin0 + HS_PATCH;
+   float *s_w0 = s_tab + 2 * HS_PATCH, *s_w1 = s_tab + 3 * HS_PATCH, *s_cw = s_tab + 4 * HS_PATCH + 4;
+   if (tid < HS_PATCH) {
+      s_bin0[tid] = tb.bin0[tid]; s_bin1[tid] = tb.bin1[tid];
+      s_w0[tid] = tb.w0[tid]; s_w1[tid] = tb.w1[tid];
+   }
+   // photometricallyNormalize helpers.cpp:253-260: mean over the pixels with mask > 0,
+   // raster order.  gsum counts them in float: exact, == (float)nm.
+   for (int i = tid; i < nm; i += blockDim.x) s_va[i] = s_patch[tb.mask_idx[i]];
+   __syncthreads();
+   if (tid == 0) s_misc[0] = hs_serial_sum(s_va, nm) / (float)nm;
+   if (tid >= 64 && tid < 128) {
+      // cell weights: spatial bin b gets weight w1[r] from rows with bin1 == b and w0[r] from
+      // rows with bin0 == b (siftdesc.cpp:55-56,61-62); clamped bins carry weight 0.
+      const int b = (tid - 64) >> 4, i = (tid - 64) & 15, r = 8 * b + i;
+      float w = 0.0f;
+      if (r < HS_PATCH) {
+         if (s_bin0[r] == 8 * b && s_w0[r] != 0.0f) w = s_w0[r];
+         else if (s_bin1[r] == 8 * b) w = s_w1[r];
+      }
+      s_cw[tid - 64] = w;
+   }
+   __syncthreads();
+   {
+      const float sum = s_misc[0];
+      for (int i = tid; i < nm; i += blockDim.x) { const float d = sum - s_va[i]; s_va[i] = d * d; }   // helpers.cpp:266
+   }
+   __syncthreads();
+   if (tid == 0) s_misc[1] = sqrtf(hs_serial_sum(s_va, nm) / (float)nm);   // helpers.cpp:268
+   __syncthreads();
+   {
+      const float sum = s_misc[0], var = s_misc[1];
+      if (!((double)var < 0.0001)) {
+         const float fac = 50.0f / var;
+         for (int i = tid; i < HS_PATCH_PIX; i += blockDim.x) {
+            float v = 128 + fac * (s_patch[i] - sum);
+            if (v > 255) v = 255;
+            if (v < 0) v = 0;
+            s_patch[i] = v;
+         }
+      }
+   }
+   __syncthreads();
+   // gradient magnitude / orientation, siftdesc.cpp:123-137, and the per-pixel part of samplePatch
+   float2 *s_vo = reinterpret_cast<float2 *>(s_va);
+   for (int i = tid; i < HS_PATCH_PIX; i += blockDim.x) {
+      const int r = i / HS_PATCH, c = i - r * HS_PATCH;
+      float gx, gy;
+      hs_grad(s_patch, HS_PATCH, r, c, gx, gy);
+      const float grad = sqrtf(gx * gx + gy * gy);
+      const float ori = hm_atan2f(gy, gx);
+      // float(orientationBins) * (ori + 2*M_PI) / (2*M_PI), evaluated in double (M_PI)
+      const float o = (float)((double)8.0f * ((double)ori + 2 * 3.14159265358979323846) / (2 * 3.14159265358979323846));
+      s_vo[i] = make_float2(tb.sift_mask[i] * grad, o);
+   }
+   __syncthreads();
+   // samplePatch siftdesc.cpp:51-81
+   if (tid < 128 && !(flags & 2)) {
+      const int cb_r = tid >> 5, cb_c = (tid >> 3) & 3, my_bo = tid & 7;
+      float acc = 0.0f;
+      for (int i = 0; i < 16; i++) {
+         const int r = 8 * cb_r + i;   // <= 39
+         const float wr = s_cw[cb_r * 16 + i];
+         const float2 *row = s_vo + r * HS_PATCH + 8 * cb_c;
+#pragma unroll
+         for (int j = 0; j < 16; j++) {
+            const float2 q = row[j];
+            const float wc = s_cw[cb_c * 16 + j] * q.x;   // w[c] * (mask*grad)
+            const float v = wr * wc;
+            int bo0 = (int)q.y;
+            const float wo1 = q.y - (float)bo0;
+            bo0 &= 7;
+            const float wo0 = 1.0f - wo1;
+            const float wo = (bo0 == my_bo) ? wo0 : ((((bo0 + 1) & 7) == my_bo) ? wo1 : 0.0f);
+            const float term = v * wo;
+            acc += (v > 0.0f) ? term : 0.0f;
+         }
+      }
+      s_vec[tid] = acc;
+   }
+   __syncthreads();
+   // sample() siftdesc.cpp:98-113: normalize, clip, renormalize, quantise (s_va is free again)
+   for (int pass = 0; pass < 2; pass++) {
+      if (tid < 128) { const float v = s_vec[tid]; s_va[tid] = v * v; }
+      __syncthreads();
+      if (tid == 0) {
+         const float vectlen = sqrtf(hs_serial_sum(s_va, 128));
+         s_misc[2] = 1.0f / vectlen;
+         s_misc[3] = 0.0f;
+      }
+      __syncthreads();
+      if (tid < 128) {
+         float v = s_vec[tid] * s_misc[2];
+         if (pass == 0 && v > k.maxBinValue) { v = k.maxBinValue; s_misc[3] = 1.0f; }
+         s_vec[tid] = v;
+      }
+      __syncthreads();
+      const bool changed = s_misc[3] != 0.0f;
+      __syncthreads();
+      if (!changed) break;
+   }
+   if (tid < 128) {
+      const float q = 512.0f * s_vec[tid];
+      int bq = (q == q) ? (int)q : 0;   // NaN -> 0 (x86: INT_MIN, then the uchar cast gives 0)
+      bq = min(bq, 255);
+      desc_out[tid] = (uint8_t)bq;
+   }
+   __syncthreads();
+}
+
+// stand-alone SIFT over patches in global memory (stage API)
+__global__ __launch_bounds__(256) void k_sift_stage(const float *__restrict__ patches, int n, KpTables tb, DConsts k,
+                                                    uint8_t *__restrict__ desc)
+{
+   __shared__ __attribute__((aligned(16))) float s_va[2 * HS_SIFT_ARR], s_vec[128];
+   __shared__ float s_patch[HS_PATCH_PIX], s_misc[8], s_tab[HS_SIFT_TAB];
+   for (int h = blockIdx.x; h < n; h += gridDim.x) {
+      for (int i = threadIdx.x; i < HS_PATCH_PIX; i += blockDim.x) s_patch[i] = patches[(size_t)h * HS_PATCH_PIX + i];
+      __syncthreads();
+      hs_sift_block(s_patch, s_va, s_vec, s_misc, s_tab, tb, k, desc + (size_t)h * 128);
+   }
+}
+
+// shared tail of every patch kernel: optional patch dump + descriptor
+__device__ __forceinline__ void hs_patch_finish(uint32_t h, float *s_patch, float *s_va, float *s_vec, float *s_misc, float *s_tab,
+                                                const PatchIO &io, const KpTables &tb, const DConsts &k, int flags)
+{
+   if (io.patches)
+      for (int i = threadIdx.x; i < HS_PATCH_PIX; i += 256) io.patches[(size_t)h * HS_PATCH_PIX + i] = s_patch[i];
+   if (flags & 1) hs_sift_block(s_patch, s_va, s_vec, s_misc, s_tab, tb, k, io.desc + (size_t)h * 128, flags);
+   __syncthreads();
+}
+
+// resample of affine.cpp:131 from a fully blurred P x P window in LDS
+__device__ __forceinline__ void hs_resample_full(const float *S, int P, float scale, float *s_patch)
+{
+   const float c0 = (float)(P >> 1);
+   for (int idx = threadIdx.x; idx < HS_PATCH_PIX; idx += 256) {
+      const int jj = idx / HS_PATCH, ii = idx - jj * HS_PATCH;
+      const int j = jj - (HS_PATCH >> 1), i = ii - (HS_PATCH >> 1);
+      const float rx = c0 + (float)j * 0.0f, ry = c0 + (float)j * scale;
+      const float wx = rx + (float)i * scale, wy = ry + (float)i * 0.0f;
+      bool o2 = false;
+      s_patch[idx] = hs_bilinear(S, P, P - 1, P - 1, wx, wy, o2);
+   }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_patch_small<BIN>: P <= 41 (BIN 0) or <= 64 (BIN 1), plus the direct branch
+// (imageToPatchScale <= 0.4, affine.cpp:137-141).  grid-stride over the bin's work list.
+// LDS: S | T (WIN floats each; later the SIFT scratch), s_vec, s_patch, s_misc, s_tab, taps.
+// ---------------------------------------------------------------------------------------
+template <int BIN>
+__global__ __launch_bounds__(256) void k_patch_small(HessList hl, PatchWork pw, PatchIO io, KpTables tb, DConsts k, int flags)
+{
+   extern __shared__ __attribute__((aligned(16))) float smem[];
+   constexpr int PMAX = BIN == 0 ? 41 : 64;
+   constexpr int WIN = (PMAX * PMAX + 3) & ~3;
+   constexpr int REGION = (2 * WIN > 2 * HS_SIFT_ARR) ? 2 * WIN : 2 * HS_SIFT_ARR;
+   float *S = smem, *T = smem + WIN;
+   float *s_vec = smem + REGION;
+   float *s_patch = s_vec + 128;
+   float *s_misc = s_patch + HS_SIFT_ARR;
+   float *s_tab = s_misc + 8;
+   float *s_taps = s_tab + HS_SIFT_TAB;   // K <= 15
+   __shared__ int s_flag;
+
+   const int tid = threadIdx.x;
+   const uint32_t cnt = min(pw.bin_count[BIN], pw.cap);
+   const int imRows = io.image.rows, imCols = io.image.cols, imPitch = io.image.pitch;
+   const int width = imCols - 1, height = imRows - 1;
+
+   for (uint32_t wi = blockIdx.x; wi < cnt; wi += gridDim.x) {
+      const uint32_t h = pw.bin_items[(size_t)BIN * pw.cap + wi];
+      const int b = hl.meta[h] >> 8;
+      const float *img = io.image.img(b);
+      const float x = hl.x[h], y = hl.y[h];
+      const float a11 = pw.A[4 * h], a12 = pw.A[4 * h + 1], a21 = pw.A[4 * h + 2], a22 = pw.A[4 * h + 3];
+      const int P0 = pw.P0[h];
+      const float scale = (float)P0 / (float)HS_PATCH;
+      if (tid == 0) s_flag = 0;
+      __syncthreads();
+      bool rejected = false;
+      if (!((double)scale > 0.4)) {
+         // direct branch, affine.cpp:137-141
+         const float b11 = a11 * scale, b12 = a12 * scale, b21 = a21 * scale, b22 = a22 * scale;
+         for (int idx = tid; idx < HS_PATCH_PIX; idx += 256) {
+            const int jj = idx / HS_PATCH, ii = idx - jj * HS_PATCH;
+            const int j = jj - (HS_PATCH >> 1), i = ii - (HS_PATCH >> 1);
+            const float rx = x + (float)j * b12, ry = y + (float)j * b22;
+            const float wx = rx + (float)i * b11, wy = ry + (float)i * b21;
+            bool outside = false;
+            s_patch[idx] = hs_bilinear(img, imPitch, width, height, wx, wy, outside);
+         }
+         __syncthreads();
+      } else {
+         const int P = P0 + 2, half = P >> 1, pm = P - 1;
+         const int K = tb.patch_tap_k[(P0 - 1) >> 1];
+         const float *taps_g = tb.patch_taps + tb.patch_tap_off[(P0 - 1) >> 1];
+         const int r = K >> 1;
+         if (tid < K) s_taps[tid] = taps_g[tid];
+         // 1. warp, affine.cpp:126 ; touching the image boundary rejects the keypoint
+         bool outside = false;
+         for (int idx = tid; idx < P * P; idx += 256) {
+            const int jj = idx / P, ii = idx - jj * P;
+            const int j = jj - half, i = ii - half;
+            const float rx = x + (float)j * a12, ry = y + (float)j * a22;
+            const float wx = rx + (float)i * a11, wy = ry + (float)i * a21;
+            S[idx] = (flags & 16) ? 1.0f : hs_bilinear(img, imPitch, width, height, wx, wy, outside);
+         }
+         if (outside) s_flag = 1;
+         __syncthreads();
+         rejected = s_flag != 0;
+         if (!rejected) {
+            // 2a. row pass
+            for (int idx = tid; idx < ((flags & 8) ? 0 : P * P); idx += 256) {
+               const int yy = idx / P, xx = idx - yy * P;
+               const float *Srow = S + yy * P;
+               float t;
+               if (K <= 5) {
+                  t = Srow[xx] * s_taps[r] + (Srow[max(xx - 1, 0)] + Srow[min(xx + 1, pm)]) * s_taps[r + 1];
+                  if (K == 5) t = t + (Srow[max(xx - 2, 0)] + Srow[min(xx + 2, pm)]) * s_taps[r + 2];
+               } else {
+                  t = s_taps[0] * Srow[min(max(xx - r, 0), pm)];
+                  for (int j = 1; j < K; j++) t += s_taps[j] * Srow[min(max(xx - r + j, 0), pm)];
+               }
+               T[idx] = t;
+            }
+            __syncthreads();
+            // 2b. column pass, result back into S
+            for (int idx = tid; idx < ((flags & 8) ? 0 : P * P); idx += 256) {
+               const int yy = idx / P, xx = idx - yy * P;
+               float d = s_taps[r] * T[idx];
+               for (int j = 1; j <= r; j++) d += s_taps[r + j] * (T[min(yy + j, pm) * P + xx] + T[max(yy - j, 0) * P + xx]);
+               S[idx] = d;
+            }
+            __syncthreads();
+            // 3. resample, affine.cpp:131
+            hs_resample_full(S, P, scale, s_patch);
+            __syncthreads();
+         }
+      }
+      if (rejected) {
+         if (tid == 0) pw.alive[h] = 0;
+         __syncthreads();
+         continue;
+      }
+      hs_patch_finish(h, s_patch, smem, s_vec, s_misc, s_tab, io, tb, k, flags);
+   }
+}
+
+// blurred value at (row yy, needed-column q) from the row-pass plane Tp[rows][82] (column pass)
+__device__ __forceinline__ float hs_colpass(const float *__restrict__ Tp, int yy, int q, int pm, const float *__restrict__ taps, int r)
+{
+   float d = taps[r] * Tp[(long long)min(max(yy, 0), pm) * HS_NEED + q];
+   for (int j = 1; j <= r; j++)
+      d += taps[r + j] * (Tp[(long long)min(max(yy + j, 0), pm) * HS_NEED + q] + Tp[(long long)min(max(yy - j, 0), pm) * HS_NEED + q]);
+   return d;
+}
+
+// resample of affine.cpp:131 when only the row-pass plane at the 82 needed columns exists:
+// the four blurred neighbours of each output are column-pass sums evaluated on the spot.
+// xq(q) = floor(c0 + ((q>>1)-20)*scale) + (q&1) is the needed column (and row) list.
+__device__ __forceinline__ void hs_resample_reduced(const float *__restrict__ Tp, int P, float scale, const float *__restrict__ taps, int r,
+                                                    float *s_patch)
+{
+   const float c0 = (float)(P >> 1);
+   const int pm = P - 1;
+   for (int idx = threadIdx.x; idx < HS_PATCH_PIX; idx += 256) {
+      const int jj = idx / HS_PATCH, ii = idx - jj * HS_PATCH;
+      const int j = jj - (HS_PATCH >> 1), i = ii - (HS_PATCH >> 1);
+      const float rx = c0 + (float)j * 0.0f, ry = c0 + (float)j * scale;
+      float wx = rx + (float)i * scale, wy = ry + (float)i * 0.0f;
+      const float fx = floorf(wx), fy = floorf(wy);
+      wx -= fx; wy -= fy;
+      const int y0 = (int)fy;
+      const float p00 = hs_colpass(Tp, y0, 2 * ii, pm, taps, r), p01 = hs_colpass(Tp, y0, 2 * ii + 1, pm, taps, r);
+      const float p10 = hs_colpass(Tp, y0 + 1, 2 * ii, pm, taps, r), p11 = hs_colpass(Tp, y0 + 1, 2 * ii + 1, pm, taps, r);
+      s_patch[idx] = (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + (wy) * ((1.0f - wx) * p10 + wx * p11);
+   }
+}
+
+// one window row: warp (affine.cpp:126) into the wave's LDS row, then the row pass at the 82
+// needed columns.  Called by all 64 lanes of a wave.
+__device__ __forceinline__ void hs_row_stream(const float *__restrict__ img, int imPitch, int width, int height, float x, float y,
+                                              float a11, float a12, float a21, float a22, int P, int yy, float scale,
+                                              const float *__restrict__ taps, int K, float *__restrict__ srow, float *__restrict__ out82,
+                                              bool &outside)
+{
+   const int lane = threadIdx.x & 63, half = P >> 1, pm = P - 1, r = K >> 1;
+   const int j = yy - half;
+   const float rx = x + (float)j * a12, ry = y + (float)j * a22;
+   for (int xx = lane; xx < P; xx += 64) {
+      const int i = xx - half;
+      const float wx = rx + (float)i * a11, wy = ry + (float)i * a21;
+      srow[xx] = hs_bilinear(img, imPitch, width, height, wx, wy, outside);
+   }
+   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+   __builtin_amdgcn_wave_barrier();
+   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+   const float c0 = (float)half;
+   for (int q = lane; q < HS_NEED; q += 64) {
+      const float wq = c0 + (float)((q >> 1) - 20) * scale;
+      const int xx = (int)floorf(wq) + (q & 1);
+      float t = taps[0] * srow[min(max(xx - r, 0), pm)];
+      for (int jt = 1; jt < K; jt++) t += taps[jt] * srow[min(max(xx - r + jt, 0), pm)];
+      out82[q] = t;
+   }
+   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+   __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------------
+// k_patch_mid: 64 < P <= 128.  Each of the 4 waves streams window rows (warp -> row pass at
+// the 82 needed columns) into Tp[P][82] in LDS; then the resample evaluates the column
+// pass where it reads.  LDS ~52 KB -> 3 blocks per CU.
+// ---------------------------------------------------------------------------------------
+#define HS_MID_PMAX 128
+__global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, PatchIO io, KpTables tb, DConsts k, int flags)
+{
+   extern __shared__ __attribute__((aligned(16))) float smem[];
+   float *Tp = smem;                                   // 128 x 82 (later the SIFT scratch)
+   float *s_vec = smem + HS_MID_PMAX * HS_NEED;        // 10496: multiple of 4
+   float *s_patch = s_vec + 128;
+   float *s_misc = s_patch + HS_SIFT_ARR;
+   float *s_tab = s_misc + 8;
+   float *s_taps = s_tab + HS_SIFT_TAB;                // K <= 29 -> 32
+   float *s_srow = s_taps + 32;                        // 4 waves x 128
+   __shared__ int s_flag;
+
+   const int tid = threadIdx.x, wave = tid >> 6;
+   const uint32_t cnt = min(pw.bin_count[2], pw.cap);
+   const int imPitch = io.image.pitch, width = io.image.cols - 1, height = io.image.rows - 1;
+
+   for (uint32_t wi = blockIdx.x; wi < cnt; wi += gridDim.x) {
+      const uint32_t h = pw.bin_items[(size_t)2 * pw.cap + wi];
+      const int b = hl.meta[h] >> 8;
+      const float *img = io.image.img(b);
+      const float x = hl.x[h], y = hl.y[h];
+      const float a11 = pw.A[4 * h], a12 = pw.A[4 * h + 1], a21 = pw.A[4 * h + 2], a22 = pw.A[4 * h + 3];
+      const int P0 = pw.P0[h], P = P0 + 2;
+      const float scale = (float)P0 / (float)HS_PATCH;
+      const int K = tb.patch_tap_k[(P0 - 1) >> 1];
+      const float *taps_g = tb.patch_taps + tb.patch_tap_off[(P0 - 1) >> 1];
+      if (tid == 0) s_flag = 0;
+      if (tid < K) s_taps[tid] = taps_g[tid];
+      __syncthreads();
+      bool outside = false;
+      for (int yy = wave; yy < P; yy += 4)
+         hs_row_stream(img, imPitch, width, height, x, y, a11, a12, a21, a22, P, yy, scale, s_taps, K, s_srow + wave * HS_MID_PMAX,
+                       Tp + yy * HS_NEED, outside);
+      if (outside) s_flag = 1;
+      __syncthreads();
+      if (s_flag != 0) {
+         if (tid == 0) pw.alive[h] = 0;
+         __syncthreads();
+         continue;
+      }
+      hs_resample_reduced(Tp, P, scale, s_taps, K >> 1, s_patch);
+      __syncthreads();
+      hs_patch_finish(h, s_patch, smem, s_vec, s_misc, s_tab, io, tb, k, flags);
+   }
+}
+
+// ---------------------------------------------------------------------------------------
+// Large windows (P > 128, ~2 % of the keypoints, most of the blur work).
+// k_patch_large_rows: grid-stride over ALL window rows of the round's keypoints, one
+//   wavefront per row (binary search of the row id in the prefix of P); writes T' rows to HBM.
+// k_patch_large_finish: one block per keypoint: column pass at the resample taps + SIFT.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork pw, PatchIO io, KpTables tb, int srow_stride)
+{
+   extern __shared__ __attribute__((aligned(16))) float smem[];
+   const int wave = threadIdx.x >> 6;
+   float *srow = smem + (size_t)wave * srow_stride;
+   const uint32_t *pre = io.row_prefix;
+   const uint32_t row_lo = pre[io.item0], row_hi = pre[io.item1];
+   const int imPitch = io.image.pitch, width = io.image.cols - 1, height = io.image.rows - 1;
+   for (uint32_t row = row_lo + blockIdx.x * 4 + wave; row < row_hi; row += gridDim.x * 4) {
+      // largest item index kk in [item0, item1) with pre[kk] <= row
+      uint32_t lo = io.item0, hi = io.item1;
+      while (hi - lo > 1) {
+         const uint32_t mid = (lo + hi) >> 1;
+         if (pre[mid] <= row) lo = mid; else hi = mid;
+      }
+      const uint32_t h = pw.bin_items[(size_t)3 * pw.cap + lo];
+      const int yy = (int)(row - pre[lo]);
+      const int b = hl.meta[h] >> 8;
+      const int P0 = pw.P0[h], P = P0 + 2;
+      const float scale = (float)P0 / (float)HS_PATCH;
+      const int K = tb.patch_tap_k[(P0 - 1) >> 1];
+      const float *taps = tb.patch_taps + tb.patch_tap_off[(P0 - 1) >> 1];
+      bool outside = false;
+      hs_row_stream(io.image.img(b), imPitch, width, height, hl.x[h], hl.y[h], pw.A[4 * h], pw.A[4 * h + 1], pw.A[4 * h + 2],
+                    pw.A[4 * h + 3], P, yy, scale, taps, K, srow, io.trows + (size_t)(row - row_lo) * HS_NEED, outside);
+      if (outside) pw.alive[h] = 0;   // every writer stores the same value
+   }
+}
+
+__global__ __launch_bounds__(256) void k_patch_large_finish(HessList hl, PatchWork pw, PatchIO io, KpTables tb, DConsts k, int flags)
+{
+   __shared__ __attribute__((aligned(16))) float s_va[2 * HS_SIFT_ARR], s_vec[128];
+   __shared__ float s_patch[HS_SIFT_ARR], s_misc[8], s_tab[HS_SIFT_TAB];
+   const uint32_t *pre = io.row_prefix;
+   const uint32_t row_lo = pre[io.item0];
+   for (uint32_t it = io.item0 + blockIdx.x; it < io.item1; it += gridDim.x) {
+      const uint32_t h = pw.bin_items[(size_t)3 * pw.cap + it];
+      if (!pw.alive[h]) continue;   // uniform for the block
+      const int P0 = pw.P0[h], P = P0 + 2;
+      const float scale = (float)P0 / (float)HS_PATCH;
+      const int K = tb.patch_tap_k[(P0 - 1) >> 1];
+      const float *taps = tb.patch_taps + tb.patch_tap_off[(P0 - 1) >> 1];
+      hs_resample_reduced(io.trows + (size_t)(pre[it] - row_lo) * HS_NEED, P, scale, taps, K >> 1, s_patch);
+      __syncthreads();
+      hs_patch_finish(h, s_patch, s_va, s_vec, s_misc, s_tab, io, tb, k, flags);
+   }
+}
+
+// P of the i-th item of the large bin (scan operand for the row prefix)
+struct LoadLargeP {
+   const uint32_t *items;
+   const int32_t *P0;
+   __device__ uint32_t operator()(long long i) const { return (uint32_t)(P0[items[i]] + 2); }
+};

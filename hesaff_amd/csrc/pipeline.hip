@@ -19,6 +19,7 @@
 #include "../../include/hesaff_amd.h"
 #include "host_tables.h"
 #include "kernels_keypoint.h"
+#include "kernels_patch.h"
 #include "kernels_pyramid.h"
 
 namespace hesaff {
@@ -110,6 +111,7 @@ struct hesaff_ctx {
    int pyr_K[5];          // [0] initial blur, [1..4] octave blurs
    int pyr_tap_off[5];
    int max_p0 = 0;        // tap table covers odd P0 <= max_p0
+   int n_masked = 0;
    KpTables tables;
 
    // geometry of the current buffer plan
@@ -130,10 +132,12 @@ struct hesaff_ctx {
    DevBuf b_input;          // staging for host images
    std::vector<hesaff_keypoint> host_keys;
    std::vector<int32_t> h_starts;
-   int n_patch_blocks3 = 64;
+   DevBuf t_mask_idx, b_rowprefix, b_trows;
+   uint32_t trows_budget = 4u << 20;   // rows of T' (82 floats each) per large-window round: 1.3 GB
 
    hesaff_timings tm;
    int profiling = 0;
+   int ablate = 0;          // HESAFF_ABLATE: profiling-only ablation bits, breaks results when set
    std::vector<hipEvent_t> ev_pool;
    size_t ev_used = 0;
 };
@@ -165,6 +169,13 @@ void build_tables(hesaff_ctx *c)
    hesaff::gauss_mask(HS_SMM, smm.data());
    hesaff::circ_gauss_mask(HS_PATCH, sm.data());
    hesaff::sift_bins(b0.data(), b1.data(), w0.data(), w1.data());
+   {
+      std::vector<int32_t> midx;
+      for (int i = 0; i < HS_PATCH_PIX; i++)
+         if (sm[i] > 0) midx.push_back(i);
+      c->n_masked = (int)midx.size();
+      upload(c->t_mask_idx, midx);
+   }
    upload(c->t_smm, smm); upload(c->t_sift, sm); upload(c->t_bin0, b0); upload(c->t_bin1, b1); upload(c->t_w0, w0); upload(c->t_w1, w1);
    c->sched = hesaff::make_schedule(c->par.initialSigma);
    std::vector<float> taps;
@@ -221,6 +232,8 @@ void refresh_tables_struct(hesaff_ctx *c)
    t.w0 = c->t_w0.as<float>(); t.w1 = c->t_w1.as<float>();
    t.patch_taps = c->t_patch_taps.as<float>(); t.patch_tap_off = c->t_patch_off.as<int32_t>(); t.patch_tap_k = c->t_patch_k.as<int32_t>();
    t.max_p0 = c->max_p0;
+   t.mask_idx = c->t_mask_idx.as<int32_t>();
+   t.n_masked = c->n_masked;
 }
 
 DPlane make_plane(float *p, int B, int rows, int cols, int pitch)
@@ -300,9 +313,6 @@ void plan(hesaff_ctx *c, int B, int H, int W)
    // patch taps + BIN 3 scratch: P <= sqrt(W*H) + small (the det-1 window must fit)
    const int max_p0 = (int)std::floor(std::sqrt((double)W * (double)H)) + 3;
    ensure_patch_taps(c, max_p0);
-   const long long Pm = c->max_p0 + 2;
-   const long long slot = Pm * Pm + Pm * 82 + 82 * 82 + 64;
-   c->b_scratch.ensure((size_t)slot * 4 * c->n_patch_blocks3);
    refresh_tables_struct(c);
    c->B = B; c->H = H; c->W = W;
 }
@@ -379,38 +389,76 @@ Lists make_lists(hesaff_ctx *c)
    return s;
 }
 
-size_t patch_lds_bytes(int bin)
+template <class KERNEL> void set_dyn_lds(KERNEL kern, size_t lds)
 {
-   const int PMAX = bin == 0 ? 41 : (bin == 1 ? 64 : (bin == 2 ? 128 : 0));
-   const int WIN = PMAX * PMAX;
-   const int REGION = std::max(2 * WIN, 2 * HS_PATCH_PIX);
-   return (size_t)(REGION + HS_PATCH_PIX + 128 + 8 + 32) * 4;
+   HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 }
 
-template <int BIN> void launch_patch(hesaff_ctx *c, const Lists &s, const PatchIO &io, int blocks, int do_sift)
+size_t small_lds_bytes(int bin)
 {
-   const size_t lds = patch_lds_bytes(BIN);
-   static bool attr_set[HS_NBINS] = {false, false, false, false};
-   if (!attr_set[BIN]) {
-      HIP_TRY(hipFuncSetAttribute((const void *)k_patch_sift<BIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set[BIN] = true;
-   }
-   hipLaunchKernelGGL(k_patch_sift<BIN>, dim3(blocks), dim3(256), lds, c->stream, s.hl, s.pw, io, c->tables, c->consts, do_sift);
+   const int PMAX = bin == 0 ? 41 : 64;
+   const int WIN = (PMAX * PMAX + 3) & ~3;
+   const int REGION = std::max(2 * WIN, 2 * HS_SIFT_ARR);
+   return (size_t)(REGION + 128 + HS_SIFT_ARR + 8 + HS_SIFT_TAB + 16) * 4;
 }
+size_t mid_lds_bytes() { return (size_t)(HS_MID_PMAX * HS_NEED + 128 + HS_SIFT_ARR + 8 + HS_SIFT_TAB + 32 + 4 * HS_MID_PMAX) * 4; }
 
-void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *patches_out, int do_sift)
+// normalizeAffine + SIFT for every keypoint k_prepare_patch left alive.  The bin counts are
+// read back once (a ~20 us bubble per batch) so that every launch is sized exactly and the
+// large windows can be processed in rounds that fit the T' row buffer.
+void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *patches_out, int flags)
 {
+   hipStream_t st = c->stream;
    PatchIO io;
+   memset(&io, 0, sizeof io);
    io.image = image;
    io.patches = patches_out;
    io.desc = c->b_desc.as<uint8_t>();
-   io.scratch = c->b_scratch.as<float>();
-   const long long Pm = c->max_p0 + 2;
-   io.scratch_stride = Pm * Pm + Pm * 82 + 82 * 82 + 64;
-   launch_patch<0>(c, s, io, 256 * 8, do_sift);
-   launch_patch<1>(c, s, io, 256 * 4, do_sift);
-   launch_patch<2>(c, s, io, 256 * 2, do_sift);
-   launch_patch<3>(c, s, io, c->n_patch_blocks3, do_sift);
+   uint32_t bins[HS_NBINS];
+   HIP_TRY(hipMemcpyAsync(bins, s.pw.bin_count, sizeof bins, hipMemcpyDeviceToHost, st));
+   HIP_TRY(hipStreamSynchronize(st));
+   static bool attrs = false;
+   if (!attrs) {
+      set_dyn_lds(k_patch_small<0>, small_lds_bytes(0));
+      set_dyn_lds(k_patch_small<1>, small_lds_bytes(1));
+      set_dyn_lds(k_patch_mid, mid_lds_bytes());
+      attrs = true;
+   }
+   if (bins[0]) hipLaunchKernelGGL(k_patch_small<0>, dim3(std::min<uint32_t>(bins[0], 256 * 8)), dim3(256), small_lds_bytes(0), st, s.hl, s.pw, io, c->tables, c->consts, flags);
+   if (bins[1]) hipLaunchKernelGGL(k_patch_small<1>, dim3(std::min<uint32_t>(bins[1], 256 * 4)), dim3(256), small_lds_bytes(1), st, s.hl, s.pw, io, c->tables, c->consts, flags);
+   if (bins[2]) hipLaunchKernelGGL(k_patch_mid, dim3(std::min<uint32_t>(bins[2], 256 * 3)), dim3(256), mid_lds_bytes(), st, s.hl, s.pw, io, c->tables, c->consts, flags);
+   const uint32_t n3 = bins[3];
+   if (n3) {
+      // exclusive prefix of P over the large bin -> row ids
+      c->b_rowprefix.ensure((size_t)(n3 + 1) * 4);
+      uint32_t *pre = c->b_rowprefix.as<uint32_t>();
+      LoadLargeP lp; lp.items = s.pw.bin_items + (size_t)3 * s.pw.cap; lp.P0 = s.pw.P0;
+      exclusive_scan(c, lp, (long long)n3, pre, pre + n3);
+      std::vector<uint32_t> hpre(n3 + 1);
+      HIP_TRY(hipMemcpyAsync(hpre.data(), pre, (size_t)(n3 + 1) * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      const int srow_stride = round_up(c->max_p0 + 2, 64);
+      const size_t rows_lds = (size_t)4 * srow_stride * 4;
+      if (rows_lds > 160 * 1024) throw HsError(HESAFF_ERR_ARG, "image too large for the large-window row kernel");
+      static size_t rows_lds_set = 0;
+      if (rows_lds > rows_lds_set) { set_dyn_lds(k_patch_large_rows, rows_lds); rows_lds_set = rows_lds; }
+      const uint32_t budget = c->trows_budget;
+      c->b_trows.ensure((size_t)budget * HS_NEED * 4);
+      io.trows = c->b_trows.as<float>();
+      io.row_prefix = pre;
+      uint32_t k0 = 0;
+      while (k0 < n3) {
+         uint32_t k1 = k0 + 1;
+         while (k1 < n3 && hpre[k1 + 1] - hpre[k0] <= budget) k1++;
+         const uint32_t rows = hpre[k1] - hpre[k0];
+         if (rows > budget) throw HsError(HESAFF_ERR_NOMEM, "window larger than the T' row buffer");
+         io.item0 = k0; io.item1 = k1;
+         const uint32_t gblocks = std::min<uint32_t>((rows + 3) / 4, 256 * 12);
+         hipLaunchKernelGGL(k_patch_large_rows, dim3(gblocks), dim3(256), rows_lds, st, s.hl, s.pw, io, c->tables, srow_stride);
+         hipLaunchKernelGGL(k_patch_large_finish, dim3(std::min<uint32_t>(k1 - k0, 256 * 8)), dim3(256), 0, st, s.hl, s.pw, io, c->tables, c->consts, flags);
+         k0 = k1;
+      }
+   }
 }
 
 // The scale-space + detection part for the current plan; fills the ordered Hessian list.
@@ -572,7 +620,7 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
    t = tm.begin(T_PATCH);
    hipLaunchKernelGGL(k_prepare_patch, dim3(1024), dim3(256), 0, st, s.hl, (const uint32_t *)(cnt + 3), s.ao, H, W, c->consts,
                       c->tables, s.pw);
-   run_patch_stage(c, s, c->gray, nullptr, 1);
+   run_patch_stage(c, s, c->gray, nullptr, 1 | c->ablate);
    tm.end(t);
    t = tm.begin(T_SIFT);
    // final stable compaction (hesaff.cpp:87: keys.push_back in detection order)
