@@ -63,6 +63,14 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch bundles its own HIP runtime (torch/lib/libamdhip64.so).  Two HIP runtimes in one
+    # process cannot both see the GPU, so when torch is installed it is imported FIRST and
+    # libhesaff_amd.so binds to the runtime torch already loaded (same SONAME).  Without torch
+    # (e.g. the hesaff CLI) the library uses the system ROCm runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     p = lib_path()
     if not os.path.exists(p):
         raise HesaffError(-1, "%s not built: run `make -C hesaff_amd/csrc` (or __graft_entry__.build())" % p)

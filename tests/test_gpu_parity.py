@@ -143,3 +143,111 @@ def test_end_to_end(ctx, oracle, hw, seed, bands):
     import hesaff_amd
     txt = hesaff_amd.format_sift(keys, ctx.params.mrSize)
     assert txt == o.export_text()
+
+
+# ------------------------------------------------------------------------------------------
+# golden files, batching, colour input, device-resident entry point, CLI, full-size properties
+# ------------------------------------------------------------------------------------------
+import os
+import re
+import shutil
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.mark.parametrize("name", ["band_131x77", "band_96x96", "band_160x120", "tiny_20x15", "thin_12x40"])
+def test_golden_files(ctx, name):
+    import hesaff_amd
+    img = hesaff_amd.read_pnm(os.path.join(GOLD, name + ".pgm"))
+    (n_hess, keys), = ctx.detect_batch([img])
+    txt = hesaff_amd.format_sift(keys, ctx.params.mrSize)
+    assert txt == open(os.path.join(GOLD, name + ".hesaff.sift"), "rb").read()
+
+
+def test_cli_drop_in(tmp_path):
+    """`hesaff <image>` writes <image>.hesaff.sift and prints the reference's stdout line (hesaff.cpp:168-175)."""
+    src = os.path.join(GOLD, "band_160x120.pgm")
+    dst = tmp_path / "img.pgm"
+    shutil.copy(src, dst)
+    r = subprocess.run([os.path.join(ROOT, "hesaff_amd", "bin", "hesaff"), str(dst)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    m = re.fullmatch(r"Detected (\d+) keypoints and (\d+) affine shapes in [0-9.e+-]+ sec\.\n", r.stdout)
+    assert m, r.stdout
+    out = (tmp_path / "img.pgm.hesaff.sift").read_bytes()
+    assert out == open(os.path.join(GOLD, "band_160x120.hesaff.sift"), "rb").read()
+    assert int(m.group(2)) == int(out.split(b"\n")[1])
+
+
+def test_batch_and_mixed_sizes(ctx):
+    a = band_noise_image(200, 300, 31, SMALL_BANDS)
+    b = band_noise_image(200, 300, 32, SMALL_BANDS)
+    c = band_noise_image(131, 77, 7, SMALL_BANDS)
+    single = {k: ctx.detect_batch([im])[0] for k, im in (("a", a), ("b", b), ("c", c))}
+    res = ctx.detect_batch([a, c, b, a, c])
+    for got, want in zip(res, ["a", "c", "b", "a", "c"]):
+        assert got[0] == single[want][0]
+        assert got[1].tobytes() == single[want][1].tobytes(), "result depends on the batch position"
+
+
+def test_colour_input(ctx, oracle):
+    rng = np.random.default_rng(4)
+    base = band_noise_image(150, 210, 33, SMALL_BANDS).astype(np.int32)
+    bgr = np.stack([np.clip(base + rng.integers(-20, 20, base.shape), 0, 255) for _ in range(3)], axis=-1).astype(np.uint8)
+    o = oracle.OracleRun(oracle.gray_from_u8(bgr))
+    (n_hess, keys), = ctx.detect_batch([bgr])
+    g, t, d = o.keys()
+    assert n_hess == o.n_hessian and len(keys) == o.n_keys and o.n_keys > 50
+    assert np.array_equal(keys["desc"], d)
+    assert_bit_equal(keys["x"], g[:, 0], "x")
+
+
+def test_device_resident_entry_point(ctx):
+    import torch
+    import hesaff_amd
+    imgs = np.stack([band_noise_image(240, 320, 40 + i, SMALL_BANDS) for i in range(3)])
+    host = ctx.detect_batch(list(imgs))
+    p = hesaff_amd.default_params(); p.max_batch = 4
+    with hesaff_amd.HesaffContext(p, device=0) as c2:
+        t = torch.from_numpy(imgs).cuda()
+        ch, cd, dkeys, total = c2.detect_batch_device(t.data_ptr(), 3, 320, 240)
+        assert [int(v) for v in ch] == [h[0] for h in host]
+        assert [int(v) for v in cd] == [len(h[1]) for h in host] and total == sum(len(h[1]) for h in host)
+        # copy the device records back through torch and compare bytes
+        import ctypes
+        buf = torch.empty(total * 164, dtype=torch.uint8, device="cuda")
+        # the HIP runtime torch loaded (a second runtime in the process would not see the GPU)
+        hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        assert hip.hipMemcpy(ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(dkeys), ctypes.c_size_t(total * 164), 3) == 0
+        got = buf.cpu().numpy().tobytes()
+        assert got == b"".join(h[1].tobytes() for h in host)
+
+
+def test_full_size_4k(ctx, oracle):
+    """BASELINE config size (3840x2160): full parity against the oracle plus size-independent properties."""
+    import hesaff_amd
+    img = band_noise_image(2160, 3840, 1234)
+    (n1, k1), = ctx.detect_batch([img])
+    (n2, k2), = ctx.detect_batch([img])
+    assert n1 == n2 and k1.tobytes() == k2.tobytes(), "run-to-run determinism"
+    assert len(k1) <= n1 and len(k1) > 50000
+    # rectified shapes: a12 == 0, det == 1 (helpers.cpp:95-96, affine.cpp:105)
+    assert not k1["a12"].any()
+    assert np.abs(k1["a11"].astype(np.float64) * k1["a22"] - 1).max() < 1e-5
+    assert (np.abs(k1["response"]) >= np.float32(16.0 / 3.0) ** 2).all() and set(np.unique(k1["type"])) <= {0, 1, 2}
+    # descriptor: clipped at 0.2 then renormalised and x512 -> no element above 255, norm ~ 512
+    nrm = np.sqrt((k1["desc"].astype(np.float64) ** 2).sum(axis=1))
+    assert nrm.min() > 400 and nrm.max() < 520
+    o = oracle.OracleRun(oracle.gray_from_u8(img))
+    g, t, d = o.keys()
+    assert n1 == o.n_hessian and len(k1) == o.n_keys
+    assert np.array_equal(k1["desc"], d)
+    for j, name in enumerate(["x", "y", "s", "a11", "a12", "a21", "a22", "response"]):
+        assert_bit_equal(k1[name], g[:, j], name)
+    # exported ellipse within the north_star tolerance (1e-4 relative) of the oracle's closed form
+    e = hesaff_amd.ellipse(k1[:2000], ctx.params.mrSize)
+    ref = np.zeros((2000, 3), np.float32)
+    for i in range(2000):
+        oracle.lib().ho_ellipse(g[i], ctx.params.mrSize, ref[i])
+    assert np.abs(e - ref).max() <= 1e-4 * np.abs(ref).max()

@@ -1,0 +1,137 @@
+"""CPU suite: host-side pieces of the product (tables, PNM reader, .hesaff.sift writer,
+pinned libm restatements) against the oracle / libm / golden files.  No GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import hesaff_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_tables_bit_identical_to_oracle(oracle):
+    L = oracle.lib()
+    m = np.zeros((19, 19), np.float32); L.ho_gauss_mask(19, m.reshape(-1))
+    assert np.array_equal(hesaff_amd.table_gauss_mask(19).view(np.uint32), m.view(np.uint32))
+    m = np.zeros((41, 41), np.float32); L.ho_circ_gauss_mask(41, m.reshape(-1))
+    assert np.array_equal(hesaff_amd.table_circ_gauss_mask(41).view(np.uint32), m.view(np.uint32))
+    b0 = np.zeros(41, np.int32); b1 = np.zeros(41, np.int32); w0 = np.zeros(41, np.float32); w1 = np.zeros(41, np.float32)
+    L.ho_sift_tables(b0, b1, w0, w1)
+    pb0, pb1, pw0, pw1 = hesaff_amd.table_sift_bins()
+    assert np.array_equal(pb0, b0) and np.array_equal(pb1, b1) and np.array_equal(pw0, w0) and np.array_equal(pw1, w1)
+    for sigma in [0.62, 0.7, 0.8, 1.2262737, 1.5198685, 1.545008, 1.946588, 2.4525473, 5.0, 33.3]:
+        k = L.ho_gauss_ksize(sigma)
+        ref = np.zeros(k, np.float32); L.ho_gauss_kernel(k, sigma, ref)
+        got = hesaff_amd.table_gauss_kernel(sigma)
+        assert len(got) == k and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), sigma
+
+
+def test_pyramid_kernel_sizes_match_survey():
+    # K = 11 (initial), 9, 11, 13, 15 for the per-octave blurs
+    ks = [len(hesaff_amd.table_gauss_kernel(s)) for s in (1.5198685, 1.2262737, 1.545008, 1.946588, 2.4525473)]
+    assert ks == [11, 9, 11, 13, 15]
+
+
+@pytest.fixture(scope="module")
+def hmath_host(tmp_path_factory):
+    d = tmp_path_factory.mktemp("hm")
+    src = d / "hm.cpp"
+    src.write_text('#include "%s/hesaff_amd/csrc/hmath.h"\n'
+                   'extern "C" void hm_atan2f_v(int n,const float*y,const float*x,float*o){for(int i=0;i<n;i++)o[i]=hm_atan2f(y[i],x[i]);}\n'
+                   'extern "C" void hm_pow2f_v(int n,const float*y,float*o){for(int i=0;i<n;i++)o[i]=hm_pow2f(y[i]);}\n' % ROOT)
+    so = d / "hm.so"
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", str(so), str(src)])
+    return C.CDLL(str(so))
+
+
+def test_hmath_restatements_equal_glibc(hmath_host):
+    """hm_atan2f == atan2f and hm_pow2f == powf(2,.) of this image's glibc, bit for bit."""
+    libm = C.CDLL("libm.so.6")
+    libm.atan2f.restype = C.c_float; libm.atan2f.argtypes = [C.c_float, C.c_float]
+    libm.powf.restype = C.c_float; libm.powf.argtypes = [C.c_float, C.c_float]
+    rng = np.random.default_rng(1)
+    n = 400000
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C")
+    hmath_host.hm_atan2f_v.argtypes = [C.c_int, f32p, f32p, f32p]
+    hmath_host.hm_pow2f_v.argtypes = [C.c_int, f32p, f32p]
+    # gradient-like operands (differences of values in 0..255) and random bit patterns
+    y = np.concatenate([(rng.standard_normal(n // 2) * 40).astype(np.float32), rng.integers(0, 2**32, n // 2, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    x = np.concatenate([(rng.standard_normal(n // 2) * 40).astype(np.float32), rng.integers(0, 2**32, n // 2, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    y[:2000] = 0; x[2000:4000] = 0; x[4000:6000] = 1.0; y[6000:8000] = -0.0
+    got = np.zeros(n, np.float32)
+    hmath_host.hm_atan2f_v(n, y, x, got)
+    sub = 60000
+    ref = np.array([libm.atan2f(float(a), float(b)) for a, b in zip(y[:sub], x[:sub])] +
+                   [libm.atan2f(float(a), float(b)) for a, b in zip(y[-sub:], x[-sub:])], np.float32)
+    g2 = np.concatenate([got[:sub], got[-sub:]])
+    same = (g2.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(g2) & np.isnan(ref))
+    assert same.all(), int((~same).sum())
+    e = rng.uniform(-1.0, 1.0, 100000).astype(np.float32)
+    e[:3] = [1.0 / 3.0, 0.0, -0.5]
+    gp = np.zeros_like(e)
+    hmath_host.hm_pow2f_v(len(e), e, gp)
+    rp = np.array([libm.powf(2.0, float(a)) for a in e], np.float32)
+    assert np.array_equal(gp.view(np.uint32), rp.view(np.uint32))
+
+
+def test_read_pnm_and_grey_conversion(tmp_path, oracle):
+    rng = np.random.default_rng(3)
+    g = rng.integers(0, 256, (13, 17), dtype=np.uint8)
+    p = tmp_path / "a.pgm"
+    p.write_bytes(b"P5\n# comment\n17 13\n255\n" + g.tobytes())
+    assert np.array_equal(hesaff_amd.read_pnm(str(p)), g)
+    c = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    p = tmp_path / "b.ppm"
+    p.write_bytes(b"P6 7 5 255\n" + c.tobytes())
+    assert np.array_equal(hesaff_amd.read_pnm(str(p)), c)
+    with pytest.raises(hesaff_amd.HesaffError):
+        hesaff_amd.read_pnm(str(tmp_path / "missing.pgm"))
+    # grey of a grey image is the byte value exactly (hesaff.cpp:145 with B=G=R)
+    assert np.array_equal(oracle.gray_from_u8(g), g.astype(np.float32))
+
+
+def _keys_from_text(txt):
+    lines = txt.decode().split("\n")
+    assert lines[0] == "128"
+    n = int(lines[1])
+    rows = [l.split(" ") for l in lines[2:2 + n]]
+    return n, rows
+
+
+@pytest.mark.parametrize("name", ["band_131x77", "band_96x96", "band_160x120", "tiny_20x15", "thin_12x40"])
+def test_writer_reproduces_golden_files(oracle, name):
+    """hesaff_format_sift (product) on the oracle's keypoints == golden .hesaff.sift bytes."""
+    img = hesaff_amd.read_pnm(os.path.join(GOLD, name + ".pgm"))
+    o = oracle.OracleRun(oracle.gray_from_u8(img))
+    g, t, d = o.keys()
+    keys = np.zeros(len(g), hesaff_amd.KEYPOINT_DTYPE)
+    for j, f in enumerate(["x", "y", "s", "a11", "a12", "a21", "a22", "response"]):
+        keys[f] = g[:, j]
+    keys["type"] = t; keys["desc"] = d
+    txt = hesaff_amd.format_sift(keys, hesaff_amd.default_params().mrSize)
+    gold = open(os.path.join(GOLD, name + ".hesaff.sift"), "rb").read()
+    assert txt == gold
+    n, rows = _keys_from_text(txt)
+    assert n == len(keys) and all(len(r) == 5 + 128 for r in rows)
+
+
+def test_write_sift_file(tmp_path):
+    keys = np.zeros(2, hesaff_amd.KEYPOINT_DTYPE)
+    keys["x"] = [10.5, 123456.7]; keys["y"] = [3.25, 0.000123]; keys["s"] = [2.0, 3.0]
+    keys["a11"] = [1.0, 2.0]; keys["a21"] = [0.0, 0.3]; keys["a22"] = [1.0, 0.5]
+    keys["desc"][0, :3] = [0, 9, 255]; keys["desc"][1, 127] = 100
+    p = tmp_path / "o.sift"
+    hesaff_amd.write_sift(str(p), keys, 5.196152)
+    lines = p.read_text().split("\n")
+    assert lines[0] == "128" and lines[1] == "2" and lines[4] == ""
+    r0 = lines[2].split(" ")
+    assert r0[0] == "10.5" and r0[1] == "3.25" and r0[5:8] == ["0", "9", "255"]
+    r1 = lines[3].split(" ")
+    assert r1[0] == "123457" and r1[1] == "0.000123"      # 6 significant digits like operator<<(float)
+    # ellipse of the identity shape: a = c = 1/(mrSize*s)^2, b = 0
+    e = hesaff_amd.ellipse(keys[:1], 5.196152)[0]
+    assert abs(e[0] - 1.0 / (5.196152 * 2.0) ** 2) < 1e-9 and e[1] == 0 and abs(e[2] - e[0]) < 1e-12
