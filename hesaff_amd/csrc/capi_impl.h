@@ -77,6 +77,8 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       refresh_tables_struct(c);
       memset(&c->tm, 0, sizeof c->tm);
       if (const char *ab = getenv("HESAFF_ABLATE")) c->ablate = atoi(ab) & ~1;
+      if (const char *pk = getenv("HESAFF_PYR")) c->use_tile_kernel = strcmp(pk, "tile") == 0;
+      if (const char *bd = getenv("HESAFF_BAND")) c->band_rows = std::max(8, atoi(bd));
    } catch (const HsError &e) {
       delete c;
       return fail(nullptr, e);

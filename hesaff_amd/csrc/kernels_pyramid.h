@@ -472,3 +472,168 @@ __global__ void k_image_counts(const uint32_t *__restrict__ prefix, long long st
    if (b > nimg) return;
    starts[b] = (b == nimg) ? (int32_t)*total : (int32_t)prefix[(long long)b * stride];
 }
+
+// ---------------------------------------------------------------------------------------
+// k_blur_hess_march<K,...> (v2): the roofline kernel.  Same contract and the same pinned
+// operation order as k_blur_hess_tile, different schedule:
+//  * one WAVEFRONT owns a strip of 256 blurred columns (4 per lane; 248 of them are stored,
+//    the outer 4+4 are the halo the Hessian needs) and marches down a band of rows;
+//  * each input row is read once from HBM/L2 into a per-wave LDS row (coalesced dword loads,
+//    replicate border = clamped per-lane column index), the row pass reads its 4+2r inputs
+//    back as aligned float4;
+//  * the K most recent row-pass results live in a REGISTER ring (statically indexed: the row
+//    loop is unrolled K times), so the column pass never touches memory;
+//  * the three most recent blurred rows stay in registers for the 3x3 Hessian; horizontal
+//    neighbours come from the adjacent lanes (shuffle);
+//  * outputs are float4 stores (blur, response) and float2 (decimated next-octave level).
+// Reads per output pixel: (256+16)/248 x (HB+2r+2)/HB ~ 1.2x, out of L2; HBM sees each input
+// byte about once.  No block-level synchronisation: the 4 waves of a block are independent.
+// grid (ceil(strips/4), bands, B), block 256.
+// ---------------------------------------------------------------------------------------
+#define BM_STRIP 248
+#define BM_ROWBUF 272   // floats: 8 + 256 + 8
+
+template <int K, bool WRITE_L, bool WRITE_R, bool WRITE_HALF>
+__global__ __launch_bounds__(256) void k_blur_hess_march(DPlane in, DPlane outL, DPlane outR, DPlane outHalf,
+                                                          const float *__restrict__ taps, float norm2, int band_rows)
+{
+   constexpr int R = K >> 1;
+   constexpr int Q0 = (8 - R) / 4;               // first aligned float4 of the row-pass window, relative to the lane
+   constexpr int OFF = (8 - R) - 4 * Q0;         // position of column x-R inside it
+   constexpr int NQ = (OFF + 4 + 2 * R + 3) / 4; // float4 reads per lane
+   __shared__ __attribute__((aligned(16))) float s_rows[4][2][BM_ROWBUF];
+
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const int strip = blockIdx.x * 4 + wave;
+   const int rows = in.rows, cols = in.cols, pitch = in.pitch;
+   const int xs = strip * BM_STRIP;
+   if (xs >= cols) return;
+   const int b = blockIdx.z;
+   const int yh0 = blockIdx.y * band_rows, yh1 = min(yh0 + band_rows, rows);
+   const int steps = (yh1 - yh0) + 2 * R + 2;
+   const float *src = in.img(b);
+
+   float kk[K];
+#pragma unroll
+   for (int j = 0; j < K; j++) kk[j] = taps[j];
+
+   // row buffer float f <-> column xs - 12 + f ; this lane loads f = lane + 64 m
+   int cx[5];
+#pragma unroll
+   for (int m = 0; m < 5; m++) cx[m] = min(max(xs - 12 + lane + 64 * m, 0), cols - 1);
+   const int xl = xs - 4 + 4 * lane;   // first of this lane's 4 columns
+   const bool store_lane = lane >= 1 && lane <= 62 && xl < cols;
+   const bool full4 = xl + 3 < cols;
+
+   float ring[K][4];
+   float Lm2[6], Lm1[6];
+#pragma unroll
+   for (int i = 0; i < 6; i++) { Lm2[i] = 0.0f; Lm1[i] = 0.0f; }
+#pragma unroll
+   for (int u = 0; u < K; u++) { ring[u][0] = ring[u][1] = ring[u][2] = ring[u][3] = 0.0f; }
+
+   float pre[5];
+   {
+      const int y = min(max(yh0 - 1 - R, 0), rows - 1);
+      const float *rp = src + (long long)y * pitch;
+#pragma unroll
+      for (int m = 0; m < 4; m++) pre[m] = rp[cx[m]];
+      pre[4] = (lane < 16) ? rp[cx[4]] : 0.0f;
+      float *wb = s_rows[wave][0];
+#pragma unroll
+      for (int m = 0; m < 4; m++) wb[lane + 64 * m] = pre[m];
+      if (lane < 16) wb[lane + 256] = pre[4];
+   }
+
+   for (int t0 = 0; t0 < steps; t0 += K) {
+#pragma unroll
+      for (int u = 0; u < K; u++) {
+         const int t = t0 + u;
+         if (t >= steps) break;
+         const bool more = t + 1 < steps;
+         if (more) {
+            const int y = min(max(yh0 - R + t, 0), rows - 1);   // input row of step t+1
+            const float *rp = src + (long long)y * pitch;
+#pragma unroll
+            for (int m = 0; m < 4; m++) pre[m] = rp[cx[m]];
+            pre[4] = (lane < 16) ? rp[cx[4]] : 0.0f;
+         }
+         // ---- row pass of input row t: t = k[0]*S[x-R]; t += k[j]*S[x-R+j] ----
+         {
+            const float4 *rb = reinterpret_cast<const float4 *>(s_rows[wave][t & 1]) + lane + Q0;
+            float sv[4 * NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+               const float4 v = rb[q];
+               sv[4 * q] = v.x; sv[4 * q + 1] = v.y; sv[4 * q + 2] = v.z; sv[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+               float tt = kk[0] * sv[OFF + c];
+#pragma unroll
+               for (int j = 1; j < K; j++) tt += kk[j] * sv[OFF + c + j];
+               ring[u][c] = tt;
+            }
+         }
+         // ---- column pass: blurred row yl = yh0 - 1 + (t - 2R) ----
+         if (t >= 2 * R) {
+            const int yl = yh0 - 1 + (t - 2 * R);
+            float L[6];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+               float d = kk[R] * ring[(u - R + K) % K][c];
+#pragma unroll
+               for (int j = 1; j <= R; j++) d += kk[R + j] * (ring[(u - R + j + K) % K][c] + ring[(u - R - j + 2 * K) % K][c]);
+               L[1 + c] = d;
+            }
+            L[0] = __shfl_up(L[4], 1, 64);
+            L[5] = __shfl_down(L[1], 1, 64);
+            const bool row_in = yl >= yh0 && yl < yh1;
+            if (row_in && store_lane) {
+               if (WRITE_L) {
+                  float *o = outL.img(b) + (long long)yl * outL.pitch + xl;
+                  if (full4) *reinterpret_cast<float4 *>(o) = make_float4(L[1], L[2], L[3], L[4]);
+                  else
+                     for (int c = 0; c < 4; c++)
+                        if (xl + c < cols) o[c] = L[1 + c];
+               }
+               if (WRITE_HALF) {
+                  if ((yl & 1) == 0 && (yl >> 1) < outHalf.rows) {
+                     float *o = outHalf.img(b) + (long long)(yl >> 1) * outHalf.pitch + (xl >> 1);
+                     if ((xl >> 1) + 1 < outHalf.cols) *reinterpret_cast<float2 *>(o) = make_float2(L[1], L[3]);
+                     else if ((xl >> 1) < outHalf.cols) o[0] = L[1];
+                  }
+               }
+            }
+            // ---- response of row yh = yl - 1 from rows (Lm2, Lm1, L) ----
+            if (WRITE_R) {
+               const int yh = yl - 1;
+               if (yh >= yh0 && yh < yh1 && store_lane) {
+                  float rr[4];
+                  const bool yin = yh > 0 && yh < rows - 1;
+#pragma unroll
+                  for (int c = 0; c < 4; c++) {
+                     const int x = xl + c;
+                     const float v = hs_hessian(Lm2[c], Lm2[c + 1], Lm2[c + 2], Lm1[c], Lm1[c + 1], Lm1[c + 2], L[c], L[c + 1], L[c + 2], norm2);
+                     rr[c] = (yin && x > 0 && x < cols - 1) ? v : 0.0f;
+                  }
+                  float *o = outR.img(b) + (long long)yh * outR.pitch + xl;
+                  if (full4) *reinterpret_cast<float4 *>(o) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+                  else
+                     for (int c = 0; c < 4; c++)
+                        if (xl + c < cols) o[c] = rr[c];
+               }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) { Lm2[i] = Lm1[i]; Lm1[i] = L[i]; }
+         }
+         // ---- stage the prefetched row for step t+1 ----
+         if (more) {
+            float *wb = s_rows[wave][(t + 1) & 1];
+#pragma unroll
+            for (int m = 0; m < 4; m++) wb[lane + 64 * m] = pre[m];
+            if (lane < 16) wb[lane + 256] = pre[4];
+         }
+      }
+   }
+}

@@ -137,6 +137,8 @@ struct hesaff_ctx {
 
    hesaff_timings tm;
    int profiling = 0;
+   bool use_tile_kernel = false;   // HESAFF_PYR=tile: v1 LDS-tile pyramid kernel (cross-check / fallback)
+   int band_rows = 96;             // HESAFF_BAND: rows per wavefront band of k_blur_hess_march
    int ablate = 0;          // HESAFF_ABLATE: profiling-only ablation bits, breaks results when set
    std::vector<hipEvent_t> ev_pool;
    size_t ev_used = 0;
@@ -346,13 +348,37 @@ struct StageTimer {
 
 enum { T_PYR = 0, T_DET = 1, T_AFF = 2, T_PATCH = 3, T_SIFT = 4, T_TOTAL = 5, T_BLURHESS = 100 };
 
+template <int K, bool WL, bool WR, bool WH>
+void launch_march(hesaff_ctx *c, const DPlane &in, const DPlane &outL, const DPlane &outR, const DPlane &outHalf, const float *taps,
+                  float norm2, int B)
+{
+   const int strips = (in.cols + BM_STRIP - 1) / BM_STRIP;
+   // band height: enough wavefronts to fill 256 CUs x 12 waves a few times over, but not so
+   // short that the 2r+2 warm-up rows dominate
+   int band = c->band_rows;
+   const long long waves_per_band_row = (long long)strips * B;
+   while (band > 24 && waves_per_band_row * ((in.rows + band - 1) / band) < 256 * 12 * 2) band /= 2;
+   const dim3 grid((strips + 3) / 4, (in.rows + band - 1) / band, B);
+   hipLaunchKernelGGL((k_blur_hess_march<K, WL, WR, WH>), grid, dim3(256), 0, c->stream, in, outL, outR, outHalf, taps, norm2, band);
+}
+
 template <bool WL, bool WR, bool WH>
 void launch_blur_hess(hesaff_ctx *c, const DPlane &in, const DPlane &outL, const DPlane &outR, const DPlane &outHalf, int tapIdx,
                       float norm2, int B)
 {
+   const float *taps = c->t_pyr_taps.as<float>() + c->pyr_tap_off[tapIdx];
+   const int K = c->pyr_K[tapIdx];
+   if (!c->use_tile_kernel) {
+      switch (K) {
+         case 9: launch_march<9, WL, WR, WH>(c, in, outL, outR, outHalf, taps, norm2, B); return;
+         case 11: launch_march<11, WL, WR, WH>(c, in, outL, outR, outHalf, taps, norm2, B); return;
+         case 13: launch_march<13, WL, WR, WH>(c, in, outL, outR, outHalf, taps, norm2, B); return;
+         case 15: launch_march<15, WL, WR, WH>(c, in, outL, outR, outHalf, taps, norm2, B); return;
+         default: break;   // non-default initialSigma: generic tile kernel
+      }
+   }
    const dim3 grid((in.cols + BH_TW - 1) / BH_TW, (in.rows + BH_TH - 1) / BH_TH, B);
-   hipLaunchKernelGGL((k_blur_hess_tile<WL, WR, WH>), grid, dim3(256), 0, c->stream, in, outL, outR, outHalf,
-                      c->t_pyr_taps.as<float>() + c->pyr_tap_off[tapIdx], c->pyr_K[tapIdx], norm2);
+   hipLaunchKernelGGL((k_blur_hess_tile<WL, WR, WH>), grid, dim3(256), 0, c->stream, in, outL, outR, outHalf, taps, K, norm2);
 }
 
 struct Lists {
