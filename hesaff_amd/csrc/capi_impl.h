@@ -77,8 +77,11 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       refresh_tables_struct(c);
       memset(&c->tm, 0, sizeof c->tm);
       if (const char *ab = getenv("HESAFF_ABLATE")) c->ablate = atoi(ab) & ~1;
-      if (const char *pk = getenv("HESAFF_PYR")) c->use_tile_kernel = strcmp(pk, "tile") == 0;
+      if (const char *pk = getenv("HESAFF_PYR")) { c->use_tile_kernel = strcmp(pk, "tile") == 0; c->use_glds = strcmp(pk, "glds") == 0; }
       if (const char *bd = getenv("HESAFF_BAND")) c->band_rows = std::max(8, atoi(bd));
+      c->debug = getenv("HESAFF_DEBUG") != nullptr;
+      if (const char *sp = getenv("HESAFF_STOP")) c->stop_after_detect = strcmp(sp, "detect") == 0;
+      if (const char *wv = getenv("HESAFF_BANDS")) c->force_bands = std::max(0, atoi(wv));
    } catch (const HsError &e) {
       delete c;
       return fail(nullptr, e);

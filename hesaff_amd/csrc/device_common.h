@@ -38,20 +38,21 @@ struct DConsts {
 // ---- helpers.cpp:227-240 : one bilinear tap; `outside` is OR-ed like `ret` ----
 // (int)floor(w) of the reference is cvttss2si (INT_MIN on NaN/overflow -> "outside");
 // comparing the floored float gives the same classification without the cast.
+// Branch-free: an outside tap reads pixel (0,0) and discards the value, so that a loop of
+// taps can issue all its loads before the first use.  Needs an image of at least 2x2.
 __device__ __forceinline__ float hs_bilinear(const float *__restrict__ im, int pitch, int width, int height,
                                              float wx, float wy, bool &outside)
 {
    const float fx = floorf(wx), fy = floorf(wy);
-   if (!(fx >= 0.0f && fy >= 0.0f && fx < (float)width && fy < (float)height)) {
-      outside = true;
-      return 0.0f;
-   }
-   const int x = (int)fx, y = (int)fy;
+   const bool in = (fx >= 0.0f && fy >= 0.0f && fx < (float)width && fy < (float)height);
+   const int x = in ? (int)fx : 0, y = in ? (int)fy : 0;
    wx -= fx;
    wy -= fy;
    const float *p = im + (long long)y * pitch + x;
    const float p00 = p[0], p01 = p[1], p10 = p[pitch], p11 = p[pitch + 1];
-   return (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + (wy) * ((1.0f - wx) * p10 + wx * p11);
+   const float v = (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + (wy) * ((1.0f - wx) * p10 + wx * p11);
+   outside = outside || !in;
+   return in ? v : 0.0f;
 }
 
 // ---- helpers.cpp:46-88 solveLinear3x3 (value swaps, partial pivoting) ----

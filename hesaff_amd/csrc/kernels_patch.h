@@ -51,42 +51,67 @@ __device__ __forceinline__ float hs_serial_sum(const float *__restrict__ v, int 
 // the work around them is parallel and branch-free:
 //  * masked pixels are gathered into a contiguous array, the serial thread only runs the
 //    dependent chain of additions over float4 LDS reads;
-//  * histogram: thread t owns vec[t] = cell (row bin, col bin, orientation) and walks its
-//    16x16 pixel support in raster order.  Each pixel adds at most one term to a cell
-//    (siftdesc.cpp:75-78); where the reference adds nothing this adds 0.0f (x + 0 == x).
+//  * histogram: one wavefront; lane = (spatial cell, orientation pair {q, q+4}) walks the
+//    cell's 16x16 pixel support in raster order.  Each pixel adds at most one term to a
+//    histogram bin (siftdesc.cpp:75-78); where the reference adds nothing this adds 0.0f.
+// Everything that does not depend on the keypoint (bin tables, cell weights, this thread's
+// slice of the circular mask and of the masked-pixel index list) is loaded ONCE per block
+// by hs_sift_setup and kept in LDS / registers across the block's keypoint loop.
 // flags: profiling ablations only (HESAFF_ABLATE), 0 on every product path.
 // ---------------------------------------------------------------------------------------
-__device__ inline void hs_sift_block(float *s_patch, float *s_va, float *s_vec, float *s_misc, float *s_tab, const KpTables &tb,
-                                     const DConsts &k, uint8_t *__restrict__ desc_out, int flags = 0)
+#define HS_SIFT_PIX_IT 7   // ceil(1681 / 256)
+#define HS_SIFT_MSK_IT 5   // ceil(1245 / 256)
+
+struct SiftRegs {
+   float mask[HS_SIFT_PIX_IT];   // sift_mask[tid + 256 k]
+   int midx[HS_SIFT_MSK_IT];     // mask_idx[tid + 256 k] (0 beyond n_masked)
+};
+
+__device__ __forceinline__ void hs_sift_setup(const KpTables &tb, float *s_tab, SiftRegs &rg)
 {
    const int tid = threadIdx.x;
-   const int nm = (flags & 4) ? 8 : tb.n_masked;
    int *s_bin0 = reinterpret_cast<int *>(s_tab), *s_bin1 = s_bin0 + HS_PATCH;
    float *s_w0 = s_tab + 2 * HS_PATCH, *s_w1 = s_tab + 3 * HS_PATCH, *s_cw = s_tab + 4 * HS_PATCH + 4;
    if (tid < HS_PATCH) {
       s_bin0[tid] = tb.bin0[tid]; s_bin1[tid] = tb.bin1[tid];
       s_w0[tid] = tb.w0[tid]; s_w1[tid] = tb.w1[tid];
    }
-   // photometricallyNormalize helpers.cpp:253-260: mean over the pixels with mask > 0,
-   // raster order.  gsum counts them in float: exact, == (float)nm.
-   for (int i = tid; i < nm; i += blockDim.x) s_va[i] = s_patch[tb.mask_idx[i]];
+#pragma unroll
+   for (int k = 0; k < HS_SIFT_PIX_IT; k++) { const int i = tid + 256 * k; rg.mask[k] = (i < HS_PATCH_PIX) ? tb.sift_mask[i] : 0.0f; }
+#pragma unroll
+   for (int k = 0; k < HS_SIFT_MSK_IT; k++) { const int i = tid + 256 * k; rg.midx[k] = (i < tb.n_masked) ? tb.mask_idx[i] : 0; }
    __syncthreads();
-   if (tid == 0) s_misc[0] = hs_serial_sum(s_va, nm) / (float)nm;
-   if (tid >= 64 && tid < 128) {
+   if (tid < 64) {
       // cell weights: spatial bin b gets weight w1[r] from rows with bin1 == b and w0[r] from
       // rows with bin0 == b (siftdesc.cpp:55-56,61-62); clamped bins carry weight 0.
-      const int b = (tid - 64) >> 4, i = (tid - 64) & 15, r = 8 * b + i;
+      const int b = tid >> 4, i = tid & 15, r = 8 * b + i;
       float w = 0.0f;
       if (r < HS_PATCH) {
          if (s_bin0[r] == 8 * b && s_w0[r] != 0.0f) w = s_w0[r];
          else if (s_bin1[r] == 8 * b) w = s_w1[r];
       }
-      s_cw[tid - 64] = w;
+      s_cw[tid] = w;
    }
+   __syncthreads();
+}
+
+__device__ inline void hs_sift_block(float *s_patch, float *s_va, float *s_vec, float *s_misc, const float *s_tab, const SiftRegs &rg,
+                                     const KpTables &tb, const DConsts &k, uint8_t *__restrict__ desc_out, int flags = 0)
+{
+   const int tid = threadIdx.x;
+   const int nm = (flags & 4) ? 8 : tb.n_masked;
+   const float *s_cw = s_tab + 4 * HS_PATCH + 4;
+   // photometricallyNormalize helpers.cpp:253-260: mean over the pixels with mask > 0,
+   // raster order.  gsum counts them in float: exact, == (float)nm.
+#pragma unroll
+   for (int q = 0; q < HS_SIFT_MSK_IT; q++) { const int i = tid + 256 * q; if (i < nm) s_va[i] = s_patch[rg.midx[q]]; }
+   __syncthreads();
+   if (tid == 0) s_misc[0] = hs_serial_sum(s_va, nm) / (float)nm;
    __syncthreads();
    {
       const float sum = s_misc[0];
-      for (int i = tid; i < nm; i += blockDim.x) { const float d = sum - s_va[i]; s_va[i] = d * d; }   // helpers.cpp:266
+#pragma unroll
+      for (int q = 0; q < HS_SIFT_MSK_IT; q++) { const int i = tid + 256 * q; if (i < nm) { const float d = sum - s_va[i]; s_va[i] = d * d; } }   // helpers.cpp:266
    }
    __syncthreads();
    if (tid == 0) s_misc[1] = sqrtf(hs_serial_sum(s_va, nm) / (float)nm);   // helpers.cpp:268
@@ -95,51 +120,69 @@ __device__ inline void hs_sift_block(float *s_patch, float *s_va, float *s_vec, 
       const float sum = s_misc[0], var = s_misc[1];
       if (!((double)var < 0.0001)) {
          const float fac = 50.0f / var;
-         for (int i = tid; i < HS_PATCH_PIX; i += blockDim.x) {
-            float v = 128 + fac * (s_patch[i] - sum);
-            if (v > 255) v = 255;
-            if (v < 0) v = 0;
-            s_patch[i] = v;
+#pragma unroll
+         for (int q = 0; q < HS_SIFT_PIX_IT; q++) {
+            const int i = tid + 256 * q;
+            if (i < HS_PATCH_PIX) {
+               float v = 128 + fac * (s_patch[i] - sum);
+               if (v > 255) v = 255;
+               if (v < 0) v = 0;
+               s_patch[i] = v;
+            }
          }
       }
    }
    __syncthreads();
    // gradient magnitude / orientation, siftdesc.cpp:123-137, and the per-pixel part of samplePatch
    float2 *s_vo = reinterpret_cast<float2 *>(s_va);
-   for (int i = tid; i < HS_PATCH_PIX; i += blockDim.x) {
-      const int r = i / HS_PATCH, c = i - r * HS_PATCH;
-      float gx, gy;
-      hs_grad(s_patch, HS_PATCH, r, c, gx, gy);
-      const float grad = sqrtf(gx * gx + gy * gy);
-      const float ori = hm_atan2f(gy, gx);
-      // float(orientationBins) * (ori + 2*M_PI) / (2*M_PI), evaluated in double (M_PI)
-      const float o = (float)((double)8.0f * ((double)ori + 2 * 3.14159265358979323846) / (2 * 3.14159265358979323846));
-      s_vo[i] = make_float2(tb.sift_mask[i] * grad, o);
+#pragma unroll 1
+   for (int q = 0; q < HS_SIFT_PIX_IT; q++) {
+      const int i = tid + 256 * q;
+      if (i < HS_PATCH_PIX) {
+         const int r = i / HS_PATCH, c = i - r * HS_PATCH;
+         float gx, gy;
+         hs_grad(s_patch, HS_PATCH, r, c, gx, gy);
+         const float grad = sqrtf(gx * gx + gy * gy);
+         const float ori = hm_atan2f(gy, gx);
+         // float(orientationBins) * (ori + 2*M_PI) / (2*M_PI), evaluated in double (M_PI)
+         const float o = (float)((double)8.0f * ((double)ori + 2 * 3.14159265358979323846) / (2 * 3.14159265358979323846));
+         s_vo[i] = make_float2(tb.sift_mask[i] * grad, o);
+      }
+      // the loop is unrolled only so that rg.mask[q] is a register; do not let the scheduler
+      // interleave the iterations (7 atan2 bodies in flight cost ~80 VGPRs)
+      __builtin_amdgcn_sched_barrier(0);
    }
    __syncthreads();
    // samplePatch siftdesc.cpp:51-81
-   if (tid < 128 && !(flags & 2)) {
-      const int cb_r = tid >> 5, cb_c = (tid >> 3) & 3, my_bo = tid & 7;
-      float acc = 0.0f;
+   if (tid < 64 && !(flags & 2)) {
+      const int cell = tid >> 2, cb_r = cell >> 2, cb_c = cell & 3;
+      const int bA = tid & 3, bB = bA + 4;
+      const int pA = (bA + 7) & 7, pB = (bB + 7) & 7;   // a pixel whose bo0 is pA feeds bin bA through bo1
+      float cwc[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) cwc[j] = s_cw[cb_c * 16 + j];
+      float accA = 0.0f, accB = 0.0f;
       for (int i = 0; i < 16; i++) {
          const int r = 8 * cb_r + i;   // <= 39
          const float wr = s_cw[cb_r * 16 + i];
          const float2 *row = s_vo + r * HS_PATCH + 8 * cb_c;
-#pragma unroll
+#pragma unroll 2
          for (int j = 0; j < 16; j++) {
             const float2 q = row[j];
-            const float wc = s_cw[cb_c * 16 + j] * q.x;   // w[c] * (mask*grad)
+            const float wc = cwc[j] * q.x;   // w[c] * (mask*grad)
             const float v = wr * wc;
-            int bo0 = (int)q.y;
-            const float wo1 = q.y - (float)bo0;
-            bo0 &= 7;
+            const int bo0 = ((int)q.y) & 7;
+            const float wo1 = q.y - (float)(int)q.y;
             const float wo0 = 1.0f - wo1;
-            const float wo = (bo0 == my_bo) ? wo0 : ((((bo0 + 1) & 7) == my_bo) ? wo1 : 0.0f);
-            const float term = v * wo;
-            acc += (v > 0.0f) ? term : 0.0f;
+            const bool pos = v > 0.0f;
+            const float t0 = pos ? v * wo0 : 0.0f;   // goes to bin bo0
+            const float t1 = pos ? v * wo1 : 0.0f;   // goes to bin bo0+1
+            accA += (bo0 == bA) ? t0 : ((bo0 == pA) ? t1 : 0.0f);
+            accB += (bo0 == bB) ? t0 : ((bo0 == pB) ? t1 : 0.0f);
          }
       }
-      s_vec[tid] = acc;
+      s_vec[cell * 8 + bA] = accA;
+      s_vec[cell * 8 + bB] = accB;
    }
    __syncthreads();
    // sample() siftdesc.cpp:98-113: normalize, clip, renormalize, quantise (s_va is free again)
@@ -177,20 +220,22 @@ __global__ __launch_bounds__(256) void k_sift_stage(const float *__restrict__ pa
 {
    __shared__ __attribute__((aligned(16))) float s_va[2 * HS_SIFT_ARR], s_vec[128];
    __shared__ float s_patch[HS_PATCH_PIX], s_misc[8], s_tab[HS_SIFT_TAB];
+   SiftRegs rg;
+   hs_sift_setup(tb, s_tab, rg);
    for (int h = blockIdx.x; h < n; h += gridDim.x) {
       for (int i = threadIdx.x; i < HS_PATCH_PIX; i += blockDim.x) s_patch[i] = patches[(size_t)h * HS_PATCH_PIX + i];
       __syncthreads();
-      hs_sift_block(s_patch, s_va, s_vec, s_misc, s_tab, tb, k, desc + (size_t)h * 128);
+      hs_sift_block(s_patch, s_va, s_vec, s_misc, s_tab, rg, tb, k, desc + (size_t)h * 128);
    }
 }
 
 // shared tail of every patch kernel: optional patch dump + descriptor
-__device__ __forceinline__ void hs_patch_finish(uint32_t h, float *s_patch, float *s_va, float *s_vec, float *s_misc, float *s_tab,
-                                                const PatchIO &io, const KpTables &tb, const DConsts &k, int flags)
+__device__ __forceinline__ void hs_patch_finish(uint32_t h, float *s_patch, float *s_va, float *s_vec, float *s_misc, const float *s_tab,
+                                                const SiftRegs &rg, const PatchIO &io, const KpTables &tb, const DConsts &k, int flags)
 {
    if (io.patches)
       for (int i = threadIdx.x; i < HS_PATCH_PIX; i += 256) io.patches[(size_t)h * HS_PATCH_PIX + i] = s_patch[i];
-   if (flags & 1) hs_sift_block(s_patch, s_va, s_vec, s_misc, s_tab, tb, k, io.desc + (size_t)h * 128, flags);
+   if (flags & 1) hs_sift_block(s_patch, s_va, s_vec, s_misc, s_tab, rg, tb, k, io.desc + (size_t)h * 128, flags);
    __syncthreads();
 }
 
@@ -229,6 +274,8 @@ __global__ __launch_bounds__(256) void k_patch_small(HessList hl, PatchWork pw, 
    __shared__ int s_flag;
 
    const int tid = threadIdx.x;
+   SiftRegs rg;
+   hs_sift_setup(tb, s_tab, rg);
    const uint32_t cnt = min(pw.bin_count[BIN], pw.cap);
    const int imRows = io.image.rows, imCols = io.image.cols, imPitch = io.image.pitch;
    const int width = imCols - 1, height = imRows - 1;
@@ -308,7 +355,7 @@ __global__ __launch_bounds__(256) void k_patch_small(HessList hl, PatchWork pw, 
          __syncthreads();
          continue;
       }
-      hs_patch_finish(h, s_patch, smem, s_vec, s_misc, s_tab, io, tb, k, flags);
+      hs_patch_finish(h, s_patch, smem, s_vec, s_misc, s_tab, rg, io, tb, k, flags);
    }
 }
 
@@ -316,6 +363,7 @@ __global__ __launch_bounds__(256) void k_patch_small(HessList hl, PatchWork pw, 
 __device__ __forceinline__ float hs_colpass(const float *__restrict__ Tp, int yy, int q, int pm, const float *__restrict__ taps, int r)
 {
    float d = taps[r] * Tp[(long long)min(max(yy, 0), pm) * HS_NEED + q];
+#pragma unroll 2
    for (int j = 1; j <= r; j++)
       d += taps[r + j] * (Tp[(long long)min(max(yy + j, 0), pm) * HS_NEED + q] + Tp[(long long)min(max(yy - j, 0), pm) * HS_NEED + q]);
    return d;
@@ -353,6 +401,7 @@ __device__ __forceinline__ void hs_row_stream(const float *__restrict__ img, int
    const int lane = threadIdx.x & 63, half = P >> 1, pm = P - 1, r = K >> 1;
    const int j = yy - half;
    const float rx = x + (float)j * a12, ry = y + (float)j * a22;
+#pragma unroll 1
    for (int xx = lane; xx < P; xx += 64) {
       const int i = xx - half;
       const float wx = rx + (float)i * a11, wy = ry + (float)i * a21;
@@ -366,6 +415,7 @@ __device__ __forceinline__ void hs_row_stream(const float *__restrict__ img, int
       const float wq = c0 + (float)((q >> 1) - 20) * scale;
       const int xx = (int)floorf(wq) + (q & 1);
       float t = taps[0] * srow[min(max(xx - r, 0), pm)];
+#pragma unroll 4
       for (int jt = 1; jt < K; jt++) t += taps[jt] * srow[min(max(xx - r + jt, 0), pm)];
       out82[q] = t;
    }
@@ -392,6 +442,8 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
    __shared__ int s_flag;
 
    const int tid = threadIdx.x, wave = tid >> 6;
+   SiftRegs rg;
+   hs_sift_setup(tb, s_tab, rg);
    const uint32_t cnt = min(pw.bin_count[2], pw.cap);
    const int imPitch = io.image.pitch, width = io.image.cols - 1, height = io.image.rows - 1;
 
@@ -409,6 +461,7 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
       if (tid < K) s_taps[tid] = taps_g[tid];
       __syncthreads();
       bool outside = false;
+#pragma unroll 1
       for (int yy = wave; yy < P; yy += 4)
          hs_row_stream(img, imPitch, width, height, x, y, a11, a12, a21, a22, P, yy, scale, s_taps, K, s_srow + wave * HS_MID_PMAX,
                        Tp + yy * HS_NEED, outside);
@@ -421,7 +474,7 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
       }
       hs_resample_reduced(Tp, P, scale, s_taps, K >> 1, s_patch);
       __syncthreads();
-      hs_patch_finish(h, s_patch, smem, s_vec, s_misc, s_tab, io, tb, k, flags);
+      hs_patch_finish(h, s_patch, smem, s_vec, s_misc, s_tab, rg, io, tb, k, flags);
    }
 }
 
@@ -460,12 +513,14 @@ __global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork
    }
 }
 
-__global__ __launch_bounds__(256) void k_patch_large_finish(HessList hl, PatchWork pw, PatchIO io, KpTables tb, DConsts k, int flags)
+__global__ __launch_bounds__(256, 5) void k_patch_large_finish(HessList hl, PatchWork pw, PatchIO io, KpTables tb, DConsts k, int flags)
 {
    __shared__ __attribute__((aligned(16))) float s_va[2 * HS_SIFT_ARR], s_vec[128];
    __shared__ float s_patch[HS_SIFT_ARR], s_misc[8], s_tab[HS_SIFT_TAB];
    const uint32_t *pre = io.row_prefix;
    const uint32_t row_lo = pre[io.item0];
+   SiftRegs rg;
+   hs_sift_setup(tb, s_tab, rg);
    for (uint32_t it = io.item0 + blockIdx.x; it < io.item1; it += gridDim.x) {
       const uint32_t h = pw.bin_items[(size_t)3 * pw.cap + it];
       if (!pw.alive[h]) continue;   // uniform for the block
@@ -475,7 +530,7 @@ __global__ __launch_bounds__(256) void k_patch_large_finish(HessList hl, PatchWo
       const float *taps = tb.patch_taps + tb.patch_tap_off[(P0 - 1) >> 1];
       hs_resample_reduced(io.trows + (size_t)(pre[it] - row_lo) * HS_NEED, P, scale, taps, K >> 1, s_patch);
       __syncthreads();
-      hs_patch_finish(h, s_patch, s_va, s_vec, s_misc, s_tab, io, tb, k, flags);
+      hs_patch_finish(h, s_patch, s_va, s_vec, s_misc, s_tab, rg, io, tb, k, flags);
    }
 }
 

@@ -493,14 +493,24 @@ __global__ void k_image_counts(const uint32_t *__restrict__ prefix, long long st
 #define BM_STRIP 248
 #define BM_ROWBUF 272   // floats: 8 + 256 + 8
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f hs_hessian2(v2f ul, v2f uc, v2f ur, v2f ml, v2f mc, v2f mr, v2f dl, v2f dc, v2f dr, float norm2)
+{
+   // pyramid.cpp:95-100 on two adjacent columns at once (component-wise IEEE mul/add/sub/div)
+   const v2f Lxx = (ml - 2.0f * mc) + mr;
+   const v2f Lyy = (uc - 2.0f * mc) + dc;
+   const v2f Lxy = (((ur - ul) + dl) - dr) / 4.0f;
+   return ((Lxx * Lyy) - (Lxy * Lxy)) * norm2;
+}
+
 template <int K, bool WRITE_L, bool WRITE_R, bool WRITE_HALF>
 __global__ __launch_bounds__(256) void k_blur_hess_march(DPlane in, DPlane outL, DPlane outR, DPlane outHalf,
                                                           const float *__restrict__ taps, float norm2, int band_rows)
 {
    constexpr int R = K >> 1;
-   constexpr int Q0 = (8 - R) / 4;               // first aligned float4 of the row-pass window, relative to the lane
-   constexpr int OFF = (8 - R) - 4 * Q0;         // position of column x-R inside it
-   constexpr int NQ = (OFF + 4 + 2 * R + 3) / 4; // float4 reads per lane
+   constexpr int U = K + 1;                      // ring size and unroll factor (even: static prefetch parity)
+   constexpr int W0 = 8 - R;                     // row-buffer float of column x-R, relative to 4*lane
    __shared__ __attribute__((aligned(16))) float s_rows[4][2][BM_ROWBUF];
 
    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -524,116 +534,128 @@ __global__ __launch_bounds__(256) void k_blur_hess_march(DPlane in, DPlane outL,
    const int xl = xs - 4 + 4 * lane;   // first of this lane's 4 columns
    const bool store_lane = lane >= 1 && lane <= 62 && xl < cols;
    const bool full4 = xl + 3 < cols;
+   // response is 0 on the image frame (pyramid.cpp:70: never written there)
+   const bool cin0 = xl > 0 && xl < cols - 1, cin1 = xl + 1 > 0 && xl + 1 < cols - 1;
+   const bool cin2 = xl + 2 > 0 && xl + 2 < cols - 1, cin3 = xl + 3 > 0 && xl + 3 < cols - 1;
 
-   float ring[K][4];
-   float Lm2[6], Lm1[6];
+   v2f ringA[U], ringB[U];                       // row-pass results of columns (0,1) and (2,3)
 #pragma unroll
-   for (int i = 0; i < 6; i++) { Lm2[i] = 0.0f; Lm1[i] = 0.0f; }
+   for (int u = 0; u < U; u++) { ringA[u] = (v2f)(0.0f); ringB[u] = (v2f)(0.0f); }
+   // two previous blurred rows as the five overlapping column pairs (x-1,x) (x,x+1) ... (x+3,x+4)
+   v2f P2[5], P1[5];
 #pragma unroll
-   for (int u = 0; u < K; u++) { ring[u][0] = ring[u][1] = ring[u][2] = ring[u][3] = 0.0f; }
+   for (int i = 0; i < 5; i++) { P2[i] = (v2f)(0.0f); P1[i] = (v2f)(0.0f); }
 
-   float pre[5];
-   {
-      const int y = min(max(yh0 - 1 - R, 0), rows - 1);
+   float pre[2][5];
+   auto load_row = [&](int t, float *dst5) {
+      const int y = min(max(yh0 - 1 - R + t, 0), rows - 1);
       const float *rp = src + (long long)y * pitch;
 #pragma unroll
-      for (int m = 0; m < 4; m++) pre[m] = rp[cx[m]];
-      pre[4] = (lane < 16) ? rp[cx[4]] : 0.0f;
-      float *wb = s_rows[wave][0];
+      for (int m = 0; m < 4; m++) dst5[m] = rp[cx[m]];
+      dst5[4] = rp[cx[4]];   // lanes >= 16 load a clamped in-image column they never store
+   };
+   auto stage_row = [&](int buf, const float *src5) {
+      float *wb = s_rows[wave][buf];
 #pragma unroll
-      for (int m = 0; m < 4; m++) wb[lane + 64 * m] = pre[m];
-      if (lane < 16) wb[lane + 256] = pre[4];
-   }
+      for (int m = 0; m < 4; m++) wb[lane + 64 * m] = src5[m];
+      if (lane < 16) wb[lane + 256] = src5[4];
+   };
+   load_row(0, pre[0]);
+   stage_row(0, pre[0]);
+   load_row(1, pre[1]);
 
-   for (int t0 = 0; t0 < steps; t0 += K) {
+   for (int t0 = 0; t0 < steps; t0 += U) {
 #pragma unroll
-      for (int u = 0; u < K; u++) {
-         const int t = t0 + u;
-         if (t >= steps) break;
-         const bool more = t + 1 < steps;
-         if (more) {
-            const int y = min(max(yh0 - R + t, 0), rows - 1);   // input row of step t+1
-            const float *rp = src + (long long)y * pitch;
-#pragma unroll
-            for (int m = 0; m < 4; m++) pre[m] = rp[cx[m]];
-            pre[4] = (lane < 16) ? rp[cx[4]] : 0.0f;
-         }
-         // ---- row pass of input row t: t = k[0]*S[x-R]; t += k[j]*S[x-R+j] ----
+      for (int u = 0; u < U; u++) {
+         // No control flow in the unrolled body (the compiler otherwise splits the register ring
+         // into scalars at every branch and copies it back into pairs): the step count is padded
+         // to a multiple of U; padded steps read clamped rows and store nothing.
+         const int t = t0 + u;           // t & 1 == u & 1
+         load_row(t + 2, pre[u & 1]);    // row t's registers are free (staged during step t-1)
+         // ---- row pass of input row t: acc = k[0]*S[x-R]; acc += k[j]*S[x-R+j], two columns per op ----
          {
-            const float4 *rb = reinterpret_cast<const float4 *>(s_rows[wave][t & 1]) + lane + Q0;
-            float sv[4 * NQ];
+            const float *rb = s_rows[wave][u & 1] + 4 * lane + W0;
+            v2f G[K + 2];                // G[i] = (S[x-R+i], S[x-R+i+1]), x = this lane's first column
 #pragma unroll
-            for (int q = 0; q < NQ; q++) {
-               const float4 v = rb[q];
-               sv[4 * q] = v.x; sv[4 * q + 1] = v.y; sv[4 * q + 2] = v.z; sv[4 * q + 3] = v.w;
+            for (int i = 0; i < K + 2; i++) {
+               if (((W0 + i) & 1) == 0) G[i] = *reinterpret_cast<const v2f *>(__builtin_assume_aligned(rb + i, 8));
+               else { G[i].x = rb[i]; G[i].y = rb[i + 1]; }
             }
+            v2f a = kk[0] * G[0], bq = kk[0] * G[2];
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-               float tt = kk[0] * sv[OFF + c];
-#pragma unroll
-               for (int j = 1; j < K; j++) tt += kk[j] * sv[OFF + c + j];
-               ring[u][c] = tt;
+            for (int j = 1; j < K; j++) {
+               // products first, then the two independent accumulations: a packed multiply may not be
+               // consumed by the very next instruction (1 wait state), interleaving A and B hides it
+               const v2f pa = kk[j] * G[j], pb = kk[j] * G[j + 2];
+               a = a + pa;
+               bq = bq + pb;
             }
+            ringA[u] = a;
+            ringB[u] = bq;
          }
-         // ---- column pass: blurred row yl = yh0 - 1 + (t - 2R) ----
-         if (t >= 2 * R) {
+         // ---- column pass: blurred row yl = yh0 - 1 + (t - 2R): d = k[R]*T[y]; d += k[R+j]*(T[y+j]+T[y-j]) ----
+         // (for t < 2R the ring is not full yet: yl < yh0, nothing is stored)
+         {
             const int yl = yh0 - 1 + (t - 2 * R);
-            float L[6];
+            v2f la = kk[R] * ringA[(u - R + U) % U], lb = kk[R] * ringB[(u - R + U) % U];
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-               float d = kk[R] * ring[(u - R + K) % K][c];
-#pragma unroll
-               for (int j = 1; j <= R; j++) d += kk[R + j] * (ring[(u - R + j + K) % K][c] + ring[(u - R - j + 2 * K) % K][c]);
-               L[1 + c] = d;
+            for (int j = 1; j <= R; j++) {
+               const v2f sa = ringA[(u - R + j + U) % U] + ringA[(u - R - j + 2 * U) % U];
+               const v2f sb = ringB[(u - R + j + U) % U] + ringB[(u - R - j + 2 * U) % U];
+               const v2f qa = kk[R + j] * sa, qb = kk[R + j] * sb;
+               la = la + qa;
+               lb = lb + qb;
             }
-            L[0] = __shfl_up(L[4], 1, 64);
-            L[5] = __shfl_down(L[1], 1, 64);
+            const float left = __shfl_up(lb.y, 1, 64);      // column x-1
+            const float right = __shfl_down(la.x, 1, 64);   // column x+4
+            v2f P0[5];
+            P0[0].x = left; P0[0].y = la.x;
+            P0[1] = la;
+            P0[2].x = la.y; P0[2].y = lb.x;
+            P0[3] = lb;
+            P0[4].x = lb.y; P0[4].y = right;
             const bool row_in = yl >= yh0 && yl < yh1;
             if (row_in && store_lane) {
                if (WRITE_L) {
                   float *o = outL.img(b) + (long long)yl * outL.pitch + xl;
-                  if (full4) *reinterpret_cast<float4 *>(o) = make_float4(L[1], L[2], L[3], L[4]);
-                  else
+                  if (full4) *reinterpret_cast<float4 *>(o) = make_float4(la.x, la.y, lb.x, lb.y);
+                  else {
+                     const float v[4] = {la.x, la.y, lb.x, lb.y};
                      for (int c = 0; c < 4; c++)
-                        if (xl + c < cols) o[c] = L[1 + c];
+                        if (xl + c < cols) o[c] = v[c];
+                  }
                }
                if (WRITE_HALF) {
                   if ((yl & 1) == 0 && (yl >> 1) < outHalf.rows) {
                      float *o = outHalf.img(b) + (long long)(yl >> 1) * outHalf.pitch + (xl >> 1);
-                     if ((xl >> 1) + 1 < outHalf.cols) *reinterpret_cast<float2 *>(o) = make_float2(L[1], L[3]);
-                     else if ((xl >> 1) < outHalf.cols) o[0] = L[1];
+                     if ((xl >> 1) + 1 < outHalf.cols) *reinterpret_cast<float2 *>(o) = make_float2(la.x, lb.x);
+                     else if ((xl >> 1) < outHalf.cols) o[0] = la.x;
                   }
                }
             }
-            // ---- response of row yh = yl - 1 from rows (Lm2, Lm1, L) ----
+            // ---- response of row yh = yl - 1 from rows (P2, P1, P0) ----
             if (WRITE_R) {
                const int yh = yl - 1;
                if (yh >= yh0 && yh < yh1 && store_lane) {
-                  float rr[4];
                   const bool yin = yh > 0 && yh < rows - 1;
-#pragma unroll
-                  for (int c = 0; c < 4; c++) {
-                     const int x = xl + c;
-                     const float v = hs_hessian(Lm2[c], Lm2[c + 1], Lm2[c + 2], Lm1[c], Lm1[c + 1], Lm1[c + 2], L[c], L[c + 1], L[c + 2], norm2);
-                     rr[c] = (yin && x > 0 && x < cols - 1) ? v : 0.0f;
-                  }
+                  const v2f ra = hs_hessian2(P2[0], P2[1], P2[2], P1[0], P1[1], P1[2], P0[0], P0[1], P0[2], norm2);
+                  const v2f rbv = hs_hessian2(P2[2], P2[3], P2[4], P1[2], P1[3], P1[4], P0[2], P0[3], P0[4], norm2);
+                  const float r0 = (yin && cin0) ? ra.x : 0.0f, r1 = (yin && cin1) ? ra.y : 0.0f;
+                  const float r2 = (yin && cin2) ? rbv.x : 0.0f, r3 = (yin && cin3) ? rbv.y : 0.0f;
                   float *o = outR.img(b) + (long long)yh * outR.pitch + xl;
-                  if (full4) *reinterpret_cast<float4 *>(o) = make_float4(rr[0], rr[1], rr[2], rr[3]);
-                  else
+                  if (full4) *reinterpret_cast<float4 *>(o) = make_float4(r0, r1, r2, r3);
+                  else {
+                     const float v[4] = {r0, r1, r2, r3};
                      for (int c = 0; c < 4; c++)
-                        if (xl + c < cols) o[c] = rr[c];
+                        if (xl + c < cols) o[c] = v[c];
+                  }
                }
             }
 #pragma unroll
-            for (int i = 0; i < 6; i++) { Lm2[i] = Lm1[i]; Lm1[i] = L[i]; }
+            for (int i = 0; i < 5; i++) { P2[i] = P1[i]; P1[i] = P0[i]; }
          }
-         // ---- stage the prefetched row for step t+1 ----
-         if (more) {
-            float *wb = s_rows[wave][(t + 1) & 1];
-#pragma unroll
-            for (int m = 0; m < 4; m++) wb[lane + 64 * m] = pre[m];
-            if (lane < 16) wb[lane + 256] = pre[4];
-         }
+         // ---- stage row t+1 (loaded during step t-1) for the next step ----
+         stage_row((u + 1) & 1, pre[(u + 1) & 1]);
       }
    }
 }

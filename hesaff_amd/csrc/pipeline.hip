@@ -137,8 +137,12 @@ struct hesaff_ctx {
 
    hesaff_timings tm;
    int profiling = 0;
+   bool use_glds = false;          // HESAFF_PYR=glds: LDS-DMA prefetch variant of the marching kernel
    bool use_tile_kernel = false;   // HESAFF_PYR=tile: v1 LDS-tile pyramid kernel (cross-check / fallback)
-   int band_rows = 96;             // HESAFF_BAND: rows per wavefront band of k_blur_hess_march
+   int band_rows = 16;             // HESAFF_BAND: minimum rows per wavefront band of k_blur_hess_march
+   bool stop_after_detect = false; // HESAFF_STOP=detect
+   bool debug = false;             // HESAFF_DEBUG=1: launch geometry on stderr
+   int force_bands = 0;            // HESAFF_BANDS: force the band count of k_blur_hess_march (tuning)
    int ablate = 0;          // HESAFF_ABLATE: profiling-only ablation bits, breaks results when set
    std::vector<hipEvent_t> ev_pool;
    size_t ev_used = 0;
@@ -348,16 +352,37 @@ struct StageTimer {
 
 enum { T_PYR = 0, T_DET = 1, T_AFF = 2, T_PATCH = 3, T_SIFT = 4, T_TOTAL = 5, T_BLURHESS = 100 };
 
+// Band height of k_blur_hess_march.  The kernel is VALU-bound and every wavefront does the
+// same amount of work per row, so a launch costs  rounds x steps:  rounds = how many times the
+// resident-block capacity (256 CUs x blocks per CU) is refilled, steps = rows a wavefront
+// marches through (band + K + 1 warm-up rows, padded to the unroll factor K + 1).  Pick the
+// band count that minimises it (ties: fewer, taller bands = less warm-up).
 template <int K, bool WL, bool WR, bool WH>
 void launch_march(hesaff_ctx *c, const DPlane &in, const DPlane &outL, const DPlane &outR, const DPlane &outHalf, const float *taps,
                   float norm2, int B)
 {
+   static int occ = 0;   // resident 256-thread blocks per CU for this instantiation
+   if (occ == 0) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_blur_hess_march<K, WL, WR, WH>, 256, 0) != hipSuccess || nb < 1) nb = 3;
+      occ = nb;
+   }
+   constexpr int U = K + 1;
    const int strips = (in.cols + BM_STRIP - 1) / BM_STRIP;
-   // band height: enough wavefronts to fill 256 CUs x 12 waves a few times over, but not so
-   // short that the 2r+2 warm-up rows dominate
-   int band = c->band_rows;
-   const long long waves_per_band_row = (long long)strips * B;
-   while (band > 24 && waves_per_band_row * ((in.rows + band - 1) / band) < 256 * 12 * 2) band /= 2;
+   const long long blocks_per_band = (long long)((strips + 3) / 4) * B;
+   const long long capacity = 256LL * occ;
+   // Measured on MI355X (16 x 4K): the launch is bandwidth/latency-bound, not issue-bound, once
+   // about 2/3 of the resident-block capacity is filled; beyond that more (shorter) bands only
+   // add warm-up rows.  So: blocks ~ 0.65 x capacity, bands at least 32 rows tall.
+   (void)capacity;
+   // 16 bands is the measured optimum for 16 x 4K at every octave (sweeps in profiles/r01_notes.md);
+   // small batches get proportionally more bands to keep ~1000 blocks in flight on octave 0.
+   int best_nb = 16 * (int)std::max<long long>(1, std::min<long long>(4, 64 / std::max<long long>(1, blocks_per_band)));
+   best_nb = std::max(1, std::min(best_nb, std::max(1, in.rows / 8)));
+   (void)U;
+   if (c->force_bands > 0) best_nb = std::min(c->force_bands, in.rows);
+   const int band = (in.rows + best_nb - 1) / best_nb;
+   if (c->debug) fprintf(stderr, "[hesaff] march K=%d %dx%d B=%d occ=%d bands=%d band=%d blocks=%lld\n", K, in.cols, in.rows, B, occ, best_nb, band, blocks_per_band * best_nb);
    const dim3 grid((strips + 3) / 4, (in.rows + band - 1) / band, B);
    hipLaunchKernelGGL((k_blur_hess_march<K, WL, WR, WH>), grid, dim3(256), 0, c->stream, in, outL, outR, outHalf, taps, norm2, band);
 }
@@ -635,6 +660,14 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
    uint32_t *cnt = s.counters;
    const int tt = tm.begin(T_TOTAL);
    run_detection(c, d_src, channels, src_img_stride, src_row_stride, B, s, tm, false, nullptr);
+   if (c->stop_after_detect) {
+      // HESAFF_STOP=detect (kernel tuning only): time the scale-space + detection part alone
+      tm.end(tt);
+      HIP_TRY(hipStreamSynchronize(st));
+      if (c->profiling) collect_timings(c, tm, B);
+      c->h_starts.assign(2 * (B + 1) + 8, 0);
+      return;
+   }
 
    int t = tm.begin(T_AFF);
    PlaneTab pt;
