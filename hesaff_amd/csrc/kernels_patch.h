@@ -392,7 +392,12 @@ __device__ __forceinline__ void hs_resample_reduced(const float *__restrict__ Tp
 }
 
 // one window row: warp (affine.cpp:126) into the wave's LDS row, then the row pass at the 82
-// needed columns.  Called by all 64 lanes of a wave.
+// needed columns.  Called by all 64 lanes of a wave.  The LDS row is stored with r replicated
+// border samples on either side (BORDER_REPLICATE), so the tap loop has no index clamps:
+//   srow[r + x] = S[x],  srow[0..r) = S[0],  srow[r+P .. r+P+r) = S[P-1]     (needs P + 2r floats)
+// Each lane owns output q = lane and (lanes < 18) q = lane + 64; the two accumulation chains
+// are interleaved.
+template <bool UNIFORM_GLOBAL_TAPS, int BIL_UNROLL>
 __device__ __forceinline__ void hs_row_stream(const float *__restrict__ img, int imPitch, int width, int height, float x, float y,
                                               float a11, float a12, float a21, float a22, int P, int yy, float scale,
                                               const float *__restrict__ taps, int K, float *__restrict__ srow, float *__restrict__ out82,
@@ -401,24 +406,45 @@ __device__ __forceinline__ void hs_row_stream(const float *__restrict__ img, int
    const int lane = threadIdx.x & 63, half = P >> 1, pm = P - 1, r = K >> 1;
    const int j = yy - half;
    const float rx = x + (float)j * a12, ry = y + (float)j * a22;
-#pragma unroll 1
+#pragma unroll BIL_UNROLL
    for (int xx = lane; xx < P; xx += 64) {
       const int i = xx - half;
       const float wx = rx + (float)i * a11, wy = ry + (float)i * a21;
-      srow[xx] = hs_bilinear(img, imPitch, width, height, wx, wy, outside);
+      srow[r + xx] = hs_bilinear(img, imPitch, width, height, wx, wy, outside);
    }
    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
    __builtin_amdgcn_wave_barrier();
    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-   const float c0 = (float)half;
-   for (int q = lane; q < HS_NEED; q += 64) {
-      const float wq = c0 + (float)((q >> 1) - 20) * scale;
-      const int xx = (int)floorf(wq) + (q & 1);
-      float t = taps[0] * srow[min(max(xx - r, 0), pm)];
-#pragma unroll 4
-      for (int jt = 1; jt < K; jt++) t += taps[jt] * srow[min(max(xx - r + jt, 0), pm)];
-      out82[q] = t;
+   {
+      const float first = srow[r], last = srow[r + pm];
+      for (int i = lane; i < r; i += 64) { srow[i] = first; srow[r + P + i] = last; }
    }
+   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+   __builtin_amdgcn_wave_barrier();
+   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+   const float *tp = taps;
+   if (UNIFORM_GLOBAL_TAPS) {
+      // the tap pointer is the same in every lane: make that visible so the loads are scalar
+      const unsigned long long a = (unsigned long long)taps;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+      tp = (const float *)(((unsigned long long)hi << 32) | lo);
+   }
+   const float c0 = (float)half;
+   const int q0 = lane, q1 = lane + 64;
+   const bool has1 = q1 < HS_NEED;
+   const float w0 = c0 + (float)((q0 >> 1) - 20) * scale, w1 = c0 + (float)(((has1 ? q1 : q0) >> 1) - 20) * scale;
+   const int x0 = min(max((int)floorf(w0) + (q0 & 1), 0), pm), x1 = min(max((int)floorf(w1) + (q1 & 1), 0), pm);
+   const float *s0 = srow + x0, *s1 = srow + x1;   // s[jt] = S[clamp(x - r + jt)]
+   float t0 = tp[0] * s0[0], t1 = tp[0] * s1[0];
+#pragma unroll 8
+   for (int jt = 1; jt < K; jt++) {
+      const float k = tp[jt];
+      const float p0 = k * s0[jt], p1 = k * s1[jt];
+      t0 += p0;
+      t1 += p1;
+   }
+   out82[q0] = t0;
+   if (has1) out82[q1] = t1;
    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
    __builtin_amdgcn_wave_barrier();
 }
@@ -429,6 +455,7 @@ __device__ __forceinline__ void hs_row_stream(const float *__restrict__ img, int
 // pass where it reads.  LDS ~52 KB -> 3 blocks per CU.
 // ---------------------------------------------------------------------------------------
 #define HS_MID_PMAX 128
+#define HS_MID_SROW 160   // 128 + 2 x 14 border samples, padded
 __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, PatchIO io, KpTables tb, DConsts k, int flags)
 {
    extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -438,7 +465,7 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
    float *s_misc = s_patch + HS_SIFT_ARR;
    float *s_tab = s_misc + 8;
    float *s_taps = s_tab + HS_SIFT_TAB;                // K <= 29 -> 32
-   float *s_srow = s_taps + 32;                        // 4 waves x 128
+   float *s_srow = s_taps + 32;                        // 4 waves x HS_MID_SROW
    __shared__ int s_flag;
 
    const int tid = threadIdx.x, wave = tid >> 6;
@@ -463,8 +490,8 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
       bool outside = false;
 #pragma unroll 1
       for (int yy = wave; yy < P; yy += 4)
-         hs_row_stream(img, imPitch, width, height, x, y, a11, a12, a21, a22, P, yy, scale, s_taps, K, s_srow + wave * HS_MID_PMAX,
-                       Tp + yy * HS_NEED, outside);
+         hs_row_stream<false, 1>(img, imPitch, width, height, x, y, a11, a12, a21, a22, P, yy, scale, s_taps, K, s_srow + wave * HS_MID_SROW,
+                              Tp + yy * HS_NEED, outside);
       if (outside) s_flag = 1;
       __syncthreads();
       if (s_flag != 0) {
@@ -484,6 +511,8 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
 //   wavefront per row (binary search of the row id in the prefix of P); writes T' rows to HBM.
 // k_patch_large_finish: one block per keypoint: column pass at the resample taps + SIFT.
 // ---------------------------------------------------------------------------------------
+#define HS_LARGE_CHUNK 16   // consecutive window rows per wavefront task
+
 __global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork pw, PatchIO io, KpTables tb, int srow_stride)
 {
    extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -492,24 +521,36 @@ __global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork
    const uint32_t *pre = io.row_prefix;
    const uint32_t row_lo = pre[io.item0], row_hi = pre[io.item1];
    const int imPitch = io.image.pitch, width = io.image.cols - 1, height = io.image.rows - 1;
-   for (uint32_t row = row_lo + blockIdx.x * 4 + wave; row < row_hi; row += gridDim.x * 4) {
-      // largest item index kk in [item0, item1) with pre[kk] <= row
+   const uint32_t ntasks = (row_hi - row_lo + HS_LARGE_CHUNK - 1) / HS_LARGE_CHUNK;
+   for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+      uint32_t row = row_lo + task * HS_LARGE_CHUNK;
+      const uint32_t row_end = min(row + HS_LARGE_CHUNK, row_hi);
+      // item of the first row: largest kk in [item0, item1) with pre[kk] <= row (one search per task)
       uint32_t lo = io.item0, hi = io.item1;
       while (hi - lo > 1) {
          const uint32_t mid = (lo + hi) >> 1;
          if (pre[mid] <= row) lo = mid; else hi = mid;
       }
-      const uint32_t h = pw.bin_items[(size_t)3 * pw.cap + lo];
-      const int yy = (int)(row - pre[lo]);
-      const int b = hl.meta[h] >> 8;
-      const int P0 = pw.P0[h], P = P0 + 2;
-      const float scale = (float)P0 / (float)HS_PATCH;
-      const int K = tb.patch_tap_k[(P0 - 1) >> 1];
-      const float *taps = tb.patch_taps + tb.patch_tap_off[(P0 - 1) >> 1];
-      bool outside = false;
-      hs_row_stream(io.image.img(b), imPitch, width, height, hl.x[h], hl.y[h], pw.A[4 * h], pw.A[4 * h + 1], pw.A[4 * h + 2],
-                    pw.A[4 * h + 3], P, yy, scale, taps, K, srow, io.trows + (size_t)(row - row_lo) * HS_NEED, outside);
-      if (outside) pw.alive[h] = 0;   // every writer stores the same value
+      uint32_t it = lo;
+      while (row < row_end) {
+         const uint32_t it_rows_end = min(pre[it + 1], row_end);
+         const uint32_t h = pw.bin_items[(size_t)3 * pw.cap + it];
+         const int b = hl.meta[h] >> 8;
+         const int P0 = pw.P0[h], P = P0 + 2;
+         const float scale = (float)P0 / (float)HS_PATCH;
+         const int K = tb.patch_tap_k[(P0 - 1) >> 1];
+         const float *taps = tb.patch_taps + tb.patch_tap_off[(P0 - 1) >> 1];
+         const float *img = io.image.img(b);
+         const float kx = hl.x[h], ky = hl.y[h];
+         const float a11 = pw.A[4 * h], a12 = pw.A[4 * h + 1], a21 = pw.A[4 * h + 2], a22 = pw.A[4 * h + 3];
+         const uint32_t first = pre[it];
+         bool outside = false;
+         for (; row < it_rows_end; row++)
+            hs_row_stream<true, 1>(img, imPitch, width, height, kx, ky, a11, a12, a21, a22, P, (int)(row - first), scale, taps, K, srow,
+                                io.trows + (size_t)(row - row_lo) * HS_NEED, outside);
+         if (outside) pw.alive[h] = 0;   // every writer stores the same value
+         it++;
+      }
    }
 }
 

@@ -659,3 +659,80 @@ __global__ __launch_bounds__(256) void k_blur_hess_march(DPlane in, DPlane outL,
       }
    }
 }
+
+// ---------------------------------------------------------------------------------------
+// k_extrema3: the three extrema scans of one octave (pyramid.cpp:245-250 for i = 2,3,4) in
+// one pass over the five response planes.  A block stages a 128 x 8 pixel tile (+1 halo) of
+// R0..R4 in LDS (each plane is read once from HBM/L2 instead of up to three times, and the
+// 27-neighbour tests hit LDS), then every thread tests its 4 pixels at the 3 levels.
+// Candidate = val > positiveThreshold and no strictly greater value among the 27 neighbours
+// (resp. < negativeThreshold and none strictly smaller), pyramid.cpp:39-61,211-218.
+// grid (ceil(cols/128), ceil(rows/8), B), block 256.
+// ---------------------------------------------------------------------------------------
+#define EX_TW 128
+#define EX_TH 8
+#define EX_LW (EX_TW + 2)
+#define EX_LH (EX_TH + 2)
+#define EX_LIST 768
+
+struct FivePlanes { DPlane R[5]; };
+
+__global__ __launch_bounds__(256) void k_extrema3(FivePlanes fp, float posThr, float negThr, CandList cl)
+{
+   __shared__ float s_r[5][EX_LH][EX_LW + 2];
+   const int tid = threadIdx.x, b = blockIdx.z;
+   const int x0 = blockIdx.x * EX_TW, y0 = blockIdx.y * EX_TH;
+   const int rows = fp.R[0].rows, cols = fp.R[0].cols, pitch = fp.R[0].pitch;
+   // stage: clamped coordinates (values outside the scanned region are never candidates' neighbours:
+   // the scan stays HS_BORDER pixels away from the frame)
+   for (int idx = tid; idx < 5 * EX_LH * EX_LW; idx += 256) {
+      const int p = idx / (EX_LH * EX_LW), rem = idx - p * (EX_LH * EX_LW);
+      const int ly = rem / EX_LW, lx = rem - ly * EX_LW;
+      const int gy = min(max(y0 - 1 + ly, 0), rows - 1), gx = min(max(x0 - 1 + lx, 0), cols - 1);
+      s_r[p][ly][lx] = fp.R[p].img(b)[(long long)gy * pitch + gx];
+   }
+   __shared__ uint2 s_list[EX_LIST];
+   __shared__ uint32_t s_n, s_base;
+   if (tid == 0) s_n = 0;
+   __syncthreads();
+   for (int k = 0; k < (EX_TW * EX_TH) / 256; k++) {
+      const int idx = tid + 256 * k;
+      const int ty = idx / EX_TW, tx = idx - ty * EX_TW;
+      const int r = y0 + ty, c = x0 + tx;
+      if (r < HS_BORDER || r >= rows - HS_BORDER || c < HS_BORDER || c >= cols - HS_BORDER) continue;
+#pragma unroll
+      for (int level = 0; level < 3; level++) {
+         const float val = s_r[level + 1][ty + 1][tx + 1];
+         const bool isPos = val > posThr, isNeg = val < negThr;
+         if (!(isPos || isNeg)) continue;
+         bool ok = true;
+#pragma unroll
+         for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+               for (int dx = 0; dx < 3; dx++) {
+                  const float v = s_r[level + p][ty + dy][tx + dx];
+                  ok = ok && (isPos ? !(v > val) : !(v < val));
+               }
+         if (!ok) continue;
+         const uint2 item = make_uint2(((uint32_t)b << 2) | (uint32_t)level, ((uint32_t)r << 16) | (uint32_t)c);
+         // one global atomic per BLOCK: candidates are collected in LDS first (a single global
+         // counter hit once per candidate serialises in L2: ~10 ns each, 0.9 ms per 4K image)
+         const uint32_t ls = atomicAdd(&s_n, 1u);
+         if (ls < EX_LIST) s_list[ls] = item;
+         else {
+            const uint32_t slot = atomicAdd(cl.count, 1u);
+            if (slot < cl.cap) cl.items[slot] = item;
+         }
+      }
+   }
+   __syncthreads();
+   const uint32_t n = min(s_n, (uint32_t)EX_LIST);
+   if (tid == 0 && n > 0) s_base = atomicAdd(cl.count, n);
+   __syncthreads();
+   for (uint32_t i = tid; i < n; i += 256) {
+      const uint32_t slot = s_base + i;
+      if (slot < cl.cap) cl.items[slot] = s_list[i];
+   }
+}

@@ -452,7 +452,7 @@ size_t small_lds_bytes(int bin)
    const int REGION = std::max(2 * WIN, 2 * HS_SIFT_ARR);
    return (size_t)(REGION + 128 + HS_SIFT_ARR + 8 + HS_SIFT_TAB + 16) * 4;
 }
-size_t mid_lds_bytes() { return (size_t)(HS_MID_PMAX * HS_NEED + 128 + HS_SIFT_ARR + 8 + HS_SIFT_TAB + 32 + 4 * HS_MID_PMAX) * 4; }
+size_t mid_lds_bytes() { return (size_t)(HS_MID_PMAX * HS_NEED + 128 + HS_SIFT_ARR + 8 + HS_SIFT_TAB + 32 + 4 * HS_MID_SROW) * 4; }
 
 // normalizeAffine + SIFT for every keypoint k_prepare_patch left alive.  The bin counts are
 // read back once (a ~20 us bubble per batch) so that every launch is sized exactly and the
@@ -488,7 +488,8 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
       std::vector<uint32_t> hpre(n3 + 1);
       HIP_TRY(hipMemcpyAsync(hpre.data(), pre, (size_t)(n3 + 1) * 4, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
-      const int srow_stride = round_up(c->max_p0 + 2, 64);
+      // window row + r replicated border samples on each side, r = K/2 <= (6 * 1.5 * P0/41 + 2) / 2
+      const int srow_stride = round_up((int)((c->max_p0 + 2) * 1.23) + 16, 64);
       const size_t rows_lds = (size_t)4 * srow_stride * 4;
       if (rows_lds > 160 * 1024) throw HsError(HESAFF_ERR_ARG, "image too large for the large-window row kernel");
       static size_t rows_lds_set = 0;
@@ -504,7 +505,7 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
          const uint32_t rows = hpre[k1] - hpre[k0];
          if (rows > budget) throw HsError(HESAFF_ERR_NOMEM, "window larger than the T' row buffer");
          io.item0 = k0; io.item1 = k1;
-         const uint32_t gblocks = std::min<uint32_t>((rows + 3) / 4, 256 * 12);
+         const uint32_t gblocks = std::min<uint32_t>((rows + 4 * HS_LARGE_CHUNK - 1) / (4 * HS_LARGE_CHUNK), 256 * 12);
          hipLaunchKernelGGL(k_patch_large_rows, dim3(gblocks), dim3(256), rows_lds, st, s.hl, s.pw, io, c->tables, srow_stride);
          hipLaunchKernelGGL(k_patch_large_finish, dim3(std::min<uint32_t>(k1 - k0, 256 * 8)), dim3(256), 0, st, s.hl, s.pw, io, c->tables, c->consts, flags);
          k0 = k1;
@@ -593,10 +594,10 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
       oc.words_per_image = c->words_per_image;
       oc.words_per_row = g.words_per_row;
       if (g.rows > 2 * HS_BORDER && g.cols > 2 * HS_BORDER) {
-         const dim3 grid((g.cols + 63) / 64, (g.rows + 3) / 4, B);
-         for (int level = 0; level < 3; level++)
-            hipLaunchKernelGGL(k_extrema, grid, dim3(64, 4), 0, st, Ro[level], Ro[level + 1], Ro[level + 2], level,
-                               c->consts.positiveThreshold, c->consts.negativeThreshold, s.cl);
+         FivePlanes fp;
+         for (int l = 0; l < 5; l++) fp.R[l] = Ro[l];
+         const dim3 grid((g.cols + EX_TW - 1) / EX_TW, (g.rows + EX_TH - 1) / EX_TH, B);
+         hipLaunchKernelGGL(k_extrema3, grid, dim3(256), 0, st, fp, c->consts.positiveThreshold, c->consts.negativeThreshold, s.cl);
          hipLaunchKernelGGL(k_localize, dim3(1024), dim3(256), 0, st, oc, s.cl, s.rl, c->consts);
          hipLaunchKernelGGL(k_dedupe, dim3(512), dim3(256), 0, st, oc, s.rl, (const uint32_t *)(cnt + 16 + o),
                             c->b_bitmask.as<unsigned long long>());
