@@ -73,6 +73,12 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
          throw HsError(HESAFF_ERR_DEVICE, m);
       }
       HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+      for (int i = 0; i < 3; i++) {
+         HIP_TRY(hipStreamCreateWithFlags(&c->side_streams[i], hipStreamNonBlocking));
+         HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+      }
+      HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+      if (const char *ov = getenv("HESAFF_OVERLAP")) c->no_overlap = atoi(ov) == 0;
       build_tables(c);
       refresh_tables_struct(c);
       memset(&c->tm, 0, sizeof c->tm);
@@ -105,6 +111,11 @@ void hesaff_destroy(hesaff_ctx *c)
                      &c->b_stage, &c->b_input, &c->t_mask_idx, &c->b_rowprefix, &c->b_trows};
    for (DevBuf *b : bufs) b->release();
    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+   for (int i = 0; i < 3; i++) {
+      if (c->side_streams[i]) { (void)hipStreamSynchronize(c->side_streams[i]); (void)hipStreamDestroy(c->side_streams[i]); }
+      if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+   }
+   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
    if (c->stream) (void)hipStreamDestroy(c->stream);
    delete c;
 }

@@ -161,8 +161,9 @@ __global__ __launch_bounds__(64) void k_affine_stage(DPlane P, const float *__re
 // interpolateCheckBorders.  Thread per keypoint.  Survivors are binned by window size P so
 // that each patch kernel launch has a uniform LDS footprint.
 // ---------------------------------------------------------------------------------------
-#define HS_NBINS 4   // window size P: 0: <=41, 1: <=64 (full blur in LDS); 2: <=128 (row-streamed, LDS); 3: larger (row-streamed, HBM)
-__host__ __device__ inline int hs_patch_bin(int P) { return P <= 41 ? 0 : (P <= 64 ? 1 : (P <= 128 ? 2 : 3)); }
+#define HS_NBINS 5   // window size P: 0: <=41, 1: <=64 (full blur in LDS); 2: <=128 (row-streamed, LDS); 3: <=512, 4: larger (row-streamed, HBM)
+#define HS_BIN3_PMAX 512
+__host__ __device__ inline int hs_patch_bin(int P) { return P <= 41 ? 0 : (P <= 64 ? 1 : (P <= 128 ? 2 : (P <= HS_BIN3_PMAX ? 3 : 4))); }
 
 struct PatchWork {
    float *A;            // [n][4] rectified a11,a12,a21,a22

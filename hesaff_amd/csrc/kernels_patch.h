@@ -26,6 +26,7 @@ struct PatchIO {
    float *trows;         // large bin: T' rows, [rows][82]
    const uint32_t *row_prefix;   // large bin: exclusive prefix of P over the bin's items (+ total)
    uint32_t item0, item1;        // large bin: item range of this round
+   int bin;                      // large bin index (3 or 4)
 };
 
 __device__ __forceinline__ float hs_serial_sum(const float *__restrict__ v, int n)
@@ -359,14 +360,25 @@ __global__ __launch_bounds__(256) void k_patch_small(HessList hl, PatchWork pw, 
    }
 }
 
-// blurred value at (row yy, needed-column q) from the row-pass plane Tp[rows][82] (column pass)
-__device__ __forceinline__ float hs_colpass(const float *__restrict__ Tp, int yy, int q, int pm, const float *__restrict__ taps, int r)
+// Four column-pass sums at once: rows (y0, y0+1) x needed columns (q, q+1) of the row-pass plane
+// Tp[rows][82].  Each sum keeps the SymmColumnFilter order d = k[r]*T[y]; d += k[r+j]*(T[y+j]+T[y-j]);
+// the four chains are interleaved so that their loads overlap.
+__device__ __forceinline__ void hs_colpass4(const float *__restrict__ Tp, int y0, int q, int pm, const float *__restrict__ taps, int r,
+                                            float &p00, float &p01, float &p10, float &p11)
 {
-   float d = taps[r] * Tp[(long long)min(max(yy, 0), pm) * HS_NEED + q];
+   const int ya = min(max(y0, 0), pm), yb = min(max(y0 + 1, 0), pm);
+   const float kc = taps[r];
+   float d00 = kc * Tp[(long long)ya * HS_NEED + q], d01 = kc * Tp[(long long)ya * HS_NEED + q + 1];
+   float d10 = kc * Tp[(long long)yb * HS_NEED + q], d11 = kc * Tp[(long long)yb * HS_NEED + q + 1];
 #pragma unroll 2
-   for (int j = 1; j <= r; j++)
-      d += taps[r + j] * (Tp[(long long)min(max(yy + j, 0), pm) * HS_NEED + q] + Tp[(long long)min(max(yy - j, 0), pm) * HS_NEED + q]);
-   return d;
+   for (int j = 1; j <= r; j++) {
+      const float kj = taps[r + j];
+      const float *ap = Tp + (long long)min(y0 + j, pm) * HS_NEED + q, *am = Tp + (long long)max(y0 - j, 0) * HS_NEED + q;
+      const float *bp = Tp + (long long)min(y0 + 1 + j, pm) * HS_NEED + q, *bm = Tp + (long long)max(y0 + 1 - j, 0) * HS_NEED + q;
+      const float s00 = ap[0] + am[0], s01 = ap[1] + am[1], s10 = bp[0] + bm[0], s11 = bp[1] + bm[1];
+      d00 += kj * s00; d01 += kj * s01; d10 += kj * s10; d11 += kj * s11;
+   }
+   p00 = d00; p01 = d01; p10 = d10; p11 = d11;
 }
 
 // resample of affine.cpp:131 when only the row-pass plane at the 82 needed columns exists:
@@ -384,9 +396,8 @@ __device__ __forceinline__ void hs_resample_reduced(const float *__restrict__ Tp
       float wx = rx + (float)i * scale, wy = ry + (float)i * 0.0f;
       const float fx = floorf(wx), fy = floorf(wy);
       wx -= fx; wy -= fy;
-      const int y0 = (int)fy;
-      const float p00 = hs_colpass(Tp, y0, 2 * ii, pm, taps, r), p01 = hs_colpass(Tp, y0, 2 * ii + 1, pm, taps, r);
-      const float p10 = hs_colpass(Tp, y0 + 1, 2 * ii, pm, taps, r), p11 = hs_colpass(Tp, y0 + 1, 2 * ii + 1, pm, taps, r);
+      float p00, p01, p10, p11;
+      hs_colpass4(Tp, (int)fy, 2 * ii, pm, taps, r, p00, p01, p10, p11);
       s_patch[idx] = (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + (wy) * ((1.0f - wx) * p10 + wx * p11);
    }
 }
@@ -534,7 +545,7 @@ __global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork
       uint32_t it = lo;
       while (row < row_end) {
          const uint32_t it_rows_end = min(pre[it + 1], row_end);
-         const uint32_t h = pw.bin_items[(size_t)3 * pw.cap + it];
+         const uint32_t h = pw.bin_items[(size_t)io.bin * pw.cap + it];
          const int b = hl.meta[h] >> 8;
          const int P0 = pw.P0[h], P = P0 + 2;
          const float scale = (float)P0 / (float)HS_PATCH;
@@ -563,7 +574,7 @@ __global__ __launch_bounds__(256, 5) void k_patch_large_finish(HessList hl, Patc
    SiftRegs rg;
    hs_sift_setup(tb, s_tab, rg);
    for (uint32_t it = io.item0 + blockIdx.x; it < io.item1; it += gridDim.x) {
-      const uint32_t h = pw.bin_items[(size_t)3 * pw.cap + it];
+      const uint32_t h = pw.bin_items[(size_t)io.bin * pw.cap + it];
       if (!pw.alive[h]) continue;   // uniform for the block
       const int P0 = pw.P0[h], P = P0 + 2;
       const float scale = (float)P0 / (float)HS_PATCH;

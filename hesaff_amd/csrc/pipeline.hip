@@ -140,6 +140,9 @@ struct hesaff_ctx {
    bool use_glds = false;          // HESAFF_PYR=glds: LDS-DMA prefetch variant of the marching kernel
    bool use_tile_kernel = false;   // HESAFF_PYR=tile: v1 LDS-tile pyramid kernel (cross-check / fallback)
    int band_rows = 16;             // HESAFF_BAND: minimum rows per wavefront band of k_blur_hess_march
+   hipStream_t side_streams[3] = {nullptr, nullptr, nullptr};
+   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+   bool no_overlap = false;        // HESAFF_OVERLAP=0: run the patch bins one after the other
    bool stop_after_detect = false; // HESAFF_STOP=detect
    bool debug = false;             // HESAFF_DEBUG=1: launch geometry on stderr
    int force_bands = 0;            // HESAFF_BANDS: force the band count of k_blur_hess_march (tuning)
@@ -475,21 +478,36 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
       set_dyn_lds(k_patch_mid, mid_lds_bytes());
       attrs = true;
    }
-   if (bins[0]) hipLaunchKernelGGL(k_patch_small<0>, dim3(std::min<uint32_t>(bins[0], 256 * 8)), dim3(256), small_lds_bytes(0), st, s.hl, s.pw, io, c->tables, c->consts, flags);
-   if (bins[1]) hipLaunchKernelGGL(k_patch_small<1>, dim3(std::min<uint32_t>(bins[1], 256 * 4)), dim3(256), small_lds_bytes(1), st, s.hl, s.pw, io, c->tables, c->consts, flags);
-   if (bins[2]) hipLaunchKernelGGL(k_patch_mid, dim3(std::min<uint32_t>(bins[2], 256 * 3)), dim3(256), mid_lds_bytes(), st, s.hl, s.pw, io, c->tables, c->consts, flags);
-   const uint32_t n3 = bins[3];
-   if (n3) {
-      // exclusive prefix of P over the large bin -> row ids
+   // The bins are independent (disjoint keypoints) and each kernel leaves CU resources idle
+   // (LDS- or latency-bound), so they run concurrently on side streams; the large-window bins
+   // stay on the main stream (they need host round trips for their row prefix).
+   hipStream_t s0 = st, s1 = st, s2 = st;
+   if (c->side_streams[0] && !c->no_overlap) {
+      HIP_TRY(hipEventRecord(c->ev_fork, st));
+      for (int i = 0; i < 3; i++) HIP_TRY(hipStreamWaitEvent(c->side_streams[i], c->ev_fork, 0));
+      s0 = c->side_streams[0]; s1 = c->side_streams[1]; s2 = c->side_streams[2];
+   }
+   if (bins[0]) hipLaunchKernelGGL(k_patch_small<0>, dim3(std::min<uint32_t>(bins[0], 256 * 8)), dim3(256), small_lds_bytes(0), s0, s.hl, s.pw, io, c->tables, c->consts, flags);
+   if (bins[1]) hipLaunchKernelGGL(k_patch_small<1>, dim3(std::min<uint32_t>(bins[1], 256 * 4)), dim3(256), small_lds_bytes(1), s1, s.hl, s.pw, io, c->tables, c->consts, flags);
+   if (bins[2]) hipLaunchKernelGGL(k_patch_mid, dim3(std::min<uint32_t>(bins[2], 256 * 3)), dim3(256), mid_lds_bytes(), s2, s.hl, s.pw, io, c->tables, c->consts, flags);
+   if (s0 != st) {
+      for (int i = 0; i < 3; i++) HIP_TRY(hipEventRecord(c->ev_join[i], c->side_streams[i]));
+   }
+   // large windows: bin 3 (P <= 512, small LDS rows -> full occupancy) and bin 4 (the rare huge ones)
+   for (int lb = 3; lb <= 4; lb++) {
+      const uint32_t n3 = bins[lb];
+      if (!n3) continue;
+      // exclusive prefix of P over the bin -> row ids
       c->b_rowprefix.ensure((size_t)(n3 + 1) * 4);
       uint32_t *pre = c->b_rowprefix.as<uint32_t>();
-      LoadLargeP lp; lp.items = s.pw.bin_items + (size_t)3 * s.pw.cap; lp.P0 = s.pw.P0;
+      LoadLargeP lp; lp.items = s.pw.bin_items + (size_t)lb * s.pw.cap; lp.P0 = s.pw.P0;
       exclusive_scan(c, lp, (long long)n3, pre, pre + n3);
       std::vector<uint32_t> hpre(n3 + 1);
       HIP_TRY(hipMemcpyAsync(hpre.data(), pre, (size_t)(n3 + 1) * 4, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       // window row + r replicated border samples on each side, r = K/2 <= (6 * 1.5 * P0/41 + 2) / 2
-      const int srow_stride = round_up((int)((c->max_p0 + 2) * 1.23) + 16, 64);
+      const int pmax = lb == 3 ? HS_BIN3_PMAX : c->max_p0 + 2;
+      const int srow_stride = round_up((int)(pmax * 1.23) + 16, 64);
       const size_t rows_lds = (size_t)4 * srow_stride * 4;
       if (rows_lds > 160 * 1024) throw HsError(HESAFF_ERR_ARG, "image too large for the large-window row kernel");
       static size_t rows_lds_set = 0;
@@ -498,6 +516,7 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
       c->b_trows.ensure((size_t)budget * HS_NEED * 4);
       io.trows = c->b_trows.as<float>();
       io.row_prefix = pre;
+      io.bin = lb;
       uint32_t k0 = 0;
       while (k0 < n3) {
          uint32_t k1 = k0 + 1;
@@ -505,12 +524,14 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
          const uint32_t rows = hpre[k1] - hpre[k0];
          if (rows > budget) throw HsError(HESAFF_ERR_NOMEM, "window larger than the T' row buffer");
          io.item0 = k0; io.item1 = k1;
-         const uint32_t gblocks = std::min<uint32_t>((rows + 4 * HS_LARGE_CHUNK - 1) / (4 * HS_LARGE_CHUNK), 256 * 12);
+         const uint32_t gblocks = std::min<uint32_t>((rows + 4 * HS_LARGE_CHUNK - 1) / (4 * HS_LARGE_CHUNK), 256 * 16);
          hipLaunchKernelGGL(k_patch_large_rows, dim3(gblocks), dim3(256), rows_lds, st, s.hl, s.pw, io, c->tables, srow_stride);
          hipLaunchKernelGGL(k_patch_large_finish, dim3(std::min<uint32_t>(k1 - k0, 256 * 8)), dim3(256), 0, st, s.hl, s.pw, io, c->tables, c->consts, flags);
          k0 = k1;
       }
    }
+   if (s0 != st)
+      for (int i = 0; i < 3; i++) HIP_TRY(hipStreamWaitEvent(st, c->ev_join[i], 0));
 }
 
 // The scale-space + detection part for the current plan; fills the ordered Hessian list.
