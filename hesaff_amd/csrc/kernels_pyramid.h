@@ -504,14 +504,19 @@ __device__ __forceinline__ v2f hs_hessian2(v2f ul, v2f uc, v2f ur, v2f ml, v2f m
    return ((Lxx * Lyy) - (Lxy * Lxy)) * norm2;
 }
 
-template <int K, bool WRITE_L, bool WRITE_R, bool WRITE_HALF>
+// WRITE_R0: additionally emit the response of the INPUT plane (R0 = hessianResponse(L0),
+// pyramid.cpp:230) from the input rows that pass through LDS anyway; used by the first blur
+// of every octave so that L0 is read from HBM once instead of twice.
+template <int K, bool WRITE_L, bool WRITE_R, bool WRITE_HALF, bool WRITE_R0 = false>
 __global__ __launch_bounds__(256) void k_blur_hess_march(DPlane in, DPlane outL, DPlane outR, DPlane outHalf,
-                                                          const float *__restrict__ taps, float norm2, int band_rows)
+                                                          const float *__restrict__ taps, float norm2, int band_rows,
+                                                          DPlane outR0 = DPlane(), float norm2_in = 0.0f)
 {
    constexpr int R = K >> 1;
    constexpr int U = K + 1;                      // ring size and unroll factor (even: static prefetch parity)
    constexpr int W0 = 8 - R;                     // row-buffer float of column x-R, relative to 4*lane
-   __shared__ __attribute__((aligned(16))) float s_rows[4][2][BM_ROWBUF];
+   constexpr int NB = WRITE_R0 ? 3 : 2;          // input rows kept in LDS
+   __shared__ __attribute__((aligned(16))) float s_rows[4][NB][BM_ROWBUF];
 
    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
    const int strip = blockIdx.x * 4 + wave;
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(256) void k_blur_hess_march(DPlane in, DPlane outL,
          load_row(t + 2, pre[u & 1]);    // row t's registers are free (staged during step t-1)
          // ---- row pass of input row t: acc = k[0]*S[x-R]; acc += k[j]*S[x-R+j], two columns per op ----
          {
-            const float *rb = s_rows[wave][u & 1] + 4 * lane + W0;
+            const float *rb = s_rows[wave][WRITE_R0 ? (t % 3) : (u & 1)] + 4 * lane + W0;
             v2f G[K + 2];                // G[i] = (S[x-R+i], S[x-R+i+1]), x = this lane's first column
 #pragma unroll
             for (int i = 0; i < K + 2; i++) {
@@ -654,8 +659,38 @@ __global__ __launch_bounds__(256) void k_blur_hess_march(DPlane in, DPlane outL,
 #pragma unroll
             for (int i = 0; i < 5; i++) { P2[i] = P1[i]; P1[i] = P0[i]; }
          }
+         // ---- response of the input plane: row y(t-1) from the input rows t-2, t-1, t in LDS ----
+         if (WRITE_R0) {
+            const int yr = yh0 - 1 - R + (t - 1);
+            if (yr >= yh0 && yr < yh1 && store_lane) {
+               v2f Q[3][5];
+#pragma unroll
+               for (int k = 0; k < 3; k++) {
+                  const float *rr = s_rows[wave][(t + 1 + k) % 3] + 4 * lane + 7;   // rows t-2, t-1, t ; column x-1
+                  const float e0 = rr[0], e5 = rr[5];
+                  const float4 m = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(rr + 1, 16));
+                  Q[k][0].x = e0; Q[k][0].y = m.x;
+                  Q[k][1].x = m.x; Q[k][1].y = m.y;
+                  Q[k][2].x = m.y; Q[k][2].y = m.z;
+                  Q[k][3].x = m.z; Q[k][3].y = m.w;
+                  Q[k][4].x = m.w; Q[k][4].y = e5;
+               }
+               const bool yin = yr > 0 && yr < rows - 1;
+               const v2f ra = hs_hessian2(Q[0][0], Q[0][1], Q[0][2], Q[1][0], Q[1][1], Q[1][2], Q[2][0], Q[2][1], Q[2][2], norm2_in);
+               const v2f rbv = hs_hessian2(Q[0][2], Q[0][3], Q[0][4], Q[1][2], Q[1][3], Q[1][4], Q[2][2], Q[2][3], Q[2][4], norm2_in);
+               const float r0 = (yin && cin0) ? ra.x : 0.0f, r1 = (yin && cin1) ? ra.y : 0.0f;
+               const float r2 = (yin && cin2) ? rbv.x : 0.0f, r3 = (yin && cin3) ? rbv.y : 0.0f;
+               float *o = outR0.img(b) + (long long)yr * outR0.pitch + xl;
+               if (full4) *reinterpret_cast<float4 *>(o) = make_float4(r0, r1, r2, r3);
+               else {
+                  const float v[4] = {r0, r1, r2, r3};
+                  for (int c = 0; c < 4; c++)
+                     if (xl + c < cols) o[c] = v[c];
+               }
+            }
+         }
          // ---- stage row t+1 (loaded during step t-1) for the next step ----
-         stage_row((u + 1) & 1, pre[(u + 1) & 1]);
+         stage_row(WRITE_R0 ? ((t + 1) % 3) : ((u + 1) & 1), pre[(u + 1) & 1]);
       }
    }
 }

@@ -360,14 +360,14 @@ enum { T_PYR = 0, T_DET = 1, T_AFF = 2, T_PATCH = 3, T_SIFT = 4, T_TOTAL = 5, T_
 // resident-block capacity (256 CUs x blocks per CU) is refilled, steps = rows a wavefront
 // marches through (band + K + 1 warm-up rows, padded to the unroll factor K + 1).  Pick the
 // band count that minimises it (ties: fewer, taller bands = less warm-up).
-template <int K, bool WL, bool WR, bool WH>
+template <int K, bool WL, bool WR, bool WH, bool WR0 = false>
 void launch_march(hesaff_ctx *c, const DPlane &in, const DPlane &outL, const DPlane &outR, const DPlane &outHalf, const float *taps,
-                  float norm2, int B)
+                  float norm2, int B, const DPlane &outR0 = DPlane(), float norm2_in = 0.0f)
 {
    static int occ = 0;   // resident 256-thread blocks per CU for this instantiation
    if (occ == 0) {
       int nb = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_blur_hess_march<K, WL, WR, WH>, 256, 0) != hipSuccess || nb < 1) nb = 3;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_blur_hess_march<K, WL, WR, WH, WR0>, 256, 0) != hipSuccess || nb < 1) nb = 3;
       occ = nb;
    }
    constexpr int U = K + 1;
@@ -387,7 +387,7 @@ void launch_march(hesaff_ctx *c, const DPlane &in, const DPlane &outL, const DPl
    const int band = (in.rows + best_nb - 1) / best_nb;
    if (c->debug) fprintf(stderr, "[hesaff] march K=%d %dx%d B=%d occ=%d bands=%d band=%d blocks=%lld\n", K, in.cols, in.rows, B, occ, best_nb, band, blocks_per_band * best_nb);
    const dim3 grid((strips + 3) / 4, (in.rows + band - 1) / band, B);
-   hipLaunchKernelGGL((k_blur_hess_march<K, WL, WR, WH>), grid, dim3(256), 0, c->stream, in, outL, outR, outHalf, taps, norm2, band);
+   hipLaunchKernelGGL((k_blur_hess_march<K, WL, WR, WH, WR0>), grid, dim3(256), 0, c->stream, in, outL, outR, outHalf, taps, norm2, band, outR0, norm2_in);
 }
 
 template <bool WL, bool WR, bool WH>
@@ -571,15 +571,25 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
       if (keep_all_planes) Lo[4] = make_plane(c->b_stage.as<float>(), B, g.rows, g.cols, g.pitch);
       for (int l = 0; l < 5; l++) Ro[l] = make_plane(c->b_R.as<float>() + l * planeF, B, g.rows, g.cols, g.pitch);
       t = tm.begin(T_PYR);
-      {
+      // R0 = hessianResponse(L0) (pyramid.cpp:230) is fused into the first blur launch when the
+      // marching kernel handles it (default sigmas: K = 9); otherwise a separate pass.
+      const bool fuse_r0 = !c->use_tile_kernel && c->pyr_K[1] == 9;
+      if (!fuse_r0) {
          const dim3 grid((g.cols + 255) / 256, g.rows, B);
          hipLaunchKernelGGL(k_hess, grid, dim3(256), 0, st, Lo[0], Ro[0], sc.norm2[0]);
       }
       const bool has_next = o + 1 < c->oct.size();
       for (int i = 1; i <= 4; i++) {
-         const double bytes = 12.0 * (double)B * g.rows * g.cols;
+         // algorithmic bytes of this launch: 12 N, + 8 N when it also produces R0
+         // (read L0 + write R0 of the stand-alone pass), + 2 N for the fused decimation
+         double bytes = 12.0 * (double)B * g.rows * g.cols;
+         if (i == 1 && fuse_r0) bytes += 8.0 * (double)B * g.rows * g.cols;
+         if (i == 3 && has_next) bytes += 2.0 * (double)B * g.rows * g.cols;
          const int tb = tm.begin(T_BLURHESS, bytes);
-         if (i < 3) launch_blur_hess<true, true, false>(c, Lo[i - 1], Lo[i], Ro[i], none, i, sc.norm2[i], B);
+         if (i == 1 && fuse_r0)
+            launch_march<9, true, true, false, true>(c, Lo[0], Lo[1], Ro[1], none, c->t_pyr_taps.as<float>() + c->pyr_tap_off[1], sc.norm2[1], B,
+                                                     Ro[0], sc.norm2[0]);
+         else if (i < 3) launch_blur_hess<true, true, false>(c, Lo[i - 1], Lo[i], Ro[i], none, i, sc.norm2[i], B);
          else if (i == 3) {
             if (has_next) launch_blur_hess<true, true, true>(c, Lo[2], Lo[3], Ro[3], c->L[(o + 1) * 3], 3, sc.norm2[3], B);
             else launch_blur_hess<true, true, false>(c, Lo[2], Lo[3], Ro[3], none, 3, sc.norm2[3], B);
