@@ -86,6 +86,7 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       if (const char *pk = getenv("HESAFF_PYR")) { c->use_tile_kernel = strcmp(pk, "tile") == 0; c->use_glds = strcmp(pk, "glds") == 0; }
       if (const char *bd = getenv("HESAFF_BAND")) c->band_rows = std::max(8, atoi(bd));
       c->debug = getenv("HESAFF_DEBUG") != nullptr;
+      if (const char *sf = getenv("HESAFF_SIFT")) c->fused_sift = strcmp(sf, "fused") == 0;
       if (const char *sp = getenv("HESAFF_STOP")) c->stop_after_detect = strcmp(sp, "detect") == 0;
       if (const char *wv = getenv("HESAFF_BANDS")) c->force_bands = std::max(0, atoi(wv));
    } catch (const HsError &e) {
@@ -108,7 +109,7 @@ void hesaff_destroy(hesaff_ctx *c)
                      &c->t_patch_off, &c->t_patch_k, &c->b_gray, &c->b_L, &c->b_L3, &c->b_R, &c->b_map, &c->b_bitmask, &c->b_prefix,
                      &c->b_blocksums, &c->b_counters, &c->b_cand, &c->b_rec_f, &c->b_rec_i, &c->b_rec_w, &c->b_hess_f, &c->b_hess_i,
                      &c->b_aff, &c->b_pw, &c->b_bins, &c->b_rank, &c->b_desc, &c->b_out, &c->b_starts, &c->b_scratch, &c->b_patches,
-                     &c->b_stage, &c->b_input, &c->t_mask_idx, &c->b_rowprefix, &c->b_trows};
+                     &c->b_stage, &c->b_input, &c->t_mask_idx, &c->b_rowprefix, &c->b_trows, &c->b_siftvec, &c->b_meanvar};
    for (DevBuf *b : bufs) b->release();
    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
    for (int i = 0; i < 3; i++) {
@@ -405,7 +406,7 @@ int hesaff_stage_normalize_affine(hesaff_ctx *c, const float *img, int rows, int
                       c->consts, c->tables, s.pw);
    c->b_patches.ensure((size_t)n * HS_PATCH_PIX * 4);
    HIP_TRY(hipMemsetAsync(c->b_patches.p, 0, (size_t)n * HS_PATCH_PIX * 4, st));
-   run_patch_stage(c, s, c->gray, c->b_patches.as<float>(), 0);
+   run_patch_stage(c, s, c->gray, c->b_patches.as<float>(), 0, 0);
    HIP_TRY(hipMemcpyAsync(alive.data(), s.pw.alive, (size_t)n * 4, hipMemcpyDeviceToHost, st));
    if (patches) HIP_TRY(hipMemcpyAsync(patches, c->b_patches.p, (size_t)n * HS_PATCH_PIX * 4, hipMemcpyDeviceToHost, st));
    HIP_TRY(hipStreamSynchronize(st));

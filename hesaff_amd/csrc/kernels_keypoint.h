@@ -175,10 +175,10 @@ struct PatchWork {
 };
 
 template <bool RECTIFY>
-__device__ __forceinline__ void hs_prepare_patch_body(const HessList &hl, uint32_t n, const AffineOut &aff, int imRows, int imCols,
+__device__ __forceinline__ void hs_prepare_patch_body(const HessList &hl, uint32_t h_lo, uint32_t n, const AffineOut &aff, int imRows, int imCols,
                                                       const DConsts &k, const KpTables &tb, const PatchWork &pw)
 {
-   for (uint32_t h0 = blockIdx.x * blockDim.x; h0 < n; h0 += gridDim.x * blockDim.x) {
+   for (uint32_t h0 = h_lo + blockIdx.x * blockDim.x; h0 < n; h0 += gridDim.x * blockDim.x) {
       const uint32_t h = h0 + threadIdx.x;
       const bool valid = h < n;
       int alive = 0, P0 = 0;
@@ -227,10 +227,10 @@ __device__ __forceinline__ void hs_prepare_patch_body(const HessList &hl, uint32
    }
 }
 
-__global__ __launch_bounds__(256) void k_prepare_patch(HessList hl, const uint32_t *__restrict__ n_ptr, AffineOut aff, int imRows,
+__global__ __launch_bounds__(256) void k_prepare_patch(HessList hl, uint32_t h_lo, const uint32_t *__restrict__ n_ptr, AffineOut aff, int imRows,
                                                        int imCols, DConsts k, KpTables tb, PatchWork pw)
 {
-   hs_prepare_patch_body<true>(hl, min(*n_ptr, hl.cap), aff, imRows, imCols, k, tb, pw);
+   hs_prepare_patch_body<true>(hl, h_lo, min(*n_ptr, hl.cap), aff, imRows, imCols, k, tb, pw);
 }
 
 // stage API: the rectified matrices are already in pw.A (normalizeAffine's own arguments)
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_prepare_patch_given_A(HessList hl, cons
 {
    AffineOut none;
    none.converged = nullptr; none.U = nullptr; none.iters = nullptr;
-   hs_prepare_patch_body<false>(hl, min(*n_ptr, hl.cap), none, imRows, imCols, k, tb, pw);
+   hs_prepare_patch_body<false>(hl, 0u, min(*n_ptr, hl.cap), none, imRows, imCols, k, tb, pw);
 }
 
 // ---------------------------------------------------------------------------------------

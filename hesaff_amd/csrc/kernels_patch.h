@@ -21,7 +21,8 @@
 
 struct PatchIO {
    DPlane image;         // original float image batch (normalizeAffine samples the ORIGINAL image, hesaff.cpp:82)
-   float *patches;       // optional [n][1681] output (stage API), may be null
+   float *patches;       // optional [n][1681] output, row index h - h_base; may be null
+   uint32_t h_base;
    uint8_t *desc;        // [n][128]
    float *trows;         // large bin: T' rows, [rows][82]
    const uint32_t *row_prefix;   // large bin: exclusive prefix of P over the bin's items (+ total)
@@ -235,7 +236,7 @@ __device__ __forceinline__ void hs_patch_finish(uint32_t h, float *s_patch, floa
                                                 const SiftRegs &rg, const PatchIO &io, const KpTables &tb, const DConsts &k, int flags)
 {
    if (io.patches)
-      for (int i = threadIdx.x; i < HS_PATCH_PIX; i += 256) io.patches[(size_t)h * HS_PATCH_PIX + i] = s_patch[i];
+      for (int i = threadIdx.x; i < HS_PATCH_PIX; i += 256) io.patches[(size_t)(h - io.h_base) * HS_PATCH_PIX + i] = s_patch[i];
    if (flags & 1) hs_sift_block(s_patch, s_va, s_vec, s_misc, s_tab, rg, tb, k, io.desc + (size_t)h * 128, flags);
    __syncthreads();
 }

@@ -20,6 +20,7 @@
 #include "host_tables.h"
 #include "kernels_keypoint.h"
 #include "kernels_patch.h"
+#include "kernels_sift.h"
 #include "kernels_pyramid.h"
 
 namespace hesaff {
@@ -132,7 +133,9 @@ struct hesaff_ctx {
    DevBuf b_input;          // staging for host images
    std::vector<hesaff_keypoint> host_keys;
    std::vector<int32_t> h_starts;
-   DevBuf t_mask_idx, b_rowprefix, b_trows;
+   DevBuf t_mask_idx, b_rowprefix, b_trows, b_siftvec, b_meanvar;
+   bool fused_sift = false;            // HESAFF_SIFT=fused: descriptor inside the patch kernels (v1 structure)
+   uint32_t sift_group_kpts = 2500000; // keypoints per patch-buffer group (6.7 KB each)
    uint32_t trows_budget = 4u << 20;   // rows of T' (82 floats each) per large-window round: 1.3 GB
 
    hesaff_timings tm;
@@ -460,13 +463,14 @@ size_t mid_lds_bytes() { return (size_t)(HS_MID_PMAX * HS_NEED + 128 + HS_SIFT_A
 // normalizeAffine + SIFT for every keypoint k_prepare_patch left alive.  The bin counts are
 // read back once (a ~20 us bubble per batch) so that every launch is sized exactly and the
 // large windows can be processed in rounds that fit the T' row buffer.
-void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *patches_out, int flags)
+void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *patches_out, uint32_t h_base, int flags)
 {
    hipStream_t st = c->stream;
    PatchIO io;
    memset(&io, 0, sizeof io);
    io.image = image;
    io.patches = patches_out;
+   io.h_base = h_base;
    io.desc = c->b_desc.as<uint8_t>();
    uint32_t bins[HS_NBINS];
    HIP_TRY(hipMemcpyAsync(bins, s.pw.bin_count, sizeof bins, hipMemcpyDeviceToHost, st));
@@ -708,11 +712,47 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       for (int l = 0; l < 3; l++) pt.L[o][l] = c->L[o * 3 + l];
    hipLaunchKernelGGL(k_affine, dim3(256 * 32), dim3(64), 0, st, pt, s.hl, (const uint32_t *)(cnt + 3), c->tables, c->consts, s.ao);
    tm.end(t);
-   t = tm.begin(T_PATCH);
-   hipLaunchKernelGGL(k_prepare_patch, dim3(1024), dim3(256), 0, st, s.hl, (const uint32_t *)(cnt + 3), s.ao, H, W, c->consts,
-                      c->tables, s.pw);
-   run_patch_stage(c, s, c->gray, nullptr, 1 | c->ablate);
-   tm.end(t);
+   if (c->fused_sift) {
+      // one kernel per window-size bin does normalizeAffine + SIFT (HESAFF_SIFT=fused)
+      t = tm.begin(T_PATCH);
+      hipLaunchKernelGGL(k_prepare_patch, dim3(1024), dim3(256), 0, st, s.hl, 0u, (const uint32_t *)(cnt + 3), s.ao, H, W, c->consts,
+                         c->tables, s.pw);
+      run_patch_stage(c, s, c->gray, nullptr, 0, 1 | c->ablate);
+      tm.end(t);
+   } else {
+      // split form: the bin kernels only extract the 41x41 patches (to HBM), the descriptor runs
+      // as three kernels with the parallel axis each part wants (kernels_sift.h).  Images are
+      // processed in groups so that the patch buffer stays bounded.
+      t = tm.begin(T_PATCH);
+      std::vector<int32_t> hs(B + 1);
+      HIP_TRY(hipMemcpyAsync(hs.data(), c->b_starts.p, (size_t)(B + 1) * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if ((uint32_t)hs[B] > c->cap) throw HsError(HESAFF_ERR_CAPACITY, "keypoint capacity exceeded; raise hesaff_params.max_kpts_per_mpx");
+      int g0 = 0;
+      while (g0 < B) {
+         int g1 = g0 + 1;
+         while (g1 < B && (uint32_t)(hs[g1 + 1] - hs[g0]) <= c->sift_group_kpts) g1++;
+         const uint32_t h_lo = (uint32_t)hs[g0], h_hi = (uint32_t)hs[g1], n = h_hi - h_lo;
+         g0 = g1;
+         if (n == 0) continue;
+         c->b_patches.ensure((size_t)n * HS_PATCH_PIX * 4);
+         c->b_siftvec.ensure((size_t)n * 128 * 4);
+         c->b_meanvar.ensure((size_t)n * 2 * 4);
+         HIP_TRY(hipMemsetAsync(cnt + 8, 0, HS_NBINS * 4, st));
+         HIP_TRY(hipMemcpyAsync(cnt + 5, &h_hi, 4, hipMemcpyHostToDevice, st));
+         hipLaunchKernelGGL(k_prepare_patch, dim3(1024), dim3(256), 0, st, s.hl, h_lo, (const uint32_t *)(cnt + 5), s.ao, H, W, c->consts,
+                            c->tables, s.pw);
+         run_patch_stage(c, s, c->gray, c->b_patches.as<float>(), h_lo, c->ablate & ~1);
+         SiftIO so;
+         so.patches = c->b_patches.as<float>(); so.alive = s.pw.alive; so.meanvar = c->b_meanvar.as<float>();
+         so.vec = c->b_siftvec.as<float>(); so.desc = c->b_desc.as<uint8_t>(); so.h_lo = h_lo; so.h_hi = h_hi;
+         const uint32_t nb64 = (n + 63) / 64;
+         hipLaunchKernelGGL(k_sift_meanvar, dim3(nb64), dim3(64), 0, st, so, c->tables);
+         hipLaunchKernelGGL(k_sift_hist, dim3(std::min<uint32_t>(n, 256 * 7 * 4)), dim3(64), 0, st, so, c->tables, c->ablate);
+         hipLaunchKernelGGL(k_sift_quantize, dim3(nb64), dim3(64), 0, st, so, c->consts);
+      }
+      tm.end(t);
+   }
    t = tm.begin(T_SIFT);
    // final stable compaction (hesaff.cpp:87: keys.push_back in detection order)
    LoadFlagI32 lf; lf.p = s.pw.alive;
