@@ -19,6 +19,16 @@
 #define HS_SIFT_TAB 232    // 4 x 41 bin/weight entries + 4 x 16 cell weights
 #define HS_NEED 82         // blurred columns (and rows) the 41x41 resample reads: 2 per output
 
+// Ordering of LDS traffic between the lanes of ONE wavefront: the LDS executes a wave's
+// instructions in order, so a compiler-level barrier (no reordering of memory operations) plus
+// draining the LDS counter is enough.  A wavefront-scope C++ fence would also wait for the
+// wave's outstanding GLOBAL stores (vmcnt(0)) - a full memory round trip per window row.
+#define HS_WAVE_LDS_SYNC()                                  \
+   do {                                                     \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+      __builtin_amdgcn_wave_barrier();                      \
+   } while (0)
+
 struct PatchIO {
    DPlane image;         // original float image batch (normalizeAffine samples the ORIGINAL image, hesaff.cpp:82)
    float *patches;       // optional [n][1681] output, row index h - h_base; may be null
@@ -312,13 +322,26 @@ __global__ __launch_bounds__(256) void k_patch_small(HessList hl, PatchWork pw, 
          const int r = K >> 1;
          if (tid < K) s_taps[tid] = taps_g[tid];
          // 1. warp, affine.cpp:126 ; touching the image boundary rejects the keypoint
+         // all gathers of a batch are issued before the first use (clamped index, branch-free tap)
          bool outside = false;
-         for (int idx = tid; idx < P * P; idx += 256) {
-            const int jj = idx / P, ii = idx - jj * P;
-            const int j = jj - half, i = ii - half;
-            const float rx = x + (float)j * a12, ry = y + (float)j * a22;
-            const float wx = rx + (float)i * a11, wy = ry + (float)i * a21;
-            S[idx] = (flags & 16) ? 1.0f : hs_bilinear(img, imPitch, width, height, wx, wy, outside);
+         constexpr int WNIT = BIN == 0 ? 7 : 8;
+         const int PP = P * P;
+         for (int ib = 0; ib < PP; ib += 256 * WNIT) {
+            float wv[WNIT];
+#pragma unroll
+            for (int it = 0; it < WNIT; it++) {
+               const int idx = min(ib + tid + 256 * it, PP - 1);
+               const int jj = idx / P, ii = idx - jj * P;
+               const int j = jj - half, i = ii - half;
+               const float rx = x + (float)j * a12, ry = y + (float)j * a22;
+               const float wx = rx + (float)i * a11, wy = ry + (float)i * a21;
+               wv[it] = (flags & 16) ? 1.0f : hs_bilinear(img, imPitch, width, height, wx, wy, outside);
+            }
+#pragma unroll
+            for (int it = 0; it < WNIT; it++) {
+               const int idx = ib + tid + 256 * it;
+               if (idx < PP) S[idx] = wv[it];
+            }
          }
          if (outside) s_flag = 1;
          __syncthreads();
@@ -407,9 +430,11 @@ __device__ __forceinline__ void hs_resample_reduced(const float *__restrict__ Tp
 // needed columns.  Called by all 64 lanes of a wave.  The LDS row is stored with r replicated
 // border samples on either side (BORDER_REPLICATE), so the tap loop has no index clamps:
 //   srow[r + x] = S[x],  srow[0..r) = S[0],  srow[r+P .. r+P+r) = S[P-1]     (needs P + 2r floats)
+// The image gathers of NIT x 64 window pixels are issued together (branch-free taps, clamped
+// index) before any of them is used; taps are read from LDS (`taps`, broadcast reads).
 // Each lane owns output q = lane and (lanes < 18) q = lane + 64; the two accumulation chains
 // are interleaved.
-template <bool UNIFORM_GLOBAL_TAPS, int BIL_UNROLL>
+template <int NIT>
 __device__ __forceinline__ void hs_row_stream(const float *__restrict__ img, int imPitch, int width, int height, float x, float y,
                                               float a11, float a12, float a21, float a22, int P, int yy, float scale,
                                               const float *__restrict__ taps, int K, float *__restrict__ srow, float *__restrict__ out82,
@@ -418,47 +443,44 @@ __device__ __forceinline__ void hs_row_stream(const float *__restrict__ img, int
    const int lane = threadIdx.x & 63, half = P >> 1, pm = P - 1, r = K >> 1;
    const int j = yy - half;
    const float rx = x + (float)j * a12, ry = y + (float)j * a22;
-#pragma unroll BIL_UNROLL
-   for (int xx = lane; xx < P; xx += 64) {
-      const int i = xx - half;
-      const float wx = rx + (float)i * a11, wy = ry + (float)i * a21;
-      srow[r + xx] = hs_bilinear(img, imPitch, width, height, wx, wy, outside);
+   for (int xb = 0; xb < P; xb += 64 * NIT) {
+      float v[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+         const int xx = min(xb + lane + 64 * it, pm);   // lanes past the row re-sample its last pixel (not stored)
+         const int i = xx - half;
+         const float wx = rx + (float)i * a11, wy = ry + (float)i * a21;
+         v[it] = hs_bilinear(img, imPitch, width, height, wx, wy, outside);
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+         const int xx = xb + lane + 64 * it;
+         if (xx < P) srow[r + xx] = v[it];
+      }
    }
-   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-   __builtin_amdgcn_wave_barrier();
-   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+   HS_WAVE_LDS_SYNC();
    {
       const float first = srow[r], last = srow[r + pm];
       for (int i = lane; i < r; i += 64) { srow[i] = first; srow[r + P + i] = last; }
    }
-   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-   __builtin_amdgcn_wave_barrier();
-   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-   const float *tp = taps;
-   if (UNIFORM_GLOBAL_TAPS) {
-      // the tap pointer is the same in every lane: make that visible so the loads are scalar
-      const unsigned long long a = (unsigned long long)taps;
-      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-      tp = (const float *)(((unsigned long long)hi << 32) | lo);
-   }
+   HS_WAVE_LDS_SYNC();
    const float c0 = (float)half;
    const int q0 = lane, q1 = lane + 64;
    const bool has1 = q1 < HS_NEED;
    const float w0 = c0 + (float)((q0 >> 1) - 20) * scale, w1 = c0 + (float)(((has1 ? q1 : q0) >> 1) - 20) * scale;
    const int x0 = min(max((int)floorf(w0) + (q0 & 1), 0), pm), x1 = min(max((int)floorf(w1) + (q1 & 1), 0), pm);
    const float *s0 = srow + x0, *s1 = srow + x1;   // s[jt] = S[clamp(x - r + jt)]
-   float t0 = tp[0] * s0[0], t1 = tp[0] * s1[0];
+   float t0 = taps[0] * s0[0], t1 = taps[0] * s1[0];
 #pragma unroll 8
    for (int jt = 1; jt < K; jt++) {
-      const float k = tp[jt];
+      const float k = taps[jt];
       const float p0 = k * s0[jt], p1 = k * s1[jt];
       t0 += p0;
       t1 += p1;
    }
    out82[q0] = t0;
    if (has1) out82[q1] = t1;
-   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-   __builtin_amdgcn_wave_barrier();
+   HS_WAVE_LDS_SYNC();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -468,26 +490,38 @@ __device__ __forceinline__ void hs_row_stream(const float *__restrict__ img, int
 // ---------------------------------------------------------------------------------------
 #define HS_MID_PMAX 128
 #define HS_MID_SROW 160   // 128 + 2 x 14 border samples, padded
+#define HS_BIG_SROW 704   // 512 + 2 x 57 border samples, padded
+#define HS_BIG_TAPS 128   // K <= 113 for P <= 512
+
+// PMAX = 128: bin 2, T' (P x 82) in LDS.  PMAX = 512: bin 3, same structure with T' in a
+// per-block slot of HBM scratch (io.trows), written and re-read by the same block (L2-hot).
+template <int PMAX>
 __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, PatchIO io, KpTables tb, DConsts k, int flags)
 {
+   constexpr bool TPG = PMAX > HS_MID_PMAX;
+   constexpr int BIN = TPG ? 3 : 2;
+   constexpr int SROW = TPG ? HS_BIG_SROW : HS_MID_SROW;
+   constexpr int NTAP = TPG ? HS_BIG_TAPS : 32;
+   constexpr int REGION = TPG ? 2 * HS_SIFT_ARR : HS_MID_PMAX * HS_NEED;   // T' in LDS, or just the SIFT scratch
+   constexpr int NIT = TPG ? 8 : 2;
    extern __shared__ __attribute__((aligned(16))) float smem[];
-   float *Tp = smem;                                   // 128 x 82 (later the SIFT scratch)
-   float *s_vec = smem + HS_MID_PMAX * HS_NEED;        // 10496: multiple of 4
+   float *s_vec = smem + REGION;
    float *s_patch = s_vec + 128;
    float *s_misc = s_patch + HS_SIFT_ARR;
    float *s_tab = s_misc + 8;
-   float *s_taps = s_tab + HS_SIFT_TAB;                // K <= 29 -> 32
-   float *s_srow = s_taps + 32;                        // 4 waves x HS_MID_SROW
+   float *s_taps = s_tab + HS_SIFT_TAB;
+   float *s_srow = s_taps + NTAP;                      // 4 waves x SROW
    __shared__ int s_flag;
+   float *Tp = TPG ? io.trows + (size_t)blockIdx.x * ((size_t)PMAX * HS_NEED) : smem;
 
    const int tid = threadIdx.x, wave = tid >> 6;
    SiftRegs rg;
    hs_sift_setup(tb, s_tab, rg);
-   const uint32_t cnt = min(pw.bin_count[2], pw.cap);
+   const uint32_t cnt = min(pw.bin_count[BIN], pw.cap);
    const int imPitch = io.image.pitch, width = io.image.cols - 1, height = io.image.rows - 1;
 
    for (uint32_t wi = blockIdx.x; wi < cnt; wi += gridDim.x) {
-      const uint32_t h = pw.bin_items[(size_t)2 * pw.cap + wi];
+      const uint32_t h = pw.bin_items[(size_t)BIN * pw.cap + wi];
       const int b = hl.meta[h] >> 8;
       const float *img = io.image.img(b);
       const float x = hl.x[h], y = hl.y[h];
@@ -502,16 +536,16 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
       bool outside = false;
 #pragma unroll 1
       for (int yy = wave; yy < P; yy += 4)
-         hs_row_stream<false, 1>(img, imPitch, width, height, x, y, a11, a12, a21, a22, P, yy, scale, s_taps, K, s_srow + wave * HS_MID_SROW,
-                              Tp + yy * HS_NEED, outside);
+         hs_row_stream<NIT>(img, (flags & 16) ? 0 : imPitch, (flags & 16) ? 1 : width, (flags & 16) ? 1 : height, x, y, a11, a12, a21, a22, P, yy,
+                            scale, s_taps, (flags & 8) ? 3 : K, s_srow + wave * SROW, Tp + (size_t)yy * HS_NEED, outside);
       if (outside) s_flag = 1;
-      __syncthreads();
+      __syncthreads();   // workgroup-scope release/acquire: the T' rows of all four waves are visible
       if (s_flag != 0) {
          if (tid == 0) pw.alive[h] = 0;
          __syncthreads();
          continue;
       }
-      hs_resample_reduced(Tp, P, scale, s_taps, K >> 1, s_patch);
+      hs_resample_reduced(Tp, P, scale, s_taps, (flags & 32) ? 1 : (K >> 1), s_patch);
       __syncthreads();
       hs_patch_finish(h, s_patch, smem, s_vec, s_misc, s_tab, rg, io, tb, k, flags);
    }
@@ -525,11 +559,13 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
 // ---------------------------------------------------------------------------------------
 #define HS_LARGE_CHUNK 16   // consecutive window rows per wavefront task
 
-__global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork pw, PatchIO io, KpTables tb, int srow_stride)
+// dynamic LDS: per wave  srow_stride floats (window row + borders)  +  tap_stride floats (taps)
+__global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork pw, PatchIO io, KpTables tb, int srow_stride, int tap_stride, int flags)
 {
    extern __shared__ __attribute__((aligned(16))) float smem[];
    const int wave = threadIdx.x >> 6;
-   float *srow = smem + (size_t)wave * srow_stride;
+   float *srow = smem + (size_t)wave * (srow_stride + tap_stride);
+   float *stap = srow + srow_stride;
    const uint32_t *pre = io.row_prefix;
    const uint32_t row_lo = pre[io.item0], row_hi = pre[io.item1];
    const int imPitch = io.image.pitch, width = io.image.cols - 1, height = io.image.rows - 1;
@@ -556,10 +592,13 @@ __global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork
          const float kx = hl.x[h], ky = hl.y[h];
          const float a11 = pw.A[4 * h], a12 = pw.A[4 * h + 1], a21 = pw.A[4 * h + 2], a22 = pw.A[4 * h + 3];
          const uint32_t first = pre[it];
+         // this item's taps -> the wave's LDS tap buffer (broadcast reads in the tap loop)
+         for (int i = threadIdx.x & 63; i < K; i += 64) stap[i] = taps[i];
+         HS_WAVE_LDS_SYNC();
          bool outside = false;
          for (; row < it_rows_end; row++)
-            hs_row_stream<true, 1>(img, imPitch, width, height, kx, ky, a11, a12, a21, a22, P, (int)(row - first), scale, taps, K, srow,
-                                io.trows + (size_t)(row - row_lo) * HS_NEED, outside);
+            hs_row_stream<8>((flags & 16) ? img + 0 * (row & 1) : img, (flags & 16) ? 0 : imPitch, (flags & 16) ? 1 : width, (flags & 16) ? 1 : height, kx, ky, a11, a12, a21, a22, P, (int)(row - first), scale, stap, (flags & 8) ? 3 : K, srow,
+                             io.trows + (size_t)(row - row_lo) * HS_NEED, outside);
          if (outside) pw.alive[h] = 0;   // every writer stores the same value
          it++;
       }

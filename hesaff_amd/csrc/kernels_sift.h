@@ -6,9 +6,10 @@
 //                   (helpers.cpp:253-266, 1245 terms each).  One THREAD per keypoint runs the
 //                   chain, 64 keypoints per wavefront at full lane efficiency; the patch columns
 //                   are transposed through LDS so that global loads stay coalesced.
-//  k_sift_hist      one WAVEFRONT per keypoint: normalise, gradients + hm_atan2f, then the
-//                   4x4x8 histogram with lane = (spatial cell, orientation pair) walking its
-//                   16x16 support in raster order (siftdesc.cpp:51-81).  No inter-wave barriers.
+//  k_sift_grad      one THREAD per pixel: normalise, gradient, hm_atan2f -> (mask*grad, o) pairs.
+//  k_sift_hist      one WAVEFRONT per keypoint, no LDS: the 4x4x8 histogram with lane =
+//                   (spatial cell, orientation pair) walking its 16x16 support in raster order
+//                   (siftdesc.cpp:51-81), operands streamed from HBM/L2.
 //  k_sift_quantize  normalize / clip / renormalize / quantise (siftdesc.cpp:83-113): the two
 //                   128-term sequential sums again run one thread per keypoint.
 //
@@ -68,84 +69,91 @@ __global__ __launch_bounds__(64) void k_sift_meanvar(SiftIO io, KpTables tb)
    }
 }
 
-// one wavefront (64-thread block) per keypoint, grid-stride over [h_lo, h_hi)
-__global__ __launch_bounds__(64) void k_sift_hist(SiftIO io, KpTables tb, int flags)
+// k_sift_grad: photometric normalisation (helpers.cpp:269-280) + gradient magnitude and
+// orientation (siftdesc.cpp:123-137) + the per-pixel factors of samplePatch, one THREAD per
+// pixel, reading the patch through the caches.  Output: vo[k][pixel] = (mask*grad, o) with
+// o = float(8 * (atan2f + 2 pi) / (2 pi)) evaluated in double like the reference.
+// grid (ceil(1681/256), n), block 256.
+__global__ __launch_bounds__(256) void k_sift_grad(SiftIO io, KpTables tb, float2 *__restrict__ vo)
 {
-   __shared__ __attribute__((aligned(16))) float s_vo[2 * HS_SIFT_ARR];
-   __shared__ float s_patch[HS_SIFT_ARR], s_tab[HS_SIFT_TAB];
-   const int tid = threadIdx.x;
-   {
-      int *s_bin0 = reinterpret_cast<int *>(s_tab), *s_bin1 = s_bin0 + HS_PATCH;
-      float *s_w0 = s_tab + 2 * HS_PATCH, *s_w1 = s_tab + 3 * HS_PATCH, *s_cw = s_tab + 4 * HS_PATCH + 4;
-      if (tid < HS_PATCH) { s_bin0[tid] = tb.bin0[tid]; s_bin1[tid] = tb.bin1[tid]; s_w0[tid] = tb.w0[tid]; s_w1[tid] = tb.w1[tid]; }
-      __syncthreads();
-      // cell weights, see hs_sift_setup
-      const int b = tid >> 4, i = tid & 15, r = 8 * b + i;
-      float w = 0.0f;
-      if (r < HS_PATCH) {
-         if (s_bin0[r] == 8 * b && s_w0[r] != 0.0f) w = s_w0[r];
-         else if (s_bin1[r] == 8 * b) w = s_w1[r];
-      }
-      s_cw[tid] = w;
-      __syncthreads();
+   const uint32_t k = blockIdx.y;
+   const uint32_t h = io.h_lo + k;
+   if (!io.alive[h]) return;
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= HS_PATCH_PIX) return;
+   const float mean = io.meanvar[2 * (size_t)k], var = io.meanvar[2 * (size_t)k + 1];
+   const float *gp = io.patches + (size_t)k * HS_PATCH_PIX;
+   const bool norm = !((double)var < 0.0001);
+   const float fac = 50.0f / var;
+   const int r = i / HS_PATCH, c = i - r * HS_PATCH;
+   // the four (or three) patch values the gradient stencil reads, affine.cpp:14-33 convention
+   const int cl = (c == 0) ? c : c - 1, cr = (c == HS_PATCH - 1) ? c : c + 1;
+   const int ru = (r == 0) ? r : r - 1, rd = (r == HS_PATCH - 1) ? r : r + 1;
+   float vl = gp[r * HS_PATCH + cl], vr = gp[r * HS_PATCH + cr], vu = gp[ru * HS_PATCH + c], vd = gp[rd * HS_PATCH + c];
+   if (norm) {
+      vl = 128 + fac * (vl - mean); vl = vl > 255 ? 255.0f : vl; vl = vl < 0 ? 0.0f : vl;
+      vr = 128 + fac * (vr - mean); vr = vr > 255 ? 255.0f : vr; vr = vr < 0 ? 0.0f : vr;
+      vu = 128 + fac * (vu - mean); vu = vu > 255 ? 255.0f : vu; vu = vu < 0 ? 0.0f : vu;
+      vd = 128 + fac * (vd - mean); vd = vd > 255 ? 255.0f : vd; vd = vd < 0 ? 0.0f : vd;
    }
-   const float *s_cw = s_tab + 4 * HS_PATCH + 4;
+   const float gx = vr - vl, gy = vd - vu;
+   const float grad = sqrtf(gx * gx + gy * gy);
+   const float ori = hm_atan2f(gy, gx);
+   const float o = (float)((double)8.0f * ((double)ori + 2 * 3.14159265358979323846) / (2 * 3.14159265358979323846));
+   vo[(size_t)k * HS_PATCH_PIX + i] = make_float2(tb.sift_mask[i] * grad, o);
+}
+
+// k_sift_hist: samplePatch (siftdesc.cpp:51-81), one WAVEFRONT per keypoint with no LDS, so
+// that 8 wavefronts per SIMD hide each other's latencies: lane = (spatial cell, orientation
+// pair {q, q+4}) walks the cell's 16x16 pixel support in raster order, reading (mask*grad, o)
+// pairs from HBM/L2 sixteen at a time.  Each pixel adds at most one term per histogram bin;
+// where the reference adds nothing this adds 0.0f (x + 0 == x).
+// grid-stride over [h_lo, h_hi), block 64.
+__global__ __launch_bounds__(64, 8) void k_sift_hist(SiftIO io, KpTables tb, const float2 *__restrict__ vo, int flags)
+{
+   const int tid = threadIdx.x;
    const int cell = tid >> 2, cb_r = cell >> 2, cb_c = cell & 3;
    const int bA = tid & 3, bB = bA + 4;
-   const int pA = (bA + 7) & 7, pB = (bB + 7) & 7;
-   float cwc[16];
+   const int pA = (bA + 7) & 7, pB = (bB + 7) & 7;   // a pixel whose bo0 is pA feeds bin bA through bo1
+   // cell weights: spatial bin b gets w1[r] from rows with bin1 == b, w0[r] from rows with bin0 == b
+   // (siftdesc.cpp:55-56,61-62); clamped bins carry weight 0
+   float cwr[16], cwc[16];
 #pragma unroll
-   for (int j = 0; j < 16; j++) cwc[j] = s_cw[cb_c * 16 + j];
-   float2 *vo = reinterpret_cast<float2 *>(s_vo);
-
+   for (int i = 0; i < 16; i++) {
+      const int r = 8 * cb_r + i, c = 8 * cb_c + i;
+      float wr = 0.0f, wc = 0.0f;
+      if (r < HS_PATCH) {
+         if (tb.bin0[r] == 8 * cb_r && tb.w0[r] != 0.0f) wr = tb.w0[r];
+         else if (tb.bin1[r] == 8 * cb_r) wr = tb.w1[r];
+      }
+      if (c < HS_PATCH) {
+         if (tb.bin0[c] == 8 * cb_c && tb.w0[c] != 0.0f) wc = tb.w0[c];
+         else if (tb.bin1[c] == 8 * cb_c) wc = tb.w1[c];
+      }
+      cwr[i] = wr; cwc[i] = wc;
+   }
    for (uint32_t h = io.h_lo + blockIdx.x; h < io.h_hi; h += gridDim.x) {
-      if (!io.alive[h]) continue;   // block-uniform
+      if (!io.alive[h]) continue;   // wave-uniform
       const uint32_t k = h - io.h_lo;
-      const float mean = io.meanvar[2 * (size_t)k], var = io.meanvar[2 * (size_t)k + 1];
-      const float *gp = io.patches + (size_t)k * HS_PATCH_PIX;
-      // photometric normalisation helpers.cpp:269-280 while loading
-      if (!((double)var < 0.0001)) {
-         const float fac = 50.0f / var;
-         for (int i = tid; i < HS_PATCH_PIX; i += 64) {
-            float v = 128 + fac * (gp[i] - mean);
-            if (v > 255) v = 255;
-            if (v < 0) v = 0;
-            s_patch[i] = v;
-         }
-      } else {
-         for (int i = tid; i < HS_PATCH_PIX; i += 64) s_patch[i] = gp[i];
-      }
-      __syncthreads();
-      // gradient magnitude / orientation siftdesc.cpp:123-137
-#pragma unroll 1
-      for (int i = tid; i < HS_PATCH_PIX; i += 64) {
-         const int r = i / HS_PATCH, c = i - r * HS_PATCH;
-         float gx, gy;
-         hs_grad(s_patch, HS_PATCH, r, c, gx, gy);
-         const float grad = sqrtf(gx * gx + gy * gy);
-         const float ori = hm_atan2f(gy, gx);
-         const float o = (float)((double)8.0f * ((double)ori + 2 * 3.14159265358979323846) / (2 * 3.14159265358979323846));
-         vo[i] = make_float2(tb.sift_mask[i] * grad, o);
-      }
-      __syncthreads();
-      // samplePatch siftdesc.cpp:51-81, see hs_sift_block
+      const float2 *base = vo + (size_t)k * HS_PATCH_PIX + (8 * cb_r) * HS_PATCH + 8 * cb_c;
       float accA = 0.0f, accB = 0.0f;
       if (!(flags & 2)) {
+#pragma unroll
          for (int i = 0; i < 16; i++) {
-            const int r = 8 * cb_r + i;
-            const float wr = s_cw[cb_r * 16 + i];
-            const float2 *row = vo + r * HS_PATCH + 8 * cb_c;
-#pragma unroll 8
+            const float wr = cwr[i];
+            float2 q[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) q[j] = base[i * HS_PATCH + j];
+#pragma unroll
             for (int j = 0; j < 16; j++) {
-               const float2 q = row[j];
-               const float wc = cwc[j] * q.x;
+               const float wc = cwc[j] * q[j].x;   // w[c] * (mask*grad)
                const float v = wr * wc;
-               const int bo0 = ((int)q.y) & 7;
-               const float wo1 = q.y - (float)(int)q.y;
+               const int bo0 = ((int)q[j].y) & 7;
+               const float wo1 = q[j].y - (float)(int)q[j].y;
                const float wo0 = 1.0f - wo1;
                const bool pos = v > 0.0f;
-               const float t0 = pos ? v * wo0 : 0.0f;
-               const float t1 = pos ? v * wo1 : 0.0f;
+               const float t0 = pos ? v * wo0 : 0.0f;   // goes to bin bo0
+               const float t1 = pos ? v * wo1 : 0.0f;   // goes to bin bo0 + 1
                accA += (bo0 == bA) ? t0 : ((bo0 == pA) ? t1 : 0.0f);
                accB += (bo0 == bB) ? t0 : ((bo0 == pB) ? t1 : 0.0f);
             }
@@ -153,7 +161,6 @@ __global__ __launch_bounds__(64) void k_sift_hist(SiftIO io, KpTables tb, int fl
       }
       io.vec[(size_t)k * 128 + cell * 8 + bA] = accA;
       io.vec[(size_t)k * 128 + cell * 8 + bB] = accB;
-      __syncthreads();
    }
 }
 

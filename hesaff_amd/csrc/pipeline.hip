@@ -133,9 +133,9 @@ struct hesaff_ctx {
    DevBuf b_input;          // staging for host images
    std::vector<hesaff_keypoint> host_keys;
    std::vector<int32_t> h_starts;
-   DevBuf t_mask_idx, b_rowprefix, b_trows, b_siftvec, b_meanvar;
+   DevBuf t_mask_idx, b_rowprefix, b_trows, b_trows3, b_siftvec, b_meanvar, b_siftvo;
    bool fused_sift = false;            // HESAFF_SIFT=fused: descriptor inside the patch kernels (v1 structure)
-   uint32_t sift_group_kpts = 2500000; // keypoints per patch-buffer group (6.7 KB each)
+   uint32_t sift_group_kpts = 2000000; // keypoints per patch-buffer group (6.7 KB patch + 13.4 KB gradient pairs each)
    uint32_t trows_budget = 4u << 20;   // rows of T' (82 floats each) per large-window round: 1.3 GB
 
    hesaff_timings tm;
@@ -459,6 +459,7 @@ size_t small_lds_bytes(int bin)
    return (size_t)(REGION + 128 + HS_SIFT_ARR + 8 + HS_SIFT_TAB + 16) * 4;
 }
 size_t mid_lds_bytes() { return (size_t)(HS_MID_PMAX * HS_NEED + 128 + HS_SIFT_ARR + 8 + HS_SIFT_TAB + 32 + 4 * HS_MID_SROW) * 4; }
+size_t big_lds_bytes() { return (size_t)(2 * HS_SIFT_ARR + 128 + HS_SIFT_ARR + 8 + HS_SIFT_TAB + HS_BIG_TAPS + 4 * HS_BIG_SROW) * 4; }
 
 // normalizeAffine + SIFT for every keypoint k_prepare_patch left alive.  The bin counts are
 // read back once (a ~20 us bubble per batch) so that every launch is sized exactly and the
@@ -479,7 +480,8 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
    if (!attrs) {
       set_dyn_lds(k_patch_small<0>, small_lds_bytes(0));
       set_dyn_lds(k_patch_small<1>, small_lds_bytes(1));
-      set_dyn_lds(k_patch_mid, mid_lds_bytes());
+      set_dyn_lds(k_patch_mid<HS_MID_PMAX>, mid_lds_bytes());
+      set_dyn_lds(k_patch_mid<HS_BIN3_PMAX>, big_lds_bytes());
       attrs = true;
    }
    // The bins are independent (disjoint keypoints) and each kernel leaves CU resources idle
@@ -493,12 +495,20 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
    }
    if (bins[0]) hipLaunchKernelGGL(k_patch_small<0>, dim3(std::min<uint32_t>(bins[0], 256 * 8)), dim3(256), small_lds_bytes(0), s0, s.hl, s.pw, io, c->tables, c->consts, flags);
    if (bins[1]) hipLaunchKernelGGL(k_patch_small<1>, dim3(std::min<uint32_t>(bins[1], 256 * 4)), dim3(256), small_lds_bytes(1), s1, s.hl, s.pw, io, c->tables, c->consts, flags);
-   if (bins[2]) hipLaunchKernelGGL(k_patch_mid, dim3(std::min<uint32_t>(bins[2], 256 * 3)), dim3(256), mid_lds_bytes(), s2, s.hl, s.pw, io, c->tables, c->consts, flags);
+   if (bins[2]) hipLaunchKernelGGL(k_patch_mid<HS_MID_PMAX>, dim3(std::min<uint32_t>(bins[2], 256 * 3)), dim3(256), mid_lds_bytes(), s2, s.hl, s.pw, io, c->tables, c->consts, flags);
+   if (bins[3]) {
+      // bin 3 (128 < P <= 512): same kernel, T' rows in a per-block HBM slot; runs on the main stream
+      const uint32_t nblk = std::min<uint32_t>(bins[3], 256 * 4);
+      c->b_trows3.ensure((size_t)nblk * HS_BIN3_PMAX * HS_NEED * 4);
+      PatchIO io3 = io;
+      io3.trows = c->b_trows3.as<float>();
+      hipLaunchKernelGGL(k_patch_mid<HS_BIN3_PMAX>, dim3(nblk), dim3(256), big_lds_bytes(), st, s.hl, s.pw, io3, c->tables, c->consts, flags);
+   }
    if (s0 != st) {
       for (int i = 0; i < 3; i++) HIP_TRY(hipEventRecord(c->ev_join[i], c->side_streams[i]));
    }
    // large windows: bin 3 (P <= 512, small LDS rows -> full occupancy) and bin 4 (the rare huge ones)
-   for (int lb = 3; lb <= 4; lb++) {
+   for (int lb = 4; lb <= 4; lb++) {
       const uint32_t n3 = bins[lb];
       if (!n3) continue;
       // exclusive prefix of P over the bin -> row ids
@@ -512,7 +522,8 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
       // window row + r replicated border samples on each side, r = K/2 <= (6 * 1.5 * P0/41 + 2) / 2
       const int pmax = lb == 3 ? HS_BIN3_PMAX : c->max_p0 + 2;
       const int srow_stride = round_up((int)(pmax * 1.23) + 16, 64);
-      const size_t rows_lds = (size_t)4 * srow_stride * 4;
+      const int tap_stride = round_up((int)(pmax * 0.22) + 8, 64);   // K = odd(int(6 * 1.5 * P0/41 + 1))
+      const size_t rows_lds = (size_t)4 * (srow_stride + tap_stride) * 4;
       if (rows_lds > 160 * 1024) throw HsError(HESAFF_ERR_ARG, "image too large for the large-window row kernel");
       static size_t rows_lds_set = 0;
       if (rows_lds > rows_lds_set) { set_dyn_lds(k_patch_large_rows, rows_lds); rows_lds_set = rows_lds; }
@@ -529,7 +540,7 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
          if (rows > budget) throw HsError(HESAFF_ERR_NOMEM, "window larger than the T' row buffer");
          io.item0 = k0; io.item1 = k1;
          const uint32_t gblocks = std::min<uint32_t>((rows + 4 * HS_LARGE_CHUNK - 1) / (4 * HS_LARGE_CHUNK), 256 * 16);
-         hipLaunchKernelGGL(k_patch_large_rows, dim3(gblocks), dim3(256), rows_lds, st, s.hl, s.pw, io, c->tables, srow_stride);
+         hipLaunchKernelGGL(k_patch_large_rows, dim3(gblocks), dim3(256), rows_lds, st, s.hl, s.pw, io, c->tables, srow_stride, tap_stride, flags);
          hipLaunchKernelGGL(k_patch_large_finish, dim3(std::min<uint32_t>(k1 - k0, 256 * 8)), dim3(256), 0, st, s.hl, s.pw, io, c->tables, c->consts, flags);
          k0 = k1;
       }
@@ -748,7 +759,9 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
          so.vec = c->b_siftvec.as<float>(); so.desc = c->b_desc.as<uint8_t>(); so.h_lo = h_lo; so.h_hi = h_hi;
          const uint32_t nb64 = (n + 63) / 64;
          hipLaunchKernelGGL(k_sift_meanvar, dim3(nb64), dim3(64), 0, st, so, c->tables);
-         hipLaunchKernelGGL(k_sift_hist, dim3(std::min<uint32_t>(n, 256 * 7 * 4)), dim3(64), 0, st, so, c->tables, c->ablate);
+         c->b_siftvo.ensure((size_t)n * HS_PATCH_PIX * 8);
+         hipLaunchKernelGGL(k_sift_grad, dim3((HS_PATCH_PIX + 255) / 256, n), dim3(256), 0, st, so, c->tables, c->b_siftvo.as<float2>());
+         hipLaunchKernelGGL(k_sift_hist, dim3(std::min<uint32_t>(n, 256 * 32 * 2)), dim3(64), 0, st, so, c->tables, (const float2 *)c->b_siftvo.p, c->ablate);
          hipLaunchKernelGGL(k_sift_quantize, dim3(nb64), dim3(64), 0, st, so, c->consts);
       }
       tm.end(t);

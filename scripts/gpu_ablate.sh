@@ -5,7 +5,7 @@ for ab in "$@"; do
 done
 python3 - "$@" <<'PY'
 import csv, sys
-keys=('k_patch_small<0>','k_patch_small<1>','k_patch_mid','k_patch_large_rows','k_patch_large_finish','k_affine','k_extrema','k_localize')
+keys=('k_patch_small<0>','k_patch_small<1>','k_patch_mid<128>','k_patch_mid<512>','k_patch_large_rows','k_patch_large_finish','k_affine','k_sift_hist','k_sift_meanvar')
 for ab in sys.argv[1:]:
     rows=list(csv.DictReader(open(f'gpurun_out/abl_{ab}/p_kernel_stats.csv')))
     d={}
