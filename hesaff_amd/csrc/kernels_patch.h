@@ -478,8 +478,12 @@ __device__ __forceinline__ void hs_row_stream(const float *__restrict__ img, int
       t0 += p0;
       t1 += p1;
    }
-   out82[q0] = t0;
-   if (has1) out82[q1] = t1;
+   if (out82) {
+      out82[q0] = t0;
+      if (has1) out82[q1] = t1;
+   } else {
+      srow[0] = t0 + t1;   // ablation only: keep the sums alive without the global store
+   }
    HS_WAVE_LDS_SYNC();
 }
 
@@ -535,9 +539,9 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
       __syncthreads();
       bool outside = false;
 #pragma unroll 1
-      for (int yy = wave; yy < P; yy += 4)
+      for (int yy = wave; yy < ((flags & 64) ? 4 : P); yy += 4)
          hs_row_stream<NIT>(img, (flags & 16) ? 0 : imPitch, (flags & 16) ? 1 : width, (flags & 16) ? 1 : height, x, y, a11, a12, a21, a22, P, yy,
-                            scale, s_taps, (flags & 8) ? 3 : K, s_srow + wave * SROW, Tp + (size_t)yy * HS_NEED, outside);
+                            scale, s_taps, (flags & 8) ? 3 : K, s_srow + wave * SROW, (flags & 128) ? nullptr : Tp + (size_t)yy * HS_NEED, outside);
       if (outside) s_flag = 1;
       __syncthreads();   // workgroup-scope release/acquire: the T' rows of all four waves are visible
       if (s_flag != 0) {
