@@ -87,6 +87,7 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       if (const char *bd = getenv("HESAFF_BAND")) c->band_rows = std::max(8, atoi(bd));
       c->debug = getenv("HESAFF_DEBUG") != nullptr;
       if (const char *sf = getenv("HESAFF_SIFT")) c->fused_sift = strcmp(sf, "fused") == 0;
+      if (const char *gk = getenv("HESAFF_GROUP")) c->sift_group_kpts = (uint32_t)std::max(1000, atoi(gk));
       if (const char *sp = getenv("HESAFF_STOP")) c->stop_after_detect = strcmp(sp, "detect") == 0;
       if (const char *wv = getenv("HESAFF_BANDS")) c->force_bands = std::max(0, atoi(wv));
    } catch (const HsError &e) {

@@ -26,6 +26,7 @@ struct SiftIO {
    uint32_t h_lo, h_hi;
 };
 
+#define HS_VO_PITCH 1682   // float2 per keypoint in the gradient-pair buffer (16-byte aligned rows)
 #define SM_TILE 64
 #define SM_STRIDE 65   // LDS row stride: lane k walking row k is conflict-free
 
@@ -100,56 +101,63 @@ __global__ __launch_bounds__(256) void k_sift_grad(SiftIO io, KpTables tb, float
    const float grad = sqrtf(gx * gx + gy * gy);
    const float ori = hm_atan2f(gy, gx);
    const float o = (float)((double)8.0f * ((double)ori + 2 * 3.14159265358979323846) / (2 * 3.14159265358979323846));
-   vo[(size_t)k * HS_PATCH_PIX + i] = make_float2(tb.sift_mask[i] * grad, o);
+   vo[(size_t)k * HS_VO_PITCH + i] = make_float2(tb.sift_mask[i] * grad, o);
 }
 
-// k_sift_hist: samplePatch (siftdesc.cpp:51-81), one WAVEFRONT per keypoint with no LDS, so
-// that 8 wavefronts per SIMD hide each other's latencies: lane = (spatial cell, orientation
-// pair {q, q+4}) walks the cell's 16x16 pixel support in raster order, reading (mask*grad, o)
-// pairs from HBM/L2 sixteen at a time.  Each pixel adds at most one term per histogram bin;
-// where the reference adds nothing this adds 0.0f (x + 0 == x).
-// grid-stride over [h_lo, h_hi), block 64.
-__global__ __launch_bounds__(64, 8) void k_sift_hist(SiftIO io, KpTables tb, const float2 *__restrict__ vo, int flags)
+// k_sift_hist: samplePatch (siftdesc.cpp:51-81), one WAVEFRONT per keypoint.  The keypoint's
+// 13.4 KB of (mask*grad, o) pairs are staged in LDS with coalesced 16-byte loads that are all
+// in flight together (one HBM latency per keypoint), then lane = (spatial cell, orientation
+// pair {q, q+4}) walks the cell's 16x16 pixel support in raster order out of LDS.  Each pixel
+// adds at most one term per histogram bin; where the reference adds nothing this adds 0.0f.
+// 13.7 KB of LDS per wavefront -> 11 wavefronts per CU.  grid-stride over [h_lo, h_hi), block 64.
+#define SH_F4 841   // float4 per keypoint: 1681 float2 = 3362 floats, rounded up (the buffer is padded)
+__global__ __launch_bounds__(64) void k_sift_hist(SiftIO io, KpTables tb, const float2 *__restrict__ vo, int flags)
 {
+   __shared__ __attribute__((aligned(16))) float4 s_q[SH_F4 + 3];
+   __shared__ float s_cw[64];   // [spatial bin][offset 0..15]
    const int tid = threadIdx.x;
    const int cell = tid >> 2, cb_r = cell >> 2, cb_c = cell & 3;
    const int bA = tid & 3, bB = bA + 4;
    const int pA = (bA + 7) & 7, pB = (bB + 7) & 7;   // a pixel whose bo0 is pA feeds bin bA through bo1
-   // cell weights: spatial bin b gets w1[r] from rows with bin1 == b, w0[r] from rows with bin0 == b
-   // (siftdesc.cpp:55-56,61-62); clamped bins carry weight 0
-   float cwr[16], cwc[16];
-#pragma unroll
-   for (int i = 0; i < 16; i++) {
-      const int r = 8 * cb_r + i, c = 8 * cb_c + i;
-      float wr = 0.0f, wc = 0.0f;
+   {
+      // cell weights: spatial bin b gets w1[r] from rows with bin1 == b, w0[r] from rows with bin0 == b
+      // (siftdesc.cpp:55-56,61-62); clamped bins carry weight 0
+      const int b = tid >> 4, i = tid & 15, r = 8 * b + i;
+      float w = 0.0f;
       if (r < HS_PATCH) {
-         if (tb.bin0[r] == 8 * cb_r && tb.w0[r] != 0.0f) wr = tb.w0[r];
-         else if (tb.bin1[r] == 8 * cb_r) wr = tb.w1[r];
+         if (tb.bin0[r] == 8 * b && tb.w0[r] != 0.0f) w = tb.w0[r];
+         else if (tb.bin1[r] == 8 * b) w = tb.w1[r];
       }
-      if (c < HS_PATCH) {
-         if (tb.bin0[c] == 8 * cb_c && tb.w0[c] != 0.0f) wc = tb.w0[c];
-         else if (tb.bin1[c] == 8 * cb_c) wc = tb.w1[c];
-      }
-      cwr[i] = wr; cwc[i] = wc;
+      s_cw[tid] = w;
+      __syncthreads();
    }
+   float cwc[16];
+#pragma unroll
+   for (int j = 0; j < 16; j++) cwc[j] = s_cw[cb_c * 16 + j];
+   const float2 *s_vo = reinterpret_cast<const float2 *>(s_q);
    for (uint32_t h = io.h_lo + blockIdx.x; h < io.h_hi; h += gridDim.x) {
       if (!io.alive[h]) continue;   // wave-uniform
       const uint32_t k = h - io.h_lo;
-      const float2 *base = vo + (size_t)k * HS_PATCH_PIX + (8 * cb_r) * HS_PATCH + 8 * cb_c;
+      // stage: 841 float4 (the row pitch of vo is HS_VO_PITCH float2, 16-byte aligned)
+      const float4 *g4 = reinterpret_cast<const float4 *>(vo + (size_t)k * HS_VO_PITCH);
+      float4 stg[14];
+#pragma unroll
+      for (int m = 0; m < 14; m++) { const int i4 = min(tid + 64 * m, SH_F4 - 1); stg[m] = g4[i4]; }
+#pragma unroll
+      for (int m = 0; m < 14; m++) { const int i4 = tid + 64 * m; if (i4 < SH_F4) s_q[i4] = stg[m]; }
+      __syncthreads();
       float accA = 0.0f, accB = 0.0f;
       if (!(flags & 2)) {
-#pragma unroll
          for (int i = 0; i < 16; i++) {
-            const float wr = cwr[i];
-            float2 q[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) q[j] = base[i * HS_PATCH + j];
-#pragma unroll
+            const float wr = s_cw[cb_r * 16 + i];
+            const float2 *row = s_vo + (8 * cb_r + i) * HS_PATCH + 8 * cb_c;
+#pragma unroll 8
             for (int j = 0; j < 16; j++) {
-               const float wc = cwc[j] * q[j].x;   // w[c] * (mask*grad)
+               const float2 q = row[j];
+               const float wc = cwc[j] * q.x;   // w[c] * (mask*grad)
                const float v = wr * wc;
-               const int bo0 = ((int)q[j].y) & 7;
-               const float wo1 = q[j].y - (float)(int)q[j].y;
+               const int bo0 = ((int)q.y) & 7;
+               const float wo1 = q.y - (float)(int)q.y;
                const float wo0 = 1.0f - wo1;
                const bool pos = v > 0.0f;
                const float t0 = pos ? v * wo0 : 0.0f;   // goes to bin bo0
@@ -161,6 +169,7 @@ __global__ __launch_bounds__(64, 8) void k_sift_hist(SiftIO io, KpTables tb, con
       }
       io.vec[(size_t)k * 128 + cell * 8 + bA] = accA;
       io.vec[(size_t)k * 128 + cell * 8 + bB] = accB;
+      __syncthreads();
    }
 }
 

@@ -759,9 +759,9 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
          so.vec = c->b_siftvec.as<float>(); so.desc = c->b_desc.as<uint8_t>(); so.h_lo = h_lo; so.h_hi = h_hi;
          const uint32_t nb64 = (n + 63) / 64;
          hipLaunchKernelGGL(k_sift_meanvar, dim3(nb64), dim3(64), 0, st, so, c->tables);
-         c->b_siftvo.ensure((size_t)n * HS_PATCH_PIX * 8);
+         c->b_siftvo.ensure((size_t)n * HS_VO_PITCH * 8 + 64);
          hipLaunchKernelGGL(k_sift_grad, dim3((HS_PATCH_PIX + 255) / 256, n), dim3(256), 0, st, so, c->tables, c->b_siftvo.as<float2>());
-         hipLaunchKernelGGL(k_sift_hist, dim3(std::min<uint32_t>(n, 256 * 32 * 2)), dim3(64), 0, st, so, c->tables, (const float2 *)c->b_siftvo.p, c->ablate);
+         hipLaunchKernelGGL(k_sift_hist, dim3(std::min<uint32_t>(n, 256 * 11 * 4)), dim3(64), 0, st, so, c->tables, (const float2 *)c->b_siftvo.p, c->ablate);
          hipLaunchKernelGGL(k_sift_quantize, dim3(nb64), dim3(64), 0, st, so, c->consts);
       }
       tm.end(t);
