@@ -25,12 +25,25 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def pmc_traffic(batch, width, height, launches_per_step):
+    """HBM bytes per k_blur_hess_march launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc
+    passes of this same command, see profiles/README.md); None when no matching profile is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if (d.get("batch"), d.get("width"), d.get("height")) != (batch, width, height):
+        return None
+    return d.get("bytes_per_launch_avg")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -119,9 +132,11 @@ def main():
                        "images_per_gpu_per_step": B, "width": W, "height": H, "sharding": "image-level, %d rank(s)" % world,
                        "descriptors_per_image": tot_desc / max(tot_imgs, 1)},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
-            "roofline": {"bound": "hbm", "kernel": "k_blur_hess (Gaussian + det-of-Hessian, 12 B/px algorithmic)",
+            "roofline": {"bound": "hbm",
+                         "kernel": "k_blur_hess_march (Gaussian + det-of-Hessian; 4 launches per octave = 58 B/px algorithmic: "
+                                   "12 B/px each + 8 B/px for the fused R0 + 2 B/px for the fused decimation)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "launches": bh_launches,
+                         "traffic": pmc_traffic(B, W, H, bh_launches // max(args.steps, 1)), "launches": bh_launches,
                          "avg_launch_ms": bh_ms / max(bh_launches, 1), "bytes_per_launch_avg": bh_bytes / max(bh_launches, 1)},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -1,0 +1,34 @@
+# Round-end evidence: rocprofv3 kernel stats of the bench command + HBM traffic PMC passes.
+# usage: bash scripts/gpu_profile_round.sh <round tag>     (run through gpurun; results land in gpurun_out/)
+cd $GRAFT_REPO_ROOT
+TAG=$1
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/fetch.log
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/write.log
+cd $GRAFT_REPO_ROOT
+python3 - $OUT <<'PY'
+import csv, json, sys, collections
+out = sys.argv[1]
+def agg(path, counter):
+    tot = 0.0; n = 0
+    for r in csv.DictReader(open(path)):
+        if 'k_blur_hess_march' in r['Kernel_Name'] and r['Counter_Name'] == counter:
+            # the initial blur launch (WRITE_L only, no response) is not one of the 58 B/px launches
+            if 'true, false, false, false' in r['Kernel_Name']: continue
+            tot += float(r['Counter_Value']); n += 1
+    return tot, n
+f, nf = agg(out + '/fetch/p_counter_collection.csv', 'FETCH_SIZE')
+w, nw = agg(out + '/write/p_counter_collection.csv', 'WRITE_SIZE')
+res = {"fetch_kb_total": f, "write_kb_total": w, "launches": nf,
+       "bytes_per_launch_avg": (f + w) * 1024.0 / max(nf, 1),
+       "note": "FETCH_SIZE / WRITE_SIZE in KB as reported by rocprofv3 on gfx950, summed over the 58 B/px k_blur_hess_march launches of one bench step; uncorrected (dword-wide loads: the 1/2 FETCH_SIZE under-count of 16 B/lane streams does not apply, see profiles/README.md)"}
+print(json.dumps(res))
+json.dump(res, open(out + '/pmc_traffic_raw.json', 'w'), indent=1)
+rows = list(csv.DictReader(open(out + '/stats/p_kernel_stats.csv')))
+for r in rows[:14]:
+    print('%-70s calls=%5s total=%9.3f ms avg=%9.1f us' % (r['Name'].split('(')[0][:70], r['Calls'], float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3))
+PY
+cat $OUT/bench_under_rocprof.json | head -c 1500
