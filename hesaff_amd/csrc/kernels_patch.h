@@ -270,7 +270,7 @@ __device__ __forceinline__ void hs_resample_full(const float *S, int P, float sc
 // (imageToPatchScale <= 0.4, affine.cpp:137-141).  grid-stride over the bin's work list.
 // LDS: S | T (WIN floats each; later the SIFT scratch), s_vec, s_patch, s_misc, s_tab, taps.
 // ---------------------------------------------------------------------------------------
-template <int BIN>
+template <int BIN, bool FUSED>
 __global__ __launch_bounds__(256) void k_patch_small(HessList hl, PatchWork pw, PatchIO io, KpTables tb, DConsts k, int flags)
 {
    extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -278,16 +278,17 @@ __global__ __launch_bounds__(256) void k_patch_small(HessList hl, PatchWork pw, 
    constexpr int WIN = (PMAX * PMAX + 3) & ~3;
    constexpr int REGION = (2 * WIN > 2 * HS_SIFT_ARR) ? 2 * WIN : 2 * HS_SIFT_ARR;
    float *S = smem, *T = smem + WIN;
-   float *s_vec = smem + REGION;
-   float *s_patch = s_vec + 128;
-   float *s_misc = s_patch + HS_SIFT_ARR;
-   float *s_tab = s_misc + 8;
-   float *s_taps = s_tab + HS_SIFT_TAB;   // K <= 15
+   // extraction only (FUSED = false): just S | T | taps; the resampled patch goes straight to HBM
+   float *s_vec = smem + (FUSED ? REGION : 2 * WIN);
+   float *s_patch = FUSED ? s_vec + 128 : nullptr;
+   float *s_misc = FUSED ? s_patch + HS_SIFT_ARR : nullptr;
+   float *s_tab = FUSED ? s_misc + 8 : nullptr;
+   float *s_taps = FUSED ? s_tab + HS_SIFT_TAB : s_vec;   // K <= 15
    __shared__ int s_flag;
 
    const int tid = threadIdx.x;
    SiftRegs rg;
-   hs_sift_setup(tb, s_tab, rg);
+   if (FUSED) hs_sift_setup(tb, s_tab, rg);
    const uint32_t cnt = min(pw.bin_count[BIN], pw.cap);
    const int imRows = io.image.rows, imCols = io.image.cols, imPitch = io.image.pitch;
    const int width = imCols - 1, height = imRows - 1;
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256) void k_patch_small(HessList hl, PatchWork pw, 
             const float rx = x + (float)j * b12, ry = y + (float)j * b22;
             const float wx = rx + (float)i * b11, wy = ry + (float)i * b21;
             bool outside = false;
-            s_patch[idx] = hs_bilinear(img, imPitch, width, height, wx, wy, outside);
+            (FUSED ? s_patch : io.patches + (size_t)(h - io.h_base) * HS_PATCH_PIX)[idx] = hs_bilinear(img, imPitch, width, height, wx, wy, outside);
          }
          __syncthreads();
       } else {
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void k_patch_small(HessList hl, PatchWork pw, 
             }
             __syncthreads();
             // 3. resample, affine.cpp:131
-            hs_resample_full(S, P, scale, s_patch);
+            hs_resample_full(S, P, scale, FUSED ? s_patch : io.patches + (size_t)(h - io.h_base) * HS_PATCH_PIX);
             __syncthreads();
          }
       }
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void k_patch_small(HessList hl, PatchWork pw, 
          __syncthreads();
          continue;
       }
-      hs_patch_finish(h, s_patch, smem, s_vec, s_misc, s_tab, rg, io, tb, k, flags);
+      if (FUSED) hs_patch_finish(h, s_patch, smem, s_vec, s_misc, s_tab, rg, io, tb, k, flags);
    }
 }
 
@@ -499,28 +500,32 @@ __device__ __forceinline__ void hs_row_stream(const float *__restrict__ img, int
 
 // PMAX = 128: bin 2, T' (P x 82) in LDS.  PMAX = 512: bin 3, same structure with T' in a
 // per-block slot of HBM scratch (io.trows), written and re-read by the same block (L2-hot).
-template <int PMAX>
+// FUSED = false: extraction only (the descriptor runs in kernels_sift.h), no SIFT scratch in LDS.
+// TPG: T' rows in a per-block HBM slot instead of LDS (always for PMAX = 512).
+template <int PMAX, bool FUSED, bool TPG = (PMAX > 128)>
 __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, PatchIO io, KpTables tb, DConsts k, int flags)
 {
-   constexpr bool TPG = PMAX > HS_MID_PMAX;
-   constexpr int BIN = TPG ? 3 : 2;
-   constexpr int SROW = TPG ? HS_BIG_SROW : HS_MID_SROW;
-   constexpr int NTAP = TPG ? HS_BIG_TAPS : 32;
-   constexpr int REGION = TPG ? 2 * HS_SIFT_ARR : HS_MID_PMAX * HS_NEED;   // T' in LDS, or just the SIFT scratch
-   constexpr int NIT = TPG ? 8 : 2;
+   constexpr bool BIG = PMAX > HS_MID_PMAX;
+   static_assert(TPG || !BIG, "P > 128 does not fit T' in LDS");
+   constexpr int BIN = BIG ? 3 : 2;
+   constexpr int SROW = BIG ? HS_BIG_SROW : HS_MID_SROW;
+   constexpr int NTAP = BIG ? HS_BIG_TAPS : 32;
+   // T' in LDS (bin 2) doubles as the SIFT scratch; bin 3 keeps T' in HBM and needs LDS scratch only when fused
+   constexpr int REGION = TPG ? (FUSED ? 2 * HS_SIFT_ARR : 0) : HS_MID_PMAX * HS_NEED;
+   constexpr int NIT = BIG ? 4 : 2;
    extern __shared__ __attribute__((aligned(16))) float smem[];
    float *s_vec = smem + REGION;
-   float *s_patch = s_vec + 128;
+   float *s_patch = s_vec + (FUSED ? 128 : 0);
    float *s_misc = s_patch + HS_SIFT_ARR;
    float *s_tab = s_misc + 8;
-   float *s_taps = s_tab + HS_SIFT_TAB;
+   float *s_taps = s_tab + (FUSED ? HS_SIFT_TAB : 0);
    float *s_srow = s_taps + NTAP;                      // 4 waves x SROW
    __shared__ int s_flag;
    float *Tp = TPG ? io.trows + (size_t)blockIdx.x * ((size_t)PMAX * HS_NEED) : smem;
 
    const int tid = threadIdx.x, wave = tid >> 6;
    SiftRegs rg;
-   hs_sift_setup(tb, s_tab, rg);
+   if (FUSED) hs_sift_setup(tb, s_tab, rg);
    const uint32_t cnt = min(pw.bin_count[BIN], pw.cap);
    const int imPitch = io.image.pitch, width = io.image.cols - 1, height = io.image.rows - 1;
 
@@ -551,7 +556,11 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
       }
       hs_resample_reduced(Tp, P, scale, s_taps, (flags & 32) ? 1 : (K >> 1), s_patch);
       __syncthreads();
-      hs_patch_finish(h, s_patch, smem, s_vec, s_misc, s_tab, rg, io, tb, k, flags);
+      if (FUSED) hs_patch_finish(h, s_patch, smem, s_vec, s_misc, s_tab, rg, io, tb, k, flags);
+      else {
+         for (int i = tid; i < HS_PATCH_PIX; i += 256) io.patches[(size_t)(h - io.h_base) * HS_PATCH_PIX + i] = s_patch[i];
+         __syncthreads();
+      }
    }
 }
 

@@ -133,7 +133,7 @@ struct hesaff_ctx {
    DevBuf b_input;          // staging for host images
    std::vector<hesaff_keypoint> host_keys;
    std::vector<int32_t> h_starts;
-   DevBuf t_mask_idx, b_rowprefix, b_trows, b_trows3, b_siftvec, b_meanvar, b_siftvo;
+   DevBuf t_mask_idx, b_rowprefix, b_trows, b_trows2, b_trows3, b_siftvec, b_meanvar, b_siftvo;
    bool fused_sift = false;            // HESAFF_SIFT=fused: descriptor inside the patch kernels (v1 structure)
    uint32_t sift_group_kpts = 2000000; // keypoints per patch-buffer group (6.7 KB patch + 13.4 KB gradient pairs each)
    uint32_t trows_budget = 4u << 20;   // rows of T' (82 floats each) per large-window round: 1.3 GB
@@ -451,15 +451,17 @@ template <class KERNEL> void set_dyn_lds(KERNEL kern, size_t lds)
    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 }
 
-size_t small_lds_bytes(int bin)
+size_t small_lds_bytes(int bin, bool fused = true)
 {
    const int PMAX = bin == 0 ? 41 : 64;
    const int WIN = (PMAX * PMAX + 3) & ~3;
+   if (!fused) return (size_t)(2 * WIN + 16) * 4;
    const int REGION = std::max(2 * WIN, 2 * HS_SIFT_ARR);
    return (size_t)(REGION + 128 + HS_SIFT_ARR + 8 + HS_SIFT_TAB + 16) * 4;
 }
-size_t mid_lds_bytes() { return (size_t)(HS_MID_PMAX * HS_NEED + 128 + HS_SIFT_ARR + 8 + HS_SIFT_TAB + 32 + 4 * HS_MID_SROW) * 4; }
-size_t big_lds_bytes() { return (size_t)(2 * HS_SIFT_ARR + 128 + HS_SIFT_ARR + 8 + HS_SIFT_TAB + HS_BIG_TAPS + 4 * HS_BIG_SROW) * 4; }
+size_t mid_lds_bytes(bool fused) { return (size_t)(HS_MID_PMAX * HS_NEED + (fused ? 128 + HS_SIFT_TAB : 0) + HS_SIFT_ARR + 8 + 32 + 4 * HS_MID_SROW) * 4; }
+size_t mid_tpg_lds_bytes() { return (size_t)(HS_SIFT_ARR + 8 + 32 + 4 * HS_MID_SROW) * 4; }
+size_t big_lds_bytes(bool fused) { return (size_t)((fused ? 2 * HS_SIFT_ARR + 128 + HS_SIFT_TAB : 0) + HS_SIFT_ARR + 8 + HS_BIG_TAPS + 4 * HS_BIG_SROW) * 4; }
 
 // normalizeAffine + SIFT for every keypoint k_prepare_patch left alive.  The bin counts are
 // read back once (a ~20 us bubble per batch) so that every launch is sized exactly and the
@@ -478,10 +480,14 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
    HIP_TRY(hipStreamSynchronize(st));
    static bool attrs = false;
    if (!attrs) {
-      set_dyn_lds(k_patch_small<0>, small_lds_bytes(0));
-      set_dyn_lds(k_patch_small<1>, small_lds_bytes(1));
-      set_dyn_lds(k_patch_mid<HS_MID_PMAX>, mid_lds_bytes());
-      set_dyn_lds(k_patch_mid<HS_BIN3_PMAX>, big_lds_bytes());
+      set_dyn_lds((k_patch_small<0, true>), small_lds_bytes(0));
+      set_dyn_lds((k_patch_small<1, true>), small_lds_bytes(1));
+      set_dyn_lds((k_patch_small<0, false>), small_lds_bytes(0, false));
+      set_dyn_lds((k_patch_small<1, false>), small_lds_bytes(1, false));
+      set_dyn_lds(k_patch_mid<HS_MID_PMAX, true>, mid_lds_bytes(true));
+      set_dyn_lds(k_patch_mid<HS_BIN3_PMAX, true>, big_lds_bytes(true));
+      set_dyn_lds((k_patch_mid<HS_MID_PMAX, false, true>), mid_tpg_lds_bytes());
+      set_dyn_lds(k_patch_mid<HS_BIN3_PMAX, false>, big_lds_bytes(false));
       attrs = true;
    }
    // The bins are independent (disjoint keypoints) and each kernel leaves CU resources idle
@@ -493,16 +499,32 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
       for (int i = 0; i < 3; i++) HIP_TRY(hipStreamWaitEvent(c->side_streams[i], c->ev_fork, 0));
       s0 = c->side_streams[0]; s1 = c->side_streams[1]; s2 = c->side_streams[2];
    }
-   if (bins[0]) hipLaunchKernelGGL(k_patch_small<0>, dim3(std::min<uint32_t>(bins[0], 256 * 8)), dim3(256), small_lds_bytes(0), s0, s.hl, s.pw, io, c->tables, c->consts, flags);
-   if (bins[1]) hipLaunchKernelGGL(k_patch_small<1>, dim3(std::min<uint32_t>(bins[1], 256 * 4)), dim3(256), small_lds_bytes(1), s1, s.hl, s.pw, io, c->tables, c->consts, flags);
-   if (bins[2]) hipLaunchKernelGGL(k_patch_mid<HS_MID_PMAX>, dim3(std::min<uint32_t>(bins[2], 256 * 3)), dim3(256), mid_lds_bytes(), s2, s.hl, s.pw, io, c->tables, c->consts, flags);
+   if ((flags & 1) != 0) {
+      if (bins[0]) hipLaunchKernelGGL((k_patch_small<0, true>), dim3(std::min<uint32_t>(bins[0], 256 * 8)), dim3(256), small_lds_bytes(0), s0, s.hl, s.pw, io, c->tables, c->consts, flags);
+      if (bins[1]) hipLaunchKernelGGL((k_patch_small<1, true>), dim3(std::min<uint32_t>(bins[1], 256 * 4)), dim3(256), small_lds_bytes(1), s1, s.hl, s.pw, io, c->tables, c->consts, flags);
+   } else {
+      if (bins[0]) hipLaunchKernelGGL((k_patch_small<0, false>), dim3(std::min<uint32_t>(bins[0], 256 * 8)), dim3(256), small_lds_bytes(0, false), s0, s.hl, s.pw, io, c->tables, c->consts, flags);
+      if (bins[1]) hipLaunchKernelGGL((k_patch_small<1, false>), dim3(std::min<uint32_t>(bins[1], 256 * 4)), dim3(256), small_lds_bytes(1, false), s1, s.hl, s.pw, io, c->tables, c->consts, flags);
+   }
+   const bool fused = (flags & 1) != 0;
+   if (bins[2]) {
+      if (fused) hipLaunchKernelGGL((k_patch_mid<HS_MID_PMAX, true>), dim3(std::min<uint32_t>(bins[2], 256 * 3)), dim3(256), mid_lds_bytes(true), s2, s.hl, s.pw, io, c->tables, c->consts, flags);
+      else {
+         const uint32_t nblk = std::min<uint32_t>(bins[2], 256 * 7);
+         c->b_trows2.ensure((size_t)nblk * HS_MID_PMAX * HS_NEED * 4);
+         PatchIO io2 = io;
+         io2.trows = c->b_trows2.as<float>();
+         hipLaunchKernelGGL((k_patch_mid<HS_MID_PMAX, false, true>), dim3(nblk), dim3(256), mid_tpg_lds_bytes(), s2, s.hl, s.pw, io2, c->tables, c->consts, flags);
+      }
+   }
    if (bins[3]) {
       // bin 3 (128 < P <= 512): same kernel, T' rows in a per-block HBM slot; runs on the main stream
-      const uint32_t nblk = std::min<uint32_t>(bins[3], 256 * 4);
+      const uint32_t nblk = std::min<uint32_t>(bins[3], 256 * (fused ? 4 : 8));
       c->b_trows3.ensure((size_t)nblk * HS_BIN3_PMAX * HS_NEED * 4);
       PatchIO io3 = io;
       io3.trows = c->b_trows3.as<float>();
-      hipLaunchKernelGGL(k_patch_mid<HS_BIN3_PMAX>, dim3(nblk), dim3(256), big_lds_bytes(), st, s.hl, s.pw, io3, c->tables, c->consts, flags);
+      if (fused) hipLaunchKernelGGL((k_patch_mid<HS_BIN3_PMAX, true>), dim3(nblk), dim3(256), big_lds_bytes(true), st, s.hl, s.pw, io3, c->tables, c->consts, flags);
+      else hipLaunchKernelGGL((k_patch_mid<HS_BIN3_PMAX, false>), dim3(nblk), dim3(256), big_lds_bytes(false), st, s.hl, s.pw, io3, c->tables, c->consts, flags);
    }
    if (s0 != st) {
       for (int i = 0; i < 3; i++) HIP_TRY(hipEventRecord(c->ev_join[i], c->side_streams[i]));
