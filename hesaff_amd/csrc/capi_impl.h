@@ -78,6 +78,11 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
          HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
       }
       HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+      HIP_TRY(hipStreamCreateWithFlags(&c->sift_stream, hipStreamNonBlocking));
+      for (int i = 0; i < 2; i++) {
+         HIP_TRY(hipEventCreateWithFlags(&c->ev_extract_done[i], hipEventDisableTiming));
+         HIP_TRY(hipEventCreateWithFlags(&c->ev_sift_done[i], hipEventDisableTiming));
+      }
       if (const char *ov = getenv("HESAFF_OVERLAP")) c->no_overlap = atoi(ov) == 0;
       build_tables(c);
       refresh_tables_struct(c);
@@ -118,6 +123,12 @@ void hesaff_destroy(hesaff_ctx *c)
       if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
    }
    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+   if (c->sift_stream) { (void)hipStreamSynchronize(c->sift_stream); (void)hipStreamDestroy(c->sift_stream); }
+   for (int i = 0; i < 2; i++) {
+      if (c->ev_extract_done[i]) (void)hipEventDestroy(c->ev_extract_done[i]);
+      if (c->ev_sift_done[i]) (void)hipEventDestroy(c->ev_sift_done[i]);
+      c->b_patches2[i].release(); c->b_siftvec2[i].release(); c->b_meanvar2[i].release(); c->b_siftvo2[i].release();
+   }
    if (c->stream) (void)hipStreamDestroy(c->stream);
    delete c;
 }

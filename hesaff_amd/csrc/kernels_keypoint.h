@@ -80,9 +80,15 @@ __device__ __forceinline__ void hs_affine_one(const float *__restrict__ blur, in
       }
       __syncthreads();
       if (lane < 3) {
-         const float *p = lane == 0 ? s_pa : (lane == 1 ? s_pb : s_pc);
+         // 361 terms in index order (affine.cpp:57-68); float4 LDS reads, the adds stay sequential
+         const float4 *p4 = reinterpret_cast<const float4 *>(lane == 0 ? s_pa : (lane == 1 ? s_pb : s_pc));
          float acc = 0.0f;
-         for (int i = 0; i < HS_SMM_PIX; i++) acc += p[i];
+#pragma unroll 2
+         for (int i = 0; i < HS_SMM_PIX / 4; i++) {
+            const float4 q = p4[i];
+            acc += q.x; acc += q.y; acc += q.z; acc += q.w;
+         }
+         acc += (lane == 0 ? s_pa : (lane == 1 ? s_pb : s_pc))[HS_SMM_PIX - 1];   // 361 = 4 * 90 + 1
          s_bc[lane] = acc / (float)HS_SMM_PIX;
       }
       __syncthreads();
@@ -116,7 +122,7 @@ __device__ __forceinline__ void hs_affine_one(const float *__restrict__ blur, in
 __global__ __launch_bounds__(64) void k_affine(PlaneTab pt, HessList hl, const uint32_t *__restrict__ n_ptr, KpTables tb, DConsts k,
                                                AffineOut out)
 {
-   __shared__ float s_img[HS_SMM_PIX + 3], s_pa[HS_SMM_PIX + 3], s_pb[HS_SMM_PIX + 3], s_pc[HS_SMM_PIX + 3];
+   __shared__ __attribute__((aligned(16))) float s_img[HS_SMM_PIX + 3], s_pa[HS_SMM_PIX + 3], s_pb[HS_SMM_PIX + 3], s_pc[HS_SMM_PIX + 3];
    __shared__ float s_bc[8];
    const uint32_t n = min(*n_ptr, hl.cap);
    for (uint32_t h = blockIdx.x; h < n; h += gridDim.x) {
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(64) void k_affine(PlaneTab pt, HessList hl, const u
 __global__ __launch_bounds__(64) void k_affine_stage(DPlane P, const float *__restrict__ kp /*n x 4*/, int n, KpTables tb, DConsts k,
                                                      AffineOut out)
 {
-   __shared__ float s_img[HS_SMM_PIX + 3], s_pa[HS_SMM_PIX + 3], s_pb[HS_SMM_PIX + 3], s_pc[HS_SMM_PIX + 3];
+   __shared__ __attribute__((aligned(16))) float s_img[HS_SMM_PIX + 3], s_pa[HS_SMM_PIX + 3], s_pb[HS_SMM_PIX + 3], s_pc[HS_SMM_PIX + 3];
    __shared__ float s_bc[8];
    for (int h = blockIdx.x; h < n; h += gridDim.x) {
       int conv, iters;

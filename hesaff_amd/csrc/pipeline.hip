@@ -135,7 +135,7 @@ struct hesaff_ctx {
    std::vector<int32_t> h_starts;
    DevBuf t_mask_idx, b_rowprefix, b_trows, b_trows2, b_trows3, b_siftvec, b_meanvar, b_siftvo;
    bool fused_sift = false;            // HESAFF_SIFT=fused: descriptor inside the patch kernels (v1 structure)
-   uint32_t sift_group_kpts = 2000000; // keypoints per patch-buffer group (6.7 KB patch + 13.4 KB gradient pairs each)
+   uint32_t sift_group_kpts = 300000;  // keypoints per group of images (20.6 KB of patch + gradient-pair buffers each, two slots)
    uint32_t trows_budget = 4u << 20;   // rows of T' (82 floats each) per large-window round: 1.3 GB
 
    hesaff_timings tm;
@@ -144,6 +144,9 @@ struct hesaff_ctx {
    bool use_tile_kernel = false;   // HESAFF_PYR=tile: v1 LDS-tile pyramid kernel (cross-check / fallback)
    int band_rows = 16;             // HESAFF_BAND: minimum rows per wavefront band of k_blur_hess_march
    hipStream_t side_streams[3] = {nullptr, nullptr, nullptr};
+   hipStream_t sift_stream = nullptr;
+   hipEvent_t ev_extract_done[2] = {nullptr, nullptr}, ev_sift_done[2] = {nullptr, nullptr};
+   DevBuf b_patches2[2], b_siftvec2[2], b_meanvar2[2], b_siftvo2[2];
    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
    bool no_overlap = false;        // HESAFF_OVERLAP=0: run the patch bins one after the other
    bool stop_after_detect = false; // HESAFF_STOP=detect
@@ -761,31 +764,44 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       HIP_TRY(hipMemcpyAsync(hs.data(), c->b_starts.p, (size_t)(B + 1) * 4, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       if ((uint32_t)hs[B] > c->cap) throw HsError(HESAFF_ERR_CAPACITY, "keypoint capacity exceeded; raise hesaff_params.max_kpts_per_mpx");
-      int g0 = 0;
+      // Two buffer slots: the descriptor kernels of group g (throughput-bound, on their own stream)
+      // overlap the patch extraction of group g+1 (latency-bound, on the main + side streams).
+      int g0 = 0, gi = 0;
+      bool slot_used[2] = {false, false};
       while (g0 < B) {
          int g1 = g0 + 1;
          while (g1 < B && (uint32_t)(hs[g1 + 1] - hs[g0]) <= c->sift_group_kpts) g1++;
          const uint32_t h_lo = (uint32_t)hs[g0], h_hi = (uint32_t)hs[g1], n = h_hi - h_lo;
          g0 = g1;
          if (n == 0) continue;
-         c->b_patches.ensure((size_t)n * HS_PATCH_PIX * 4);
-         c->b_siftvec.ensure((size_t)n * 128 * 4);
-         c->b_meanvar.ensure((size_t)n * 2 * 4);
+         const int slot = gi & 1;
+         gi++;
+         if (slot_used[slot]) HIP_TRY(hipStreamWaitEvent(st, c->ev_sift_done[slot], 0));   // the slot's previous descriptors are finished
+         c->b_patches2[slot].ensure((size_t)n * HS_PATCH_PIX * 4);
+         c->b_siftvec2[slot].ensure((size_t)n * 128 * 4);
+         c->b_meanvar2[slot].ensure((size_t)n * 2 * 4);
+         c->b_siftvo2[slot].ensure((size_t)n * HS_VO_PITCH * 8 + 64);
          HIP_TRY(hipMemsetAsync(cnt + 8, 0, HS_NBINS * 4, st));
          HIP_TRY(hipMemcpyAsync(cnt + 5, &h_hi, 4, hipMemcpyHostToDevice, st));
          hipLaunchKernelGGL(k_prepare_patch, dim3(1024), dim3(256), 0, st, s.hl, h_lo, (const uint32_t *)(cnt + 5), s.ao, H, W, c->consts,
                             c->tables, s.pw);
-         run_patch_stage(c, s, c->gray, c->b_patches.as<float>(), h_lo, c->ablate & ~1);
+         run_patch_stage(c, s, c->gray, c->b_patches2[slot].as<float>(), h_lo, c->ablate & ~1);
+         HIP_TRY(hipEventRecord(c->ev_extract_done[slot], st));
+         hipStream_t ss = c->no_overlap ? st : c->sift_stream;
+         if (ss != st) HIP_TRY(hipStreamWaitEvent(ss, c->ev_extract_done[slot], 0));
          SiftIO so;
-         so.patches = c->b_patches.as<float>(); so.alive = s.pw.alive; so.meanvar = c->b_meanvar.as<float>();
-         so.vec = c->b_siftvec.as<float>(); so.desc = c->b_desc.as<uint8_t>(); so.h_lo = h_lo; so.h_hi = h_hi;
+         so.patches = c->b_patches2[slot].as<float>(); so.alive = s.pw.alive; so.meanvar = c->b_meanvar2[slot].as<float>();
+         so.vec = c->b_siftvec2[slot].as<float>(); so.desc = c->b_desc.as<uint8_t>(); so.h_lo = h_lo; so.h_hi = h_hi;
          const uint32_t nb64 = (n + 63) / 64;
-         hipLaunchKernelGGL(k_sift_meanvar, dim3(nb64), dim3(64), 0, st, so, c->tables);
-         c->b_siftvo.ensure((size_t)n * HS_VO_PITCH * 8 + 64);
-         hipLaunchKernelGGL(k_sift_grad, dim3((HS_PATCH_PIX + 255) / 256, n), dim3(256), 0, st, so, c->tables, c->b_siftvo.as<float2>());
-         hipLaunchKernelGGL(k_sift_hist, dim3(std::min<uint32_t>(n, 256 * 11 * 4)), dim3(64), 0, st, so, c->tables, (const float2 *)c->b_siftvo.p, c->ablate);
-         hipLaunchKernelGGL(k_sift_quantize, dim3(nb64), dim3(64), 0, st, so, c->consts);
+         hipLaunchKernelGGL(k_sift_meanvar, dim3(nb64), dim3(64), 0, ss, so, c->tables);
+         hipLaunchKernelGGL(k_sift_grad, dim3((HS_PATCH_PIX + 255) / 256, n), dim3(256), 0, ss, so, c->tables, c->b_siftvo2[slot].as<float2>());
+         hipLaunchKernelGGL(k_sift_hist, dim3(std::min<uint32_t>(n, 256 * 11 * 4)), dim3(64), 0, ss, so, c->tables, (const float2 *)c->b_siftvo2[slot].p, c->ablate);
+         hipLaunchKernelGGL(k_sift_quantize, dim3(nb64), dim3(64), 0, ss, so, c->consts);
+         HIP_TRY(hipEventRecord(c->ev_sift_done[slot], ss));
+         slot_used[slot] = true;
       }
+      for (int sl = 0; sl < 2; sl++)
+         if (slot_used[sl]) HIP_TRY(hipStreamWaitEvent(st, c->ev_sift_done[sl], 0));
       tm.end(t);
    }
    t = tm.begin(T_SIFT);
