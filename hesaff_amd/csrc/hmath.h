@@ -42,6 +42,8 @@ HM_HD float hm_atanf(float x)
                aT9 = hm_u2f(0xbd15a221u), aT10 = hm_u2f(0x3c8569d7u);
    const int32_t hx = (int32_t)hm_f2u(x);
    const int32_t ix = hx & 0x7fffffff;
+   // argument reduction: x' = num / den with (num, den) chosen per interval -- ONE division
+   // (fdlibm writes four branches with a division each; the quotients are the same)
    int id;
    float hi = 0.0f, lo = 0.0f;
    if (ix >= 0x4c000000) {                 // |x| >= 2^25
@@ -53,13 +55,15 @@ HM_HD float hm_atanf(float x)
       id = -1;
    } else {
       x = hm_fabsf(x);
+      float num, den;
       if (ix < 0x3f980000) {               // |x| < 1.1875
-         if (ix < 0x3f300000) { id = 0; hi = atanhi0; lo = atanlo0; x = (2.0f * x - 1.0f) / (2.0f + x); }
-         else                 { id = 1; hi = atanhi1; lo = atanlo1; x = (x - 1.0f) / (x + 1.0f); }
+         if (ix < 0x3f300000) { id = 0; hi = atanhi0; lo = atanlo0; num = 2.0f * x - 1.0f; den = 2.0f + x; }
+         else                 { id = 1; hi = atanhi1; lo = atanlo1; num = x - 1.0f; den = x + 1.0f; }
       } else {
-         if (ix < 0x401c0000) { id = 2; hi = atanhi2; lo = atanlo2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
-         else                 { id = 3; hi = atanhi3; lo = atanlo3; x = -1.0f / x; }
+         if (ix < 0x401c0000) { id = 2; hi = atanhi2; lo = atanlo2; num = x - 1.5f; den = 1.0f + 1.5f * x; }
+         else                 { id = 3; hi = atanhi3; lo = atanlo3; num = -1.0f; den = x; }
       }
+      x = num / den;
    }
    const float z = x * x;
    const float w = z * z;
@@ -120,6 +124,54 @@ HM_HD float hm_atan2f(float y, float x)
    }
 }
 
+// ---- atan2f again, written with selects instead of branches for the wide-SIMD device
+//      (a wavefront that diverges over fdlibm's interval branches executes every one of them,
+//      each with its own division).  Same operations on the taken path, hence the same bits:
+//        * atanf(|y/x|): (num, den, hi, lo) of the interval are selected, ONE division; the
+//          "|x| < 0.4375" interval is num = q, den = 1, hi = lo = 0, where
+//          hi - ((t - lo) - x) == x - t exactly; fdlibm's "|x| < 2^-29 -> x" shortcut returns
+//          what the polynomial path returns anyway (x*x*... is below half an ulp of x);
+//        * the quadrant fix-up  m = 1: -z,  m = 3: (z - pi_lo) - pi == -(pi - (z - pi_lo));
+//        * y == 0 with x != 0 needs no special case (q = 0 gives +-0 / +-pi);
+//        * x == 1 needs none either (y / 1 == y and atanf is odd in every interval).
+//      Inputs fdlibm treats separately and gradients never produce (NaN, infinities, exponent
+//      gaps above 60) leave through hm_atan2f.  Checked against libm in tests/test_host_side.py.
+HM_HD float hm_atan2f_sel(float y, float x)
+{
+   const float pi_o_2 = hm_u2f(0x3fc90fdbu), pi = hm_u2f(0x40490fdbu), pi_lo = hm_u2f(0xb3bbbd2eu);
+   const int32_t hx = (int32_t)hm_f2u(x), hy = (int32_t)hm_f2u(y);
+   const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+   const int32_t k = (iy - ix) >> 23;
+   if ((ix >= 0x7f800000) | (iy >= 0x7f800000) | ((iy != 0) & (ix != 0) & ((k > 60) | (k < -60)))) return hm_atan2f(y, x);
+   const float q = hm_fabsf(y / x);   // NaN for 0/0, +inf for y/0: both replaced below
+   const int32_t iq = (int32_t)hm_f2u(q);
+   const bool i0 = iq < 0x3f300000, i1 = iq < 0x3f980000, i2 = iq < 0x401c0000, im = iq < 0x3ee00000;
+   // fdlibm s_atanf.c: (2x-1)/(2+x) | (x-1)/(x+1) | (x-1.5)/(1+1.5x) | -1/x
+   float num = i1 ? (i0 ? 2.0f * q - 1.0f : q - 1.0f) : (i2 ? q - 1.5f : -1.0f);
+   float den = i1 ? (i0 ? 2.0f + q : q + 1.0f) : (i2 ? 1.0f + 1.5f * q : q);
+   float hi = i1 ? (i0 ? hm_u2f(0x3eed6338u) : hm_u2f(0x3f490fdau)) : (i2 ? hm_u2f(0x3f7b985eu) : hm_u2f(0x3fc90fdau));
+   float lo = i1 ? (i0 ? hm_u2f(0x31ac3769u) : hm_u2f(0x33222168u)) : (i2 ? hm_u2f(0x33140fb4u) : hm_u2f(0x33a22168u));
+   num = im ? q : num;
+   den = im ? 1.0f : den;
+   hi = im ? 0.0f : hi;
+   lo = im ? 0.0f : lo;
+   const float xr = num / den;
+   const float z = xr * xr;
+   const float w = z * z;
+   const float aT0 = hm_u2f(0x3eaaaaabu), aT1 = hm_u2f(0xbe4ccccdu), aT2 = hm_u2f(0x3e124925u),
+               aT3 = hm_u2f(0xbde38e38u), aT4 = hm_u2f(0x3dba2e6eu), aT5 = hm_u2f(0xbd9d8795u),
+               aT6 = hm_u2f(0x3d886b35u), aT7 = hm_u2f(0xbd6ef16bu), aT8 = hm_u2f(0x3d4bda59u),
+               aT9 = hm_u2f(0xbd15a221u), aT10 = hm_u2f(0x3c8569d7u);
+   const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+   const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+   float za = hi - ((xr * (s1 + s2) - lo) - xr);
+   za = (iq >= 0x4c000000) ? hm_u2f(0x3fc90fdau) + hm_u2f(0x33a22168u) : za;   // |q| >= 2^25
+   float r = (hx < 0) ? pi - (za - pi_lo) : za;
+   // x == 0: +-pi/2 (pi_o_2 + tiny), or, with y == 0 too, y itself / +-pi by the sign of x
+   r = (ix == 0) ? ((iy == 0) ? ((hx < 0) ? pi : 0.0f) : pi_o_2) : r;
+   return hm_u2f(hm_f2u(r) ^ ((uint32_t)hy & 0x80000000u));
+}
+
 // ---- powf(2.0f, y) for |y| < 126 (no overflow/underflow handling needed on this path:
 //      callers pass y = b/3 with |b| <= 1.5, or 1/numberOfScales) ----
 // log2(2.0f) evaluates to exactly 1.0 in glibc's log2_inline (table entry for z == 1 has
@@ -161,4 +213,21 @@ HM_HD float hm_pow2f(float y)
 #endif
    p = p * s;
    return (float)p;
+}
+
+// ---- orientation coordinate of the SIFT histogram, siftdesc.cpp:65:
+//        o = float( float(orientationBins) * (ori + 2*M_PI) / (2*M_PI) ),   evaluated in double
+//      The double division by the constant 2*pi is replaced by Markstein's sequence
+//        q = a*y;  r = fma(-q, b, a);  q' = fma(r, y, q),   y = RN(1/b)
+//      which returns the correctly rounded quotient RN(a/b) for this b (checked exhaustively
+//      for every float `ori` in [-3.2, 3.2], tests/test_host_side.py keeps a sampled check).
+HM_HD float hm_sift_orient_coord(float ori)
+{
+   const double twopi = hm_u2d(0x401921fb54442d18ull);      // 2 * M_PI
+   const double inv_twopi = hm_u2d(0x3fc45f306dc9c883ull);  // RN(1 / (2 * M_PI))
+   const double a = 8.0 * ((double)ori + twopi);
+   const double q = a * inv_twopi;
+   const double r = __builtin_fma(-q, twopi, a);
+   const double q2 = __builtin_fma(r, inv_twopi, q);
+   return (float)q2;
 }

@@ -155,9 +155,9 @@ __device__ inline void hs_sift_block(float *s_patch, float *s_va, float *s_vec, 
          float gx, gy;
          hs_grad(s_patch, HS_PATCH, r, c, gx, gy);
          const float grad = sqrtf(gx * gx + gy * gy);
-         const float ori = hm_atan2f(gy, gx);
+         const float ori = hm_atan2f_sel(gy, gx);
          // float(orientationBins) * (ori + 2*M_PI) / (2*M_PI), evaluated in double (M_PI)
-         const float o = (float)((double)8.0f * ((double)ori + 2 * 3.14159265358979323846) / (2 * 3.14159265358979323846));
+         const float o = hm_sift_orient_coord(ori);
          s_vo[i] = make_float2(tb.sift_mask[i] * grad, o);
       }
       // the loop is unrolled only so that rg.mask[q] is a register; do not let the scheduler

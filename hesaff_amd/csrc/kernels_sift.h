@@ -71,37 +71,49 @@ __global__ __launch_bounds__(64) void k_sift_meanvar(SiftIO io, KpTables tb)
 }
 
 // k_sift_grad: photometric normalisation (helpers.cpp:269-280) + gradient magnitude and
-// orientation (siftdesc.cpp:123-137) + the per-pixel factors of samplePatch, one THREAD per
-// pixel, reading the patch through the caches.  Output: vo[k][pixel] = (mask*grad, o) with
+// orientation (siftdesc.cpp:123-137) + the per-pixel factors of samplePatch.  One block per
+// keypoint: every pixel is normalised once into LDS, then one thread per pixel takes the
+// gradient stencil from LDS.  Output: vo[k][pixel] = (mask*grad, o) with
 // o = float(8 * (atan2f + 2 pi) / (2 pi)) evaluated in double like the reference.
-// grid (ceil(1681/256), n), block 256.
+// All per-pixel math is select-based (hm_atan2f_sel): no divergence inside a wavefront.
+// grid n, block 256.
 __global__ __launch_bounds__(256) void k_sift_grad(SiftIO io, KpTables tb, float2 *__restrict__ vo)
 {
-   const uint32_t k = blockIdx.y;
+   __shared__ float s_p[HS_PATCH_PIX];
+   const uint32_t k = blockIdx.x;
    const uint32_t h = io.h_lo + k;
    if (!io.alive[h]) return;
-   const int i = blockIdx.x * 256 + threadIdx.x;
-   if (i >= HS_PATCH_PIX) return;
+   const int tid = threadIdx.x;
    const float mean = io.meanvar[2 * (size_t)k], var = io.meanvar[2 * (size_t)k + 1];
    const float *gp = io.patches + (size_t)k * HS_PATCH_PIX;
    const bool norm = !((double)var < 0.0001);
    const float fac = 50.0f / var;
-   const int r = i / HS_PATCH, c = i - r * HS_PATCH;
-   // the four (or three) patch values the gradient stencil reads, affine.cpp:14-33 convention
-   const int cl = (c == 0) ? c : c - 1, cr = (c == HS_PATCH - 1) ? c : c + 1;
-   const int ru = (r == 0) ? r : r - 1, rd = (r == HS_PATCH - 1) ? r : r + 1;
-   float vl = gp[r * HS_PATCH + cl], vr = gp[r * HS_PATCH + cr], vu = gp[ru * HS_PATCH + c], vd = gp[rd * HS_PATCH + c];
-   if (norm) {
-      vl = 128 + fac * (vl - mean); vl = vl > 255 ? 255.0f : vl; vl = vl < 0 ? 0.0f : vl;
-      vr = 128 + fac * (vr - mean); vr = vr > 255 ? 255.0f : vr; vr = vr < 0 ? 0.0f : vr;
-      vu = 128 + fac * (vu - mean); vu = vu > 255 ? 255.0f : vu; vu = vu < 0 ? 0.0f : vu;
-      vd = 128 + fac * (vd - mean); vd = vd > 255 ? 255.0f : vd; vd = vd < 0 ? 0.0f : vd;
+#pragma unroll
+   for (int q = 0; q < (HS_PATCH_PIX + 255) / 256; q++) {
+      const int i = tid + 256 * q;
+      if (i < HS_PATCH_PIX) {
+         float v = gp[i];
+         if (norm) { v = 128 + fac * (v - mean); v = v > 255 ? 255.0f : v; v = v < 0 ? 0.0f : v; }
+         s_p[i] = v;
+      }
    }
-   const float gx = vr - vl, gy = vd - vu;
-   const float grad = sqrtf(gx * gx + gy * gy);
-   const float ori = hm_atan2f(gy, gx);
-   const float o = (float)((double)8.0f * ((double)ori + 2 * 3.14159265358979323846) / (2 * 3.14159265358979323846));
-   vo[(size_t)k * HS_VO_PITCH + i] = make_float2(tb.sift_mask[i] * grad, o);
+   __syncthreads();
+   float2 *out = vo + (size_t)k * HS_VO_PITCH;
+#pragma unroll 1
+   for (int q = 0; q < (HS_PATCH_PIX + 255) / 256; q++) {
+      const int i = tid + 256 * q;
+      if (i < HS_PATCH_PIX) {
+         const int r = i / HS_PATCH, c = i - r * HS_PATCH;
+         // the four (or three) patch values the gradient stencil reads, affine.cpp:14-33 convention
+         const int il = (c == 0) ? i : i - 1, ir = (c == HS_PATCH - 1) ? i : i + 1;
+         const int iu = (r == 0) ? i : i - HS_PATCH, id = (r == HS_PATCH - 1) ? i : i + HS_PATCH;
+         const float gx = s_p[ir] - s_p[il], gy = s_p[id] - s_p[iu];
+         const float grad = sqrtf(gx * gx + gy * gy);
+         const float ori = hm_atan2f_sel(gy, gx);
+         const float o = hm_sift_orient_coord(ori);
+         out[i] = make_float2(tb.sift_mask[i] * grad, o);
+      }
+   }
 }
 
 // k_sift_hist: samplePatch (siftdesc.cpp:51-81), one WAVEFRONT per keypoint.  The keypoint's

@@ -42,7 +42,8 @@ def hmath_host(tmp_path_factory):
     src = d / "hm.cpp"
     src.write_text('#include "%s/hesaff_amd/csrc/hmath.h"\n'
                    'extern "C" void hm_atan2f_v(int n,const float*y,const float*x,float*o){for(int i=0;i<n;i++)o[i]=hm_atan2f(y[i],x[i]);}\n'
-                   'extern "C" void hm_pow2f_v(int n,const float*y,float*o){for(int i=0;i<n;i++)o[i]=hm_pow2f(y[i]);}\n' % ROOT)
+                   'extern "C" void hm_pow2f_v(int n,const float*y,float*o){for(int i=0;i<n;i++)o[i]=hm_pow2f(y[i]);}\n'
+                   'extern "C" void hm_orient_v(int n,const float*y,float*o){for(int i=0;i<n;i++)o[i]=hm_sift_orient_coord(y[i]);}\n' % ROOT)
     so = d / "hm.so"
     subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", str(so), str(src)])
     return C.CDLL(str(so))
@@ -76,6 +77,13 @@ def test_hmath_restatements_equal_glibc(hmath_host):
     hmath_host.hm_pow2f_v(len(e), e, gp)
     rp = np.array([libm.powf(2.0, float(a)) for a in e], np.float32)
     assert np.array_equal(gp.view(np.uint32), rp.view(np.uint32))
+    # siftdesc.cpp:65 in double, as numpy evaluates it (IEEE add / mul / div)
+    hmath_host.hm_orient_v.argtypes = [C.c_int, f32p, f32p]
+    ori = np.concatenate([rng.uniform(-np.pi, np.pi, 500000), [0.0, -0.0, np.pi, -np.pi, np.pi / 2, -np.pi / 2]]).astype(np.float32)
+    go = np.zeros_like(ori)
+    hmath_host.hm_orient_v(len(ori), ori, go)
+    ro = (np.float64(8.0) * (ori.astype(np.float64) + 2 * np.pi) / (2 * np.pi)).astype(np.float32)
+    assert np.array_equal(go.view(np.uint32), ro.view(np.uint32))
 
 
 def test_read_pnm_and_grey_conversion(tmp_path, oracle):
