@@ -6,10 +6,12 @@
 //                   (helpers.cpp:253-266, 1245 terms each).  One THREAD per keypoint runs the
 //                   chain, 64 keypoints per wavefront at full lane efficiency; the patch columns
 //                   are transposed through LDS so that global loads stay coalesced.
-//  k_sift_grad      one THREAD per pixel: normalise, gradient, hm_atan2f -> (mask*grad, o) pairs.
-//  k_sift_hist      one WAVEFRONT per keypoint, no LDS: the 4x4x8 histogram with lane =
-//                   (spatial cell, orientation pair) walking its 16x16 support in raster order
-//                   (siftdesc.cpp:51-81), operands streamed from HBM/L2.
+//  k_sift_grad      one block per keypoint, one THREAD per pixel: normalise (once, through LDS),
+//                   gradient, hm_atan2f_sel -> (mask*grad, o) pairs of the 40x40 weighted pixels.
+//  k_sift_hist      FOUR keypoints per wavefront, lane = (keypoint, spatial cell): the cell's 8
+//                   orientation bins live in LDS ([bin][lane], conflict-free) and the lane walks
+//                   its 16x16 support in raster order (siftdesc.cpp:51-81), operands streamed
+//                   from HBM/L2 one 128-byte cell row at a time.
 //  k_sift_quantize  normalize / clip / renormalize / quantise (siftdesc.cpp:83-113): the two
 //                   128-term sequential sums again run one thread per keypoint.
 //
@@ -26,7 +28,8 @@ struct SiftIO {
    uint32_t h_lo, h_hi;
 };
 
-#define HS_VO_PITCH 1682   // float2 per keypoint in the gradient-pair buffer (16-byte aligned rows)
+#define HS_VO_DIM 40                          // rows/columns of the patch that carry weight in samplePatch
+#define HS_VO_PITCH (HS_VO_DIM * HS_VO_DIM)   // float2 per keypoint in the gradient-pair buffer (rows 16-byte aligned)
 #define SM_TILE 64
 #define SM_STRIDE 65   // LDS row stride: lane k walking row k is conflict-free
 
@@ -73,8 +76,10 @@ __global__ __launch_bounds__(64) void k_sift_meanvar(SiftIO io, KpTables tb)
 // k_sift_grad: photometric normalisation (helpers.cpp:269-280) + gradient magnitude and
 // orientation (siftdesc.cpp:123-137) + the per-pixel factors of samplePatch.  One block per
 // keypoint: every pixel is normalised once into LDS, then one thread per pixel takes the
-// gradient stencil from LDS.  Output: vo[k][pixel] = (mask*grad, o) with
-// o = float(8 * (atan2f + 2 pi) / (2 pi)) evaluated in double like the reference.
+// gradient stencil from LDS.  Output: vo[k][r][c] = (mask*grad, o), r, c < 40, with
+// o = float(8 * (atan2f + 2 pi) / (2 pi)) evaluated in double like the reference.  Row and
+// column 40 are not produced: their spatial weights are zero (bin0 and bin1 both clamped,
+// siftdesc.cpp:33-44) so samplePatch adds nothing for them.
 // All per-pixel math is select-based (hm_atan2f_sel): no divergence inside a wavefront.
 // grid n, block 256.
 __global__ __launch_bounds__(256) void k_sift_grad(SiftIO io, KpTables tb, float2 *__restrict__ vo)
@@ -100,37 +105,38 @@ __global__ __launch_bounds__(256) void k_sift_grad(SiftIO io, KpTables tb, float
    __syncthreads();
    float2 *out = vo + (size_t)k * HS_VO_PITCH;
 #pragma unroll 1
-   for (int q = 0; q < (HS_PATCH_PIX + 255) / 256; q++) {
-      const int i = tid + 256 * q;
-      if (i < HS_PATCH_PIX) {
-         const int r = i / HS_PATCH, c = i - r * HS_PATCH;
+   for (int q = 0; q < (HS_VO_PITCH + 255) / 256; q++) {
+      const int o_i = tid + 256 * q;
+      if (o_i < HS_VO_PITCH) {
+         const int r = o_i / HS_VO_DIM, c = o_i - r * HS_VO_DIM;
+         const int i = r * HS_PATCH + c;
          // the four (or three) patch values the gradient stencil reads, affine.cpp:14-33 convention
-         const int il = (c == 0) ? i : i - 1, ir = (c == HS_PATCH - 1) ? i : i + 1;
-         const int iu = (r == 0) ? i : i - HS_PATCH, id = (r == HS_PATCH - 1) ? i : i + HS_PATCH;
+         const int il = (c == 0) ? i : i - 1, ir = i + 1;                  // c <= 39 < patchSize - 1
+         const int iu = (r == 0) ? i : i - HS_PATCH, id = i + HS_PATCH;    // r <= 39
          const float gx = s_p[ir] - s_p[il], gy = s_p[id] - s_p[iu];
          const float grad = sqrtf(gx * gx + gy * gy);
          const float ori = hm_atan2f_sel(gy, gx);
          const float o = hm_sift_orient_coord(ori);
-         out[i] = make_float2(tb.sift_mask[i] * grad, o);
+         out[o_i] = make_float2(tb.sift_mask[i] * grad, o);
       }
    }
 }
 
-// k_sift_hist: samplePatch (siftdesc.cpp:51-81), one WAVEFRONT per keypoint.  The keypoint's
-// 13.4 KB of (mask*grad, o) pairs are staged in LDS with coalesced 16-byte loads that are all
-// in flight together (one HBM latency per keypoint), then lane = (spatial cell, orientation
-// pair {q, q+4}) walks the cell's 16x16 pixel support in raster order out of LDS.  Each pixel
-// adds at most one term per histogram bin; where the reference adds nothing this adds 0.0f.
-// 13.7 KB of LDS per wavefront -> 11 wavefronts per CU.  grid-stride over [h_lo, h_hi), block 64.
-#define SH_F4 841   // float4 per keypoint: 1681 float2 = 3362 floats, rounded up (the buffer is padded)
+// k_sift_hist: samplePatch (siftdesc.cpp:51-81).  A wavefront takes FOUR keypoints; lane =
+// (keypoint, spatial cell) owns the cell's 8 orientation bins as 8 LDS words laid out
+// [bin][lane] (a lane only ever touches its own bank) and walks the cell's 16x16 pixel support
+// in raster order, which is the order the reference adds a bin's terms in.  Per pixel: one
+// product chain wr*(wc*val), two read-modify-writes at bins bo0 and bo0+1 (dynamic index, hence
+// LDS and not registers).  Where the reference adds nothing (val <= 0) this adds +0.0f.
+// The (mask*grad, o) rows are read straight from global memory, 8 x 16 bytes per cell row and
+// lane, the next row in flight while the current one is consumed.
+// grid-stride over groups of 4 keypoints, block 64.
 __global__ __launch_bounds__(64) void k_sift_hist(SiftIO io, KpTables tb, const float2 *__restrict__ vo, int flags)
 {
-   __shared__ __attribute__((aligned(16))) float4 s_q[SH_F4 + 3];
+   __shared__ float s_acc[8 * 64];
    __shared__ float s_cw[64];   // [spatial bin][offset 0..15]
    const int tid = threadIdx.x;
-   const int cell = tid >> 2, cb_r = cell >> 2, cb_c = cell & 3;
-   const int bA = tid & 3, bB = bA + 4;
-   const int pA = (bA + 7) & 7, pB = (bB + 7) & 7;   // a pixel whose bo0 is pA feeds bin bA through bo1
+   const int kq = tid >> 4, cell = tid & 15, cb_r = cell >> 2, cb_c = cell & 3;
    {
       // cell weights: spatial bin b gets w1[r] from rows with bin1 == b, w0[r] from rows with bin0 == b
       // (siftdesc.cpp:55-56,61-62); clamped bins carry weight 0
@@ -146,42 +152,51 @@ __global__ __launch_bounds__(64) void k_sift_hist(SiftIO io, KpTables tb, const 
    float cwc[16];
 #pragma unroll
    for (int j = 0; j < 16; j++) cwc[j] = s_cw[cb_c * 16 + j];
-   const float2 *s_vo = reinterpret_cast<const float2 *>(s_q);
-   for (uint32_t h = io.h_lo + blockIdx.x; h < io.h_hi; h += gridDim.x) {
-      if (!io.alive[h]) continue;   // wave-uniform
-      const uint32_t k = h - io.h_lo;
-      // stage: 841 float4 (the row pitch of vo is HS_VO_PITCH float2, 16-byte aligned)
-      const float4 *g4 = reinterpret_cast<const float4 *>(vo + (size_t)k * HS_VO_PITCH);
-      float4 stg[14];
+   const uint32_t n = io.h_hi - io.h_lo;
+   float *acc = s_acc + tid;
+   for (uint32_t g = blockIdx.x; 4 * g < n; g += gridDim.x) {
+      const uint32_t k = 4 * g + kq;
+      const bool valid = k < n && io.alive[io.h_lo + min(k, n - 1)];
 #pragma unroll
-      for (int m = 0; m < 14; m++) { const int i4 = min(tid + 64 * m, SH_F4 - 1); stg[m] = g4[i4]; }
+      for (int b = 0; b < 8; b++) acc[64 * b] = 0.0f;
+      if (valid && !(flags & 2)) {
+         // float4 index of the cell's first pixel pair: rows are HS_VO_DIM float2 = 20 float4
+         const float4 *g4 = reinterpret_cast<const float4 *>(vo + (size_t)k * HS_VO_PITCH) + (8 * cb_r) * (HS_VO_DIM / 2) + 4 * cb_c;
+         float4 cur[8], nxt[8];
 #pragma unroll
-      for (int m = 0; m < 14; m++) { const int i4 = tid + 64 * m; if (i4 < SH_F4) s_q[i4] = stg[m]; }
-      __syncthreads();
-      float accA = 0.0f, accB = 0.0f;
-      if (!(flags & 2)) {
+         for (int m = 0; m < 8; m++) cur[m] = g4[m];
+#pragma unroll 1
          for (int i = 0; i < 16; i++) {
+            const float4 *gn = g4 + min(i + 1, 15) * (HS_VO_DIM / 2);
+#pragma unroll
+            for (int m = 0; m < 8; m++) nxt[m] = gn[m];
             const float wr = s_cw[cb_r * 16 + i];
-            const float2 *row = s_vo + (8 * cb_r + i) * HS_PATCH + 8 * cb_c;
-#pragma unroll 8
+#pragma unroll
             for (int j = 0; j < 16; j++) {
-               const float2 q = row[j];
-               const float wc = cwc[j] * q.x;   // w[c] * (mask*grad)
+               const float qx = (j & 1) ? cur[j >> 1].z : cur[j >> 1].x;
+               const float qy = (j & 1) ? cur[j >> 1].w : cur[j >> 1].y;
+               const float wc = cwc[j] * qx;   // w[c] * (mask*grad)
                const float v = wr * wc;
-               const int bo0 = ((int)q.y) & 7;
-               const float wo1 = q.y - (float)(int)q.y;
+               const int io0 = (int)qy;
+               const int bo0 = io0 & 7, bo1 = (io0 + 1) & 7;
+               const float wo1 = qy - (float)io0;
                const float wo0 = 1.0f - wo1;
                const bool pos = v > 0.0f;
                const float t0 = pos ? v * wo0 : 0.0f;   // goes to bin bo0
                const float t1 = pos ? v * wo1 : 0.0f;   // goes to bin bo0 + 1
-               accA += (bo0 == bA) ? t0 : ((bo0 == pA) ? t1 : 0.0f);
-               accB += (bo0 == bB) ? t0 : ((bo0 == pB) ? t1 : 0.0f);
+               const float a0 = acc[64 * bo0], a1 = acc[64 * bo1];   // bo0 != bo1: both reads in flight together
+               acc[64 * bo0] = a0 + t0;
+               acc[64 * bo1] = a1 + t1;
             }
+#pragma unroll
+            for (int m = 0; m < 8; m++) cur[m] = nxt[m];
          }
       }
-      io.vec[(size_t)k * 128 + cell * 8 + bA] = accA;
-      io.vec[(size_t)k * 128 + cell * 8 + bB] = accB;
-      __syncthreads();
+      if (k < n) {
+         float4 *dst = reinterpret_cast<float4 *>(io.vec + (size_t)k * 128 + cell * 8);
+         dst[0] = make_float4(acc[0], acc[64], acc[128], acc[192]);
+         dst[1] = make_float4(acc[256], acc[320], acc[384], acc[448]);
+      }
    }
 }
 

@@ -795,7 +795,7 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
          const uint32_t nb64 = (n + 63) / 64;
          hipLaunchKernelGGL(k_sift_meanvar, dim3(nb64), dim3(64), 0, ss, so, c->tables);
          hipLaunchKernelGGL(k_sift_grad, dim3(n), dim3(256), 0, ss, so, c->tables, c->b_siftvo2[slot].as<float2>());
-         hipLaunchKernelGGL(k_sift_hist, dim3(std::min<uint32_t>(n, 256 * 11 * 4)), dim3(64), 0, ss, so, c->tables, (const float2 *)c->b_siftvo2[slot].p, c->ablate);
+         hipLaunchKernelGGL(k_sift_hist, dim3(std::min<uint32_t>((n + 3) / 4, 256 * 32)), dim3(64), 0, ss, so, c->tables, (const float2 *)c->b_siftvo2[slot].p, c->ablate);
          hipLaunchKernelGGL(k_sift_quantize, dim3(nb64), dim3(64), 0, ss, so, c->consts);
          HIP_TRY(hipEventRecord(c->ev_sift_done[slot], ss));
          slot_used[slot] = true;
