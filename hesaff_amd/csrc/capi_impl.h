@@ -79,6 +79,8 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       }
       HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
       HIP_TRY(hipStreamCreateWithFlags(&c->sift_stream, hipStreamNonBlocking));
+      HIP_TRY(hipStreamCreateWithFlags(&c->aff_stream, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&c->ev_detect_done, hipEventDisableTiming));
       for (int i = 0; i < 2; i++) {
          HIP_TRY(hipEventCreateWithFlags(&c->ev_extract_done[i], hipEventDisableTiming));
          HIP_TRY(hipEventCreateWithFlags(&c->ev_sift_done[i], hipEventDisableTiming));
@@ -124,6 +126,9 @@ void hesaff_destroy(hesaff_ctx *c)
    }
    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
    if (c->sift_stream) { (void)hipStreamSynchronize(c->sift_stream); (void)hipStreamDestroy(c->sift_stream); }
+   if (c->aff_stream) { (void)hipStreamSynchronize(c->aff_stream); (void)hipStreamDestroy(c->aff_stream); }
+   if (c->ev_detect_done) (void)hipEventDestroy(c->ev_detect_done);
+   for (hipEvent_t e : c->ev_aff) (void)hipEventDestroy(e);
    for (int i = 0; i < 2; i++) {
       if (c->ev_extract_done[i]) (void)hipEventDestroy(c->ev_extract_done[i]);
       if (c->ev_sift_done[i]) (void)hipEventDestroy(c->ev_sift_done[i]);

@@ -119,13 +119,13 @@ __device__ __forceinline__ void hs_affine_one(const float *__restrict__ blur, in
    U_out[0] = u11; U_out[1] = u12; U_out[2] = u21; U_out[3] = u22;
 }
 
-__global__ __launch_bounds__(64) void k_affine(PlaneTab pt, HessList hl, const uint32_t *__restrict__ n_ptr, KpTables tb, DConsts k,
-                                               AffineOut out)
+__global__ __launch_bounds__(64) void k_affine(PlaneTab pt, HessList hl, uint32_t h_lo, uint32_t h_hi, const uint32_t *__restrict__ n_ptr,
+                                               KpTables tb, DConsts k, AffineOut out)
 {
    __shared__ __attribute__((aligned(16))) float s_img[HS_SMM_PIX + 3], s_pa[HS_SMM_PIX + 3], s_pb[HS_SMM_PIX + 3], s_pc[HS_SMM_PIX + 3];
    __shared__ float s_bc[8];
-   const uint32_t n = min(*n_ptr, hl.cap);
-   for (uint32_t h = blockIdx.x; h < n; h += gridDim.x) {
+   const uint32_t n = min(min(*n_ptr, hl.cap), h_hi);   // keypoints [h_lo, h_hi) of the list
+   for (uint32_t h = h_lo + blockIdx.x; h < n; h += gridDim.x) {
       const int meta = hl.meta[h];
       const int b = meta >> 8, octave = (meta >> 4) & 15, level = (meta >> 2) & 3;
       const DPlane &P = pt.L[octave][level];

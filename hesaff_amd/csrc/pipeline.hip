@@ -145,6 +145,9 @@ struct hesaff_ctx {
    int band_rows = 16;             // HESAFF_BAND: minimum rows per wavefront band of k_blur_hess_march
    hipStream_t side_streams[3] = {nullptr, nullptr, nullptr};
    hipStream_t sift_stream = nullptr;
+   hipStream_t aff_stream = nullptr;      // affine shape of image group g+1 runs beside the patch extraction of group g
+   hipEvent_t ev_detect_done = nullptr;
+   std::vector<hipEvent_t> ev_aff;        // one per image group, grown on demand
    hipEvent_t ev_extract_done[2] = {nullptr, nullptr}, ev_sift_done[2] = {nullptr, nullptr};
    DevBuf b_patches2[2], b_siftvec2[2], b_meanvar2[2], b_siftvo2[2];
    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -741,15 +744,16 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       return;
    }
 
-   int t = tm.begin(T_AFF);
+   int t;
    PlaneTab pt;
    memset(&pt, 0, sizeof pt);
    for (size_t o = 0; o < c->oct.size(); o++)
       for (int l = 0; l < 3; l++) pt.L[o][l] = c->L[o * 3 + l];
-   hipLaunchKernelGGL(k_affine, dim3(256 * 32), dim3(64), 0, st, pt, s.hl, (const uint32_t *)(cnt + 3), c->tables, c->consts, s.ao);
-   tm.end(t);
    if (c->fused_sift) {
       // one kernel per window-size bin does normalizeAffine + SIFT (HESAFF_SIFT=fused)
+      t = tm.begin(T_AFF);
+      hipLaunchKernelGGL(k_affine, dim3(256 * 32), dim3(64), 0, st, pt, s.hl, 0u, 0xffffffffu, (const uint32_t *)(cnt + 3), c->tables, c->consts, s.ao);
+      tm.end(t);
       t = tm.begin(T_PATCH);
       hipLaunchKernelGGL(k_prepare_patch, dim3(1024), dim3(256), 0, st, s.hl, 0u, (const uint32_t *)(cnt + 3), s.ao, H, W, c->consts,
                          c->tables, s.pw);
@@ -759,23 +763,46 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       // split form: the bin kernels only extract the 41x41 patches (to HBM), the descriptor runs
       // as three kernels with the parallel axis each part wants (kernels_sift.h).  Images are
       // processed in groups so that the patch buffer stays bounded.
-      t = tm.begin(T_PATCH);
       std::vector<int32_t> hs(B + 1);
       HIP_TRY(hipMemcpyAsync(hs.data(), c->b_starts.p, (size_t)(B + 1) * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipEventRecord(c->ev_detect_done, st));
       HIP_TRY(hipStreamSynchronize(st));
       if ((uint32_t)hs[B] > c->cap) throw HsError(HESAFF_ERR_CAPACITY, "keypoint capacity exceeded; raise hesaff_params.max_kpts_per_mpx");
-      // Two buffer slots: the descriptor kernels of group g (throughput-bound, on their own stream)
-      // overlap the patch extraction of group g+1 (latency-bound, on the main + side streams).
-      int g0 = 0, gi = 0;
-      bool slot_used[2] = {false, false};
-      while (g0 < B) {
+      // image groups [h_lo, h_hi) of at most sift_group_kpts keypoints
+      std::vector<std::pair<uint32_t, uint32_t>> groups;
+      for (int g0 = 0; g0 < B;) {
          int g1 = g0 + 1;
          while (g1 < B && (uint32_t)(hs[g1 + 1] - hs[g0]) <= c->sift_group_kpts) g1++;
-         const uint32_t h_lo = (uint32_t)hs[g0], h_hi = (uint32_t)hs[g1], n = h_hi - h_lo;
+         if (hs[g1] > hs[g0]) groups.push_back({(uint32_t)hs[g0], (uint32_t)hs[g1]});
          g0 = g1;
-         if (n == 0) continue;
-         const int slot = gi & 1;
-         gi++;
+      }
+      while (c->ev_aff.size() < groups.size()) {
+         hipEvent_t e;
+         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+         c->ev_aff.push_back(e);
+      }
+      // Three-deep software pipeline over image groups, one stream per stage:
+      //   affine shape of group g+1 (aff_stream)  |  patch extraction of group g (main + side
+      //   streams, latency-bound)  |  descriptor kernels of group g-1 (sift_stream).
+      // Two patch/descriptor buffer slots alternate.
+      hipStream_t as = c->no_overlap ? st : c->aff_stream;
+      if (as != st) HIP_TRY(hipStreamWaitEvent(as, c->ev_detect_done, 0));
+      auto launch_affine = [&](size_t gi) {
+         hipLaunchKernelGGL(k_affine, dim3(256 * 32), dim3(64), 0, as, pt, s.hl, groups[gi].first, groups[gi].second, (const uint32_t *)(cnt + 3),
+                            c->tables, c->consts, s.ao);
+         if (as != st) HIP_TRY(hipEventRecord(c->ev_aff[gi], as));
+      };
+      t = tm.begin(T_AFF);
+      if (!groups.empty()) launch_affine(0);
+      if (as != st && !groups.empty()) HIP_TRY(hipStreamWaitEvent(st, c->ev_aff[0], 0));
+      tm.end(t);
+      t = tm.begin(T_PATCH);
+      bool slot_used[2] = {false, false};
+      for (size_t gi = 0; gi < groups.size(); gi++) {
+         const uint32_t h_lo = groups[gi].first, h_hi = groups[gi].second, n = h_hi - h_lo;
+         if (gi + 1 < groups.size()) launch_affine(gi + 1);
+         if (as != st && gi > 0) HIP_TRY(hipStreamWaitEvent(st, c->ev_aff[gi], 0));
+         const int slot = (int)(gi & 1);
          if (slot_used[slot]) HIP_TRY(hipStreamWaitEvent(st, c->ev_sift_done[slot], 0));   // the slot's previous descriptors are finished
          c->b_patches2[slot].ensure((size_t)n * HS_PATCH_PIX * 4);
          c->b_siftvec2[slot].ensure((size_t)n * 128 * 4);
