@@ -771,3 +771,149 @@ __global__ __launch_bounds__(256) void k_extrema3(FivePlanes fp, float posThr, f
       if (slot < cl.cap) cl.items[slot] = s_list[i];
    }
 }
+
+// ---------------------------------------------------------------------------------------
+// k_extrema_march: the same three extrema scans, HBM-streaming form.  One wavefront marches
+// down a strip of 248 columns (lane = 4 adjacent columns, one halo lane per side) over a band
+// of rows, each response value is read from HBM exactly once (float4, two rows ahead) and
+// lives in a register ring of 5 rows x 5 planes.  The 27-neighbour test is evaluated as a
+// separable max / min:
+//    "no neighbour strictly greater than val"  <=>  !(max27 > val)
+//    max27 = max over x-1..x+1 of ( max over the 3 planes of ( max over rows y-1..y+1 ) )
+// (v_max3_f32 / v_min3_f32 skip NaN operands exactly like the comparisons of
+// pyramid.cpp:39-61 let a NaN neighbour pass), ~45 VALU operations per pixel for all three
+// levels instead of ~400.  Candidates are collected in LDS and flushed with one global atomic.
+// grid (ceil(cols/248), ceil(rows/band), B), block 64.
+// ---------------------------------------------------------------------------------------
+#define EXM_STRIP 248
+#define EXM_CAP 2048
+#define EXM_RS 5
+#define EXM_ROWMAX (3 * EXM_STRIP)   // candidates one row step can add
+
+__device__ __forceinline__ float hs_max3(float a, float b, float c)
+{
+   float r;
+   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+   return r;
+}
+__device__ __forceinline__ float hs_min3(float a, float b, float c)
+{
+   float r;
+   asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+   return r;
+}
+
+__global__ __launch_bounds__(64) void k_extrema_march(FivePlanes fp, float posThr, float negThr, CandList cl, int band)
+{
+   __shared__ uint2 s_list[EXM_CAP];
+   __shared__ uint32_t s_n;
+   const int lane = threadIdx.x, b = blockIdx.z;
+   const int rows = fp.R[0].rows, cols = fp.R[0].cols, pitch = fp.R[0].pitch;
+   const int ya = max((int)blockIdx.y * band, HS_BORDER), yb = min(((int)blockIdx.y + 1) * band, rows - HS_BORDER);   // scanned rows
+   if (ya >= yb) return;
+   const int x = (int)blockIdx.x * EXM_STRIP - 4 + 4 * lane;   // my 4 columns; lanes 0 and 63 only feed their neighbours
+   // Always a valid aligned 16-byte load: lanes outside the image read some in-range columns whose
+   // values can only reach columns that are not scanned (HS_BORDER >= 1 away from the frame).
+   const int xc = min(max(x, 0), pitch - 4);
+   const bool own = lane >= 1 && lane <= 62;
+   uint32_t colmask = 0;   // bit c: column x + c is scanned
+#pragma unroll
+   for (int c = 0; c < 4; c++)
+      if (own && x + c >= HS_BORDER && x + c < cols - HS_BORDER) colmask |= 1u << c;
+   const float *base[5];
+#pragma unroll
+   for (int p = 0; p < 5; p++) base[p] = fp.R[p].img(b) + xc;
+   if (lane == 0) s_n = 0;
+   __syncthreads();
+
+   float4 ring[5][EXM_RS];
+   const int nsteps = yb - ya + 2;   // step k brings row ya - 1 + k; rows ya .. yb-1 are tested at steps 2 .. nsteps-1
+   // prologue: rows of steps 0 and 1
+#pragma unroll
+   for (int k = 0; k < 2; k++) {
+      const long long off = (long long)min(ya - 1 + k, rows - 1) * pitch;
+#pragma unroll
+      for (int p = 0; p < 5; p++) ring[p][k] = *reinterpret_cast<const float4 *>(base[p] + off);
+   }
+   for (int k0 = 0; k0 < nsteps; k0 += EXM_RS) {
+#pragma unroll
+      for (int u = 0; u < EXM_RS; u++) {
+         const int k = k0 + u;
+         {
+            // two rows ahead, into the slot whose row (k - 3) is no longer needed
+            const long long off = (long long)min(ya - 1 + k + 2, rows - 1) * pitch;
+#pragma unroll
+            for (int p = 0; p < 5; p++) ring[p][(u + 2) % EXM_RS] = *reinterpret_cast<const float4 *>(base[p] + off);
+         }
+         const uint32_t n_lagged = s_n;   // count before the previous step's candidates are all in
+         const int y = ya - 2 + k;        // row under test: slots (u-2, u-1, u) = rows y-1, y, y+1
+         const int s0 = (u + EXM_RS - 2) % EXM_RS, s1 = (u + EXM_RS - 1) % EXM_RS, s2 = u;
+         float A[3][4], I[3][4];   // per level: max / min over 3 rows x 3 planes, per column
+         {
+            float vmx[5][4], vmn[5][4];
+#pragma unroll
+            for (int p = 0; p < 5; p++) {
+               const float a[4] = {ring[p][s0].x, ring[p][s0].y, ring[p][s0].z, ring[p][s0].w};
+               const float m[4] = {ring[p][s1].x, ring[p][s1].y, ring[p][s1].z, ring[p][s1].w};
+               const float z[4] = {ring[p][s2].x, ring[p][s2].y, ring[p][s2].z, ring[p][s2].w};
+#pragma unroll
+               for (int c = 0; c < 4; c++) { vmx[p][c] = hs_max3(a[c], m[c], z[c]); vmn[p][c] = hs_min3(a[c], m[c], z[c]); }
+            }
+#pragma unroll
+            for (int l = 0; l < 3; l++)
+#pragma unroll
+               for (int c = 0; c < 4; c++) {
+                  A[l][c] = hs_max3(vmx[l][c], vmx[l + 1][c], vmx[l + 2][c]);
+                  I[l][c] = hs_min3(vmn[l][c], vmn[l + 1][c], vmn[l + 2][c]);
+               }
+         }
+         uint32_t hits = 0;   // bit 4 * l + c
+#pragma unroll
+         for (int l = 0; l < 3; l++) {
+            const float Al = __shfl_up(A[l][3], 1, 64), Ar = __shfl_down(A[l][0], 1, 64);
+            const float Il = __shfl_up(I[l][3], 1, 64), Ir = __shfl_down(I[l][0], 1, 64);
+            const float M[4] = {hs_max3(Al, A[l][0], A[l][1]), hs_max3(A[l][0], A[l][1], A[l][2]), hs_max3(A[l][1], A[l][2], A[l][3]), hs_max3(A[l][2], A[l][3], Ar)};
+            const float N[4] = {hs_min3(Il, I[l][0], I[l][1]), hs_min3(I[l][0], I[l][1], I[l][2]), hs_min3(I[l][1], I[l][2], I[l][3]), hs_min3(I[l][2], I[l][3], Ir)};
+            const float v[4] = {ring[l + 1][s1].x, ring[l + 1][s1].y, ring[l + 1][s1].z, ring[l + 1][s1].w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+               const bool pos = v[c] > posThr && !(M[c] > v[c]);
+               const bool neg = v[c] < negThr && !(N[c] < v[c]);
+               if (pos || neg) hits |= 1u << (4 * l + c);
+            }
+         }
+         hits &= colmask * 0x111u;
+         if (k < 2 || k >= nsteps) hits = 0;
+         if (n_lagged > EXM_CAP - 2 * EXM_ROWMAX) {
+            // flush (wave-uniform): everything the earlier steps collected goes out with one global atomic
+            __syncthreads();
+            const uint32_t n = min(s_n, (uint32_t)EXM_CAP);
+            uint32_t gbase = 0;
+            if (lane == 0) { gbase = atomicAdd(cl.count, n); s_n = 0; }
+            gbase = __shfl(gbase, 0, 64);
+            for (uint32_t i = lane; i < n; i += 64)
+               if (gbase + i < cl.cap) cl.items[gbase + i] = s_list[i];
+            __syncthreads();
+         }
+         while (hits) {
+            const int bit = __ffs(hits) - 1;
+            hits &= hits - 1;
+            const int l = bit >> 2, c = bit & 3;
+            const uint2 item = make_uint2(((uint32_t)b << 2) | (uint32_t)l, ((uint32_t)y << 16) | (uint32_t)(x + c));
+            const uint32_t ls = atomicAdd(&s_n, 1u);
+            if (ls < EXM_CAP) s_list[ls] = item;
+            else {
+               const uint32_t slot = atomicAdd(cl.count, 1u);
+               if (slot < cl.cap) cl.items[slot] = item;
+            }
+         }
+      }
+   }
+   __syncthreads();
+   const uint32_t n = min(s_n, (uint32_t)EXM_CAP);
+   uint32_t gbase = 0;
+   if (lane == 0 && n > 0) gbase = atomicAdd(cl.count, n);
+   gbase = __shfl(gbase, 0, 64);
+   for (uint32_t i = lane; i < n; i += 64)
+      if (gbase + i < cl.cap) cl.items[gbase + i] = s_list[i];
+}

@@ -153,6 +153,7 @@ struct hesaff_ctx {
    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
    bool no_overlap = false;        // HESAFF_OVERLAP=0: run the patch bins one after the other
    bool stop_after_detect = false; // HESAFF_STOP=detect
+   bool use_tile_extrema = false;  // HESAFF_EXTREMA=tile: the LDS-tile extrema kernel (k_extrema3) instead of the marching one
    bool debug = false;             // HESAFF_DEBUG=1: launch geometry on stderr
    int force_bands = 0;            // HESAFF_BANDS: force the band count of k_blur_hess_march (tuning)
    int ablate = 0;          // HESAFF_ABLATE: profiling-only ablation bits, breaks results when set
@@ -484,6 +485,7 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
    uint32_t bins[HS_NBINS];
    HIP_TRY(hipMemcpyAsync(bins, s.pw.bin_count, sizeof bins, hipMemcpyDeviceToHost, st));
    HIP_TRY(hipStreamSynchronize(st));
+   if (c->debug) fprintf(stderr, "[hesaff] patch bins (P<=41, 64, 128, 512, larger): %u %u %u %u %u\n", bins[0], bins[1], bins[2], bins[3], bins[4]);
    static bool attrs = false;
    if (!attrs) {
       set_dyn_lds((k_patch_small<0, true>), small_lds_bytes(0));
@@ -670,8 +672,16 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
       if (g.rows > 2 * HS_BORDER && g.cols > 2 * HS_BORDER) {
          FivePlanes fp;
          for (int l = 0; l < 5; l++) fp.R[l] = Ro[l];
-         const dim3 grid((g.cols + EX_TW - 1) / EX_TW, (g.rows + EX_TH - 1) / EX_TH, B);
-         hipLaunchKernelGGL(k_extrema3, grid, dim3(256), 0, st, fp, c->consts.positiveThreshold, c->consts.negativeThreshold, s.cl);
+         if (c->use_tile_extrema) {
+            const dim3 grid((g.cols + EX_TW - 1) / EX_TW, (g.rows + EX_TH - 1) / EX_TH, B);
+            hipLaunchKernelGGL(k_extrema3, grid, dim3(256), 0, st, fp, c->consts.positiveThreshold, c->consts.negativeThreshold, s.cl);
+         } else {
+            // bands of 64 rows; 32 when that would leave the chip short of wavefronts
+            const int strips = (g.cols + EXM_STRIP - 1) / EXM_STRIP;
+            const int band = ((long long)strips * ((g.rows + 63) / 64) * B >= 4096) ? 64 : 32;
+            const dim3 grid(strips, (g.rows + band - 1) / band, B);
+            hipLaunchKernelGGL(k_extrema_march, grid, dim3(64), 0, st, fp, c->consts.positiveThreshold, c->consts.negativeThreshold, s.cl, band);
+         }
          hipLaunchKernelGGL(k_localize, dim3(1024), dim3(256), 0, st, oc, s.cl, s.rl, c->consts);
          hipLaunchKernelGGL(k_dedupe, dim3(512), dim3(256), 0, st, oc, s.rl, (const uint32_t *)(cnt + 16 + o),
                             c->b_bitmask.as<unsigned long long>());
