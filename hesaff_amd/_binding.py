@@ -55,7 +55,8 @@ _lib = None
 
 
 def lib_path():
-    return os.path.join(_HERE, "libhesaff_amd.so")
+    # HESAFF_AMD_LIB: alternative build of the same library (kernel tuning A/B runs)
+    return os.environ.get("HESAFF_AMD_LIB") or os.path.join(_HERE, "libhesaff_amd.so")
 
 
 def load_library():

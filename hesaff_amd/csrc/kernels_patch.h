@@ -385,6 +385,178 @@ __global__ __launch_bounds__(256) void k_patch_small(HessList hl, PatchWork pw, 
    }
 }
 
+// ---------------------------------------------------------------------------------------
+// k_patch_extract_small<BIN>: the extraction-only form of k_patch_small (the descriptor runs in
+// kernels_sift.h): warp -> blur -> resample for windows P <= 43 (BIN 0) / 66 (BIN 1), result
+// straight to io.patches.  Same arithmetic, cheaper addressing:
+//   * the window S is stored with r replicated columns on either side and the row-pass plane
+//     T with r replicated rows above and below (BORDER_REPLICATE materialised), so no tap
+//     needs an index clamp;
+//   * the tap count K is a template parameter (K = 5..15 here, affine.cpp:129): the loops
+//     are unrolled, taps sit in registers and all LDS reads of an output are in flight together
+//     (the rolled loop waited one LDS round trip per tap);
+//   * idx -> (row, column) uses a float reciprocal (exact for these sizes) instead of the
+//     ~20-instruction integer division.
+// LDS: S[PMAX][PMAX + 14] | T[PMAX + 14][PMAX + 1] | taps.
+// ---------------------------------------------------------------------------------------
+#define HS_SMALL_RMAX 7
+#ifndef HS_WNIT1
+#define HS_WNIT1 6
+#endif
+#ifndef HS_WNIT0
+#define HS_WNIT0 4
+#endif
+
+__device__ __forceinline__ int hs_div_small(int idx, float inv)   // floor(idx / P) for idx < 2^16, P < 2^8, inv = 1.0f / P
+{
+   return (int)(((float)idx + 0.5f) * inv);
+}
+
+template <int KT, int SPITCH, int TPITCH>
+__device__ __forceinline__ void hs_small_blur(float *S, float *T, int P, const float *s_taps, int Krt)
+{
+   const int K = KT ? KT : Krt, r = K >> 1;
+   const int tid = threadIdx.x;
+   const float invP = 1.0f / (float)P;
+   float kk[KT ? KT : 2 * HS_SMALL_RMAX + 1];
+#pragma unroll
+   for (int j = 0; j < (KT ? KT : 2 * HS_SMALL_RMAX + 1); j++) kk[j] = (j < K) ? s_taps[j] : 0.0f;
+   // replicated border columns of S
+   {
+      const float inv2r = 1.0f / (float)(2 * r);
+      for (int i = tid; i < 2 * r * P; i += 256) {
+         const int yy = hs_div_small(i, inv2r), m = i - yy * 2 * r;
+         float *row = S + yy * SPITCH;
+         if (m < r) row[m] = row[r];
+         else row[P + m] = row[r + P - 1];   // column r + P + (m - r)
+      }
+   }
+   __syncthreads();
+   // row pass: T[r + y][x]; rows y = 0 and y = P-1 are also written into the r border rows
+   for (int idx = tid; idx < P * P; idx += 256) {
+      const int yy = hs_div_small(idx, invP), xx = idx - yy * P;
+      const float *sp = S + yy * SPITCH + xx;   // sp[j] = S[clamp(xx - r + j)]
+      float t;
+      if (K <= 5) {
+         t = sp[r] * kk[r] + (sp[r - 1] + sp[r + 1]) * kk[r + 1];
+         if (K == 5) t = t + (sp[r - 2] + sp[r + 2]) * kk[r + 2];
+      } else {
+         t = kk[0] * sp[0];
+#pragma unroll
+         for (int j = 1; j < K; j++) t += kk[j] * sp[j];
+      }
+      T[(r + yy) * TPITCH + xx] = t;
+      if (yy == 0)
+         for (int j = 0; j < r; j++) T[j * TPITCH + xx] = t;
+      if (yy == P - 1)
+         for (int j = 0; j < r; j++) T[(r + P + j) * TPITCH + xx] = t;
+   }
+   __syncthreads();
+   // column pass, blurred window back into S with pitch P
+   for (int idx = tid; idx < P * P; idx += 256) {
+      const int yy = hs_div_small(idx, invP), xx = idx - yy * P;
+      const float *tp = T + (r + yy) * TPITCH + xx;
+      float d = kk[r] * tp[0];
+#pragma unroll
+      for (int j = 1; j <= r; j++) d += kk[r + j] * (tp[j * TPITCH] + tp[-j * TPITCH]);
+      S[idx] = d;
+   }
+   __syncthreads();
+}
+
+template <int BIN>
+__global__ __launch_bounds__(256) void k_patch_extract_small(HessList hl, PatchWork pw, PatchIO io, KpTables tb, int flags)
+{
+   extern __shared__ __attribute__((aligned(16))) float smem[];
+   constexpr int PMAX = BIN == 0 ? 43 : 66;
+   constexpr int SPITCH = PMAX + 2 * HS_SMALL_RMAX, TPITCH = PMAX + 1;
+   constexpr int SSZ = (PMAX * SPITCH + 3) & ~3;
+   float *S = smem, *T = smem + SSZ, *s_taps = T + (PMAX + 2 * HS_SMALL_RMAX) * TPITCH;
+   __shared__ int s_flag;
+
+   const int tid = threadIdx.x;
+   const uint32_t cnt = min(pw.bin_count[BIN], pw.cap);
+   const int imCols = io.image.cols, imRows = io.image.rows, imPitch = io.image.pitch;
+   const int width = imCols - 1, height = imRows - 1;
+
+   for (uint32_t wi = blockIdx.x; wi < cnt; wi += gridDim.x) {
+      const uint32_t h = pw.bin_items[(size_t)BIN * pw.cap + wi];
+      const int b = hl.meta[h] >> 8;
+      const float *img = io.image.img(b);
+      const float x = hl.x[h], y = hl.y[h];
+      const float a11 = pw.A[4 * h], a12 = pw.A[4 * h + 1], a21 = pw.A[4 * h + 2], a22 = pw.A[4 * h + 3];
+      const int P0 = pw.P0[h];
+      const float scale = (float)P0 / (float)HS_PATCH;
+      float *out = io.patches + (size_t)(h - io.h_base) * HS_PATCH_PIX;
+      if (!((double)scale > 0.4)) {
+         // direct branch, affine.cpp:137-141
+         const float b11 = a11 * scale, b12 = a12 * scale, b21 = a21 * scale, b22 = a22 * scale;
+         for (int idx = tid; idx < HS_PATCH_PIX; idx += 256) {
+            const int jj = idx / HS_PATCH, ii = idx - jj * HS_PATCH;
+            const int j = jj - (HS_PATCH >> 1), i = ii - (HS_PATCH >> 1);
+            const float rx = x + (float)j * b12, ry = y + (float)j * b22;
+            const float wx = rx + (float)i * b11, wy = ry + (float)i * b21;
+            bool outside = false;
+            out[idx] = hs_bilinear(img, imPitch, width, height, wx, wy, outside);
+         }
+         continue;
+      }
+      const int P = P0 + 2, half = P >> 1;
+      const int K = tb.patch_tap_k[(P0 - 1) >> 1], r = K >> 1;
+      const float *taps_g = tb.patch_taps + tb.patch_tap_off[(P0 - 1) >> 1];
+      if (tid == 0) s_flag = 0;
+      if (tid < K) s_taps[tid] = taps_g[tid];
+      __syncthreads();
+      // 1. warp, affine.cpp:126 ; touching the image boundary rejects the keypoint.  All gathers of
+      // a batch are issued before the first use (clamped index, branch-free tap).
+      bool outside = false;
+      constexpr int WNIT = BIN == 0 ? HS_WNIT0 : HS_WNIT1;
+      const int PP = P * P;
+      const float invP = 1.0f / (float)P;
+      for (int ib = 0; ib < PP; ib += 256 * WNIT) {
+         float wv[WNIT];
+#pragma unroll
+         for (int it = 0; it < WNIT; it++) {
+            const int idx = min(ib + tid + 256 * it, PP - 1);
+            const int jj = hs_div_small(idx, invP), ii = idx - jj * P;
+            const int j = jj - half, i = ii - half;
+            const float rx = x + (float)j * a12, ry = y + (float)j * a22;
+            const float wx = rx + (float)i * a11, wy = ry + (float)i * a21;
+            wv[it] = hs_bilinear(img, imPitch, width, height, wx, wy, outside);
+         }
+#pragma unroll
+         for (int it = 0; it < WNIT; it++) {
+            const int idx = ib + tid + 256 * it;
+            if (idx < PP) {
+               const int jj = hs_div_small(idx, invP), ii = idx - jj * P;
+               S[jj * SPITCH + r + ii] = wv[it];
+            }
+         }
+      }
+      if (outside) s_flag = 1;
+      __syncthreads();
+      if (s_flag != 0) {
+         if (tid == 0) pw.alive[h] = 0;
+         __syncthreads();
+         continue;
+      }
+      // 2. blur, affine.cpp:129 (pinned cv::GaussianBlur order, see the file header)
+      switch (K) {
+         case 3: hs_small_blur<3, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
+         case 5: hs_small_blur<5, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
+         case 7: hs_small_blur<7, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
+         case 9: hs_small_blur<9, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
+         case 11: hs_small_blur<11, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
+         case 13: hs_small_blur<13, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
+         case 15: hs_small_blur<15, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
+         default: hs_small_blur<0, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
+      }
+      // 3. resample, affine.cpp:131
+      hs_resample_full(S, P, scale, out);
+      __syncthreads();
+   }
+}
+
 // Four column-pass sums at once: rows (y0, y0+1) x needed columns (q, q+1) of the row-pass plane
 // Tp[rows][82].  Each sum keeps the SymmColumnFilter order d = k[r]*T[y]; d += k[r+j]*(T[y+j]+T[y-j]);
 // the four chains are interleaved so that their loads overlap.

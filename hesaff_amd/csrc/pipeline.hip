@@ -153,6 +153,7 @@ struct hesaff_ctx {
    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
    bool no_overlap = false;        // HESAFF_OVERLAP=0: run the patch bins one after the other
    bool stop_after_detect = false; // HESAFF_STOP=detect
+   bool old_small = false;         // HESAFF_SMALL=old: k_patch_small<BIN, false> instead of k_patch_extract_small<BIN>
    bool use_tile_extrema = false;  // HESAFF_EXTREMA=tile: the LDS-tile extrema kernel (k_extrema3) instead of the marching one
    bool debug = false;             // HESAFF_DEBUG=1: launch geometry on stderr
    int force_bands = 0;            // HESAFF_BANDS: force the band count of k_blur_hess_march (tuning)
@@ -458,6 +459,13 @@ template <class KERNEL> void set_dyn_lds(KERNEL kern, size_t lds)
    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 }
 
+size_t small_extract_lds_bytes(int bin)
+{
+   const int PMAX = bin == 0 ? 43 : 66;
+   const int SSZ = (PMAX * (PMAX + 2 * HS_SMALL_RMAX) + 3) & ~3;
+   return (size_t)(SSZ + (PMAX + 2 * HS_SMALL_RMAX) * (PMAX + 1) + 16) * 4;
+}
+
 size_t small_lds_bytes(int bin, bool fused = true)
 {
    const int PMAX = bin == 0 ? 41 : 64;
@@ -490,6 +498,8 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
    if (!attrs) {
       set_dyn_lds((k_patch_small<0, true>), small_lds_bytes(0));
       set_dyn_lds((k_patch_small<1, true>), small_lds_bytes(1));
+      set_dyn_lds(k_patch_extract_small<0>, small_extract_lds_bytes(0));
+      set_dyn_lds(k_patch_extract_small<1>, small_extract_lds_bytes(1));
       set_dyn_lds((k_patch_small<0, false>), small_lds_bytes(0, false));
       set_dyn_lds((k_patch_small<1, false>), small_lds_bytes(1, false));
       set_dyn_lds(k_patch_mid<HS_MID_PMAX, true>, mid_lds_bytes(true));
@@ -511,8 +521,13 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
       if (bins[0]) hipLaunchKernelGGL((k_patch_small<0, true>), dim3(std::min<uint32_t>(bins[0], 256 * 8)), dim3(256), small_lds_bytes(0), s0, s.hl, s.pw, io, c->tables, c->consts, flags);
       if (bins[1]) hipLaunchKernelGGL((k_patch_small<1, true>), dim3(std::min<uint32_t>(bins[1], 256 * 4)), dim3(256), small_lds_bytes(1), s1, s.hl, s.pw, io, c->tables, c->consts, flags);
    } else {
-      if (bins[0]) hipLaunchKernelGGL((k_patch_small<0, false>), dim3(std::min<uint32_t>(bins[0], 256 * 8)), dim3(256), small_lds_bytes(0, false), s0, s.hl, s.pw, io, c->tables, c->consts, flags);
-      if (bins[1]) hipLaunchKernelGGL((k_patch_small<1, false>), dim3(std::min<uint32_t>(bins[1], 256 * 4)), dim3(256), small_lds_bytes(1, false), s1, s.hl, s.pw, io, c->tables, c->consts, flags);
+      if (c->old_small) {
+         if (bins[0]) hipLaunchKernelGGL((k_patch_small<0, false>), dim3(std::min<uint32_t>(bins[0], 256 * 8)), dim3(256), small_lds_bytes(0, false), s0, s.hl, s.pw, io, c->tables, c->consts, flags);
+         if (bins[1]) hipLaunchKernelGGL((k_patch_small<1, false>), dim3(std::min<uint32_t>(bins[1], 256 * 4)), dim3(256), small_lds_bytes(1, false), s1, s.hl, s.pw, io, c->tables, c->consts, flags);
+      } else {
+         if (bins[0]) hipLaunchKernelGGL(k_patch_extract_small<0>, dim3(std::min<uint32_t>(bins[0], 256 * 8)), dim3(256), small_extract_lds_bytes(0), s0, s.hl, s.pw, io, c->tables, flags);
+         if (bins[1]) hipLaunchKernelGGL(k_patch_extract_small<1>, dim3(std::min<uint32_t>(bins[1], 256 * 3)), dim3(256), small_extract_lds_bytes(1), s1, s.hl, s.pw, io, c->tables, flags);
+      }
    }
    const bool fused = (flags & 1) != 0;
    if (bins[2]) {
