@@ -35,6 +35,11 @@ struct DConsts {
    int maxIterations;           // affine.h:39
 };
 
+// Pins a value: everything it depends on (in particular its global loads) is issued before this
+// point instead of being sunk by the compiler into a later conditional block, where each load
+// would be followed by its own full memory round trip.
+#define HS_KEEP(x) asm volatile("" : "+v"(x))
+
 // ---- helpers.cpp:227-240 : one bilinear tap; `outside` is OR-ed like `ret` ----
 // (int)floor(w) of the reference is cvttss2si (INT_MIN on NaN/overflow -> "outside");
 // comparing the floored float gives the same classification without the cast.

@@ -56,15 +56,29 @@ __device__ __forceinline__ void hs_affine_one(const float *__restrict__ blur, in
    for (int l = 0; l < k.maxIterations; l++) {
       const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
       // interpolate(), helpers.cpp:209-244 (return value ignored at affine.cpp:47)
-      for (int idx = lane; idx < HS_SMM_PIX; idx += 64) {
-         const int jj = idx / HS_SMM, ii = idx - jj * HS_SMM;
-         const int j = jj - (HS_SMM >> 1), i = ii - (HS_SMM >> 1);
-         const float rx = lx + (float)j * a12;
-         const float ry = ly + (float)j * a22;
-         const float wx = rx + (float)i * a11;
-         const float wy = ry + (float)i * a21;
-         bool outside = false;
-         s_img[idx] = hs_bilinear(blur, pitch, width, height, wx, wy, outside);
+      // the 6 taps of a lane are gathered together (clamped index, branch-free tap), then stored
+      {
+         constexpr int NT = (HS_SMM_PIX + 63) / 64;
+         float sv[NT];
+#pragma unroll
+         for (int it = 0; it < NT; it++) {
+            const int idx = min(lane + 64 * it, HS_SMM_PIX - 1);
+            const int jj = idx / HS_SMM, ii = idx - jj * HS_SMM;
+            const int j = jj - (HS_SMM >> 1), i = ii - (HS_SMM >> 1);
+            const float rx = lx + (float)j * a12;
+            const float ry = ly + (float)j * a22;
+            const float wx = rx + (float)i * a11;
+            const float wy = ry + (float)i * a21;
+            bool outside = false;
+            sv[it] = hs_bilinear(blur, pitch, width, height, wx, wy, outside);
+         }
+#pragma unroll
+         for (int it = 0; it < NT; it++) HS_KEEP(sv[it]);
+#pragma unroll
+         for (int it = 0; it < NT; it++) {
+            const int idx = lane + 64 * it;
+            if (idx < HS_SMM_PIX) s_img[idx] = sv[it];
+         }
       }
       __syncthreads();
       // computeGradient affine.cpp:14-33 + products affine.cpp:62-68

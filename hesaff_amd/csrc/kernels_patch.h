@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void k_patch_small(HessList hl, PatchWork pw, 
 //     (the rolled loop waited one LDS round trip per tap);
 //   * idx -> (row, column) uses a float reciprocal (exact for these sizes) instead of the
 //     ~20-instruction integer division.
-// LDS: S[PMAX][PMAX + 14] | T[PMAX + 14][PMAX + 1] | taps.
+// LDS: S[PMAX][PMAX + 14] | T[PMAX + 14][PMAX] | taps  (18 KB / 40 KB: 8 / 4 blocks per CU).
 // ---------------------------------------------------------------------------------------
 #define HS_SMALL_RMAX 7
 #ifndef HS_WNIT1
@@ -468,8 +468,8 @@ template <int BIN>
 __global__ __launch_bounds__(256) void k_patch_extract_small(HessList hl, PatchWork pw, PatchIO io, KpTables tb, int flags)
 {
    extern __shared__ __attribute__((aligned(16))) float smem[];
-   constexpr int PMAX = BIN == 0 ? 43 : 66;
-   constexpr int SPITCH = PMAX + 2 * HS_SMALL_RMAX, TPITCH = PMAX + 1;
+   constexpr int PMAX = BIN == 0 ? 41 : 64;   // the bins are cut on P = P0 + 2 (hs_patch_bin)
+   constexpr int SPITCH = PMAX + 2 * HS_SMALL_RMAX, TPITCH = PMAX;
    constexpr int SSZ = (PMAX * SPITCH + 3) & ~3;
    float *S = smem, *T = smem + SSZ, *s_taps = T + (PMAX + 2 * HS_SMALL_RMAX) * TPITCH;
    __shared__ int s_flag;
@@ -491,13 +491,23 @@ __global__ __launch_bounds__(256) void k_patch_extract_small(HessList hl, PatchW
       if (!((double)scale > 0.4)) {
          // direct branch, affine.cpp:137-141
          const float b11 = a11 * scale, b12 = a12 * scale, b21 = a21 * scale, b22 = a22 * scale;
-         for (int idx = tid; idx < HS_PATCH_PIX; idx += 256) {
+         float dv[HS_SIFT_PIX_IT];
+#pragma unroll
+         for (int it = 0; it < HS_SIFT_PIX_IT; it++) {
+            const int idx = min(tid + 256 * it, HS_PATCH_PIX - 1);
             const int jj = idx / HS_PATCH, ii = idx - jj * HS_PATCH;
             const int j = jj - (HS_PATCH >> 1), i = ii - (HS_PATCH >> 1);
             const float rx = x + (float)j * b12, ry = y + (float)j * b22;
             const float wx = rx + (float)i * b11, wy = ry + (float)i * b21;
             bool outside = false;
-            out[idx] = hs_bilinear(img, imPitch, width, height, wx, wy, outside);
+            dv[it] = hs_bilinear(img, imPitch, width, height, wx, wy, outside);
+         }
+#pragma unroll
+         for (int it = 0; it < HS_SIFT_PIX_IT; it++) HS_KEEP(dv[it]);
+#pragma unroll
+         for (int it = 0; it < HS_SIFT_PIX_IT; it++) {
+            const int idx = tid + 256 * it;
+            if (idx < HS_PATCH_PIX) out[idx] = dv[it];
          }
          continue;
       }
@@ -524,6 +534,8 @@ __global__ __launch_bounds__(256) void k_patch_extract_small(HessList hl, PatchW
             const float wx = rx + (float)i * a11, wy = ry + (float)i * a21;
             wv[it] = hs_bilinear(img, imPitch, width, height, wx, wy, outside);
          }
+#pragma unroll
+         for (int it = 0; it < WNIT; it++) HS_KEEP(wv[it]);
 #pragma unroll
          for (int it = 0; it < WNIT; it++) {
             const int idx = ib + tid + 256 * it;
@@ -599,6 +611,62 @@ __device__ __forceinline__ void hs_resample_reduced(const float *__restrict__ Tp
    }
 }
 
+// The same four column-pass sums from a T' plane stored with r replicated rows above and below
+// (row index r + y), as k_patch_mid keeps it in its HBM slot: no index clamps, the two chains
+// share their rows (row y0 + j of chain (y0) is row (y0 + 1) + (j - 1) of chain (y0 + 1)), and
+// the loads of JC tap steps are issued together - the plane is read through L2, where a load
+// per tap step followed by its use is a full round trip per step.
+//   tc -> T'[r + y0][q];  chain a = row y0, chain b = row y0 + 1.
+template <int JC>
+__device__ __forceinline__ void hs_colpass4_padded(const float *__restrict__ tc, const float *__restrict__ taps, int r,
+                                                   float &p00, float &p01, float &p10, float &p11)
+{
+   const float2 c0 = *reinterpret_cast<const float2 *>(tc), c1 = *reinterpret_cast<const float2 *>(tc + HS_NEED);
+   const float kc = taps[r];
+   float d00 = kc * c0.x, d01 = kc * c0.y, d10 = kc * c1.x, d11 = kc * c1.y;
+   float2 pj = c1;   // row y0 + j      (j = 1)
+   float2 mj = c0;   // row y0 + 1 - j  (j = 1)
+   for (int j0 = 1; j0 <= r; j0 += JC) {
+      float2 pn[JC], mn[JC];   // rows y0 + j + 1 and y0 - j
+#pragma unroll
+      for (int u = 0; u < JC; u++) {
+         const int j = min(j0 + u, r);   // steps past r re-read step r's rows (inside the padding), unused
+         pn[u] = *reinterpret_cast<const float2 *>(tc + (j + 1) * HS_NEED);
+         mn[u] = *reinterpret_cast<const float2 *>(tc - j * HS_NEED);
+      }
+#pragma unroll
+      for (int u = 0; u < JC; u++) {
+         const int j = j0 + u;
+         if (j <= r) {   // block-uniform
+            const float kj = taps[r + j];
+            const float s00 = pj.x + mn[u].x, s01 = pj.y + mn[u].y, s10 = pn[u].x + mj.x, s11 = pn[u].y + mj.y;
+            d00 += kj * s00; d01 += kj * s01; d10 += kj * s10; d11 += kj * s11;
+            pj = pn[u];
+            mj = mn[u];
+         }
+      }
+   }
+   p00 = d00; p01 = d01; p10 = d10; p11 = d11;
+}
+
+__device__ __forceinline__ void hs_resample_reduced_padded(const float *__restrict__ Tpad, int P, float scale, const float *__restrict__ taps, int r,
+                                                           float *s_patch)
+{
+   const float c0 = (float)(P >> 1);
+   for (int idx = threadIdx.x; idx < HS_PATCH_PIX; idx += 256) {
+      const int jj = idx / HS_PATCH, ii = idx - jj * HS_PATCH;
+      const int j = jj - (HS_PATCH >> 1), i = ii - (HS_PATCH >> 1);
+      const float rx = c0 + (float)j * 0.0f, ry = c0 + (float)j * scale;
+      float wx = rx + (float)i * scale, wy = ry + (float)i * 0.0f;
+      const float fx = floorf(wx), fy = floorf(wy);
+      wx -= fx; wy -= fy;
+      const int y0 = min(max((int)fy, 0), P - 2);   // always inside: |j * scale| < P0 / 2
+      float p00, p01, p10, p11;
+      hs_colpass4_padded<8>(Tpad + (r + y0) * HS_NEED + 2 * ii, taps, r, p00, p01, p10, p11);
+      s_patch[idx] = (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + (wy) * ((1.0f - wx) * p10 + wx * p11);
+   }
+}
+
 // one window row: warp (affine.cpp:126) into the wave's LDS row, then the row pass at the 82
 // needed columns.  Called by all 64 lanes of a wave.  The LDS row is stored with r replicated
 // border samples on either side (BORDER_REPLICATE), so the tap loop has no index clamps:
@@ -611,7 +679,7 @@ template <int NIT>
 __device__ __forceinline__ void hs_row_stream(const float *__restrict__ img, int imPitch, int width, int height, float x, float y,
                                               float a11, float a12, float a21, float a22, int P, int yy, float scale,
                                               const float *__restrict__ taps, int K, float *__restrict__ srow, float *__restrict__ out82,
-                                              bool &outside)
+                                              bool &outside, int pad_r = 0)
 {
    const int lane = threadIdx.x & 63, half = P >> 1, pm = P - 1, r = K >> 1;
    const int j = yy - half;
@@ -625,6 +693,8 @@ __device__ __forceinline__ void hs_row_stream(const float *__restrict__ img, int
          const float wx = rx + (float)i * a11, wy = ry + (float)i * a21;
          v[it] = hs_bilinear(img, imPitch, width, height, wx, wy, outside);
       }
+#pragma unroll
+      for (int it = 0; it < NIT; it++) HS_KEEP(v[it]);
 #pragma unroll
       for (int it = 0; it < NIT; it++) {
          const int xx = xb + lane + 64 * it;
@@ -654,6 +724,14 @@ __device__ __forceinline__ void hs_row_stream(const float *__restrict__ img, int
    if (out82) {
       out82[q0] = t0;
       if (has1) out82[q1] = t1;
+      // padded T' plane: the first / last window row is replicated pad_r times above / below (wave-uniform)
+      if (pad_r > 0 && (yy == 0 || yy == pm)) {
+         const int step = (yy == 0) ? -HS_NEED : HS_NEED;
+         for (int jr = 1; jr <= pad_r; jr++) {
+            out82[jr * step + q0] = t0;
+            if (has1) out82[jr * step + q1] = t1;
+         }
+      }
    } else {
       srow[0] = t0 + t1;   // ablation only: keep the sums alive without the global store
    }
@@ -669,6 +747,8 @@ __device__ __forceinline__ void hs_row_stream(const float *__restrict__ img, int
 #define HS_MID_SROW 160   // 128 + 2 x 14 border samples, padded
 #define HS_BIG_SROW 704   // 512 + 2 x 57 border samples, padded
 #define HS_BIG_TAPS 128   // K <= 113 for P <= 512
+#define HS_MID_RPAD 14    // K / 2 for P <= 128
+#define HS_BIG_RPAD 57    // K / 2 for P <= 512
 
 // PMAX = 128: bin 2, T' (P x 82) in LDS.  PMAX = 512: bin 3, same structure with T' in a
 // per-block slot of HBM scratch (io.trows), written and re-read by the same block (L2-hot).
@@ -693,7 +773,9 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
    float *s_taps = s_tab + (FUSED ? HS_SIFT_TAB : 0);
    float *s_srow = s_taps + NTAP;                      // 4 waves x SROW
    __shared__ int s_flag;
-   float *Tp = TPG ? io.trows + (size_t)blockIdx.x * ((size_t)PMAX * HS_NEED) : smem;
+   // TPG: T' with r replicated rows above and below, row index r + y (hs_colpass4_padded)
+   constexpr int RPAD = BIG ? HS_BIG_RPAD : HS_MID_RPAD;
+   float *Tp = TPG ? io.trows + (size_t)blockIdx.x * ((size_t)(PMAX + 2 * RPAD) * HS_NEED) : smem;
 
    const int tid = threadIdx.x, wave = tid >> 6;
    SiftRegs rg;
@@ -718,7 +800,8 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
 #pragma unroll 1
       for (int yy = wave; yy < ((flags & 64) ? 4 : P); yy += 4)
          hs_row_stream<NIT>(img, (flags & 16) ? 0 : imPitch, (flags & 16) ? 1 : width, (flags & 16) ? 1 : height, x, y, a11, a12, a21, a22, P, yy,
-                            scale, s_taps, (flags & 8) ? 3 : K, s_srow + wave * SROW, (flags & 128) ? nullptr : Tp + (size_t)yy * HS_NEED, outside);
+                            scale, s_taps, (flags & 8) ? 3 : K, s_srow + wave * SROW,
+                            (flags & 128) ? nullptr : Tp + (size_t)(yy + (TPG ? (K >> 1) : 0)) * HS_NEED, outside, TPG ? (K >> 1) : 0);
       if (outside) s_flag = 1;
       __syncthreads();   // workgroup-scope release/acquire: the T' rows of all four waves are visible
       if (s_flag != 0) {
@@ -726,7 +809,8 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
          __syncthreads();
          continue;
       }
-      hs_resample_reduced(Tp, P, scale, s_taps, (flags & 32) ? 1 : (K >> 1), s_patch);
+      if (TPG) hs_resample_reduced_padded(Tp, P, scale, s_taps, K >> 1, s_patch);
+      else hs_resample_reduced(Tp, P, scale, s_taps, (flags & 32) ? 1 : (K >> 1), s_patch);
       __syncthreads();
       if (FUSED) hs_patch_finish(h, s_patch, smem, s_vec, s_misc, s_tab, rg, io, tb, k, flags);
       else {

@@ -461,9 +461,9 @@ template <class KERNEL> void set_dyn_lds(KERNEL kern, size_t lds)
 
 size_t small_extract_lds_bytes(int bin)
 {
-   const int PMAX = bin == 0 ? 43 : 66;
+   const int PMAX = bin == 0 ? 41 : 64;
    const int SSZ = (PMAX * (PMAX + 2 * HS_SMALL_RMAX) + 3) & ~3;
-   return (size_t)(SSZ + (PMAX + 2 * HS_SMALL_RMAX) * (PMAX + 1) + 16) * 4;
+   return (size_t)(SSZ + (PMAX + 2 * HS_SMALL_RMAX) * PMAX + 16) * 4;
 }
 
 size_t small_lds_bytes(int bin, bool fused = true)
@@ -526,7 +526,7 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
          if (bins[1]) hipLaunchKernelGGL((k_patch_small<1, false>), dim3(std::min<uint32_t>(bins[1], 256 * 4)), dim3(256), small_lds_bytes(1, false), s1, s.hl, s.pw, io, c->tables, c->consts, flags);
       } else {
          if (bins[0]) hipLaunchKernelGGL(k_patch_extract_small<0>, dim3(std::min<uint32_t>(bins[0], 256 * 8)), dim3(256), small_extract_lds_bytes(0), s0, s.hl, s.pw, io, c->tables, flags);
-         if (bins[1]) hipLaunchKernelGGL(k_patch_extract_small<1>, dim3(std::min<uint32_t>(bins[1], 256 * 3)), dim3(256), small_extract_lds_bytes(1), s1, s.hl, s.pw, io, c->tables, flags);
+         if (bins[1]) hipLaunchKernelGGL(k_patch_extract_small<1>, dim3(std::min<uint32_t>(bins[1], 256 * 4)), dim3(256), small_extract_lds_bytes(1), s1, s.hl, s.pw, io, c->tables, flags);
       }
    }
    const bool fused = (flags & 1) != 0;
@@ -534,7 +534,7 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
       if (fused) hipLaunchKernelGGL((k_patch_mid<HS_MID_PMAX, true>), dim3(std::min<uint32_t>(bins[2], 256 * 3)), dim3(256), mid_lds_bytes(true), s2, s.hl, s.pw, io, c->tables, c->consts, flags);
       else {
          const uint32_t nblk = std::min<uint32_t>(bins[2], 256 * 7);
-         c->b_trows2.ensure((size_t)nblk * HS_MID_PMAX * HS_NEED * 4);
+         c->b_trows2.ensure((size_t)nblk * (HS_MID_PMAX + 2 * HS_MID_RPAD) * HS_NEED * 4);
          PatchIO io2 = io;
          io2.trows = c->b_trows2.as<float>();
          hipLaunchKernelGGL((k_patch_mid<HS_MID_PMAX, false, true>), dim3(nblk), dim3(256), mid_tpg_lds_bytes(), s2, s.hl, s.pw, io2, c->tables, c->consts, flags);
@@ -543,7 +543,7 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
    if (bins[3]) {
       // bin 3 (128 < P <= 512): same kernel, T' rows in a per-block HBM slot; runs on the main stream
       const uint32_t nblk = std::min<uint32_t>(bins[3], 256 * (fused ? 4 : 8));
-      c->b_trows3.ensure((size_t)nblk * HS_BIN3_PMAX * HS_NEED * 4);
+      c->b_trows3.ensure((size_t)nblk * (HS_BIN3_PMAX + 2 * HS_BIG_RPAD) * HS_NEED * 4);
       PatchIO io3 = io;
       io3.trows = c->b_trows3.as<float>();
       if (fused) hipLaunchKernelGGL((k_patch_mid<HS_BIN3_PMAX, true>), dim3(nblk), dim3(256), big_lds_bytes(true), st, s.hl, s.pw, io3, c->tables, c->consts, flags);
