@@ -40,6 +40,16 @@ struct DConsts {
 // would be followed by its own full memory round trip.
 #define HS_KEEP(x) asm volatile("" : "+v"(x))
 
+// Ordering of LDS traffic between the lanes of ONE wavefront: the LDS executes a wave's
+// instructions in order, so a compiler-level barrier (no reordering of memory operations) plus
+// draining the LDS counter is enough.  A wavefront-scope C++ fence would also wait for the
+// wave's outstanding GLOBAL stores (vmcnt(0)) - a full memory round trip per window row.
+#define HS_WAVE_LDS_SYNC()                                  \
+   do {                                                     \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+      __builtin_amdgcn_wave_barrier();                      \
+   } while (0)
+
 // ---- helpers.cpp:227-240 : one bilinear tap; `outside` is OR-ed like `ret` ----
 // (int)floor(w) of the reference is cvttss2si (INT_MIN on NaN/overflow -> "outside");
 // comparing the floored float gives the same classification without the cast.

@@ -29,11 +29,10 @@ struct KpTables {   // device tables built on the host once per context
 };
 
 // ---------------------------------------------------------------------------------------
-// k_affine: AffineShape::findAffineShape affine.cpp:35-100, one wavefront (one 64-thread
-// block) per Hessian keypoint.
-//  per iteration: 361 bilinear taps spread over the 64 lanes -> LDS img; gradients and the
-//  three products per pixel -> LDS; lanes 0,1,2 add the 361 terms of a,b,c in index order;
-//  lane 0 runs the double-precision invSqrt and the U update; result broadcast through LDS.
+// k_affine: AffineShape::findAffineShape affine.cpp:35-100.
+//  per iteration: 361 bilinear taps -> LDS img; gradients and the three products per pixel ->
+//  LDS; three lanes add the 361 terms of a,b,c in index order; one lane runs the
+//  double-precision invSqrt and the U update; result broadcast through LDS.
 // ---------------------------------------------------------------------------------------
 struct AffineOut {
    int32_t *converged;   // 1 = onAffineShapeFound was called
@@ -41,138 +40,190 @@ struct AffineOut {
    int32_t *iters;
 };
 
-__device__ __forceinline__ void hs_affine_one(const float *__restrict__ blur, int rows, int cols, int pitch, float x, float y,
-                                              float s, float pd, const float *__restrict__ mask, const DConsts &k,
-                                              float *s_img, float *s_pa, float *s_pb, float *s_pc, float *s_bc,
-                                              int &conv_out, float *U_out, int &iters_out)
+// ---------------------------------------------------------------------------------------
+// hs_affine_groups: the same iteration with FOUR keypoints per wavefront (16 lanes each).
+// Per iteration a keypoint needs 361 parallel taps + products, then three 361-term sequential
+// sums and one double-precision invSqrt.  With one keypoint per wavefront the sums keep 3 lanes
+// busy and the invSqrt one lane; with four keypoints side by side those serial stretches are
+// shared by four (12 and 4 lanes busy) and the wavefront executes ~2.3x fewer instructions per
+// keypoint.  The 16-lane groups are persistent: a group whose keypoint converged (or was
+// rejected) takes the next keypoint at the end of the round, so keypoints with different
+// iteration counts do not wait for each other.
+// block = 64 threads (one wavefront), LDS 4 x 4 x 364 floats + mask.
+// ---------------------------------------------------------------------------------------
+#define HS_AFF_G 4
+#define HS_AFF_NT 23    // ceil(361 / 16)
+#define HS_AFF_ARR 364  // 361 rounded up to a multiple of 4 floats
+
+struct AffKp { const float *blur; int rows, cols, pitch; float x, y, s, pd; };
+
+template <class Fetch>
+__device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, const float *__restrict__ mask_g, const DConsts &k, AffineOut out,
+                                                 Fetch fetch)
 {
-   const int lane = threadIdx.x;
-   float eigen_ratio_act = 0.0f, eigen_ratio_bef = 0.0f;
-   float u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f, l1 = 1.0f, l2 = 1.0f;
-   const float lx = x / pd, ly = y / pd;
-   const float ratio = s / (k.affInitialSigma * pd);
-   const int width = cols - 1, height = rows - 1;
-   int converged = 0, iters = 0;
-   for (int l = 0; l < k.maxIterations; l++) {
-      const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
-      // interpolate(), helpers.cpp:209-244 (return value ignored at affine.cpp:47)
-      // the 6 taps of a lane are gathered together (clamped index, branch-free tap), then stored
-      {
-         constexpr int NT = (HS_SMM_PIX + 63) / 64;
-         float sv[NT];
-#pragma unroll
-         for (int it = 0; it < NT; it++) {
-            const int idx = min(lane + 64 * it, HS_SMM_PIX - 1);
-            const int jj = idx / HS_SMM, ii = idx - jj * HS_SMM;
-            const int j = jj - (HS_SMM >> 1), i = ii - (HS_SMM >> 1);
-            const float rx = lx + (float)j * a12;
-            const float ry = ly + (float)j * a22;
-            const float wx = rx + (float)i * a11;
-            const float wy = ry + (float)i * a21;
-            bool outside = false;
-            sv[it] = hs_bilinear(blur, pitch, width, height, wx, wy, outside);
+   __shared__ __attribute__((aligned(16))) float s_arr[HS_AFF_G][4][HS_AFF_ARR];   // img | a | b | c terms
+   __shared__ float s_mask[HS_AFF_ARR];
+   __shared__ float s_bc[HS_AFF_G][8];
+   const int lane = threadIdx.x, grp = lane >> 4, li = lane & 15;
+   for (int i = lane; i < HS_SMM_PIX; i += 64) s_mask[i] = mask_g[i];
+   float *s_img = s_arr[grp][0], *s_pa = s_arr[grp][1], *s_pb = s_arr[grp][2], *s_pc = s_arr[grp][3];
+   const uint32_t hstep = gridDim.x * HS_AFF_G;
+   uint32_t h = first + blockIdx.x * HS_AFF_G + grp;
+   if (k.maxIterations <= 0) {   // no iteration: U = identity, not converged
+      for (; h < n; h += hstep)
+         if (li == 0) {
+            out.converged[h] = 0; out.iters[h] = 0;
+            out.U[4 * h + 0] = 1.0f; out.U[4 * h + 1] = 0.0f; out.U[4 * h + 2] = 0.0f; out.U[4 * h + 3] = 1.0f;
          }
+      return;
+   }
+   // per-group state, replicated in the group's 16 lanes
+   const float *blur = nullptr;
+   int pitch = 0, width = 0, height = 0, l = 0;
+   float lx = 0, ly = 0, ratio = 0, u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f;
+   float eigen_ratio_act = 0.0f, eigen_ratio_bef = 0.0f;   // used by lane li == 0
+   bool active = h < n;
+   auto load_kp = [&]() {
+      if (active) {
+         const AffKp q = fetch(h);
+         blur = q.blur; pitch = q.pitch; width = q.cols - 1; height = q.rows - 1;
+         lx = q.x / q.pd; ly = q.y / q.pd;
+         ratio = q.s / (k.affInitialSigma * q.pd);
+         u11 = 1.0f; u12 = 0.0f; u21 = 0.0f; u22 = 1.0f;
+         eigen_ratio_act = 0.0f; eigen_ratio_bef = 0.0f;
+         l = 0;
+      }
+   };
+   load_kp();
+   HS_WAVE_LDS_SYNC();
+   while (__ballot(active) != 0ull) {
+      if (active) {
+         const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
+         // interpolate(), helpers.cpp:209-244 (return value ignored at affine.cpp:47): 23 taps per lane in two batches
 #pragma unroll
-         for (int it = 0; it < NT; it++) HS_KEEP(sv[it]);
+         for (int half = 0; half < 2; half++) {
+            constexpr int NB = (HS_AFF_NT + 1) / 2;
+            float sv[NB];
 #pragma unroll
-         for (int it = 0; it < NT; it++) {
-            const int idx = lane + 64 * it;
-            if (idx < HS_SMM_PIX) s_img[idx] = sv[it];
+            for (int t = 0; t < NB; t++) {
+               const int idx = min(li + 16 * (half * NB + t), HS_SMM_PIX - 1);
+               const int jj = idx / HS_SMM, ii = idx - jj * HS_SMM;
+               const int j = jj - (HS_SMM >> 1), i = ii - (HS_SMM >> 1);
+               const float rx = lx + (float)j * a12;
+               const float ry = ly + (float)j * a22;
+               const float wx = rx + (float)i * a11;
+               const float wy = ry + (float)i * a21;
+               bool outside = false;
+               sv[t] = hs_bilinear(blur, pitch, width, height, wx, wy, outside);
+            }
+#pragma unroll
+            for (int t = 0; t < NB; t++) HS_KEEP(sv[t]);
+#pragma unroll
+            for (int t = 0; t < NB; t++) {
+               const int idx = li + 16 * (half * NB + t);
+               if (idx < HS_SMM_PIX) s_img[idx] = sv[t];
+            }
          }
       }
-      __syncthreads();
-      // computeGradient affine.cpp:14-33 + products affine.cpp:62-68
-      for (int idx = lane; idx < HS_SMM_PIX; idx += 64) {
-         const int r = idx / HS_SMM, c = idx - r * HS_SMM;
-         float gxx, gyy;
-         hs_grad(s_img, HS_SMM, r, c, gxx, gyy);
-         const float v = mask[idx];
-         const float gxy = gxx * gyy;
-         s_pa[idx] = gxx * gxx * v;
-         s_pb[idx] = gxy * v;
-         s_pc[idx] = gyy * gyy * v;
+      HS_WAVE_LDS_SYNC();
+      if (active) {
+         // computeGradient affine.cpp:14-33 + products affine.cpp:62-68
+#pragma unroll 6
+         for (int t = 0; t < HS_AFF_NT; t++) {
+            const int idx = li + 16 * t;
+            if (idx < HS_SMM_PIX) {
+               const int r = idx / HS_SMM, c = idx - r * HS_SMM;
+               // hs_grad with clamped neighbour indices (one-sided differences at the tile border)
+               const float gxx = s_img[idx + (c < HS_SMM - 1 ? 1 : 0)] - s_img[idx - (c > 0 ? 1 : 0)];
+               const float gyy = s_img[idx + (r < HS_SMM - 1 ? HS_SMM : 0)] - s_img[idx - (r > 0 ? HS_SMM : 0)];
+               const float v = s_mask[idx];
+               const float gxy = gxx * gyy;
+               s_pa[idx] = gxx * gxx * v;
+               s_pb[idx] = gxy * v;
+               s_pc[idx] = gyy * gyy * v;
+            }
+         }
       }
-      __syncthreads();
-      if (lane < 3) {
+      HS_WAVE_LDS_SYNC();
+      if (active && li < 3) {
          // 361 terms in index order (affine.cpp:57-68); float4 LDS reads, the adds stay sequential
-         const float4 *p4 = reinterpret_cast<const float4 *>(lane == 0 ? s_pa : (lane == 1 ? s_pb : s_pc));
+         const float *pp = s_arr[grp][1 + li];
+         const float4 *p4 = reinterpret_cast<const float4 *>(pp);
          float acc = 0.0f;
-#pragma unroll 2
-         for (int i = 0; i < HS_SMM_PIX / 4; i++) {
-            const float4 q = p4[i];
-            acc += q.x; acc += q.y; acc += q.z; acc += q.w;
+         for (int i0 = 0; i0 < HS_SMM_PIX / 4; i0 += 10) {   // 90 = 9 x 10 float4, ten reads in flight
+            float4 q[10];
+#pragma unroll
+            for (int u = 0; u < 10; u++) q[u] = p4[i0 + u];
+#pragma unroll
+            for (int u = 0; u < 10; u++) { acc += q[u].x; acc += q[u].y; acc += q[u].z; acc += q[u].w; }
          }
-         acc += (lane == 0 ? s_pa : (lane == 1 ? s_pb : s_pc))[HS_SMM_PIX - 1];   // 361 = 4 * 90 + 1
-         s_bc[lane] = acc / (float)HS_SMM_PIX;
+         acc += pp[HS_SMM_PIX - 1];   // 361 = 4 * 90 + 1
+         s_bc[grp][li] = acc / (float)HS_SMM_PIX;
       }
-      __syncthreads();
-      if (lane == 0) {
-         float a = s_bc[0], b = s_bc[1], c = s_bc[2];
+      HS_WAVE_LDS_SYNC();
+      if (active && li == 0) {
+         float a = s_bc[grp][0], b = s_bc[grp][1], c = s_bc[grp][2];
+         float l1, l2;
          hs_inv_sqrt(a, b, c, l1, l2);
          eigen_ratio_bef = eigen_ratio_act;
          eigen_ratio_act = 1 - l2 / l1;
          const float u11t = u11, u12t = u12;
-         u11 = a * u11t + b * u21; u12 = a * u12t + b * u22;
-         u21 = b * u11t + c * u21; u22 = b * u12t + c * u22;
+         const float n11 = a * u11t + b * u21, n12 = a * u12t + b * u22;
+         const float n21 = b * u11t + c * u21, n22 = b * u12t + c * u22;
          int state = 0;   // 0 continue, 1 break (rejected), 2 converged
-         if (!hs_eigenvalues(u11, u12, u21, u22, l1, l2)) state = 1;
+         if (!hs_eigenvalues(n11, n12, n21, n22, l1, l2)) state = 1;
          else if ((l1 / l2 > 6) || (l2 / l1 > 6)) state = 1;
          else if (eigen_ratio_act < k.convergenceThreshold && eigen_ratio_bef < k.convergenceThreshold) state = 2;
-         s_bc[3] = u11; s_bc[4] = u12; s_bc[5] = u21; s_bc[6] = u22;
-         s_bc[7] = __int_as_float(state);
+         s_bc[grp][3] = n11; s_bc[grp][4] = n12; s_bc[grp][5] = n21; s_bc[grp][6] = n22;
+         s_bc[grp][7] = __int_as_float(state);
       }
-      __syncthreads();
-      u11 = s_bc[3]; u12 = s_bc[4]; u21 = s_bc[5]; u22 = s_bc[6];
-      const int state = __float_as_int(s_bc[7]);
-      __syncthreads();
-      if (state == 2) { converged = 1; iters = l; break; }
-      if (state == 1) break;
+      HS_WAVE_LDS_SYNC();
+      if (active) {
+         u11 = s_bc[grp][3]; u12 = s_bc[grp][4]; u21 = s_bc[grp][5]; u22 = s_bc[grp][6];
+         const int state = __float_as_int(s_bc[grp][7]);
+         if (state != 0 || l + 1 >= k.maxIterations) {
+            // affine.cpp:88-99: converged -> onAffineShapeFound(..., l); otherwise the keypoint is dropped
+            if (li == 0) {
+               out.converged[h] = (state == 2) ? 1 : 0;
+               out.iters[h] = (state == 2) ? l : 0;
+               out.U[4 * h + 0] = u11; out.U[4 * h + 1] = u12; out.U[4 * h + 2] = u21; out.U[4 * h + 3] = u22;
+            }
+            h += hstep;
+            active = h < n;
+            load_kp();
+         } else {
+            l++;
+         }
+      }
+      HS_WAVE_LDS_SYNC();
    }
-   conv_out = converged;
-   iters_out = iters;
-   U_out[0] = u11; U_out[1] = u12; U_out[2] = u21; U_out[3] = u22;
 }
 
 __global__ __launch_bounds__(64) void k_affine(PlaneTab pt, HessList hl, uint32_t h_lo, uint32_t h_hi, const uint32_t *__restrict__ n_ptr,
                                                KpTables tb, DConsts k, AffineOut out)
 {
-   __shared__ __attribute__((aligned(16))) float s_img[HS_SMM_PIX + 3], s_pa[HS_SMM_PIX + 3], s_pb[HS_SMM_PIX + 3], s_pc[HS_SMM_PIX + 3];
-   __shared__ float s_bc[8];
    const uint32_t n = min(min(*n_ptr, hl.cap), h_hi);   // keypoints [h_lo, h_hi) of the list
-   for (uint32_t h = h_lo + blockIdx.x; h < n; h += gridDim.x) {
+   hs_affine_groups(h_lo, n, tb.smm_mask, k, out, [&](uint32_t h) {
       const int meta = hl.meta[h];
       const int b = meta >> 8, octave = (meta >> 4) & 15, level = (meta >> 2) & 3;
       const DPlane &P = pt.L[octave][level];
-      const float pd = (float)(1 << octave);
-      int conv, iters;
-      float U[4];
-      hs_affine_one(P.img(b), P.rows, P.cols, P.pitch, hl.x[h], hl.y[h], hl.s[h], pd, tb.smm_mask, k, s_img, s_pa, s_pb, s_pc,
-                    s_bc, conv, U, iters);
-      if (threadIdx.x == 0) {
-         out.converged[h] = conv;
-         out.iters[h] = iters;
-         out.U[4 * h + 0] = U[0]; out.U[4 * h + 1] = U[1]; out.U[4 * h + 2] = U[2]; out.U[4 * h + 3] = U[3];
-      }
-   }
+      AffKp q;
+      q.blur = P.img(b); q.rows = P.rows; q.cols = P.cols; q.pitch = P.pitch;
+      q.x = hl.x[h]; q.y = hl.y[h]; q.s = hl.s[h]; q.pd = (float)(1 << octave);
+      return q;
+   });
 }
 
 // stage API flavour: n keypoints on a single plane, pixelDistance given explicitly
 __global__ __launch_bounds__(64) void k_affine_stage(DPlane P, const float *__restrict__ kp /*n x 4*/, int n, KpTables tb, DConsts k,
                                                      AffineOut out)
 {
-   __shared__ __attribute__((aligned(16))) float s_img[HS_SMM_PIX + 3], s_pa[HS_SMM_PIX + 3], s_pb[HS_SMM_PIX + 3], s_pc[HS_SMM_PIX + 3];
-   __shared__ float s_bc[8];
-   for (int h = blockIdx.x; h < n; h += gridDim.x) {
-      int conv, iters;
-      float U[4];
-      hs_affine_one(P.img(0), P.rows, P.cols, P.pitch, kp[4 * h], kp[4 * h + 1], kp[4 * h + 2], kp[4 * h + 3], tb.smm_mask, k,
-                    s_img, s_pa, s_pb, s_pc, s_bc, conv, U, iters);
-      if (threadIdx.x == 0) {
-         out.converged[h] = conv;
-         out.iters[h] = iters;
-         out.U[4 * h + 0] = U[0]; out.U[4 * h + 1] = U[1]; out.U[4 * h + 2] = U[2]; out.U[4 * h + 3] = U[3];
-      }
-   }
+   hs_affine_groups(0u, (uint32_t)n, tb.smm_mask, k, out, [&](uint32_t h) {
+      AffKp q;
+      q.blur = P.img(0); q.rows = P.rows; q.cols = P.cols; q.pitch = P.pitch;
+      q.x = kp[4 * h]; q.y = kp[4 * h + 1]; q.s = kp[4 * h + 2]; q.pd = kp[4 * h + 3];
+      return q;
+   });
 }
 
 // ---------------------------------------------------------------------------------------

@@ -19,16 +19,6 @@
 #define HS_SIFT_TAB 232    // 4 x 41 bin/weight entries + 4 x 16 cell weights
 #define HS_NEED 82         // blurred columns (and rows) the 41x41 resample reads: 2 per output
 
-// Ordering of LDS traffic between the lanes of ONE wavefront: the LDS executes a wave's
-// instructions in order, so a compiler-level barrier (no reordering of memory operations) plus
-// draining the LDS counter is enough.  A wavefront-scope C++ fence would also wait for the
-// wave's outstanding GLOBAL stores (vmcnt(0)) - a full memory round trip per window row.
-#define HS_WAVE_LDS_SYNC()                                  \
-   do {                                                     \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
-      __builtin_amdgcn_wave_barrier();                      \
-   } while (0)
-
 struct PatchIO {
    DPlane image;         // original float image batch (normalizeAffine samples the ORIGINAL image, hesaff.cpp:82)
    float *patches;       // optional [n][1681] output, row index h - h_base; may be null

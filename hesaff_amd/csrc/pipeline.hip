@@ -777,7 +777,7 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
    if (c->fused_sift) {
       // one kernel per window-size bin does normalizeAffine + SIFT (HESAFF_SIFT=fused)
       t = tm.begin(T_AFF);
-      hipLaunchKernelGGL(k_affine, dim3(256 * 32), dim3(64), 0, st, pt, s.hl, 0u, 0xffffffffu, (const uint32_t *)(cnt + 3), c->tables, c->consts, s.ao);
+      hipLaunchKernelGGL(k_affine, dim3(256 * 6), dim3(64), 0, st, pt, s.hl, 0u, 0xffffffffu, (const uint32_t *)(cnt + 3), c->tables, c->consts, s.ao);
       tm.end(t);
       t = tm.begin(T_PATCH);
       hipLaunchKernelGGL(k_prepare_patch, dim3(1024), dim3(256), 0, st, s.hl, 0u, (const uint32_t *)(cnt + 3), s.ao, H, W, c->consts,
@@ -813,7 +813,7 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       hipStream_t as = c->no_overlap ? st : c->aff_stream;
       if (as != st) HIP_TRY(hipStreamWaitEvent(as, c->ev_detect_done, 0));
       auto launch_affine = [&](size_t gi) {
-         hipLaunchKernelGGL(k_affine, dim3(256 * 32), dim3(64), 0, as, pt, s.hl, groups[gi].first, groups[gi].second, (const uint32_t *)(cnt + 3),
+         hipLaunchKernelGGL(k_affine, dim3(std::min<uint32_t>((groups[gi].second - groups[gi].first + 3) / 4, 256 * 6)), dim3(64), 0, as, pt, s.hl, groups[gi].first, groups[gi].second, (const uint32_t *)(cnt + 3),
                             c->tables, c->consts, s.ao);
          if (as != st) HIP_TRY(hipEventRecord(c->ev_aff[gi], as));
       };
