@@ -73,7 +73,7 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
          throw HsError(HESAFF_ERR_DEVICE, m);
       }
       HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-      for (int i = 0; i < 3; i++) {
+      for (int i = 0; i < HS_NSIDE; i++) {
          HIP_TRY(hipStreamCreateWithFlags(&c->side_streams[i], hipStreamNonBlocking));
          HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
       }
@@ -91,6 +91,7 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       memset(&c->tm, 0, sizeof c->tm);
       if (const char *ab = getenv("HESAFF_ABLATE")) c->ablate = atoi(ab) & ~1;
       if (const char *pk = getenv("HESAFF_PYR")) { c->use_tile_kernel = strcmp(pk, "tile") == 0; c->use_glds = strcmp(pk, "glds") == 0; }
+      if (const char *sd = getenv("HESAFF_SIDE")) c->side_mask = atoi(sd);
       if (const char *sm = getenv("HESAFF_SMALL")) c->old_small = strcmp(sm, "old") == 0;
       if (const char *ex = getenv("HESAFF_EXTREMA")) c->use_tile_extrema = strcmp(ex, "tile") == 0;
       if (const char *bd = getenv("HESAFF_BAND")) c->band_rows = std::max(8, atoi(bd));
@@ -122,7 +123,7 @@ void hesaff_destroy(hesaff_ctx *c)
                      &c->b_stage, &c->b_input, &c->t_mask_idx, &c->b_rowprefix, &c->b_trows, &c->b_trows2, &c->b_trows3, &c->b_siftvec, &c->b_meanvar, &c->b_siftvo};
    for (DevBuf *b : bufs) b->release();
    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-   for (int i = 0; i < 3; i++) {
+   for (int i = 0; i < HS_NSIDE; i++) {
       if (c->side_streams[i]) { (void)hipStreamSynchronize(c->side_streams[i]); (void)hipStreamDestroy(c->side_streams[i]); }
       if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
    }

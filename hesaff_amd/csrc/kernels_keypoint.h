@@ -53,6 +53,9 @@ struct AffineOut {
 // ---------------------------------------------------------------------------------------
 #define HS_AFF_G 4
 #define HS_AFF_NT 23    // ceil(361 / 16)
+#ifndef HS_AFF_BATCHES
+#define HS_AFF_BATCHES 2
+#endif
 #define HS_AFF_ARR 364  // 361 rounded up to a multiple of 4 floats
 
 struct AffKp { const float *blur; int rows, cols, pitch; float x, y, s, pd; };
@@ -101,8 +104,8 @@ __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, con
          const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
          // interpolate(), helpers.cpp:209-244 (return value ignored at affine.cpp:47): 23 taps per lane in two batches
 #pragma unroll
-         for (int half = 0; half < 2; half++) {
-            constexpr int NB = (HS_AFF_NT + 1) / 2;
+         for (int half = 0; half < HS_AFF_BATCHES; half++) {
+            constexpr int NB = (HS_AFF_NT + HS_AFF_BATCHES - 1) / HS_AFF_BATCHES;
             float sv[NB];
 #pragma unroll
             for (int t = 0; t < NB; t++) {

@@ -99,6 +99,7 @@ struct OctGeom {
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+#define HS_NSIDE 4   // side streams of the patch stage (one per window-size bin 0..3)
 struct hesaff_ctx {
    hesaff_params par;
    int device = 0;
@@ -143,16 +144,17 @@ struct hesaff_ctx {
    bool use_glds = false;          // HESAFF_PYR=glds: LDS-DMA prefetch variant of the marching kernel
    bool use_tile_kernel = false;   // HESAFF_PYR=tile: v1 LDS-tile pyramid kernel (cross-check / fallback)
    int band_rows = 16;             // HESAFF_BAND: minimum rows per wavefront band of k_blur_hess_march
-   hipStream_t side_streams[3] = {nullptr, nullptr, nullptr};
+   hipStream_t side_streams[HS_NSIDE] = {nullptr, nullptr, nullptr, nullptr};
    hipStream_t sift_stream = nullptr;
    hipStream_t aff_stream = nullptr;      // affine shape of image group g+1 runs beside the patch extraction of group g
    hipEvent_t ev_detect_done = nullptr;
    std::vector<hipEvent_t> ev_aff;        // one per image group, grown on demand
    hipEvent_t ev_extract_done[2] = {nullptr, nullptr}, ev_sift_done[2] = {nullptr, nullptr};
    DevBuf b_patches2[2], b_siftvec2[2], b_meanvar2[2], b_siftvo2[2];
-   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+   hipEvent_t ev_fork = nullptr, ev_join[HS_NSIDE] = {nullptr, nullptr, nullptr, nullptr};
    bool no_overlap = false;        // HESAFF_OVERLAP=0: run the patch bins one after the other
    bool stop_after_detect = false; // HESAFF_STOP=detect
+   int side_mask = 15;             // HESAFF_SIDE: bit i = window-size bin i runs on its own side stream
    bool old_small = false;         // HESAFF_SMALL=old: k_patch_small<BIN, false> instead of k_patch_extract_small<BIN>
    bool use_tile_extrema = false;  // HESAFF_EXTREMA=tile: the LDS-tile extrema kernel (k_extrema3) instead of the marching one
    bool debug = false;             // HESAFF_DEBUG=1: launch geometry on stderr
@@ -511,11 +513,14 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
    // The bins are independent (disjoint keypoints) and each kernel leaves CU resources idle
    // (LDS- or latency-bound), so they run concurrently on side streams; the large-window bins
    // stay on the main stream (they need host round trips for their row prefix).
-   hipStream_t s0 = st, s1 = st, s2 = st;
+   hipStream_t s0 = st, s1 = st, s2 = st, s3 = st;
    if (c->side_streams[0] && !c->no_overlap) {
       HIP_TRY(hipEventRecord(c->ev_fork, st));
-      for (int i = 0; i < 3; i++) HIP_TRY(hipStreamWaitEvent(c->side_streams[i], c->ev_fork, 0));
-      s0 = c->side_streams[0]; s1 = c->side_streams[1]; s2 = c->side_streams[2];
+      for (int i = 0; i < HS_NSIDE; i++) HIP_TRY(hipStreamWaitEvent(c->side_streams[i], c->ev_fork, 0));
+      if (c->side_mask & 1) s0 = c->side_streams[0];
+      if (c->side_mask & 2) s1 = c->side_streams[1];
+      if (c->side_mask & 4) s2 = c->side_streams[2];
+      if (c->side_mask & 8) s3 = c->side_streams[3];
    }
    if ((flags & 1) != 0) {
       if (bins[0]) hipLaunchKernelGGL((k_patch_small<0, true>), dim3(std::min<uint32_t>(bins[0], 256 * 8)), dim3(256), small_lds_bytes(0), s0, s.hl, s.pw, io, c->tables, c->consts, flags);
@@ -541,16 +546,18 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
       }
    }
    if (bins[3]) {
-      // bin 3 (128 < P <= 512): same kernel, T' rows in a per-block HBM slot; runs on the main stream
+      // bin 3 (128 < P <= 512): same kernel, T' rows in a per-block HBM slot; on its own side stream so that the
+      // host round trip of the bin-4 row prefix below does not wait for it
       const uint32_t nblk = std::min<uint32_t>(bins[3], 256 * (fused ? 4 : 8));
       c->b_trows3.ensure((size_t)nblk * (HS_BIN3_PMAX + 2 * HS_BIG_RPAD) * HS_NEED * 4);
       PatchIO io3 = io;
       io3.trows = c->b_trows3.as<float>();
-      if (fused) hipLaunchKernelGGL((k_patch_mid<HS_BIN3_PMAX, true>), dim3(nblk), dim3(256), big_lds_bytes(true), st, s.hl, s.pw, io3, c->tables, c->consts, flags);
-      else hipLaunchKernelGGL((k_patch_mid<HS_BIN3_PMAX, false>), dim3(nblk), dim3(256), big_lds_bytes(false), st, s.hl, s.pw, io3, c->tables, c->consts, flags);
+      if (fused) hipLaunchKernelGGL((k_patch_mid<HS_BIN3_PMAX, true>), dim3(nblk), dim3(256), big_lds_bytes(true), s3, s.hl, s.pw, io3, c->tables, c->consts, flags);
+      else hipLaunchKernelGGL((k_patch_mid<HS_BIN3_PMAX, false>), dim3(nblk), dim3(256), big_lds_bytes(false), s3, s.hl, s.pw, io3, c->tables, c->consts, flags);
    }
-   if (s0 != st) {
-      for (int i = 0; i < 3; i++) HIP_TRY(hipEventRecord(c->ev_join[i], c->side_streams[i]));
+   const bool forked = c->side_streams[0] && !c->no_overlap;
+   if (forked) {
+      for (int i = 0; i < HS_NSIDE; i++) HIP_TRY(hipEventRecord(c->ev_join[i], c->side_streams[i]));
    }
    // large windows: bin 3 (P <= 512, small LDS rows -> full occupancy) and bin 4 (the rare huge ones)
    for (int lb = 4; lb <= 4; lb++) {
@@ -590,8 +597,8 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
          k0 = k1;
       }
    }
-   if (s0 != st)
-      for (int i = 0; i < 3; i++) HIP_TRY(hipStreamWaitEvent(st, c->ev_join[i], 0));
+   if (forked)
+      for (int i = 0; i < HS_NSIDE; i++) HIP_TRY(hipStreamWaitEvent(st, c->ev_join[i], 0));
 }
 
 // The scale-space + detection part for the current plan; fills the ordered Hessian list.

@@ -10,7 +10,7 @@ ks = [k for k in ks if k[0] >= t0]
 t1 = max(e for s, e, n, q in ks)
 print('step span %.1f ms, %d launches' % ((t1 - t0) / 1e6, len(ks)))
 def fam(n):
-    for key, f in (('k_patch_small<0', 'small0'), ('k_patch_small<1', 'small1'), ('k_patch_mid<128', 'mid128'), ('k_patch_mid<512', 'mid512'),
+    for key, f in (('k_patch_extract_small<0', 'small0'), ('k_patch_extract_small<1', 'small1'), ('k_patch_small<0', 'small0'), ('k_patch_small<1', 'small1'), ('k_patch_mid<128', 'mid128'), ('k_patch_mid<512', 'mid512'),
                    ('k_patch_large', 'large'), ('k_sift_grad', 'grad'), ('k_sift_hist', 'hist'), ('k_sift_meanvar', 'meanvar'), ('k_sift_quant', 'quant'),
                    ('k_affine', 'affine'), ('k_blur_hess', 'pyr'), ('k_extrema', 'extrema'), ('k_localize', 'extrema'), ('k_prepare', 'prep')):
         if n.startswith(key): return f
