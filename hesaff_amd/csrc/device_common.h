@@ -70,6 +70,40 @@ __device__ __forceinline__ float hs_bilinear(const float *__restrict__ im, int p
    return in ? v : 0.0f;
 }
 
+// The same tap through a buffer resource: one image plane (< 4 GB) described by four scalar
+// registers, per-lane 32-bit byte offsets, the second row reached through the scalar offset
+// operand - no 64-bit per-lane pointer arithmetic.  The plane base must be wave-uniform.
+typedef unsigned int hs_v2u __attribute__((ext_vector_type(2)));
+struct HsPlaneBuf {
+   __amdgpu_buffer_rsrc_t rsrc;
+   uint32_t pitch, pitch_bytes;
+};
+__device__ __forceinline__ HsPlaneBuf hs_plane_buf(const float *base, int rows, int pitch)
+{
+   const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+   const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)a), hi = __builtin_amdgcn_readfirstlane((unsigned int)(a >> 32));
+   HsPlaneBuf b;
+   b.rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0,
+                                              (int)((unsigned int)rows * (unsigned int)pitch * 4u), 0x00020000);
+   b.pitch = (uint32_t)pitch;
+   b.pitch_bytes = (uint32_t)pitch * 4u;
+   return b;
+}
+__device__ __forceinline__ float hs_bilinear_buf(const HsPlaneBuf &im, int width, int height, float wx, float wy, bool &outside)
+{
+   const float fx = floorf(wx), fy = floorf(wy);
+   const bool in = (fx >= 0.0f && fy >= 0.0f && fx < (float)width && fy < (float)height);
+   wx -= fx;
+   wy -= fy;
+   const uint32_t off = in ? ((uint32_t)(int)fy * im.pitch + (uint32_t)(int)fx) * 4u : 0u;
+   const hs_v2u r0 = __builtin_amdgcn_raw_buffer_load_b64(im.rsrc, (int)off, 0, 0);
+   const hs_v2u r1 = __builtin_amdgcn_raw_buffer_load_b64(im.rsrc, (int)off, (int)im.pitch_bytes, 0);
+   const float p00 = __uint_as_float(r0.x), p01 = __uint_as_float(r0.y), p10 = __uint_as_float(r1.x), p11 = __uint_as_float(r1.y);
+   const float v = (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + (wy) * ((1.0f - wx) * p10 + wx * p11);
+   outside = outside || !in;
+   return in ? v : 0.0f;
+}
+
 // ---- helpers.cpp:46-88 solveLinear3x3 (value swaps, partial pivoting) ----
 __device__ __forceinline__ void hs_swap(float &a, float &b) { const float t = a; a = b; b = t; }
 __device__ inline void hs_solve3x3(float *A, float *b)

@@ -478,6 +478,7 @@ __global__ __launch_bounds__(256) void k_patch_extract_small(HessList hl, PatchW
       const int P0 = pw.P0[h];
       const float scale = (float)P0 / (float)HS_PATCH;
       float *out = io.patches + (size_t)(h - io.h_base) * HS_PATCH_PIX;
+      const HsPlaneBuf pbuf = hs_plane_buf(img, imRows, imPitch);
       if (!((double)scale > 0.4)) {
          // direct branch, affine.cpp:137-141
          const float b11 = a11 * scale, b12 = a12 * scale, b21 = a21 * scale, b22 = a22 * scale;
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(256) void k_patch_extract_small(HessList hl, PatchW
             const float rx = x + (float)j * b12, ry = y + (float)j * b22;
             const float wx = rx + (float)i * b11, wy = ry + (float)i * b21;
             bool outside = false;
-            dv[it] = hs_bilinear(img, imPitch, width, height, wx, wy, outside);
+            dv[it] = hs_bilinear_buf(pbuf, width, height, wx, wy, outside);
          }
 #pragma unroll
          for (int it = 0; it < HS_SIFT_PIX_IT; it++) HS_KEEP(dv[it]);
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(256) void k_patch_extract_small(HessList hl, PatchW
             const int j = jj - half, i = ii - half;
             const float rx = x + (float)j * a12, ry = y + (float)j * a22;
             const float wx = rx + (float)i * a11, wy = ry + (float)i * a21;
-            wv[it] = hs_bilinear(img, imPitch, width, height, wx, wy, outside);
+            wv[it] = hs_bilinear_buf(pbuf, width, height, wx, wy, outside);
          }
 #pragma unroll
          for (int it = 0; it < WNIT; it++) HS_KEEP(wv[it]);
@@ -666,7 +667,7 @@ __device__ __forceinline__ void hs_resample_reduced_padded(const float *__restri
 // Each lane owns output q = lane and (lanes < 18) q = lane + 64; the two accumulation chains
 // are interleaved.
 template <int NIT>
-__device__ __forceinline__ void hs_row_stream(const float *__restrict__ img, int imPitch, int width, int height, float x, float y,
+__device__ __forceinline__ void hs_row_stream(const HsPlaneBuf &img, int width, int height, float x, float y,
                                               float a11, float a12, float a21, float a22, int P, int yy, float scale,
                                               const float *__restrict__ taps, int K, float *__restrict__ srow, float *__restrict__ out82,
                                               bool &outside, int pad_r = 0)
@@ -681,7 +682,7 @@ __device__ __forceinline__ void hs_row_stream(const float *__restrict__ img, int
          const int xx = min(xb + lane + 64 * it, pm);   // lanes past the row re-sample its last pixel (not stored)
          const int i = xx - half;
          const float wx = rx + (float)i * a11, wy = ry + (float)i * a21;
-         v[it] = hs_bilinear(img, imPitch, width, height, wx, wy, outside);
+         v[it] = hs_bilinear_buf(img, width, height, wx, wy, outside);
       }
 #pragma unroll
       for (int it = 0; it < NIT; it++) HS_KEEP(v[it]);
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
    for (uint32_t wi = blockIdx.x; wi < cnt; wi += gridDim.x) {
       const uint32_t h = pw.bin_items[(size_t)BIN * pw.cap + wi];
       const int b = hl.meta[h] >> 8;
-      const float *img = io.image.img(b);
+      const HsPlaneBuf ib = hs_plane_buf(io.image.img(b), io.image.rows, imPitch);
       const float x = hl.x[h], y = hl.y[h];
       const float a11 = pw.A[4 * h], a12 = pw.A[4 * h + 1], a21 = pw.A[4 * h + 2], a22 = pw.A[4 * h + 3];
       const int P0 = pw.P0[h], P = P0 + 2;
@@ -789,7 +790,7 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
       bool outside = false;
 #pragma unroll 1
       for (int yy = wave; yy < ((flags & 64) ? 4 : P); yy += 4)
-         hs_row_stream<NIT>(img, (flags & 16) ? 0 : imPitch, (flags & 16) ? 1 : width, (flags & 16) ? 1 : height, x, y, a11, a12, a21, a22, P, yy,
+         hs_row_stream<NIT>(ib, width, height, x, y, a11, a12, a21, a22, P, yy,
                             scale, s_taps, (flags & 8) ? 3 : K, s_srow + wave * SROW,
                             (flags & 128) ? nullptr : Tp + (size_t)(yy + (TPG ? (K >> 1) : 0)) * HS_NEED, outside, TPG ? (K >> 1) : 0);
       if (outside) s_flag = 1;
@@ -847,7 +848,7 @@ __global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork
          const float scale = (float)P0 / (float)HS_PATCH;
          const int K = tb.patch_tap_k[(P0 - 1) >> 1];
          const float *taps = tb.patch_taps + tb.patch_tap_off[(P0 - 1) >> 1];
-         const float *img = io.image.img(b);
+         const HsPlaneBuf ib = hs_plane_buf(io.image.img(b), io.image.rows, imPitch);
          const float kx = hl.x[h], ky = hl.y[h];
          const float a11 = pw.A[4 * h], a12 = pw.A[4 * h + 1], a21 = pw.A[4 * h + 2], a22 = pw.A[4 * h + 3];
          const uint32_t first = pre[it];
@@ -856,7 +857,7 @@ __global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork
          HS_WAVE_LDS_SYNC();
          bool outside = false;
          for (; row < it_rows_end; row++)
-            hs_row_stream<8>((flags & 16) ? img + 0 * (row & 1) : img, (flags & 16) ? 0 : imPitch, (flags & 16) ? 1 : width, (flags & 16) ? 1 : height, kx, ky, a11, a12, a21, a22, P, (int)(row - first), scale, stap, (flags & 8) ? 3 : K, srow,
+            hs_row_stream<8>(ib, width, height, kx, ky, a11, a12, a21, a22, P, (int)(row - first), scale, stap, K, srow,
                              io.trows + (size_t)(row - row_lo) * HS_NEED, outside);
          if (outside) pw.alive[h] = 0;   // every writer stores the same value
          it++;
