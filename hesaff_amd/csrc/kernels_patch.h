@@ -664,8 +664,7 @@ __device__ __forceinline__ void hs_resample_reduced_padded(const float *__restri
 //   srow[r + x] = S[x],  srow[0..r) = S[0],  srow[r+P .. r+P+r) = S[P-1]     (needs P + 2r floats)
 // The image gathers of NIT x 64 window pixels are issued together (branch-free taps, clamped
 // index) before any of them is used; taps are read from LDS (`taps`, broadcast reads).
-// Each lane owns output q = lane and (lanes < 18) q = lane + 64; the two accumulation chains
-// are interleaved.
+// Lane i < 41 owns the output pair (2i, 2i + 1); the two accumulation chains share their reads.
 template <int NIT>
 __device__ __forceinline__ void hs_row_stream(const HsPlaneBuf &img, int width, int height, float x, float y,
                                               float a11, float a12, float a21, float a22, int P, int yy, float scale,
@@ -698,33 +697,37 @@ __device__ __forceinline__ void hs_row_stream(const HsPlaneBuf &img, int width, 
       for (int i = lane; i < r; i += 64) { srow[i] = first; srow[r + P + i] = last; }
    }
    HS_WAVE_LDS_SYNC();
-   const float c0 = (float)half;
-   const int q0 = lane, q1 = lane + 64;
-   const bool has1 = q1 < HS_NEED;
-   const float w0 = c0 + (float)((q0 >> 1) - 20) * scale, w1 = c0 + (float)(((has1 ? q1 : q0) >> 1) - 20) * scale;
-   const int x0 = min(max((int)floorf(w0) + (q0 & 1), 0), pm), x1 = min(max((int)floorf(w1) + (q1 & 1), 0), pm);
-   const float *s0 = srow + x0, *s1 = srow + x1;   // s[jt] = S[clamp(x - r + jt)]
-   float t0 = taps[0] * s0[0], t1 = taps[0] * s1[0];
+   // Lane i < 41 owns the output pair q = 2i, 2i + 1: the two blurred columns floor(w) and floor(w) + 1
+   // that output pixel i of the 41x41 resample reads.  Their tap windows overlap in all but one
+   // sample, so the pair costs K + 1 LDS reads instead of 2K.  (0 <= floor(w) <= P - 2 always:
+   // |(i - 20) * scale| < P0 / 2.)
+   if (lane < HS_PATCH) {
+      const float c0 = (float)half;
+      const float w = c0 + (float)(lane - 20) * scale;
+      const int x0 = min(max((int)floorf(w), 0), pm - 1);
+      const float *s = srow + x0;   // s[jt] = S[clamp(x0 - r + jt)],  s[jt + 1] = S[clamp(x0 + 1 - r + jt)]
+      float prev = s[1];
+      float t0 = taps[0] * s[0], t1 = taps[0] * prev;
 #pragma unroll 8
-   for (int jt = 1; jt < K; jt++) {
-      const float k = taps[jt];
-      const float p0 = k * s0[jt], p1 = k * s1[jt];
-      t0 += p0;
-      t1 += p1;
-   }
-   if (out82) {
-      out82[q0] = t0;
-      if (has1) out82[q1] = t1;
-      // padded T' plane: the first / last window row is replicated pad_r times above / below (wave-uniform)
-      if (pad_r > 0 && (yy == 0 || yy == pm)) {
-         const int step = (yy == 0) ? -HS_NEED : HS_NEED;
-         for (int jr = 1; jr <= pad_r; jr++) {
-            out82[jr * step + q0] = t0;
-            if (has1) out82[jr * step + q1] = t1;
-         }
+      for (int jt = 1; jt < K; jt++) {
+         const float k = taps[jt];
+         const float nxt = s[jt + 1];
+         const float p0 = k * prev, p1 = k * nxt;
+         t0 += p0;
+         t1 += p1;
+         prev = nxt;
       }
-   } else {
-      srow[0] = t0 + t1;   // ablation only: keep the sums alive without the global store
+      if (out82) {
+         float2 *o = reinterpret_cast<float2 *>(out82) + lane;
+         *o = make_float2(t0, t1);
+         // padded T' plane: the first / last window row is replicated pad_r times above / below (wave-uniform)
+         if (pad_r > 0 && (yy == 0 || yy == pm)) {
+            const int step = (yy == 0) ? -(HS_NEED / 2) : (HS_NEED / 2);
+            for (int jr = 1; jr <= pad_r; jr++) o[jr * step] = make_float2(t0, t1);
+         }
+      } else {
+         srow[0] = t0 + t1;   // ablation only: keep the sums alive without the global store
+      }
    }
    HS_WAVE_LDS_SYNC();
 }
