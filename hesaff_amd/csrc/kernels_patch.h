@@ -602,17 +602,22 @@ __device__ __forceinline__ void hs_resample_reduced(const float *__restrict__ Tp
    }
 }
 
-// The same four column-pass sums from a T' plane stored with r replicated rows above and below
-// (row index r + y), as k_patch_mid keeps it in its HBM slot: no index clamps, the two chains
-// share their rows (row y0 + j of chain (y0) is row (y0 + 1) + (j - 1) of chain (y0 + 1)), and
-// the loads of JC tap steps are issued together - the plane is read through L2, where a load
-// per tap step followed by its use is a full round trip per step.
-//   tc -> T'[r + y0][q];  chain a = row y0, chain b = row y0 + 1.
-template <int JC>
-__device__ __forceinline__ void hs_colpass4_padded(const float *__restrict__ tc, const float *__restrict__ taps, int r,
-                                                   float &p00, float &p01, float &p10, float &p11)
+// The same four column-pass sums with the loads batched: the two chains share their rows (row
+// y0 + j of chain (y0) is row (y0 + 1) + (j - 1) of chain (y0 + 1)), and the loads of JC tap steps
+// are issued together - the plane is read through L2 / HBM, where a load per tap step followed
+// by its use is a full round trip per step.  CLAMP = false: T points at window row 0 of a plane
+// stored with r replicated rows above and below (k_patch_mid's HBM slot), no index clamps.
+//   chain a = window row y0, chain b = window row y0 + 1, columns q and q + 1.
+template <int JC, bool CLAMP>
+__device__ __forceinline__ void hs_colpass4_rows(const float *__restrict__ T, int y0, int q, int pm, const float *__restrict__ taps, int r,
+                                                 float &p00, float &p01, float &p10, float &p11)
 {
-   const float2 c0 = *reinterpret_cast<const float2 *>(tc), c1 = *reinterpret_cast<const float2 *>(tc + HS_NEED);
+   // row y of the window -> float2 at T[row][q]; CLAMP: BORDER_REPLICATE by index clamp (unpadded plane)
+   auto ld = [&](int y) {
+      const int row = CLAMP ? min(max(y, 0), pm) : y;
+      return *reinterpret_cast<const float2 *>(T + row * HS_NEED + q);
+   };
+   const float2 c0 = ld(y0), c1 = ld(y0 + 1);
    const float kc = taps[r];
    float d00 = kc * c0.x, d01 = kc * c0.y, d10 = kc * c1.x, d11 = kc * c1.y;
    float2 pj = c1;   // row y0 + j      (j = 1)
@@ -621,9 +626,9 @@ __device__ __forceinline__ void hs_colpass4_padded(const float *__restrict__ tc,
       float2 pn[JC], mn[JC];   // rows y0 + j + 1 and y0 - j
 #pragma unroll
       for (int u = 0; u < JC; u++) {
-         const int j = min(j0 + u, r);   // steps past r re-read step r's rows (inside the padding), unused
-         pn[u] = *reinterpret_cast<const float2 *>(tc + (j + 1) * HS_NEED);
-         mn[u] = *reinterpret_cast<const float2 *>(tc - j * HS_NEED);
+         const int j = min(j0 + u, r);   // steps past r re-read step r's rows, unused
+         pn[u] = ld(y0 + j + 1);
+         mn[u] = ld(y0 - j);
       }
 #pragma unroll
       for (int u = 0; u < JC; u++) {
@@ -640,8 +645,11 @@ __device__ __forceinline__ void hs_colpass4_padded(const float *__restrict__ tc,
    p00 = d00; p01 = d01; p10 = d10; p11 = d11;
 }
 
-__device__ __forceinline__ void hs_resample_reduced_padded(const float *__restrict__ Tpad, int P, float scale, const float *__restrict__ taps, int r,
-                                                           float *s_patch)
+// resample of affine.cpp:131 from the row-pass plane at the 82 needed columns (PADDED: T points at
+// window row 0 of a plane with r replicated rows above and below; otherwise rows are clamped)
+template <bool PADDED>
+__device__ __forceinline__ void hs_resample_reduced_batched(const float *__restrict__ T, int P, float scale, const float *__restrict__ taps, int r,
+                                                            float *s_patch)
 {
    const float c0 = (float)(P >> 1);
    for (int idx = threadIdx.x; idx < HS_PATCH_PIX; idx += 256) {
@@ -653,7 +661,7 @@ __device__ __forceinline__ void hs_resample_reduced_padded(const float *__restri
       wx -= fx; wy -= fy;
       const int y0 = min(max((int)fy, 0), P - 2);   // always inside: |j * scale| < P0 / 2
       float p00, p01, p10, p11;
-      hs_colpass4_padded<8>(Tpad + (r + y0) * HS_NEED + 2 * ii, taps, r, p00, p01, p10, p11);
+      hs_colpass4_rows<8, !PADDED>(T, y0, 2 * ii, P - 1, taps, r, p00, p01, p10, p11);
       s_patch[idx] = (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + (wy) * ((1.0f - wx) * p10 + wx * p11);
    }
 }
@@ -803,7 +811,7 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
          __syncthreads();
          continue;
       }
-      if (TPG) hs_resample_reduced_padded(Tp, P, scale, s_taps, K >> 1, s_patch);
+      if (TPG) hs_resample_reduced_batched<true>(Tp + (K >> 1) * HS_NEED, P, scale, s_taps, K >> 1, s_patch);
       else hs_resample_reduced(Tp, P, scale, s_taps, (flags & 32) ? 1 : (K >> 1), s_patch);
       __syncthreads();
       if (FUSED) hs_patch_finish(h, s_patch, smem, s_vec, s_misc, s_tab, rg, io, tb, k, flags);
@@ -883,7 +891,7 @@ __global__ __launch_bounds__(256, 5) void k_patch_large_finish(HessList hl, Patc
       const float scale = (float)P0 / (float)HS_PATCH;
       const int K = tb.patch_tap_k[(P0 - 1) >> 1];
       const float *taps = tb.patch_taps + tb.patch_tap_off[(P0 - 1) >> 1];
-      hs_resample_reduced(io.trows + (size_t)(pre[it] - row_lo) * HS_NEED, P, scale, taps, K >> 1, s_patch);
+      hs_resample_reduced_batched<false>(io.trows + (size_t)(pre[it] - row_lo) * HS_NEED, P, scale, taps, K >> 1, s_patch);
       __syncthreads();
       hs_patch_finish(h, s_patch, s_va, s_vec, s_misc, s_tab, rg, io, tb, k, flags);
    }
