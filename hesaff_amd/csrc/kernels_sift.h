@@ -79,7 +79,8 @@ __global__ __launch_bounds__(64) void k_sift_meanvar(SiftIO io, KpTables tb)
 // gradient stencil from LDS.  Output: vo[k][r][c] = (mask*grad, o), r, c < 40, with
 // o = float(8 * (atan2f + 2 pi) / (2 pi)) evaluated in double like the reference.  Row and
 // column 40 are not produced: their spatial weights are zero (bin0 and bin1 both clamped,
-// siftdesc.cpp:33-44) so samplePatch adds nothing for them.
+// siftdesc.cpp:33-44) so samplePatch adds nothing for them; neither are the pixels outside the
+// circular mask (mask*grad = 0 adds nothing either).
 // All per-pixel math is select-based (hm_atan2f_sel): no divergence inside a wavefront.
 // grid n, block 256.
 __global__ __launch_bounds__(256) void k_sift_grad(SiftIO io, KpTables tb, float2 *__restrict__ vo)
@@ -104,12 +105,15 @@ __global__ __launch_bounds__(256) void k_sift_grad(SiftIO io, KpTables tb, float
    }
    __syncthreads();
    float2 *out = vo + (size_t)k * HS_VO_PITCH;
+   // Only the pixels inside the circular mask (1245 of 1681, helpers.cpp:131) are evaluated: where
+   // the mask is 0 the pair is (0, *) and samplePatch adds nothing; those entries of the buffer are
+   // zero-filled once when it is allocated and never written.
+   const int nm = tb.n_masked;
 #pragma unroll 1
-   for (int q = 0; q < (HS_VO_PITCH + 255) / 256; q++) {
-      const int o_i = tid + 256 * q;
-      if (o_i < HS_VO_PITCH) {
-         const int r = o_i / HS_VO_DIM, c = o_i - r * HS_VO_DIM;
-         const int i = r * HS_PATCH + c;
+   for (int j = tid; j < nm; j += 256) {
+      const int i = tb.mask_idx[j];
+      const int r = i / HS_PATCH, c = i - r * HS_PATCH;
+      if (r < HS_VO_DIM && c < HS_VO_DIM) {
          // the four (or three) patch values the gradient stencil reads, affine.cpp:14-33 convention
          const int il = (c == 0) ? i : i - 1, ir = i + 1;                  // c <= 39 < patchSize - 1
          const int iu = (r == 0) ? i : i - HS_PATCH, id = i + HS_PATCH;    // r <= 39
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void k_sift_grad(SiftIO io, KpTables tb, float
          const float grad = sqrtf(gx * gx + gy * gy);
          const float ori = hm_atan2f_sel(gy, gx);
          const float o = hm_sift_orient_coord(ori);
-         out[o_i] = make_float2(tb.sift_mask[i] * grad, o);
+         out[r * HS_VO_DIM + c] = make_float2(tb.sift_mask[i] * grad, o);
       }
    }
 }

@@ -839,7 +839,14 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
          c->b_patches2[slot].ensure((size_t)n * HS_PATCH_PIX * 4);
          c->b_siftvec2[slot].ensure((size_t)n * 128 * 4);
          c->b_meanvar2[slot].ensure((size_t)n * 2 * 4);
-         c->b_siftvo2[slot].ensure((size_t)n * HS_VO_PITCH * 8 + 64);
+         {
+            // the (mask*grad, o) pairs of pixels outside the circular mask stay (0, 0): zero-fill on (re)allocation
+            const void *before = c->b_siftvo2[slot].p;
+            const size_t bytes_before = c->b_siftvo2[slot].bytes;
+            c->b_siftvo2[slot].ensure((size_t)n * HS_VO_PITCH * 8 + 64);
+            if (c->b_siftvo2[slot].p != before || c->b_siftvo2[slot].bytes != bytes_before)
+               HIP_TRY(hipMemsetAsync(c->b_siftvo2[slot].p, 0, c->b_siftvo2[slot].bytes, st));
+         }
          HIP_TRY(hipMemsetAsync(cnt + 8, 0, HS_NBINS * 4, st));
          HIP_TRY(hipMemcpyAsync(cnt + 5, &h_hi, 4, hipMemcpyHostToDevice, st));
          hipLaunchKernelGGL(k_prepare_patch, dim3(1024), dim3(256), 0, st, s.hl, h_lo, (const uint32_t *)(cnt + 5), s.ao, H, W, c->consts,
