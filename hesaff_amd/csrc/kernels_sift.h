@@ -88,32 +88,48 @@ __global__ __launch_bounds__(256) void k_sift_grad(SiftIO io, KpTables tb, float
    __shared__ float s_p[HS_PATCH_PIX];
    const uint32_t k = blockIdx.x;
    const uint32_t h = io.h_lo + k;
-   if (!io.alive[h]) return;
    const int tid = threadIdx.x;
+   // Everything the block reads from global memory is requested up front, in two dependent rounds
+   // (the second one only for the mask values): a block lives for little more than its memory
+   // round trips, so a chain of dependent loads (alive -> mean -> pixels -> index -> mask) is
+   // what it would spend its time on.
+   const int alive = io.alive[h];
    const float mean = io.meanvar[2 * (size_t)k], var = io.meanvar[2 * (size_t)k + 1];
    const float *gp = io.patches + (size_t)k * HS_PATCH_PIX;
-   const bool norm = !((double)var < 0.0001);
-   const float fac = 50.0f / var;
+   float pv[HS_SIFT_PIX_IT];
 #pragma unroll
-   for (int q = 0; q < (HS_PATCH_PIX + 255) / 256; q++) {
-      const int i = tid + 256 * q;
-      if (i < HS_PATCH_PIX) {
-         float v = gp[i];
-         if (norm) { v = 128 + fac * (v - mean); v = v > 255 ? 255.0f : v; v = v < 0 ? 0.0f : v; }
-         s_p[i] = v;
-      }
-   }
-   __syncthreads();
-   float2 *out = vo + (size_t)k * HS_VO_PITCH;
+   for (int q = 0; q < HS_SIFT_PIX_IT; q++) pv[q] = gp[min(tid + 256 * q, HS_PATCH_PIX - 1)];
    // Only the pixels inside the circular mask (1245 of 1681, helpers.cpp:131) are evaluated: where
    // the mask is 0 the pair is (0, *) and samplePatch adds nothing; those entries of the buffer are
    // zero-filled once when it is allocated and never written.
    const int nm = tb.n_masked;
-#pragma unroll 1
-   for (int j = tid; j < nm; j += 256) {
-      const int i = tb.mask_idx[j];
+   int mi[HS_SIFT_MSK_IT];
+   float mv[HS_SIFT_MSK_IT];
+#pragma unroll
+   for (int q = 0; q < HS_SIFT_MSK_IT; q++) mi[q] = tb.mask_idx[min(tid + 256 * q, nm - 1)];
+#pragma unroll
+   for (int q = 0; q < HS_SIFT_MSK_IT; q++) mv[q] = tb.sift_mask[mi[q]];
+   if (!alive) return;
+   const bool norm = !((double)var < 0.0001);
+   const float fac = 50.0f / var;
+#pragma unroll
+   for (int q = 0; q < HS_SIFT_PIX_IT; q++) {
+      const int i = tid + 256 * q;
+      if (i < HS_PATCH_PIX) {
+         float v = pv[q];
+         if (norm) { v = 128 + fac * (v - mean); v = v > 255 ? 255.0f : v; v = v < 0 ? 0.0f : v; }
+         s_p[i] = v;
+      }
+   }
+#pragma unroll
+   for (int q = 0; q < HS_SIFT_MSK_IT; q++) HS_KEEP(mv[q]);
+   __syncthreads();
+   float2 *out = vo + (size_t)k * HS_VO_PITCH;
+#pragma unroll
+   for (int q = 0; q < HS_SIFT_MSK_IT; q++) {
+      const int i = mi[q];
       const int r = i / HS_PATCH, c = i - r * HS_PATCH;
-      if (r < HS_VO_DIM && c < HS_VO_DIM) {
+      if (tid + 256 * q < nm && r < HS_VO_DIM && c < HS_VO_DIM) {
          // the four (or three) patch values the gradient stencil reads, affine.cpp:14-33 convention
          const int il = (c == 0) ? i : i - 1, ir = i + 1;                  // c <= 39 < patchSize - 1
          const int iu = (r == 0) ? i : i - HS_PATCH, id = i + HS_PATCH;    // r <= 39
@@ -121,8 +137,11 @@ __global__ __launch_bounds__(256) void k_sift_grad(SiftIO io, KpTables tb, float
          const float grad = sqrtf(gx * gx + gy * gy);
          const float ori = hm_atan2f_sel(gy, gx);
          const float o = hm_sift_orient_coord(ori);
-         out[r * HS_VO_DIM + c] = make_float2(tb.sift_mask[i] * grad, o);
+         out[r * HS_VO_DIM + c] = make_float2(mv[q] * grad, o);
       }
+      // the loop is unrolled only so that mi[q] / mv[q] are registers; do not let the scheduler
+      // interleave the iterations (five atan2 bodies in flight cost ~60 VGPRs)
+      __builtin_amdgcn_sched_barrier(0);
    }
 }
 
