@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (BASELINE.json: 2048 UHD images over 8 GPUs)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")

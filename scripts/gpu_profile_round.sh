@@ -22,9 +22,15 @@ def agg(path, counter):
     return tot, n
 f, nf = agg(out + '/fetch/p_counter_collection.csv', 'FETCH_SIZE')
 w, nw = agg(out + '/write/p_counter_collection.csv', 'WRITE_SIZE')
+bench = json.loads(open(out + '/bench_under_rocprof.json').read().strip().splitlines()[-1])
+cfg = bench['config']
 res = {"fetch_kb_total": f, "write_kb_total": w, "launches": nf,
-       "bytes_per_launch_avg": (f + w) * 1024.0 / max(nf, 1),
-       "note": "FETCH_SIZE / WRITE_SIZE in KB as reported by rocprofv3 on gfx950, summed over the 58 B/px k_blur_hess_march launches of one bench step; uncorrected (dword-wide loads: the 1/2 FETCH_SIZE under-count of 16 B/lane streams does not apply, see profiles/README.md)"}
+       "bytes_per_launch_avg": (2.0 * f + w) * 1024.0 / max(nf, 1),
+       "bytes_per_launch_raw": (f + w) * 1024.0 / max(nf, 1),
+       "algorithmic_bytes_per_launch_avg": bench['roofline']['bytes_per_launch_avg'],
+       "batch": cfg['images_per_gpu_per_step'], "width": cfg['width'], "height": cfg['height'],
+       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (separate passes)",
+       "note": "FETCH_SIZE / WRITE_SIZE (KB) from two separate rocprofv3 --pmc passes, summed over the 58 B/px k_blur_hess_march launches of one bench step. bytes_per_launch_avg applies the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts 128-B line fills as 64 B: x2 on the read side); bytes_per_launch_raw is the uncorrected sum."}
 print(json.dumps(res))
 json.dump(res, open(out + '/pmc_traffic_raw.json', 'w'), indent=1)
 rows = list(csv.DictReader(open(out + '/stats/p_kernel_stats.csv')))
