@@ -136,7 +136,7 @@ struct hesaff_ctx {
    std::vector<int32_t> h_starts;
    DevBuf t_mask_idx, b_rowprefix, b_trows, b_trows2, b_trows3, b_siftvec, b_meanvar, b_siftvo;
    bool fused_sift = false;            // HESAFF_SIFT=fused: descriptor inside the patch kernels (v1 structure)
-   uint32_t sift_group_kpts = 300000;  // keypoints per group of images (20.6 KB of patch + gradient-pair buffers each, two slots)
+   uint32_t sift_group_kpts = 0;       // keypoints per group of images (20 KB of patch + gradient-pair buffers each, two slots); 0 = by batch (HESAFF_GROUP)
    uint32_t trows_budget = 4u << 20;   // rows of T' (82 floats each) per large-window round: 1.3 GB
 
    hesaff_timings tm;
@@ -800,11 +800,13 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       HIP_TRY(hipEventRecord(c->ev_detect_done, st));
       HIP_TRY(hipStreamSynchronize(st));
       if ((uint32_t)hs[B] > c->cap) throw HsError(HESAFF_ERR_CAPACITY, "keypoint capacity exceeded; raise hesaff_params.max_kpts_per_mpx");
-      // image groups [h_lo, h_hi) of at most sift_group_kpts keypoints
+      // image groups [h_lo, h_hi) of at most group_kpts keypoints: about 16 groups per batch keep the
+      // three-stage pipeline full, between 300 k (launch overheads) and 1.2 M keypoints (buffer size)
+      const uint32_t group_kpts = c->sift_group_kpts ? c->sift_group_kpts : std::min<uint32_t>(std::max<uint32_t>((uint32_t)hs[B] / 16u, 300000u), 1200000u);
       std::vector<std::pair<uint32_t, uint32_t>> groups;
       for (int g0 = 0; g0 < B;) {
          int g1 = g0 + 1;
-         while (g1 < B && (uint32_t)(hs[g1 + 1] - hs[g0]) <= c->sift_group_kpts) g1++;
+         while (g1 < B && (uint32_t)(hs[g1 + 1] - hs[g0]) <= group_kpts) g1++;
          if (hs[g1] > hs[g0]) groups.push_back({(uint32_t)hs[g0], (uint32_t)hs[g1]});
          g0 = g1;
       }
