@@ -11,7 +11,9 @@ from ._binding import (  # noqa: F401
     KEYPOINT_DTYPE,
     default_params,
     format_sift,
+    format_sift_mt,
     write_sift,
+    write_sift_batch,
     read_pnm,
     ellipse,
     lib_path,

@@ -91,6 +91,9 @@ def load_library():
     L.hesaff_ellipse.restype = None
     L.hesaff_write_sift.argtypes = [C.c_char_p, vp, C.c_int, C.c_float]
     L.hesaff_format_sift.argtypes = [vp, C.c_int, C.c_float, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.hesaff_format_sift_mt.argtypes = [vp, C.c_int, C.c_float, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.hesaff_write_sift_batch.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(_Result), C.c_float, C.c_int]
+    L.hesaff_test_fmt_g.argtypes = [_f32p, C.c_int]
     L.hesaff_free.argtypes = [vp]; L.hesaff_free.restype = None
     L.hesaff_read_pnm.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.hesaff_stage_gaussian_blur.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_float, _f32p]
@@ -119,7 +122,7 @@ ABI_SYMBOLS = [
     "hesaff_stage_hessian_response", "hesaff_stage_half_image", "hesaff_stage_pyramid", "hesaff_stage_hessian_keypoints",
     "hesaff_stage_find_affine_shape", "hesaff_stage_rectify", "hesaff_stage_normalize_affine", "hesaff_stage_sift",
     "hesaff_stage_math", "hesaff_table_gauss_mask", "hesaff_table_circ_gauss_mask", "hesaff_table_sift_bins",
-    "hesaff_table_gauss_kernel",
+    "hesaff_table_gauss_kernel", "hesaff_format_sift_mt", "hesaff_write_sift_batch", "hesaff_test_fmt_g",
 ]
 
 
@@ -181,6 +184,34 @@ def format_sift(keys, mr_size):
         return C.string_at(buf.value, n.value)
     finally:
         L.hesaff_free(buf)
+
+
+def format_sift_mt(keys, mr_size, threads=0):
+    """Same bytes as format_sift, rows formatted by `threads` host threads (0 = auto)."""
+    L = load_library()
+    keys = np.ascontiguousarray(keys, dtype=KEYPOINT_DTYPE)
+    buf = C.c_void_p(); n = C.c_size_t()
+    rc = L.hesaff_format_sift_mt(keys.ctypes.data, len(keys), C.c_float(mr_size), threads, C.byref(buf), C.byref(n))
+    if rc != 0:
+        raise HesaffError(rc, "hesaff_format_sift_mt")
+    try:
+        return C.string_at(buf.value, n.value)
+    finally:
+        L.hesaff_free(buf)
+
+
+def write_sift_batch(paths, key_arrays, mr_size, threads=0):
+    """One .hesaff.sift per image: key_arrays[i] (KEYPOINT_DTYPE) -> paths[i], images spread over host threads."""
+    L = load_library()
+    n = len(paths)
+    arrs = [np.ascontiguousarray(k, dtype=KEYPOINT_DTYPE) for k in key_arrays]
+    res = (_Result * n)()
+    for i, a in enumerate(arrs):
+        res[i].count_hessian = len(a); res[i].count_desc = len(a); res[i].keys = a.ctypes.data
+    cp = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    rc = L.hesaff_write_sift_batch(n, cp, res, C.c_float(mr_size), threads)
+    if rc != 0:
+        raise HesaffError(rc, "hesaff_write_sift_batch")
 
 
 def write_sift(path, keys, mr_size):

@@ -2,10 +2,17 @@
 // cv::imread at hesaff.cpp:137), ellipse closed form and the .hesaff.sift text writer
 // (replaces exportKeypoints hesaff.cpp:107-130).
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
 #include <string>
+#include <mutex>
+#include <thread>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/hesaff_amd.h"
@@ -29,8 +36,75 @@ int pnm_next_int(FILE *f, int *out)
 }
 
 // "%g"-style (precision 6) formatting of a float == default operator<<(ostream&, float),
-// the format exportKeypoints uses (hesaff.cpp:125).
-inline int fmt_g(char *dst, float v) { return snprintf(dst, 32, "%g", (double)v); }
+// the format exportKeypoints uses (hesaff.cpp:125).  snprintf is the definition ...
+inline int fmt_g_libc(char *dst, float v) { return snprintf(dst, 32, "%g", (double)v); }
+
+// ... and this is the fast path that produces the same bytes with exact integer arithmetic:
+// v = mant * 2^e (e < 0 in the range handled here), so the six significant digits are
+// round-half-even((mant * 10^(5-X)) >> -e) with X = floor(log10 v); the product fits 128 bits
+// for 1e-22 <= |v| < 1e6.  Everything else (larger, smaller, inf, nan) goes to libc.
+// tests/test_host_side.py compares both on millions of floats.
+typedef unsigned __int128 u128;
+struct Pow10Table {
+   u128 p[28];
+   Pow10Table() { p[0] = 1; for (int i = 1; i < 28; i++) p[i] = p[i - 1] * 10u; }
+};
+const Pow10Table kP10;
+
+inline int fmt_g(char *dst, float vf)
+{
+   uint32_t bits;
+   memcpy(&bits, &vf, 4);
+   const uint32_t ex = (bits >> 23) & 255u, fr = bits & 0x7fffffu;
+   char *p = dst;
+   if (ex == 0 && fr == 0) {
+      if (bits >> 31) *p++ = '-';
+      *p++ = '0';
+      return (int)(p - dst);
+   }
+   if (ex == 255 || ex == 0) return fmt_g_libc(dst, vf);   // inf, nan, denormal
+   const uint32_t mant = fr | 0x800000u;
+   const int e = (int)ex - 150;   // |v| = mant * 2^e, 2^23 <= mant < 2^24
+   if (e >= 0) return fmt_g_libc(dst, vf);   // |v| >= 2^23 > 1e6
+   const int sh = -e;
+   int X = (int)std::floor((23 + e) * 0.30102999566398120);   // floor(log10 |v|) or one less
+   u128 q = 0, rem = 0, half = 0;
+   for (int tries = 0;; tries++) {
+      if (X > 5 || X < -22 || tries > 2 || sh > 126) return fmt_g_libc(dst, vf);
+      const u128 N = (u128)mant * kP10.p[5 - X];   // < 2^24 * 10^27 < 2^114
+      q = N >> sh;
+      if (q >= 1000000u) { X++; continue; }
+      if (q < 100000u) { X--; continue; }
+      rem = N & ((((u128)1) << sh) - 1);
+      half = ((u128)1) << (sh - 1);
+      break;
+   }
+   unsigned d = (unsigned)q;
+   if (rem > half || (rem == half && (d & 1u))) d++;
+   if (d == 1000000u) { d = 100000u; X++; }
+   if (bits >> 31) *p++ = '-';
+   char dig[6];
+   for (int i = 5; i >= 0; i--) { dig[i] = (char)('0' + d % 10); d /= 10; }
+   int nd = 6;
+   while (nd > 1 && dig[nd - 1] == '0') nd--;   // %g strips trailing zeros
+   if (X < -4 || X >= 6) {
+      *p++ = dig[0];
+      if (nd > 1) { *p++ = '.'; for (int i = 1; i < nd; i++) *p++ = dig[i]; }
+      *p++ = 'e';
+      int ax = X;
+      if (ax < 0) { *p++ = '-'; ax = -ax; } else *p++ = '+';
+      *p++ = (char)('0' + ax / 10);
+      *p++ = (char)('0' + ax % 10);
+   } else if (X >= 0) {
+      for (int i = 0; i <= X; i++) *p++ = dig[i];   // nd may be <= X: the stripped zeros belong to the integer part
+      if (nd > X + 1) { *p++ = '.'; for (int i = X + 1; i < nd; i++) *p++ = dig[i]; }
+   } else {
+      *p++ = '0'; *p++ = '.';
+      for (int i = 0; i < -X - 1; i++) *p++ = '0';
+      for (int i = 0; i < nd; i++) *p++ = dig[i];
+   }
+   return (int)(p - dst);
+}
 
 inline char *fmt_u8(char *p, unsigned v)
 {
@@ -40,11 +114,101 @@ inline char *fmt_u8(char *p, unsigned v)
    return p;
 }
 
+// Output buffers of tens of MB are recycled: hesaff_free() parks a big block in a small cache and
+// the next formatter call takes it again.  First-touch page faults of fresh memory (tens of
+// thousands per UHD image, serialised in the kernel across writer threads) otherwise cost more
+// than the formatting itself.
+struct BigCache {
+   std::mutex mu;
+   std::unordered_map<void *, size_t> live;           // blocks handed out by big_alloc
+   std::vector<std::pair<void *, size_t>> parked;     // freed blocks kept for reuse
+   size_t parked_bytes = 0;
+   static constexpr size_t kMinBytes = (size_t)1 << 20, kMaxParked = 64, kMaxParkedBytes = (size_t)8 << 30;
+   ~BigCache() { for (auto &b : parked) free(b.first); }
+};
+BigCache g_big;
+
+char *big_alloc(size_t bytes)
+{
+   if (bytes < BigCache::kMinBytes) return (char *)malloc(bytes);
+   {
+      std::lock_guard<std::mutex> lk(g_big.mu);
+      int best = -1;
+      for (int i = 0; i < (int)g_big.parked.size(); i++)
+         if (g_big.parked[i].second >= bytes && (best < 0 || g_big.parked[i].second < g_big.parked[best].second)) best = i;
+      if (best >= 0) {
+         const auto blk = g_big.parked[best];
+         g_big.parked.erase(g_big.parked.begin() + best);
+         g_big.parked_bytes -= blk.second;
+         g_big.live[blk.first] = blk.second;
+         return (char *)blk.first;
+      }
+   }
+   const size_t cap = bytes + bytes / 8;   // some head-room so that the next, slightly larger image still fits
+   void *q = malloc(cap);
+   if (!q) return nullptr;
+   std::lock_guard<std::mutex> lk(g_big.mu);
+   g_big.live[q] = cap;
+   return (char *)q;
+}
+
+void big_free(void *p)
+{
+   if (!p) return;
+   {
+      std::lock_guard<std::mutex> lk(g_big.mu);
+      auto it = g_big.live.find(p);
+      if (it != g_big.live.end()) {
+         const size_t cap = it->second;
+         g_big.live.erase(it);
+         if (g_big.parked.size() < BigCache::kMaxParked && g_big.parked_bytes + cap <= BigCache::kMaxParkedBytes) {
+            g_big.parked.push_back({p, cap});
+            g_big.parked_bytes += cap;
+            return;
+         }
+      }
+   }
+   free(p);
+}
+
+// worst case per row: 5 floats * 16 + 128 * 4 + newline
+const size_t kRowMax = 5 * 16 + 128 * 4 + 2;
+
+char *format_rows(const hesaff_keypoint *keys, int i0, int i1, float mrSize, char *p)
+{
+   for (int i = i0; i < i1; i++) {
+      const hesaff_keypoint &k = keys[i];
+      float ea, eb, ec;
+      hesaff_ellipse(&k, mrSize, &ea, &eb, &ec);
+      p += fmt_g(p, k.x); *p++ = ' ';
+      p += fmt_g(p, k.y); *p++ = ' ';
+      p += fmt_g(p, ea); *p++ = ' ';
+      p += fmt_g(p, eb); *p++ = ' ';
+      p += fmt_g(p, ec);
+      for (int j = 0; j < 128; j++) { *p++ = ' '; p = fmt_u8(p, k.desc[j]); }
+      *p++ = '\n';
+   }
+   return p;
+}
+
 } // namespace
 
 extern "C" {
 
-void hesaff_free(void *p) { free(p); }
+// test hook: the two float formatters side by side (0 = identical bytes)
+int hesaff_test_fmt_g(const float *v, int n)
+{
+   char a[40], b[40];
+   int bad = 0;
+   for (int i = 0; i < n; i++) {
+      const int la = fmt_g(a, v[i]), lb = fmt_g_libc(b, v[i]);
+      if (la != lb || memcmp(a, b, (size_t)la) != 0) bad++;
+   }
+   return bad;
+}
+
+
+void hesaff_free(void *p) { big_free(p); }
 
 int hesaff_read_pnm(const char *path, uint8_t **data, int *width, int *height, int *channels)
 {
@@ -85,28 +249,58 @@ void hesaff_ellipse(const hesaff_keypoint *k, float mrSize, float *a, float *b, 
 
 int hesaff_format_sift(const hesaff_keypoint *keys, int n, float mrSize, char **out, size_t *len)
 {
+   return hesaff_format_sift_mt(keys, n, mrSize, 1, out, len);
+}
+
+// Rows are formatted by `threads` workers into one buffer.
+int hesaff_format_sift_mt(const hesaff_keypoint *keys, int n, float mrSize, int threads, char **out, size_t *len)
+{
    if (n < 0 || (n > 0 && !keys) || !out || !len) return HESAFF_ERR_ARG;
-   // worst case per row: 5 floats * 16 + 128 * 4 + 1
-   const size_t cap = 64 + (size_t)n * (5 * 16 + 128 * 4 + 2);
-   char *buf = (char *)malloc(cap);
+   int T = threads > 0 ? threads : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+   T = std::max(1, std::min(T, n / 4096 + 1));   // below ~4 k rows a thread costs more than it saves
+   char head[64];
+   const int hl = snprintf(head, sizeof head, "%d\n%d\n", 128, n);
+   if (T == 1) {
+      char *buf = big_alloc((size_t)hl + (size_t)n * kRowMax + 1);
+      if (!buf) return HESAFF_ERR_NOMEM;
+      memcpy(buf, head, (size_t)hl);
+      char *e = format_rows(keys, 0, n, mrSize, buf + hl);
+      *out = buf;
+      *len = (size_t)(e - buf);
+      return HESAFF_OK;
+   }
+   // one allocation at the worst-case row size: worker t formats its rows at their worst-case
+   // offset, then the blocks are moved down over the slack (left to right, so never onto unread data)
+   char *buf = big_alloc((size_t)hl + (size_t)n * kRowMax + 1);
    if (!buf) return HESAFF_ERR_NOMEM;
-   char *p = buf;
-   p += snprintf(p, 64, "%d\n%d\n", 128, n);
-   for (int i = 0; i < n; i++) {
-      const hesaff_keypoint &k = keys[i];
-      float ea, eb, ec;
-      hesaff_ellipse(&k, mrSize, &ea, &eb, &ec);
-      p += fmt_g(p, k.x); *p++ = ' ';
-      p += fmt_g(p, k.y); *p++ = ' ';
-      p += fmt_g(p, ea); *p++ = ' ';
-      p += fmt_g(p, eb); *p++ = ' ';
-      p += fmt_g(p, ec);
-      for (int j = 0; j < 128; j++) { *p++ = ' '; p = fmt_u8(p, k.desc[j]); }
-      *p++ = '\n';
+   memcpy(buf, head, (size_t)hl);
+   std::vector<size_t> plen((size_t)T, 0);
+   std::vector<std::thread> th;
+   for (int t = 0; t < T; t++)
+      th.emplace_back([&, t] {
+         const int i0 = (int)((long long)n * t / T), i1 = (int)((long long)n * (t + 1) / T);
+         char *dst = buf + hl + (size_t)i0 * kRowMax;
+         plen[t] = (size_t)(format_rows(keys, i0, i1, mrSize, dst) - dst);
+      });
+   for (auto &x : th) x.join();
+   size_t o = (size_t)hl + plen[0];
+   for (int t = 1; t < T; t++) {
+      const int i0 = (int)((long long)n * t / T);
+      memmove(buf + o, buf + hl + (size_t)i0 * kRowMax, plen[t]);
+      o += plen[t];
    }
    *out = buf;
-   *len = (size_t)(p - buf);
+   *len = o;
    return HESAFF_OK;
+}
+
+static int write_file(const char *path, const char *buf, size_t len)
+{
+   FILE *f = fopen(path, "wb");
+   if (!f) return HESAFF_ERR_IO;
+   const size_t w = fwrite(buf, 1, len, f);
+   const int ce = fclose(f);
+   return (w == len && ce == 0) ? HESAFF_OK : HESAFF_ERR_IO;
 }
 
 int hesaff_write_sift(const char *path, const hesaff_keypoint *keys, int n, float mrSize)
@@ -114,14 +308,38 @@ int hesaff_write_sift(const char *path, const hesaff_keypoint *keys, int n, floa
    if (!path) return HESAFF_ERR_ARG;
    char *buf = nullptr;
    size_t len = 0;
-   const int rc = hesaff_format_sift(keys, n, mrSize, &buf, &len);
+   const int rc = hesaff_format_sift_mt(keys, n, mrSize, 0, &buf, &len);
    if (rc != HESAFF_OK) return rc;
-   FILE *f = fopen(path, "wb");
-   if (!f) { free(buf); return HESAFF_ERR_IO; }
-   const size_t w = fwrite(buf, 1, len, f);
-   const int ce = fclose(f);
-   free(buf);
-   return (w == len && ce == 0) ? HESAFF_OK : HESAFF_ERR_IO;
+   const int wr = write_file(path, buf, len);
+   big_free(buf);
+   return wr;
+}
+
+// One file per image of a batch (exportKeypoints once per image, hesaff.cpp:170-176), images
+// taken by `threads` workers from a shared counter; every worker formats its image on its own.
+int hesaff_write_sift_batch(int n_images, const char *const *paths, const hesaff_result *results, float mrSize, int threads)
+{
+   if (n_images < 0 || (n_images > 0 && (!paths || !results))) return HESAFF_ERR_ARG;
+   int T = threads > 0 ? threads : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+   T = std::max(1, std::min(T, n_images));
+   std::atomic<int> next(0), err(HESAFF_OK);
+   auto work = [&] {
+      for (;;) {
+         const int i = next.fetch_add(1);
+         if (i >= n_images) break;
+         if (!paths[i]) { err = HESAFF_ERR_ARG; continue; }
+         char *buf = nullptr;
+         size_t len = 0;
+         int rc = hesaff_format_sift_mt(results[i].keys, results[i].count_desc, mrSize, 1, &buf, &len);
+         if (rc == HESAFF_OK) { rc = write_file(paths[i], buf, len); big_free(buf); }
+         if (rc != HESAFF_OK) err = rc;
+      }
+   };
+   std::vector<std::thread> th;
+   for (int t = 1; t < T; t++) th.emplace_back(work);
+   work();
+   for (auto &x : th) x.join();
+   return err.load();
 }
 
 } // extern "C"

@@ -113,6 +113,15 @@ void hesaff_ellipse(const hesaff_keypoint *k, float mrSize, float *a, float *b, 
 int hesaff_write_sift(const char *path, const hesaff_keypoint *keys, int n, float mrSize);
 /* formats into a malloc'ed buffer (*out, *len); caller frees with hesaff_free */
 int hesaff_format_sift(const hesaff_keypoint *keys, int n, float mrSize, char **out, size_t *len);
+/* the same bytes, rows formatted by `threads` host threads (0 = one per core, at most 64);
+ * hesaff_write_sift uses this form.  SURVEY.md 8(f) rank 1: at GPU rates the text export
+ * (42 MB per UHD image, hesaff.cpp:107-130) is the bottleneck of the file path. */
+int hesaff_format_sift_mt(const hesaff_keypoint *keys, int n, float mrSize, int threads, char **out, size_t *len);
+/* replaces: the per-image exportKeypoints + ofstream of main() (hesaff.cpp:170-176) for a whole
+ * batch: results[i] -> paths[i], images spread over `threads` host threads (0 = auto) */
+int hesaff_write_sift_batch(int n_images, const char *const *paths, const hesaff_result *results, float mrSize, int threads);
+/* test hook: number of inputs on which the fast "%g" formatter and snprintf disagree (must be 0) */
+int hesaff_test_fmt_g(const float *v, int n);
 void hesaff_free(void *p);
 
 /* replaces: cv::imread(argv[1]) hesaff.cpp:137 for binary PGM/PPM (P5/P6, maxval 255).

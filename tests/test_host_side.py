@@ -143,3 +143,43 @@ def test_write_sift_file(tmp_path):
     # ellipse of the identity shape: a = c = 1/(mrSize*s)^2, b = 0
     e = hesaff_amd.ellipse(keys[:1], 5.196152)[0]
     assert abs(e[0] - 1.0 / (5.196152 * 2.0) ** 2) < 1e-9 and e[1] == 0 and abs(e[2] - e[0]) < 1e-12
+
+
+def test_fast_float_formatter_equals_printf_g():
+    """The writer's own "%g" (six significant digits from one extended-precision scaling, libc on
+    near-ties) produces snprintf's bytes: every kind of float the file can hold, by the million."""
+    import ctypes as C
+    L = hesaff_amd.load_library()
+    rng = np.random.default_rng(7)
+    parts = [
+        rng.integers(0, 2**32, 3_000_000, dtype=np.uint64).astype(np.uint32).view(np.float32),          # any bit pattern
+        (rng.uniform(0, 4096, 2_000_000)).astype(np.float32),                                             # coordinates
+        (10.0 ** rng.uniform(-8, 2, 2_000_000) * rng.choice([-1.0, 1.0], 2_000_000)).astype(np.float32),  # ellipse terms
+        np.array([0.0, -0.0, 1.0, -1.0, 0.1, 0.5, 999999.5, 999999.4, 999999.96, 1e-5, 9.9999995e-5, 1e-4, 100000.0,
+                  123456.5, 1234565.0, 0.000123456789, 3.4028235e38, 1.17549435e-38, 1e-45, 5e-324, np.inf, -np.inf, np.nan,
+                  2.5, 0.125, 1048576.0, 8388608.0, 16777216.0, 0.3, 1e10, 1e-10, 65504.0, 1e22, 1e-22, 1e23, 9.5e-23], np.float32),
+        (np.arange(0, 2_000_000, dtype=np.float32) + 0.5) / np.float32(8.0),                               # exact binary ties .x5
+        (np.arange(1, 1_000_001, dtype=np.float64) * 1e-6 + 0.5e-6).astype(np.float32),                   # decimal near-ties
+    ]
+    v = np.ascontiguousarray(np.concatenate(parts), np.float32)
+    assert L.hesaff_test_fmt_g(v, len(v)) == 0
+
+
+def test_multithreaded_writer_same_bytes(tmp_path):
+    rng = np.random.default_rng(11)
+    n = 30000
+    keys = np.zeros(n, hesaff_amd.KEYPOINT_DTYPE)
+    keys["x"] = rng.uniform(0, 3840, n); keys["y"] = rng.uniform(0, 2160, n); keys["s"] = rng.uniform(1, 30, n)
+    keys["a11"] = rng.uniform(0.5, 2, n); keys["a21"] = rng.uniform(-1, 1, n); keys["a22"] = 1.0 / keys["a11"]
+    keys["desc"] = rng.integers(0, 256, (n, 128), dtype=np.uint8)
+    mr = hesaff_amd.default_params().mrSize
+    ref = hesaff_amd.format_sift(keys, mr)
+    for t in (0, 2, 5, 16):
+        assert hesaff_amd.format_sift_mt(keys, mr, t) == ref, t
+    assert hesaff_amd.format_sift_mt(keys[:0], mr, 4) == b"128\n0\n"
+    # batch writer: one file per image, any thread count, same bytes as the single writer
+    chunks = [keys[:7000], keys[7000:7000], keys[7000:25000], keys[25000:]]
+    paths = [str(tmp_path / ("img%d.ppm.hesaff.sift" % i)) for i in range(len(chunks))]
+    hesaff_amd.write_sift_batch(paths, chunks, mr, threads=3)
+    for p, c in zip(paths, chunks):
+        assert open(p, "rb").read() == hesaff_amd.format_sift(c, mr)
