@@ -180,6 +180,29 @@ def test_cli_drop_in(tmp_path):
     assert int(m.group(2)) == int(out.split(b"\n")[1])
 
 
+def test_cli_batch_mode(tmp_path):
+    """`hesaff --batch list` (extension): every image gets the file the single-image form writes."""
+    exe = os.path.join(ROOT, "hesaff_amd", "bin", "hesaff")
+    names = []
+    for i, (h, w, seed) in enumerate(((120, 160, 5), (131, 77, 7), (120, 160, 6))):
+        img = band_noise_image(h, w, seed, SMALL_BANDS)
+        p = tmp_path / ("b%d.pgm" % i)
+        p.write_bytes(b"P5\n%d %d\n255\n" % (w, h) + img.tobytes())
+        names.append(str(p))
+    lst = tmp_path / "list.txt"
+    lst.write_text("# three images, two sizes\n" + "\n".join(names) + "\n")
+    r = subprocess.run([exe, "--batch", str(lst)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().split("\n")
+    assert len(lines) == 4 and re.fullmatch(r"Detected \d+ keypoints and \d+ affine shapes in 3 images in [0-9.e+-]+ sec\.", lines[3]), r.stdout
+    batch_out = [open(n + ".hesaff.sift", "rb").read() for n in names]
+    for n, want in zip(names, batch_out):
+        os.remove(n + ".hesaff.sift")
+        r1 = subprocess.run([exe, n], capture_output=True, text=True)
+        assert r1.returncode == 0, r1.stderr
+        assert open(n + ".hesaff.sift", "rb").read() == want and len(want) > 1000
+
+
 def test_batch_and_mixed_sizes(ctx):
     a = band_noise_image(200, 300, 31, SMALL_BANDS)
     b = band_noise_image(200, 300, 32, SMALL_BANDS)
