@@ -38,6 +38,14 @@ def pmc_traffic(batch, width, height, launches_per_step):
     return d.get("bytes_per_launch_avg")
 
 
+def _cpu_oracle_worker(img):
+    """One image through the CPU oracle in a fresh process (cpu_baseline_multicore); no GPU, no torch."""
+    from tests import _oracle
+    t0 = time.perf_counter()
+    o = _oracle.OracleRun(_oracle.gray_from_u8(img))
+    return o.n_keys, time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,6 +56,8 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=1, help="images of the batch timed on the CPU oracle")
+    ap.add_argument("--cpu-workers", type=int, default=-1,
+                    help="worker processes of the multi-core CPU baseline, one image each (-1: min(32, host cpus / 4); 0: skip)")
     args = ap.parse_args()
 
     import torch
@@ -153,6 +163,20 @@ def main():
                                    "sample": "%d of the %d batch images (%dx%d), oracle/libhesaff_oracle.so, 1 thread, %.1f s"
                                              % (len(host), B, W, H, cdt),
                                    "host_cpus": os.cpu_count()}
+            # the same oracle, one worker process per image over W cores
+            nw = args.cpu_workers if args.cpu_workers >= 0 else min(32, max(1, (os.cpu_count() or 4) // 4))
+            nw = min(nw, B)
+            if nw > 1:
+                import multiprocessing as mp
+                sample = [imgs[i].cpu().numpy() for i in range(nw)]
+                t1 = time.perf_counter()
+                with mp.get_context("spawn").Pool(nw) as pool:
+                    res = pool.map(_cpu_oracle_worker, sample)
+                mdt = time.perf_counter() - t1
+                out["cpu_baseline_multicore"] = {"value": sum(r[0] for r in res) / mdt, "unit": "keypoints/s", "cores": nw, "kind": "port",
+                                                 "images_per_s": nw / mdt,
+                                                 "sample": "%d of the %d batch images, one oracle process each, %.1f s wall (slowest worker %.1f s)"
+                                                           % (nw, B, mdt, max(r[1] for r in res))}
         print(json.dumps(out))
     ctx.close()
     if world > 1:
