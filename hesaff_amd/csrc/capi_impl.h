@@ -91,6 +91,7 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       memset(&c->tm, 0, sizeof c->tm);
       if (const char *ab = getenv("HESAFF_ABLATE")) c->ablate = atoi(ab) & ~1;
       if (const char *pk = getenv("HESAFF_PYR")) { c->use_tile_kernel = strcmp(pk, "tile") == 0; c->use_glds = strcmp(pk, "glds") == 0; }
+      if (const char *ab = getenv("HESAFF_AFF_BLOCKS")) c->aff_blocks_per_cu = std::max(1, atoi(ab));
       if (const char *sd = getenv("HESAFF_SIDE")) c->side_mask = atoi(sd);
       if (const char *sm = getenv("HESAFF_SMALL")) c->old_small = strcmp(sm, "old") == 0;
       if (const char *ex = getenv("HESAFF_EXTREMA")) c->use_tile_extrema = strcmp(ex, "tile") == 0;

@@ -154,6 +154,7 @@ struct hesaff_ctx {
    hipEvent_t ev_fork = nullptr, ev_join[HS_NSIDE] = {nullptr, nullptr, nullptr, nullptr};
    bool no_overlap = false;        // HESAFF_OVERLAP=0: run the patch bins one after the other
    bool stop_after_detect = false; // HESAFF_STOP=detect
+   int aff_blocks_per_cu = 4;      // HESAFF_AFF_BLOCKS: persistent k_affine blocks per CU (24.9 KB of LDS each)
    int side_mask = 15;             // HESAFF_SIDE: bit i = window-size bin i runs on its own side stream
    bool old_small = false;         // HESAFF_SMALL=old: k_patch_small<BIN, false> instead of k_patch_extract_small<BIN>
    bool use_tile_extrema = false;  // HESAFF_EXTREMA=tile: the LDS-tile extrema kernel (k_extrema3) instead of the marching one
@@ -822,7 +823,7 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       hipStream_t as = c->no_overlap ? st : c->aff_stream;
       if (as != st) HIP_TRY(hipStreamWaitEvent(as, c->ev_detect_done, 0));
       auto launch_affine = [&](size_t gi) {
-         hipLaunchKernelGGL(k_affine, dim3(std::min<uint32_t>((groups[gi].second - groups[gi].first + 3) / 4, 256 * 6)), dim3(64), 0, as, pt, s.hl, groups[gi].first, groups[gi].second, (const uint32_t *)(cnt + 3),
+         hipLaunchKernelGGL(k_affine, dim3(std::min<uint32_t>((groups[gi].second - groups[gi].first + 3) / 4, 256 * c->aff_blocks_per_cu)), dim3(64), 0, as, pt, s.hl, groups[gi].first, groups[gi].second, (const uint32_t *)(cnt + 3),
                             c->tables, c->consts, s.ao);
          if (as != st) HIP_TRY(hipEventRecord(c->ev_aff[gi], as));
       };
