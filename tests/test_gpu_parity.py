@@ -274,3 +274,29 @@ def test_full_size_4k(ctx, oracle):
     for i in range(2000):
         oracle.lib().ho_ellipse(g[i], ctx.params.mrSize, ref[i])
     assert np.abs(e - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("env", ["HESAFF_EXTREMA=tile", "HESAFF_SMALL=old", "HESAFF_SIFT=fused", "HESAFF_OVERLAP=0",
+                                 "HESAFF_PYR=tile", "HESAFF_GROUP=2000", "HESAFF_SIDE=0", "HESAFF_AFF_BLOCKS=1"])
+def test_alternative_kernel_paths_agree(ctx, env):
+    """The library keeps earlier forms of several kernels behind environment switches (LDS-tile
+    extrema and pyramid kernels, fused patch+SIFT kernels, serial stream schedule, tiny image
+    groups).  They are independent implementations of the same contracts: every byte of the
+    result must be the same."""
+    import hesaff_amd
+    imgs = [band_noise_image(480, 640, 77), band_noise_image(300, 500, 78, SMALL_BANDS)]
+    want = ctx.detect_batch(imgs)
+    k, v = env.split("=")
+    old = os.environ.get(k)
+    os.environ[k] = v
+    try:
+        with hesaff_amd.HesaffContext(device=0) as alt:
+            got = alt.detect_batch(imgs)
+    finally:
+        if old is None:
+            os.environ.pop(k)
+        else:
+            os.environ[k] = old
+    for (nh_w, keys_w), (nh_g, keys_g) in zip(want, got):
+        assert nh_w == nh_g and len(keys_w) == len(keys_g) and len(keys_w) > 500
+        assert keys_w.tobytes() == keys_g.tobytes(), env
