@@ -300,3 +300,34 @@ def test_alternative_kernel_paths_agree(ctx, env):
     for (nh_w, keys_w), (nh_g, keys_g) in zip(want, got):
         assert nh_w == nh_g and len(keys_w) == len(keys_g) and len(keys_w) > 500
         assert keys_w.tobytes() == keys_g.tobytes(), env
+
+
+def test_empty_and_featureless_inputs(ctx, oracle):
+    """No images, an image without a single extremum, and a batch mixing such images with normal ones."""
+    import hesaff_amd
+    assert ctx.detect_batch([]) == []
+    flat = np.full((200, 300), 127, np.uint8)
+    ramp = np.tile(np.arange(300, dtype=np.uint8), (200, 1))
+    for im in (flat, ramp):
+        (nh, keys), = ctx.detect_batch([im])
+        o = oracle.OracleRun(oracle.gray_from_u8(im))
+        assert nh == o.n_hessian == 0 and len(keys) == o.n_keys == 0
+        assert hesaff_amd.format_sift(keys, ctx.params.mrSize) == b"128\n0\n"
+    normal = band_noise_image(200, 300, 31, SMALL_BANDS)
+    res = ctx.detect_batch([flat, normal, ramp, normal])
+    assert res[0][0] == 0 and res[2][0] == 0 and len(res[0][1]) == 0 and len(res[2][1]) == 0
+    assert res[1][0] > 100 and res[1][1].tobytes() == res[3][1].tobytes() == ctx.detect_batch([normal])[0][1].tobytes()
+
+
+def test_capacity_error_is_reported():
+    """More keypoints than max_kpts_per_mpx allows: HESAFF_ERR_CAPACITY, nothing truncated silently."""
+    import hesaff_amd
+    p = hesaff_amd.default_params()
+    p.max_kpts_per_mpx = 1000   # the library's floor: capacity = max(4096, 1000 per megapixel)
+    with hesaff_amd.HesaffContext(p, device=0) as small:
+        with pytest.raises(hesaff_amd.HesaffError) as e:
+            small.detect_batch([band_noise_image(720, 1280, 1234)])   # ~12 k keypoints against 4096
+        assert "capacity" in str(e.value).lower()
+        # the context stays usable
+        (nh, keys), = small.detect_batch([np.full((64, 64), 10, np.uint8)])
+        assert nh == 0 and len(keys) == 0
