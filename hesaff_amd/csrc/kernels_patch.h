@@ -375,6 +375,38 @@ __global__ __launch_bounds__(256) void k_patch_small(HessList hl, PatchWork pw, 
    }
 }
 
+// resample of affine.cpp:131 from the blurred window, separable bookkeeping: the sample
+// coordinate of output (jj, ii) is (c0 + (ii - 20) * scale, c0 + (jj - 20) * scale) (the cross
+// terms of the interpolate() call are multiplied by 0.0f and vanish exactly), so the integer
+// part and the fraction are tabulated once per keypoint for the 41 positions of an axis:
+//   tab_i[m] = floor(w_m) (or -1 when a tap would leave the window), tab_f[m] = w_m - floor(w_m).
+__device__ __forceinline__ void hs_resample_table(int P, float scale, int *tab_i, float *tab_f)
+{
+   const int m = threadIdx.x;
+   if (m < HS_PATCH) {
+      const float c0 = (float)(P >> 1);
+      const float w = c0 + (float)(m - (HS_PATCH >> 1)) * scale;
+      const float f = floorf(w);
+      const bool in = f >= 0.0f && f < (float)(P - 1);   // helpers.cpp:227-240 with width = height = P - 1
+      tab_i[m] = in ? (int)f : -1;
+      tab_f[m] = w - f;
+   }
+}
+
+__device__ __forceinline__ void hs_resample_full_tab(const float *S, int P, const int *tab_i, const float *tab_f, float *out)
+{
+   for (int idx = threadIdx.x; idx < HS_PATCH_PIX; idx += 256) {
+      const int jj = idx / HS_PATCH, ii = idx - jj * HS_PATCH;
+      const int xi = tab_i[ii], yi = tab_i[jj];
+      const float wx = tab_f[ii], wy = tab_f[jj];
+      const bool in = (xi | yi) >= 0;
+      const float *p = S + (in ? yi * P + xi : 0);
+      const float p00 = p[0], p01 = p[1], p10 = p[P], p11 = p[P + 1];
+      const float v = (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + (wy) * ((1.0f - wx) * p10 + wx * p11);
+      out[idx] = in ? v : 0.0f;
+   }
+}
+
 // ---------------------------------------------------------------------------------------
 // k_patch_extract_small<BIN>: the extraction-only form of k_patch_small (the descriptor runs in
 // kernels_sift.h): warp -> blur -> resample for windows P <= 43 (BIN 0) / 66 (BIN 1), result
@@ -463,6 +495,8 @@ __global__ __launch_bounds__(256) void k_patch_extract_small(HessList hl, PatchW
    constexpr int SSZ = (PMAX * SPITCH + 3) & ~3;
    float *S = smem, *T = smem + SSZ, *s_taps = T + (PMAX + 2 * HS_SMALL_RMAX) * TPITCH;
    __shared__ int s_flag;
+   __shared__ int s_tab_i[HS_PATCH];
+   __shared__ float s_tab_f[HS_PATCH];
 
    const int tid = threadIdx.x;
    const uint32_t cnt = min(pw.bin_count[BIN], pw.cap);
@@ -507,6 +541,7 @@ __global__ __launch_bounds__(256) void k_patch_extract_small(HessList hl, PatchW
       const float *taps_g = tb.patch_taps + tb.patch_tap_off[(P0 - 1) >> 1];
       if (tid == 0) s_flag = 0;
       if (tid < K) s_taps[tid] = taps_g[tid];
+      hs_resample_table(P, scale, s_tab_i, s_tab_f);
       __syncthreads();
       // 1. warp, affine.cpp:126 ; touching the image boundary rejects the keypoint.  All gathers of
       // a batch are issued before the first use (clamped index, branch-free tap).
@@ -555,7 +590,7 @@ __global__ __launch_bounds__(256) void k_patch_extract_small(HessList hl, PatchW
          default: hs_small_blur<0, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
       }
       // 3. resample, affine.cpp:131
-      hs_resample_full(S, P, scale, out);
+      hs_resample_full_tab(S, P, s_tab_i, s_tab_f, out);
       __syncthreads();
    }
 }
