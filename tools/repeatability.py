@@ -1,0 +1,212 @@
+"""Repeatability and matching score of Hessian-Affine regions under a homography
+(protocol of Mikolajczyk et al., "A comparison of affine region
+detectors", IJCV 2005, as used with the Oxford graf/wall/... sequences).
+
+Regions are the ellipses of a .hesaff.sift file:  (x-u, y-v) M (x-u, y-v)^T = 1,
+M = [[a, b], [b, c]]  (README:27-44 of the reference).
+
+  python tools/repeatability.py A.hesaff.sift B.hesaff.sift --H H.txt --size1 W H --size2 W H
+  python tools/repeatability.py --synthetic            # needs the GPU: detects on a synthetic
+                                                       # image and on homography-warped copies
+
+The Oxford sequences are not available offline; --synthetic substitutes a band-noise image
+warped by a viewpoint-like family of homographies (stated in the output).
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def read_sift(path):
+    """-> (regions [n,5] float64: u v a b c, descriptors [n,128] uint8)."""
+    with open(path, "rb") as f:
+        dim = int(f.readline()); n = int(f.readline())
+        data = np.loadtxt(f, dtype=np.float64, ndmin=2) if n > 0 else np.zeros((0, 5 + dim))
+    assert data.shape == (n, 5 + dim), (data.shape, n, dim)
+    return data[:, :5].copy(), data[:, 5:].astype(np.uint8)
+
+
+def project(H, pts):
+    q = np.c_[pts, np.ones(len(pts))] @ H.T
+    return q[:, :2] / q[:, 2:3]
+
+
+def map_regions(H, reg):
+    """Ellipses of image 1 -> image 2 through the local affine approximation of H at the centre."""
+    u, v = reg[:, 0], reg[:, 1]
+    den = H[2, 0] * u + H[2, 1] * v + H[2, 2]
+    X = (H[0, 0] * u + H[0, 1] * v + H[0, 2]) / den
+    Y = (H[1, 0] * u + H[1, 1] * v + H[1, 2]) / den
+    # Jacobian of (X, Y) wrt (u, v)
+    J = np.empty((len(reg), 2, 2))
+    J[:, 0, 0] = (H[0, 0] - H[2, 0] * X) / den; J[:, 0, 1] = (H[0, 1] - H[2, 1] * X) / den
+    J[:, 1, 0] = (H[1, 0] - H[2, 0] * Y) / den; J[:, 1, 1] = (H[1, 1] - H[2, 1] * Y) / den
+    M = np.empty((len(reg), 2, 2))
+    M[:, 0, 0] = reg[:, 2]; M[:, 0, 1] = M[:, 1, 0] = reg[:, 3]; M[:, 1, 1] = reg[:, 4]
+    Ji = np.linalg.inv(J)
+    M2 = np.transpose(Ji, (0, 2, 1)) @ M @ Ji
+    return np.c_[X, Y, M2[:, 0, 0], M2[:, 0, 1], M2[:, 1, 1]]
+
+
+def ellipse_area(reg):
+    return np.pi / np.sqrt(np.maximum(reg[:, 2] * reg[:, 4] - reg[:, 3] ** 2, 1e-300))
+
+
+def overlap_error(r1, r2, grid=48):
+    """1 - |A n B| / |A u B| for paired ellipses r1[i], r2[i] (same frame), by rasterisation on a
+    grid x grid lattice over the joint bounding box.  Both regions are first rescaled so that r1 has
+    the area of a circle of radius 30 (the protocol's size normalisation)."""
+    s = np.sqrt(ellipse_area(r1) / (np.pi * 30.0 ** 2))          # linear scale factor to remove
+    d = (r2[:, :2] - r1[:, :2]) / s[:, None]
+    a1, b1, c1 = (r1[:, 2:5] * (s ** 2)[:, None]).T
+    a2, b2, c2 = (r2[:, 2:5] * (s ** 2)[:, None]).T
+
+    def half_extent(a, b, c):
+        det = a * c - b * b
+        return np.sqrt(c / det), np.sqrt(a / det)                 # bounding box half sizes of x^T M x <= 1
+
+    hx1, hy1 = half_extent(a1, b1, c1); hx2, hy2 = half_extent(a2, b2, c2)
+    x0 = np.minimum(-hx1, d[:, 0] - hx2); x1 = np.maximum(hx1, d[:, 0] + hx2)
+    y0 = np.minimum(-hy1, d[:, 1] - hy2); y1 = np.maximum(hy1, d[:, 1] + hy2)
+    t = (np.arange(grid) + 0.5) / grid
+    gx = x0[:, None] + (x1 - x0)[:, None] * t[None, :]           # [n, grid]
+    gy = y0[:, None] + (y1 - y0)[:, None] * t[None, :]
+    X = gx[:, None, :]; Y = gy[:, :, None]
+    in1 = a1[:, None, None] * X * X + 2 * b1[:, None, None] * X * Y + c1[:, None, None] * Y * Y <= 1.0
+    Xd = X - d[:, 0, None, None]; Yd = Y - d[:, 1, None, None]
+    in2 = a2[:, None, None] * Xd * Xd + 2 * b2[:, None, None] * Xd * Yd + c2[:, None, None] * Yd * Yd <= 1.0
+    inter = (in1 & in2).sum(axis=(1, 2)).astype(np.float64)
+    union = (in1 | in2).sum(axis=(1, 2)).astype(np.float64)
+    return 1.0 - inter / np.maximum(union, 1.0)
+
+
+def evaluate(reg1, desc1, reg2, desc2, H, size1, size2, max_error=0.4, chunk=20000):
+    """-> dict with repeatability and matching score (one-to-one correspondences, overlap error < max_error)."""
+    w1, h1 = size1; w2, h2 = size2
+    Hi = np.linalg.inv(H)
+    # regions whose centre lies in the part of the scene visible in both images
+    p12 = project(H, reg1[:, :2]); p21 = project(Hi, reg2[:, :2])
+    k1 = (p12[:, 0] >= 0) & (p12[:, 0] < w2) & (p12[:, 1] >= 0) & (p12[:, 1] < h2)
+    k2 = (p21[:, 0] >= 0) & (p21[:, 0] < w1) & (p21[:, 1] >= 0) & (p21[:, 1] < h1)
+    r1 = map_regions(H, reg1[k1]); d1 = desc1[k1]
+    r2 = reg2[k2]; d2 = desc2[k2]
+    n1, n2 = len(r1), len(r2)
+    if min(n1, n2) == 0:
+        return {"n1": int(n1), "n2": int(n2), "correspondences": 0, "repeatability": 0.0, "matches": 0, "matching_score": 0.0}
+    # candidate pairs: centres closer than the sum of the mean radii (cheap prefilter on a grid of cells)
+    rad1 = np.sqrt(ellipse_area(r1) / np.pi); rad2 = np.sqrt(ellipse_area(r2) / np.pi)
+    cell = max(float(np.percentile(np.r_[rad1, rad2], 90)) * 2.0, 8.0)
+    from collections import defaultdict
+    buckets = defaultdict(list)
+    for j, (x, y) in enumerate(r2[:, :2]):
+        buckets[(int(x // cell), int(y // cell))].append(j)
+    pi_, pj_ = [], []
+    for i, (x, y) in enumerate(r1[:, :2]):
+        cx, cy = int(x // cell), int(y // cell)
+        reach = int(np.ceil((rad1[i] + cell) / cell))
+        for gx in range(cx - reach, cx + reach + 1):
+            for gy in range(cy - reach, cy + reach + 1):
+                for j in buckets.get((gx, gy), ()):
+                    if (x - r2[j, 0]) ** 2 + (y - r2[j, 1]) ** 2 < (rad1[i] + rad2[j]) ** 2:
+                        pi_.append(i); pj_.append(j)
+    pi_ = np.asarray(pi_, np.int64); pj_ = np.asarray(pj_, np.int64)
+    err = np.empty(len(pi_))
+    for s in range(0, len(pi_), chunk):
+        err[s:s + chunk] = overlap_error(r1[pi_[s:s + chunk]], r2[pj_[s:s + chunk]])
+    good = err < max_error
+    # one-to-one: greedy by increasing overlap error
+    order = np.argsort(err[good], kind="stable")
+    gi, gj, ge = pi_[good][order], pj_[good][order], err[good][order]
+    used1 = np.zeros(n1, bool); used2 = np.zeros(n2, bool)
+    pairs = []
+    for a, b in zip(gi, gj):
+        if not used1[a] and not used2[b]:
+            used1[a] = used2[b] = True
+            pairs.append((a, b))
+    ncorr = len(pairs)
+    # matching score: a correspondence counts when the region of image 2 is also the nearest
+    # neighbour of its partner in descriptor space
+    matches = 0
+    if ncorr:
+        D2 = d2.astype(np.float32)
+        for a, b in pairs:
+            dist = ((D2 - d1[a].astype(np.float32)) ** 2).sum(axis=1)
+            matches += int(np.argmin(dist) == b)
+    return {"n1": int(n1), "n2": int(n2), "correspondences": int(ncorr), "repeatability": ncorr / min(n1, n2),
+            "matches": int(matches), "matching_score": matches / min(n1, n2), "max_overlap_error": max_error}
+
+
+def viewpoint_homography(w, h, angle_deg, zoom=1.0):
+    """Homography of a plane seen after rotating the camera about the vertical axis by angle_deg
+    (focal length = image width), centred on the image: the graf-like viewpoint change."""
+    f = float(w)
+    K = np.array([[f, 0, w / 2.0], [0, f, h / 2.0], [0, 0, 1.0]])
+    t = np.deg2rad(angle_deg)
+    R = np.array([[np.cos(t), 0, np.sin(t)], [0, 1, 0], [-np.sin(t), 0, np.cos(t)]])
+    n = np.array([0, 0, 1.0]); d = 1.0
+    tr = np.array([-np.sin(t) * zoom, 0, (1 - np.cos(t)) * zoom + (zoom - 1.0)])
+    Hn = R + np.outer(tr, n) / d
+    H = K @ Hn @ np.linalg.inv(K)
+    return H / H[2, 2]
+
+
+def warp_image(img, H, out_size):
+    """img seen through H (image1 -> image2 coordinates), bilinear, outside = mid grey."""
+    from scipy.ndimage import map_coordinates
+    w2, h2 = out_size
+    yy, xx = np.mgrid[0:h2, 0:w2].astype(np.float64)
+    src = project(np.linalg.inv(H), np.c_[xx.ravel(), yy.ravel()])
+    out = map_coordinates(img.astype(np.float32), [src[:, 1], src[:, 0]], order=1, mode="constant", cval=127.0)
+    return np.clip(np.rint(out.reshape(h2, w2)), 0, 255).astype(np.uint8)
+
+
+def synthetic_sequence(width=800, height=640, angles=(10, 20, 30, 40, 50), seed=1234):
+    import hesaff_amd
+    from hesaff_amd.synth import band_noise_image
+    base = band_noise_image(height, width, seed)
+    imgs = [base]; Hs = [np.eye(3)]
+    for a in angles:
+        H = viewpoint_homography(width, height, a)
+        imgs.append(warp_image(base, H, (width, height))); Hs.append(H)
+    with hesaff_amd.HesaffContext(device=0) as ctx:
+        res = ctx.detect_batch(imgs)
+        mr = ctx.params.mrSize
+    regs = []
+    for _, keys in res:
+        e = hesaff_amd.ellipse(keys, mr).astype(np.float64)
+        regs.append((np.c_[keys["x"].astype(np.float64), keys["y"].astype(np.float64), e], np.ascontiguousarray(keys["desc"])))
+    out = []
+    for a, H, (r, d) in zip(angles, Hs[1:], regs[1:]):
+        ev = evaluate(regs[0][0], regs[0][1], r, d, H, (width, height), (width, height))
+        ev["viewpoint_deg"] = a
+        out.append(ev)
+    return {"data": "synthetic: band-noise %dx%d image and copies warped by a camera rotation about the vertical axis "
+                    "(the Oxford sequences are not available offline)" % (width, height), "pairs": out}
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("files", nargs="*")
+    ap.add_argument("--H", help="text file with the 3x3 homography image1 -> image2")
+    ap.add_argument("--size1", nargs=2, type=int, metavar=("W", "H"))
+    ap.add_argument("--size2", nargs=2, type=int, metavar=("W", "H"))
+    ap.add_argument("--synthetic", action="store_true")
+    args = ap.parse_args()
+    if args.synthetic:
+        print(json.dumps(synthetic_sequence()))
+        return
+    if len(args.files) != 2 or not args.H or not args.size1 or not args.size2:
+        ap.error("two .hesaff.sift files, --H, --size1 and --size2 are required (or --synthetic)")
+    r1, d1 = read_sift(args.files[0]); r2, d2 = read_sift(args.files[1])
+    H = np.loadtxt(args.H).reshape(3, 3)
+    print(json.dumps(evaluate(r1, d1, r2, d2, H, tuple(args.size1), tuple(args.size2))))
+
+
+if __name__ == "__main__":
+    main()
