@@ -1,12 +1,18 @@
 // kernels_patch.h -- affine patch normalisation (AffineShape::normalizeAffine,
-// affine.cpp:102-144) fused with the SIFT descriptor (siftdesc.cpp), one 256-thread block
-// per keypoint.  Keypoints are binned by the side P of the warped window:
-//   k_patch_small<0|1>  P <= 41 | 64 : window S and row-pass plane T live in LDS (full blur)
-//   k_patch_mid         P <= 128     : row-streamed; only the 82 blurred columns / rows the
-//                                      41x41 resample reads are evaluated, T' (P x 82) in LDS
-//   k_patch_large_rows + k_patch_large_finish  P > 128 : one wavefront per window ROW writes
-//                                      T' rows to HBM (all rows of all large keypoints run in
-//                                      parallel), then one block per keypoint finishes.
+// affine.cpp:102-144), one 256-thread block per keypoint.  Keypoints are binned by the side P of
+// the warped window (hs_patch_bin); the default path only EXTRACTS the 41x41 patch (to HBM, the
+// descriptor runs in kernels_sift.h):
+//   k_patch_extract_small<0|1>  P <= 41 | 64 : window S and row-pass plane T in LDS, stored with
+//                                      replicated borders; tap count as template parameter
+//   k_patch_mid<128|512>        P <= 128 | 512 : row-streamed; only the 82 blurred columns / rows
+//                                      the 41x41 resample reads are evaluated, T' (P x 82, padded)
+//                                      in a per-block HBM slot
+//   k_patch_large_rows + k_patch_large_finish  P > 512 : one wavefront per chunk of window ROWS
+//                                      writes T' rows to HBM (all rows of all huge keypoints run
+//                                      in parallel), then one block per keypoint finishes.
+// The earlier fused form (descriptor inside the patch kernel: k_patch_small<BIN, true>,
+// k_patch_mid<.., true>, hs_sift_block) is kept behind HESAFF_SIFT=fused / HESAFF_SMALL=old and
+// cross-checked against the default path by the GPU tests.
 // Skipping blur outputs nobody reads does not change any value that is read: every
 // evaluated tap sum uses the pinned cv::GaussianBlur order:
 //   row   : t = k[0]*S[x-r]; t += k[j]*S[x-r+j]  (j ascending)       K > 5
