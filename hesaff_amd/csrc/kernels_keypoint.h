@@ -49,7 +49,7 @@ struct AffineOut {
 // keypoint.  The 16-lane groups are persistent: a group whose keypoint converged (or was
 // rejected) takes the next keypoint at the end of the round, so keypoints with different
 // iteration counts do not wait for each other.
-// block = 64 threads (one wavefront), LDS 4 x 4 x 364 floats + mask.
+// block = 64 threads (one wavefront), LDS 4 x 3 x 364 floats + mask (19 KB).
 // ---------------------------------------------------------------------------------------
 #define HS_AFF_G 4
 #define HS_AFF_NT 23    // ceil(361 / 16)
@@ -64,12 +64,12 @@ template <class Fetch>
 __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, const float *__restrict__ mask_g, const DConsts &k, AffineOut out,
                                                  Fetch fetch)
 {
-   __shared__ __attribute__((aligned(16))) float s_arr[HS_AFF_G][4][HS_AFF_ARR];   // img | a | b | c terms
+   __shared__ __attribute__((aligned(16))) float s_arr[HS_AFF_G][3][HS_AFF_ARR];   // img, then a terms | b terms | c terms
    __shared__ float s_mask[HS_AFF_ARR];
    __shared__ float s_bc[HS_AFF_G][8];
    const int lane = threadIdx.x, grp = lane >> 4, li = lane & 15;
    for (int i = lane; i < HS_SMM_PIX; i += 64) s_mask[i] = mask_g[i];
-   float *s_img = s_arr[grp][0], *s_pa = s_arr[grp][1], *s_pb = s_arr[grp][2], *s_pc = s_arr[grp][3];
+   float *s_img = s_arr[grp][0], *s_pa = s_arr[grp][0], *s_pb = s_arr[grp][1], *s_pc = s_arr[grp][2];   // the a terms replace the image
    const uint32_t hstep = gridDim.x * HS_AFF_G;
    uint32_t h = first + blockIdx.x * HS_AFF_G + grp;
    if (k.maxIterations <= 0) {   // no iteration: U = identity, not converged
@@ -130,27 +130,35 @@ __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, con
       }
       HS_WAVE_LDS_SYNC();
       if (active) {
-         // computeGradient affine.cpp:14-33 + products affine.cpp:62-68
-#pragma unroll 6
+         // computeGradient affine.cpp:14-33 + products affine.cpp:62-68.  The a terms take the place of
+         // the sampled image in LDS, so they wait in registers until every lane has read its neighbours.
+         float pa[HS_AFF_NT];
+#pragma unroll
          for (int t = 0; t < HS_AFF_NT; t++) {
-            const int idx = li + 16 * t;
-            if (idx < HS_SMM_PIX) {
-               const int r = idx / HS_SMM, c = idx - r * HS_SMM;
-               // hs_grad with clamped neighbour indices (one-sided differences at the tile border)
-               const float gxx = s_img[idx + (c < HS_SMM - 1 ? 1 : 0)] - s_img[idx - (c > 0 ? 1 : 0)];
-               const float gyy = s_img[idx + (r < HS_SMM - 1 ? HS_SMM : 0)] - s_img[idx - (r > 0 ? HS_SMM : 0)];
-               const float v = s_mask[idx];
-               const float gxy = gxx * gyy;
-               s_pa[idx] = gxx * gxx * v;
+            const int idx = min(li + 16 * t, HS_SMM_PIX - 1);
+            const int r = idx / HS_SMM, c = idx - r * HS_SMM;
+            // hs_grad with clamped neighbour indices (one-sided differences at the tile border)
+            const float gxx = s_img[idx + (c < HS_SMM - 1 ? 1 : 0)] - s_img[idx - (c > 0 ? 1 : 0)];
+            const float gyy = s_img[idx + (r < HS_SMM - 1 ? HS_SMM : 0)] - s_img[idx - (r > 0 ? HS_SMM : 0)];
+            const float v = s_mask[idx];
+            const float gxy = gxx * gyy;
+            pa[t] = gxx * gxx * v;
+            if (li + 16 * t < HS_SMM_PIX) {
                s_pb[idx] = gxy * v;
                s_pc[idx] = gyy * gyy * v;
             }
+         }
+         HS_WAVE_LDS_SYNC();
+#pragma unroll
+         for (int t = 0; t < HS_AFF_NT; t++) {
+            const int idx = li + 16 * t;
+            if (idx < HS_SMM_PIX) s_pa[idx] = pa[t];
          }
       }
       HS_WAVE_LDS_SYNC();
       if (active && li < 3) {
          // 361 terms in index order (affine.cpp:57-68); float4 LDS reads, the adds stay sequential
-         const float *pp = s_arr[grp][1 + li];
+         const float *pp = s_arr[grp][li];
          const float4 *p4 = reinterpret_cast<const float4 *>(pp);
          float acc = 0.0f;
          for (int i0 = 0; i0 < HS_SMM_PIX / 4; i0 += 10) {   // 90 = 9 x 10 float4, ten reads in flight

@@ -154,7 +154,7 @@ struct hesaff_ctx {
    hipEvent_t ev_fork = nullptr, ev_join[HS_NSIDE] = {nullptr, nullptr, nullptr, nullptr};
    bool no_overlap = false;        // HESAFF_OVERLAP=0: run the patch bins one after the other
    bool stop_after_detect = false; // HESAFF_STOP=detect
-   int aff_blocks_per_cu = 4;      // HESAFF_AFF_BLOCKS: persistent k_affine blocks per CU (24.9 KB of LDS each)
+   int aff_blocks_per_cu = 6;      // HESAFF_AFF_BLOCKS: persistent k_affine blocks per CU (19 KB of LDS each)
    int side_mask = 15;             // HESAFF_SIDE: bit i = window-size bin i runs on its own side stream
    bool old_small = false;         // HESAFF_SMALL=old: k_patch_small<BIN, false> instead of k_patch_extract_small<BIN>
    bool use_tile_extrema = false;  // HESAFF_EXTREMA=tile: the LDS-tile extrema kernel (k_extrema3) instead of the marching one
