@@ -14,6 +14,7 @@ from ._binding import (  # noqa: F401
     format_sift_mt,
     write_sift,
     write_sift_batch,
+    read_image,
     read_pnm,
     ellipse,
     lib_path,

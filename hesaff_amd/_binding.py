@@ -96,6 +96,8 @@ def load_library():
     L.hesaff_test_fmt_g.argtypes = [_f32p, C.c_int]
     L.hesaff_free.argtypes = [vp]; L.hesaff_free.restype = None
     L.hesaff_read_pnm.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.hesaff_read_png.argtypes = L.hesaff_read_pnm.argtypes
+    L.hesaff_read_image.argtypes = L.hesaff_read_pnm.argtypes
     L.hesaff_stage_gaussian_blur.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_float, _f32p]
     L.hesaff_stage_hessian_response.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_float, _f32p]
     L.hesaff_stage_half_image.argtypes = [vp, _f32p, C.c_int, C.c_int, _f32p]
@@ -123,6 +125,7 @@ ABI_SYMBOLS = [
     "hesaff_stage_find_affine_shape", "hesaff_stage_rectify", "hesaff_stage_normalize_affine", "hesaff_stage_sift",
     "hesaff_stage_math", "hesaff_table_gauss_mask", "hesaff_table_circ_gauss_mask", "hesaff_table_sift_bins",
     "hesaff_table_gauss_kernel", "hesaff_format_sift_mt", "hesaff_write_sift_batch", "hesaff_test_fmt_g",
+    "hesaff_read_png", "hesaff_read_image",
 ]
 
 
@@ -221,12 +224,17 @@ def write_sift(path, keys, mr_size):
         raise HesaffError(rc, "hesaff_write_sift(%s)" % path)
 
 
-def read_pnm(path):
+def read_image(path):
+    """PGM/PPM or PNG by magic number -> uint8 array HxW (grey) or HxWx3."""
+    return read_pnm(path, _fn="hesaff_read_image")
+
+
+def read_pnm(path, _fn="hesaff_read_pnm"):
     L = load_library()
     data = C.c_void_p(); w = C.c_int(); h = C.c_int(); ch = C.c_int()
-    rc = L.hesaff_read_pnm(os.fsencode(path), C.byref(data), C.byref(w), C.byref(h), C.byref(ch))
+    rc = getattr(L, _fn)(os.fsencode(path), C.byref(data), C.byref(w), C.byref(h), C.byref(ch))
     if rc != 0:
-        raise HesaffError(rc, "hesaff_read_pnm(%s)" % path)
+        raise HesaffError(rc, "%s(%s)" % (_fn, path))
     try:
         n = w.value * h.value * ch.value
         arr = np.frombuffer(C.string_at(data.value, n), dtype=np.uint8).copy()

@@ -1,6 +1,6 @@
 // hesaff_cli.cpp -- `hesaff <image>` : same command line, stdout line and output file as
 // the reference's main() (hesaff.cpp:133-180); the work runs on the MI355X through
-// libhesaff_amd.so.  Input: binary PGM/PPM (P5/P6).
+// libhesaff_amd.so.  Input: binary PGM/PPM (P5/P6) or PNG.
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -36,7 +36,7 @@ static int run_batch_mode(const char *list_path)
       std::atomic<int> next(0), bad(-1);
       auto work = [&] {
          for (int i; (i = next.fetch_add(1)) < n;)
-            if (hesaff_read_pnm(names[i].c_str(), &data[i], &w[i], &h[i], &ch[i]) != HESAFF_OK) bad = i;
+            if (hesaff_read_image(names[i].c_str(), &data[i], &w[i], &h[i], &ch[i]) != HESAFF_OK) bad = i;
             else stride[i] = w[i] * ch[i];
       };
       std::vector<std::thread> th;
@@ -45,7 +45,7 @@ static int run_batch_mode(const char *list_path)
       work();
       for (auto &x : th) x.join();
       if (bad.load() >= 0) {
-         fprintf(stderr, "hesaff: cannot read '%s' (binary PGM/PPM with maxval 255 expected)\n", names[bad.load()].c_str());
+         fprintf(stderr, "hesaff: cannot read '%s' (binary PGM/PPM with maxval 255 or PNG expected)\n", names[bad.load()].c_str());
          rc = 1;
       }
    }
@@ -88,8 +88,8 @@ int main(int argc, char **argv)
    if (argc > 1) {
       uint8_t *data = nullptr;
       int w = 0, h = 0, ch = 0;
-      if (hesaff_read_pnm(argv[1], &data, &w, &h, &ch) != HESAFF_OK) {
-         fprintf(stderr, "hesaff: cannot read '%s' (binary PGM/PPM with maxval 255 expected)\n", argv[1]);
+      if (hesaff_read_image(argv[1], &data, &w, &h, &ch) != HESAFF_OK) {
+         fprintf(stderr, "hesaff: cannot read '%s' (binary PGM/PPM with maxval 255 or PNG expected)\n", argv[1]);
          return 1;
       }
       try {

@@ -15,6 +15,8 @@
 #include <utility>
 #include <vector>
 
+#include <zlib.h>
+
 #include "../../include/hesaff_amd.h"
 
 namespace {
@@ -33,6 +35,109 @@ int pnm_next_int(FILE *f, int *out)
    while (c >= '0' && c <= '9') { v = v * 10 + (c - '0'); if (v > 100000000) return -1; c = fgetc(f); }
    *out = (int)v;   // the single whitespace after the token has been consumed
    return 0;
+}
+
+// ---- PNG: what cv::imread(path) with its default flag returns for a PNG
+// file - 8 bits per channel, alpha dropped, 16-bit samples reduced to their high byte, palette and
+// 1/2/4-bit grey expanded - decoded with zlib only.  PNG is lossless, so the pixels do not depend on
+// the decoder (unlike JPEG, which stays out of scope).  Interlaced files are rejected.
+inline uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+int read_png_bytes(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *height, int *channels)
+{
+   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+   if (f.size() < 8 + 25 || memcmp(f.data(), sig, 8) != 0) return HESAFF_ERR_IO;
+   size_t pos = 8;
+   uint32_t W = 0, H = 0;
+   int depth = 0, ctype = -1;
+   bool have_ihdr = false, done = false;
+   std::vector<uint8_t> idat, plte;
+   while (!done && pos + 12 <= f.size()) {
+      const uint32_t len = be32(&f[pos]);
+      if (len > f.size() - pos - 12) return HESAFF_ERR_IO;
+      const uint8_t *type = &f[pos + 4], *body = &f[pos + 8];
+      if (be32(body + len) != (uint32_t)crc32(crc32(0L, Z_NULL, 0), type, 4 + len)) return HESAFF_ERR_IO;
+      if (memcmp(type, "IHDR", 4) == 0) {
+         if (len != 13 || have_ihdr) return HESAFF_ERR_IO;
+         W = be32(body); H = be32(body + 4); depth = body[8]; ctype = body[9];
+         if (body[10] != 0 || body[11] != 0 || body[12] != 0) return HESAFF_ERR_IO;   // compression, filter, interlace
+         if (W < 1 || H < 1 || W > 65535u || H > 65535u) return HESAFF_ERR_IO;
+         have_ihdr = true;
+      } else if (memcmp(type, "PLTE", 4) == 0) plte.assign(body, body + len);
+      else if (memcmp(type, "IDAT", 4) == 0) idat.insert(idat.end(), body, body + len);
+      else if (memcmp(type, "IEND", 4) == 0) done = true;
+      pos += 12 + (size_t)len;
+   }
+   if (!have_ihdr || !done || idat.empty()) return HESAFF_ERR_IO;
+   int nch;   // samples per pixel in the file
+   switch (ctype) {
+      case 0: nch = 1; break;
+      case 2: nch = 3; break;
+      case 3: nch = 1; break;
+      case 4: nch = 2; break;
+      case 6: nch = 4; break;
+      default: return HESAFF_ERR_IO;
+   }
+   const bool depth_ok = (ctype == 0) ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
+                         : (ctype == 3) ? (depth == 1 || depth == 2 || depth == 4 || depth == 8) : (depth == 8 || depth == 16);
+   if (!depth_ok || (ctype == 3 && (plte.empty() || plte.size() % 3 != 0))) return HESAFF_ERR_IO;
+   const size_t rowbytes = ((size_t)W * nch * depth + 7) / 8;
+   const int bpp = std::max(1, nch * depth / 8);   // filter unit
+   std::vector<uint8_t> raw((size_t)H * (rowbytes + 1));
+   uLongf rawlen = (uLongf)raw.size();
+   if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return HESAFF_ERR_IO;
+   // unfilter in place (PNG specification, section 9)
+   std::vector<uint8_t> zero(rowbytes, 0);
+   for (uint32_t y = 0; y < H; y++) {
+      uint8_t *row = &raw[(size_t)y * (rowbytes + 1)];
+      const int ft = row[0];
+      uint8_t *cur = row + 1;
+      const uint8_t *up = y ? cur - (rowbytes + 1) : zero.data();
+      switch (ft) {
+         case 0: break;
+         case 1: for (size_t i = bpp; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]); break;
+         case 2: for (size_t i = 0; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + up[i]); break;
+         case 3:
+            for (size_t i = 0; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + (((i >= (size_t)bpp ? cur[i - bpp] : 0) + up[i]) >> 1));
+            break;
+         case 4:
+            for (size_t i = 0; i < rowbytes; i++) {
+               const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = up[i], c = i >= (size_t)bpp ? up[i - bpp] : 0;
+               const int pq = a + b - c, pa = std::abs(pq - a), pb = std::abs(pq - b), pc = std::abs(pq - c);
+               cur[i] = (uint8_t)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)));
+            }
+            break;
+         default: return HESAFF_ERR_IO;
+      }
+   }
+   const int och = (ctype == 0 || ctype == 4) ? 1 : 3;
+   uint8_t *out = (uint8_t *)malloc((size_t)W * H * och);
+   if (!out) return HESAFF_ERR_NOMEM;
+   const int step = depth == 16 ? 2 : 1;   // 16-bit samples: the high byte (big-endian first)
+   for (uint32_t y = 0; y < H; y++) {
+      const uint8_t *cur = &raw[(size_t)y * (rowbytes + 1) + 1];
+      uint8_t *o = out + (size_t)y * W * och;
+      for (uint32_t x = 0; x < W; x++) {
+         if (depth < 8) {   // grey or palette index, packed most significant bits first
+            const int per = 8 / depth, sh = (per - 1 - (int)(x % per)) * depth;
+            const int v = (cur[x / per] >> sh) & ((1 << depth) - 1);
+            if (ctype == 3) {
+               if ((size_t)v * 3 + 2 >= plte.size()) { free(out); return HESAFF_ERR_IO; }
+               o[3 * x] = plte[3 * v]; o[3 * x + 1] = plte[3 * v + 1]; o[3 * x + 2] = plte[3 * v + 2];
+            } else o[x] = (uint8_t)(v * (255 / ((1 << depth) - 1)));
+         } else if (ctype == 3) {
+            const int v = cur[x];
+            if ((size_t)v * 3 + 2 >= plte.size()) { free(out); return HESAFF_ERR_IO; }
+            o[3 * x] = plte[3 * v]; o[3 * x + 1] = plte[3 * v + 1]; o[3 * x + 2] = plte[3 * v + 2];
+         } else {
+            const uint8_t *px = cur + (size_t)x * nch * step;
+            if (och == 1) o[x] = px[0];
+            else { o[3 * x] = px[0]; o[3 * x + 1] = px[step]; o[3 * x + 2] = px[2 * step]; }
+         }
+      }
+   }
+   *data = out; *width = (int)W; *height = (int)H; *channels = och;
+   return HESAFF_OK;
 }
 
 // "%g"-style (precision 6) formatting of a float == default operator<<(ostream&, float),
@@ -230,6 +335,31 @@ int hesaff_read_pnm(const char *path, uint8_t **data, int *width, int *height, i
    fclose(f);
    *data = buf; *width = w; *height = h; *channels = ch;
    return HESAFF_OK;
+}
+
+int hesaff_read_png(const char *path, uint8_t **data, int *width, int *height, int *channels)
+{
+   if (!path || !data || !width || !height || !channels) return HESAFF_ERR_ARG;
+   FILE *f = fopen(path, "rb");
+   if (!f) return HESAFF_ERR_IO;
+   std::vector<uint8_t> bytes;
+   uint8_t chunk[1 << 16];
+   for (size_t n; (n = fread(chunk, 1, sizeof chunk, f)) > 0;) bytes.insert(bytes.end(), chunk, chunk + n);
+   fclose(f);
+   return read_png_bytes(bytes, data, width, height, channels);
+}
+
+// the imread of hesaff.cpp:137 for the formats this library decodes itself: PGM/PPM and PNG, by magic number
+int hesaff_read_image(const char *path, uint8_t **data, int *width, int *height, int *channels)
+{
+   if (!path || !data || !width || !height || !channels) return HESAFF_ERR_ARG;
+   FILE *f = fopen(path, "rb");
+   if (!f) return HESAFF_ERR_IO;
+   const int c1 = fgetc(f), c2 = fgetc(f);
+   fclose(f);
+   if (c1 == 'P' && (c2 == '5' || c2 == '6')) return hesaff_read_pnm(path, data, width, height, channels);
+   if (c1 == 0x89 && c2 == 'P') return hesaff_read_png(path, data, width, height, channels);
+   return HESAFF_ERR_IO;
 }
 
 // hesaff.cpp:115-123: sc = mrSize*s; SVD(A) = U W V^T; M = U diag(1/(w_i^2 sc^2)) U^T

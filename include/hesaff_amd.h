@@ -127,6 +127,12 @@ void hesaff_free(void *p);
 /* replaces: cv::imread(argv[1]) hesaff.cpp:137 for binary PGM/PPM (P5/P6, maxval 255).
  * *data is malloc'ed (free with hesaff_free), tightly packed, channels 1 or 3. */
 int hesaff_read_pnm(const char *path, uint8_t **data, int *width, int *height, int *channels);
+/* the same for PNG files (decoded with zlib): what cv::imread returns with its default flag - 8 bits per
+ * channel, alpha dropped, 16-bit samples reduced to the high byte, palette / 1-2-4-bit grey expanded;
+ * channels = 1 for grey files, 3 (R,G,B order) otherwise.  Interlaced files: HESAFF_ERR_IO. */
+int hesaff_read_png(const char *path, uint8_t **data, int *width, int *height, int *channels);
+/* PGM/PPM or PNG by magic number (JPEG is not decoded: decoder-dependent pixels) */
+int hesaff_read_image(const char *path, uint8_t **data, int *width, int *height, int *channels);
 
 /* ---- stage entry points (host pointers in/out; used by the parity tests and by callers
  *      that want one operator of the reference at a time) ---- */

@@ -331,3 +331,15 @@ def test_capacity_error_is_reported():
         # the context stays usable
         (nh, keys), = small.detect_batch([np.full((64, 64), 10, np.uint8)])
         assert nh == 0 and len(keys) == 0
+
+
+def test_cli_reads_png(tmp_path):
+    """The same image as PNG (all five filter types) gives the golden file of its PGM form."""
+    import hesaff_amd
+    from tests.test_host_side import _png_bytes
+    img = hesaff_amd.read_pnm(os.path.join(GOLD, "band_160x120.pgm"))
+    dst = tmp_path / "img.png"
+    dst.write_bytes(_png_bytes(img[:, :, None], 0))
+    r = subprocess.run([os.path.join(ROOT, "hesaff_amd", "bin", "hesaff"), str(dst)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "img.png.hesaff.sift").read_bytes() == open(os.path.join(GOLD, "band_160x120.hesaff.sift"), "rb").read()

@@ -183,3 +183,89 @@ def test_multithreaded_writer_same_bytes(tmp_path):
     hesaff_amd.write_sift_batch(paths, chunks, mr, threads=3)
     for p, c in zip(paths, chunks):
         assert open(p, "rb").read() == hesaff_amd.format_sift(c, mr)
+
+
+def _png_bytes(pix, ctype, depth=8, filters=(0, 1, 2, 3, 4), palette=None, idat_split=3):
+    """Minimal PNG writer for the decoder tests: pix = uint8/uint16 array [H, W, samples]; every row
+    is encoded with the next filter type of `filters`."""
+    import struct, zlib
+    H, W, nch = pix.shape
+    if depth == 16:
+        rows = [pix[y].astype(">u2").tobytes() for y in range(H)]
+    elif depth == 8:
+        rows = [pix[y].astype(np.uint8).tobytes() for y in range(H)]
+    else:   # packed samples, most significant bits first
+        rows = []
+        for y in range(H):
+            bits = "".join(format(int(v), "0%db" % depth) for v in pix[y].ravel())
+            bits += "0" * (-len(bits) % 8)
+            rows.append(bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8)))
+    bpp = max(1, nch * depth // 8)
+    raw = bytearray(); prev = bytes(len(rows[0]))
+    for y, cur in enumerate(rows):
+        ft = filters[y % len(filters)]
+        out = bytearray(len(cur))
+        for i, v in enumerate(cur):
+            a = cur[i - bpp] if i >= bpp else 0; b = prev[i]; c = prev[i - bpp] if i >= bpp else 0
+            if ft == 0: p = 0
+            elif ft == 1: p = a
+            elif ft == 2: p = b
+            elif ft == 3: p = (a + b) >> 1
+            else:
+                q = a + b - c; pa, pb, pc = abs(q - a), abs(q - b), abs(q - c)
+                p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            out[i] = (v - p) & 255
+        raw.append(ft); raw += out; prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    z = zlib.compress(bytes(raw), 6)
+    cut = [len(z) * i // idat_split for i in range(idat_split + 1)]
+    b = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, depth, ctype, 0, 0, 0))
+    b += chunk(b"gAMA", struct.pack(">I", 45455))
+    if palette is not None:
+        b += chunk(b"PLTE", palette.astype(np.uint8).tobytes())
+    for i in range(idat_split):
+        b += chunk(b"IDAT", z[cut[i]:cut[i + 1]])
+    return b + chunk(b"IEND", b"")
+
+
+def test_read_png_matches_imread_semantics(tmp_path):
+    """hesaff_read_png: every filter type, grey / RGB / alpha / palette / 16-bit / packed grey, split IDAT."""
+    rng = np.random.default_rng(17)
+    H, W = 23, 37
+
+    def roundtrip(name, data):
+        p = tmp_path / name
+        p.write_bytes(data)
+        return hesaff_amd.read_image(str(p))
+
+    g = rng.integers(0, 256, (H, W, 1), dtype=np.uint8)
+    assert np.array_equal(roundtrip("g8.png", _png_bytes(g, 0)), g[:, :, 0])
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    assert np.array_equal(roundtrip("rgb.png", _png_bytes(rgb, 2)), rgb)
+    rgba = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+    assert np.array_equal(roundtrip("rgba.png", _png_bytes(rgba, 6, filters=(4, 3, 1))), rgba[:, :, :3])   # alpha dropped
+    ga = rng.integers(0, 256, (H, W, 2), dtype=np.uint8)
+    assert np.array_equal(roundtrip("ga.png", _png_bytes(ga, 4)), ga[:, :, 0])
+    g16 = rng.integers(0, 65536, (H, W, 1), dtype=np.uint16)
+    assert np.array_equal(roundtrip("g16.png", _png_bytes(g16, 0, depth=16)), (g16[:, :, 0] >> 8).astype(np.uint8))   # high byte
+    rgb16 = rng.integers(0, 65536, (H, W, 3), dtype=np.uint16)
+    assert np.array_equal(roundtrip("rgb16.png", _png_bytes(rgb16, 2, depth=16, filters=(3, 4))), (rgb16 >> 8).astype(np.uint8))
+    for depth, scale in ((1, 255), (2, 85), (4, 17)):
+        gp = rng.integers(0, 1 << depth, (H, W, 1), dtype=np.uint8)
+        assert np.array_equal(roundtrip("g%d.png" % depth, _png_bytes(gp, 0, depth=depth, filters=(0, 2))), gp[:, :, 0] * scale)
+    pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    idx = rng.integers(0, 16, (H, W, 1), dtype=np.uint8)
+    assert np.array_equal(roundtrip("pal8.png", _png_bytes(idx, 3, palette=pal)), pal[idx[:, :, 0]])
+    assert np.array_equal(roundtrip("pal4.png", _png_bytes(idx, 3, depth=4, palette=pal, filters=(0,))), pal[idx[:, :, 0]])
+    # PNM still goes through the same entry point; damaged files are errors, not garbage
+    (tmp_path / "a.pgm").write_bytes(b"P5\n%d %d\n255\n" % (W, H) + g.tobytes())
+    assert np.array_equal(hesaff_amd.read_image(str(tmp_path / "a.pgm")), g[:, :, 0])
+    bad = bytearray(_png_bytes(g, 0)); bad[60] ^= 0x40
+    (tmp_path / "bad.png").write_bytes(bytes(bad))
+    with pytest.raises(hesaff_amd.HesaffError):
+        hesaff_amd.read_image(str(tmp_path / "bad.png"))
+    (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0" + bytes(100))
+    with pytest.raises(hesaff_amd.HesaffError):
+        hesaff_amd.read_image(str(tmp_path / "x.jpg"))
