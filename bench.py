@@ -66,14 +66,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # BENCH_DIST_BACKEND=gloo (testing only): the multi-rank code path on a box with fewer GPUs than
+    # ranks - ranks share the visible devices and the three small collectives run on CPU tensors.
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libhesaff_amd has no CPU fallback)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     import hesaff_amd
     from hesaff_amd.synth import band_noise_batch_torch
@@ -114,11 +123,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     from hesaff_amd.shard import gather_counts
-    counts = gather_counts([n_hess, n_desc, B * args.steps], device=dev if world > 1 else None)
+    counts = gather_counts([n_hess, n_desc, B * args.steps], device=coll_dev if world > 1 else None)
     tot_hess, tot_desc, tot_imgs = [int(v) for v in counts.sum(axis=0)]
 
     if rank == 0:
