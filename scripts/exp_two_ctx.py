@@ -4,11 +4,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import hesaff_amd
 from hesaff_amd.synth import band_noise_batch_torch
-B, H, W = 32, 2160, 3840
+B, H, W = int(os.environ.get("B", "256")), 2160, 3840
 dev = torch.device("cuda", 0)
 imgs = band_noise_batch_torch(B, H, W, seed=1234, device=dev)
 torch.cuda.synchronize()
-for nctx in (1, 2, 4, 2, 1):
+for nctx in (1, 2, 1, 2):
     per = B // nctx
     ctxs = []
     for i in range(nctx):
