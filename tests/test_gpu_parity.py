@@ -343,3 +343,22 @@ def test_cli_reads_png(tmp_path):
     r = subprocess.run([os.path.join(ROOT, "hesaff_amd", "bin", "hesaff"), str(dst)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "img.png.hesaff.sift").read_bytes() == open(os.path.join(GOLD, "band_160x120.hesaff.sift"), "rb").read()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's multi-rank path (barriers, max-over-ranks time, count gather) with two ranks sharing
+    this box's GPU: BENCH_DIST_BACKEND=gloo moves the three small collectives to CPU tensors; the
+    driver's real runs use RCCL, one GPU per rank."""
+    import json
+    import sys
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "3",
+           "--width", "640", "--height", "480", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout     # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["images_per_gpu_per_step"] == 3 and abs(d["images_per_s"] * d["ms_per_step"] / 1e3 - 6) < 1e-6
