@@ -362,3 +362,52 @@ def test_bench_two_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["images_per_gpu_per_step"] == 3 and abs(d["images_per_s"] * d["ms_per_step"] / 1e3 - 6) < 1e-6
+
+
+def _structured_image(kind, h, w, rng):
+    yy, xx = np.mgrid[0:h, 0:w]
+    if kind == "checker":
+        s = int(rng.integers(3, 17))
+        img = (((yy // s) + (xx // s)) % 2) * 255
+    elif kind == "blobs":
+        img = np.zeros((h, w))
+        for _ in range(int(rng.integers(5, 60))):
+            cy, cx, r = rng.uniform(0, h), rng.uniform(0, w), rng.uniform(1.5, 25)
+            a = rng.uniform(0.3, 1.0); th = rng.uniform(0, np.pi)
+            u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th); v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+            img += rng.choice([-1.0, 1.0]) * rng.uniform(60, 400) * np.exp(-(u * u + (v / a) ** 2) / (2 * r * r))
+        img = 128 + img
+    elif kind == "lines":
+        img = np.full((h, w), 30.0)
+        for _ in range(int(rng.integers(3, 25))):
+            a, b, c = rng.normal(), rng.normal(), rng.uniform(-1, 1) * max(h, w)
+            img[np.abs(a * xx + b * yy + c) / np.hypot(a, b) < rng.uniform(0.6, 3.0)] = rng.uniform(100, 255)
+    elif kind == "saturated":
+        img = band_noise_image(h, w, int(rng.integers(1 << 30)), SMALL_BANDS).astype(np.float64) * 3.0 - 256
+    else:   # noise at pixel scale on top of a ramp
+        img = xx * (255.0 / max(w - 1, 1)) + rng.normal(0, 25, (h, w))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def test_fuzz_ragged_sizes_and_structured_content(ctx, oracle):
+    """Forty images of odd sizes and unnatural content (checkerboards, saturated blobs, thin lines,
+    clipped noise, ramps) as one ragged batch: every field and byte equals the oracle's."""
+    rng = np.random.default_rng(20261001)
+    kinds = ["checker", "blobs", "lines", "saturated", "ramp"]
+    imgs = []
+    for i in range(40):
+        h, w = int(rng.integers(13, 260)), int(rng.integers(13, 330))
+        imgs.append(_structured_image(kinds[i % len(kinds)], h, w, rng))
+    res = ctx.detect_batch(imgs)
+    total = 0
+    for i, (img, (n_hess, keys)) in enumerate(zip(imgs, res)):
+        o = oracle.OracleRun(oracle.gray_from_u8(img))
+        g, t, d = o.keys()
+        assert n_hess == o.n_hessian and len(keys) == o.n_keys, (i, img.shape, kinds[i % 5])
+        if len(keys):
+            assert np.array_equal(keys["desc"], d), (i, img.shape, kinds[i % 5])
+            assert np.array_equal(keys["type"], t)
+            for j, name in enumerate(["x", "y", "s", "a11", "a12", "a21", "a22", "response"]):
+                assert_bit_equal(keys[name], g[:, j], "%s of image %d (%s %s)" % (name, i, kinds[i % 5], img.shape))
+        total += len(keys)
+    assert total > 3000
