@@ -6,13 +6,13 @@ run() { # name counters
 }
 run a "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS"
 run b "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"
-run c "FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE"
+# (a third pass with FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE over all kernels hung the profiler once: not collected here)
 python3 - $TAG <<'PY'
 import csv, sys, collections
 tag = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 dur = collections.defaultdict(float); calls = collections.Counter()
-for part in 'abc':
+for part in 'ab':
     d = f'gpurun_out/pmcall_{tag}_{part}'
     for r in csv.DictReader(open(d + '/p_counter_collection.csv')):
         n = r['Kernel_Name'].split('(')[0].replace('void ', '')[:34]
@@ -21,14 +21,15 @@ for part in 'abc':
         for r in csv.DictReader(open(d + '/p_kernel_trace.csv')):
             n = r['Kernel_Name'].split('(')[0].replace('void ', '')[:34]
             dur[n] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6; calls[n] += 1
-print('%-34s %5s %8s %9s %8s %8s %8s %8s %8s' % ('kernel', 'calls', 'ms', 'VALUinst', 'valu%', 'salu/valu', 'lds/valu', 'rdGB/s', 'wrGB/s'))
+print('| %-34s | %5s | %8s | %9s | %6s | %9s | %8s | %8s |' % ('kernel', 'calls', 'ms', 'VALU inst', 'VALU %', 'SALU/VALU', 'LDS/VALU', 'LDS conf'))
+print('|---|---|---|---|---|---|---|---|')
 for n in sorted(dur, key=lambda k: -dur[k])[:22]:
     a = agg[n]
     if not n.startswith('k_'): continue
     ms = dur[n]
     # SIMD-cycles available: 1024 SIMDs * 2.4e6 cycles/ms ; a wave64 VALU op holds a SIMD 4 cycles
     valu_pct = 100.0 * a['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * 2.4e6 * ms) if ms else 0
-    print('%-34s %5d %8.2f %9.3g %8.1f %8.2f %8.2f %8.0f %8.0f' % (n, calls[n], ms, a['SQ_INSTS_VALU'], valu_pct,
+    print('| %-34s | %5d | %8.2f | %9.3g | %6.1f | %9.2f | %8.2f | %8.2f |' % (n, calls[n], ms, a['SQ_INSTS_VALU'], valu_pct,
           a['SQ_INSTS_SALU'] / max(a['SQ_INSTS_VALU'], 1), a['SQ_INSTS_LDS'] / max(a['SQ_INSTS_VALU'], 1),
-          a['FETCH_SIZE'] * 1024 / 1e9 / (ms / 1e3) / 1.0, a['WRITE_SIZE'] * 1024 / 1e9 / (ms / 1e3)))
+          a['SQ_LDS_BANK_CONFLICT'] / max(a['SQ_ACTIVE_INST_LDS'], 1)))
 PY
