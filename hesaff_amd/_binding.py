@@ -286,7 +286,8 @@ class HesaffContext:
         out = []
         for r in res:
             if r.count_desc > 0:
-                keys = np.frombuffer(C.string_at(r.keys, r.count_desc * 164), dtype=KEYPOINT_DTYPE).copy()
+                # one copy out of the library-owned (pinned) result buffer, valid until the next call
+                keys = np.frombuffer((C.c_char * (r.count_desc * 164)).from_address(r.keys), dtype=KEYPOINT_DTYPE).copy()
             else:
                 keys = np.zeros(0, KEYPOINT_DTYPE)
             out.append((r.count_hessian, keys))

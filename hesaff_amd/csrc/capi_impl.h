@@ -138,6 +138,16 @@ void hesaff_destroy(hesaff_ctx *c)
       if (c->ev_sift_done[i]) (void)hipEventDestroy(c->ev_sift_done[i]);
       c->b_patches2[i].release(); c->b_siftvec2[i].release(); c->b_meanvar2[i].release(); c->b_siftvo2[i].release();
    }
+   for (int i = 0; i < 2; i++) {
+      c->b_in2[i].release(); c->b_outstage[i].release(); c->pin_in[i].release();
+      if (c->ev_h2d[i]) (void)hipEventDestroy(c->ev_h2d[i]);
+      if (c->ev_in_free[i]) (void)hipEventDestroy(c->ev_in_free[i]);
+      if (c->ev_out_ready[i]) (void)hipEventDestroy(c->ev_out_ready[i]);
+      if (c->ev_d2h[i]) (void)hipEventDestroy(c->ev_d2h[i]);
+   }
+   for (auto &pb : c->pin_out) pb.release();
+   if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
+   if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
    if (c->stream) (void)hipStreamDestroy(c->stream);
    delete c;
 }
@@ -183,45 +193,114 @@ int hesaff_detect_batch(hesaff_ctx *c, int n, const uint8_t *const *images, cons
    if (!c || n < 0 || (n > 0 && (!images || !widths || !heights || !results))) return HESAFF_ERR_ARG;
    HS_API_BEGIN
    bind_device(c);
-   c->host_keys.clear();
-   std::vector<size_t> key_off(n, 0);
-   std::vector<char> done(n, 0);
-   // group by (width, height, channels); each group runs in chunks of max_batch
-   for (int i = 0; i < n; i++) {
-      if (done[i]) continue;
-      const int W = widths[i], H = heights[i], ch = channels ? channels[i] : 1;
-      if (ch != 1 && ch != 3) throw HsError(HESAFF_ERR_ARG, "channels must be 1 or 3");
-      if (!images[i] || W < 1 || H < 1) throw HsError(HESAFF_ERR_ARG, "bad image");
-      std::vector<int> grp;
-      for (int j = i; j < n; j++)
-         if (!done[j] && widths[j] == W && heights[j] == H && (channels ? channels[j] : 1) == ch) grp.push_back(j);
-      const size_t row_bytes = (size_t)W * ch, img_bytes = row_bytes * H;
-      for (size_t g0 = 0; g0 < grp.size(); g0 += c->par.max_batch) {
-         const int B = (int)std::min<size_t>(c->par.max_batch, grp.size() - g0);
-         c->b_input.ensure(img_bytes * B);
-         for (int b = 0; b < B; b++) {
-            const int j = grp[g0 + b];
-            const int stride = strides ? strides[j] : (int)row_bytes;
-            HIP_TRY(hipMemcpy2DAsync((uint8_t *)c->b_input.p + img_bytes * b, row_bytes, images[j], (size_t)stride, row_bytes, H,
-                                     hipMemcpyHostToDevice, c->stream));
-         }
-         plan(c, std::min<int>(c->par.max_batch, (int)grp.size()), H, W);
-         run_batch(c, (const uint8_t *)c->b_input.p, ch, (long long)img_bytes, (int)row_bytes, B, H, W);
-         const int32_t *hs = c->h_starts.data(), *ds = c->h_starts.data() + (B + 1);
-         const size_t base = c->host_keys.size();
-         const int total = ds[B];
-         c->host_keys.resize(base + (size_t)total);
-         if (total > 0) HIP_TRY(hipMemcpy(c->host_keys.data() + base, c->b_out.p, (size_t)total * sizeof(hesaff_keypoint), hipMemcpyDeviceToHost));
-         for (int b = 0; b < B; b++) {
-            const int j = grp[g0 + b];
-            results[j].count_hessian = hs[b + 1] - hs[b];
-            results[j].count_desc = ds[b + 1] - ds[b];
-            key_off[j] = base + (size_t)ds[b];
-            done[j] = 1;
+   if (!c->h2d_stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+      HIP_TRY(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+      for (int i = 0; i < 2; i++) {
+         HIP_TRY(hipEventCreateWithFlags(&c->ev_h2d[i], hipEventDisableTiming));
+         HIP_TRY(hipEventCreateWithFlags(&c->ev_in_free[i], hipEventDisableTiming));
+         HIP_TRY(hipEventCreateWithFlags(&c->ev_out_ready[i], hipEventDisableTiming));
+         HIP_TRY(hipEventCreateWithFlags(&c->ev_d2h[i], hipEventDisableTiming));
+      }
+   }
+   // chunks: images of equal (width, height, channels), at most max_batch each, in input order
+   struct Chunk { int W, H, ch; std::vector<int> idx; };
+   std::vector<Chunk> chunks;
+   {
+      std::vector<char> done((size_t)n, 0);
+      for (int i = 0; i < n; i++) {
+         if (done[i]) continue;
+         const int W = widths[i], H = heights[i], ch = channels ? channels[i] : 1;
+         if (ch != 1 && ch != 3) throw HsError(HESAFF_ERR_ARG, "channels must be 1 or 3");
+         std::vector<int> grp;
+         for (int j = i; j < n; j++)
+            if (!done[j] && widths[j] == W && heights[j] == H && (channels ? channels[j] : 1) == ch) {
+               if (!images[j] || W < 1 || H < 1) throw HsError(HESAFF_ERR_ARG, "bad image");
+               grp.push_back(j);
+               done[j] = 1;
+            }
+         for (size_t g0 = 0; g0 < grp.size(); g0 += c->par.max_batch) {
+            Chunk k;
+            k.W = W; k.H = H; k.ch = ch;
+            k.idx.assign(grp.begin() + g0, grp.begin() + std::min(grp.size(), g0 + (size_t)c->par.max_batch));
+            chunks.push_back(std::move(k));
          }
       }
    }
-   for (int i = 0; i < n; i++) results[i].keys = c->host_keys.data() + key_off[i];
+   const int NC = (int)chunks.size();
+   if ((int)c->pin_out.size() < NC) c->pin_out.resize((size_t)NC);
+   std::vector<size_t> key_off((size_t)n, 0);
+   std::vector<int> chunk_of((size_t)n, 0);
+
+   // stage(k): images of chunk k -> pinned buffer -> device input buffer (k & 1), on the H2D stream.
+   // Runs on a helper thread while the kernels of chunk k-1 are in flight.
+   auto stage = [&](int k) {
+      HIP_TRY(hipSetDevice(c->device));
+      const Chunk &q = chunks[k];
+      const int slot = k & 1;
+      const size_t row_bytes = (size_t)q.W * q.ch, img_bytes = row_bytes * q.H, total = img_bytes * q.idx.size();
+      HIP_TRY(hipEventSynchronize(c->ev_in_free[slot]));   // chunk k-2 no longer reads this input buffer (event unrecorded: returns at once)
+      c->pin_in[slot].ensure(total);
+      c->b_in2[slot].ensure(total);
+      for (size_t b = 0; b < q.idx.size(); b++) {
+         const int j = q.idx[b];
+         const size_t stride = strides ? (size_t)strides[j] : row_bytes;
+         uint8_t *dst = (uint8_t *)c->pin_in[slot].p + img_bytes * b;
+         if (stride == row_bytes) memcpy(dst, images[j], img_bytes);
+         else for (int y = 0; y < q.H; y++) memcpy(dst + row_bytes * y, images[j] + stride * y, row_bytes);
+      }
+      HIP_TRY(hipMemcpyAsync(c->b_in2[slot].p, c->pin_in[slot].p, total, hipMemcpyHostToDevice, c->h2d_stream));
+      HIP_TRY(hipEventRecord(c->ev_h2d[slot], c->h2d_stream));
+   };
+
+   std::future<void> staged;
+   if (NC > 0) staged = std::async(std::launch::async, stage, 0);
+   struct Pending { int chunk; int total; };
+   std::vector<int> totals((size_t)NC, 0);
+   try {
+      for (int k = 0; k < NC; k++) {
+         const Chunk &q = chunks[k];
+         const int slot = k & 1, B = (int)q.idx.size();
+         const size_t row_bytes = (size_t)q.W * q.ch, img_bytes = row_bytes * q.H;
+         staged.get();                                               // H2D of chunk k is enqueued
+         if (k + 1 < NC) staged = std::async(std::launch::async, stage, k + 1);
+         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_h2d[slot], 0));
+         plan(c, std::min<int>(c->par.max_batch, B), q.H, q.W);
+         run_batch(c, (const uint8_t *)c->b_in2[slot].p, q.ch, (long long)img_bytes, (int)row_bytes, B, q.H, q.W);
+         HIP_TRY(hipEventRecord(c->ev_in_free[slot], c->stream));
+         const int32_t *hs = c->h_starts.data(), *ds = c->h_starts.data() + (B + 1);
+         const int total = ds[B];
+         totals[k] = total;
+         for (int b = 0; b < B; b++) {
+            const int j = q.idx[b];
+            results[j].count_hessian = hs[b + 1] - hs[b];
+            results[j].count_desc = ds[b + 1] - ds[b];
+            key_off[j] = (size_t)ds[b];
+            chunk_of[j] = k;
+         }
+         // results: device copy into the staging slot (frees b_out for the next chunk), then D2H beside the next chunk
+         const size_t bytes = (size_t)total * sizeof(hesaff_keypoint);
+         c->pin_out[k].ensure(std::max<size_t>(bytes, 16));
+         if (total > 0) {
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_d2h[slot], 0));      // D2H of chunk k-2 has left this staging slot
+            c->b_outstage[slot].ensure(bytes);
+            HIP_TRY(hipMemcpyAsync(c->b_outstage[slot].p, c->b_out.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipEventRecord(c->ev_out_ready[slot], c->stream));
+            HIP_TRY(hipStreamWaitEvent(c->d2h_stream, c->ev_out_ready[slot], 0));
+            HIP_TRY(hipMemcpyAsync(c->pin_out[k].p, c->b_outstage[slot].p, bytes, hipMemcpyDeviceToHost, c->d2h_stream));
+            HIP_TRY(hipEventRecord(c->ev_d2h[slot], c->d2h_stream));
+         }
+      }
+   } catch (...) {
+      if (staged.valid()) { try { staged.get(); } catch (...) {} }
+      (void)hipStreamSynchronize(c->h2d_stream);
+      (void)hipStreamSynchronize(c->d2h_stream);
+      throw;
+   }
+   HIP_TRY(hipStreamSynchronize(c->d2h_stream));
+   HIP_TRY(hipStreamSynchronize(c->stream));
+   for (int i = 0; i < n; i++)
+      results[i].keys = (const hesaff_keypoint *)c->pin_out[chunk_of[i]].p + key_off[i];
    HS_API_END(c)
 }
 

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <future>
 
 #include "../../include/hesaff_amd.h"
 #include "host_tables.h"
@@ -131,8 +132,27 @@ struct hesaff_ctx {
                             //         [8..11] bin_count, [16..16+HS_MAX_OCTAVES) octave rec starts
    DevBuf b_cand, b_rec_f, b_rec_i, b_rec_w, b_hess_f, b_hess_i, b_aff, b_pw, b_bins, b_rank, b_desc, b_out, b_starts, b_scratch,
       b_patches, b_stage;
-   DevBuf b_input;          // staging for host images
-   std::vector<hesaff_keypoint> host_keys;
+   DevBuf b_input;          // staging for host images (stage API)
+   // hesaff_detect_batch, host entry point: chunks of max_batch images are pipelined -- pinned
+   // staging + H2D of chunk i+1 and D2H of chunk i-1 run beside the kernels of chunk i
+   DevBuf b_in2[2], b_outstage[2];
+   struct Pinned {
+      void *p = nullptr;
+      size_t bytes = 0;
+      void ensure(size_t need)
+      {
+         if (need <= bytes) return;
+         if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
+         hipError_t e = hipHostMalloc(&p, need, hipHostMallocDefault);
+         if (e != hipSuccess) { p = nullptr; throw HsError(HESAFF_ERR_NOMEM, std::string("hipHostMalloc failed: ") + hipGetErrorString(e)); }
+         bytes = need;
+      }
+      void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+   };
+   Pinned pin_in[2];
+   std::vector<Pinned> pin_out;       // one block per chunk of the current call, reused by later calls
+   hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+   hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_in_free[2] = {nullptr, nullptr}, ev_out_ready[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
    std::vector<int32_t> h_starts;
    DevBuf t_mask_idx, b_rowprefix, b_trows, b_trows2, b_trows3, b_siftvec, b_meanvar, b_siftvo;
    bool fused_sift = false;            // HESAFF_SIFT=fused: descriptor inside the patch kernels (v1 structure)

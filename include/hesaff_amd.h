@@ -91,7 +91,10 @@ const char *hesaff_last_error(const hesaff_ctx *ctx);   /* ctx may be NULL: last
  * hesaff.cpp:167 (pyramid.cpp:261) with the whole callback chain hesaff.cpp:66-105,
  * for n images at once.  images[i]: 8-bit, channels[i] = 1 (grey) or 3 (BGR as cv::imread
  * delivers; pass RGB bytes of a PPM in any order - the three are summed), row stride in
- * bytes.  Images of different sizes are allowed (grouped internally). */
+ * bytes.  Images of different sizes are allowed (grouped internally).  Chunks of max_batch images
+ * are pipelined: host staging + H2D of the next chunk and D2H of the previous one overlap the
+ * kernels of the current one.  results[i].keys point into library-owned pinned memory, valid
+ * until the next call on this context. */
 int hesaff_detect_batch(hesaff_ctx *ctx, int n, const uint8_t *const *images, const int *widths,
                         const int *heights, const int *strides, const int *channels, hesaff_result *results);
 
