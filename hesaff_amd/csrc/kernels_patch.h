@@ -522,23 +522,31 @@ __global__ __launch_bounds__(256) void k_patch_extract_small(HessList hl, PatchW
       if (!((double)scale > 0.4)) {
          // direct branch, affine.cpp:137-141
          const float b11 = a11 * scale, b12 = a12 * scale, b21 = a21 * scale, b22 = a22 * scale;
-         float dv[HS_SIFT_PIX_IT];
+         // 7 taps per thread in two batches (4 + 3): one batch of 7 costs 23 more VGPRs and with them
+         // three of the eight wavefronts a SIMD can hold
 #pragma unroll
-         for (int it = 0; it < HS_SIFT_PIX_IT; it++) {
-            const int idx = min(tid + 256 * it, HS_PATCH_PIX - 1);
-            const int jj = idx / HS_PATCH, ii = idx - jj * HS_PATCH;
-            const int j = jj - (HS_PATCH >> 1), i = ii - (HS_PATCH >> 1);
-            const float rx = x + (float)j * b12, ry = y + (float)j * b22;
-            const float wx = rx + (float)i * b11, wy = ry + (float)i * b21;
-            bool outside = false;
-            dv[it] = hs_bilinear_buf(pbuf, width, height, wx, wy, outside);
-         }
+         for (int h0 = 0; h0 < HS_SIFT_PIX_IT; h0 += 4) {
+            float dv[4];
 #pragma unroll
-         for (int it = 0; it < HS_SIFT_PIX_IT; it++) HS_KEEP(dv[it]);
+            for (int t = 0; t < 4; t++) {
+               if (h0 + t < HS_SIFT_PIX_IT) {
+                  const int idx = min(tid + 256 * (h0 + t), HS_PATCH_PIX - 1);
+                  const int jj = idx / HS_PATCH, ii = idx - jj * HS_PATCH;
+                  const int j = jj - (HS_PATCH >> 1), i = ii - (HS_PATCH >> 1);
+                  const float rx = x + (float)j * b12, ry = y + (float)j * b22;
+                  const float wx = rx + (float)i * b11, wy = ry + (float)i * b21;
+                  bool outside = false;
+                  dv[t] = hs_bilinear_buf(pbuf, width, height, wx, wy, outside);
+               }
+            }
 #pragma unroll
-         for (int it = 0; it < HS_SIFT_PIX_IT; it++) {
-            const int idx = tid + 256 * it;
-            if (idx < HS_PATCH_PIX) out[idx] = dv[it];
+            for (int t = 0; t < 4; t++)
+               if (h0 + t < HS_SIFT_PIX_IT) HS_KEEP(dv[t]);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+               const int idx = tid + 256 * (h0 + t);
+               if (h0 + t < HS_SIFT_PIX_IT && idx < HS_PATCH_PIX) out[idx] = dv[t];
+            }
          }
          continue;
       }
