@@ -72,8 +72,8 @@ struct AffineHessianDetector {
    {
       char *buf = nullptr;
       size_t len = 0;
-      if (hesaff_format_sift(keys.data(), (int)keys.size(), p_.mrSize, &buf, &len) != HESAFF_OK)
-         throw std::runtime_error("hesaff_format_sift failed");
+      if (hesaff_format_sift_mt(keys.data(), (int)keys.size(), p_.mrSize, 0, &buf, &len) != HESAFF_OK)   // rows on all host cores
+         throw std::runtime_error("hesaff_format_sift_mt failed");
       out.write(buf, (std::streamsize)len);
       out.flush();
       hesaff_free(buf);
