@@ -362,19 +362,38 @@ int hesaff_read_image(const char *path, uint8_t **data, int *width, int *height,
    return HESAFF_ERR_IO;
 }
 
-// hesaff.cpp:115-123: sc = mrSize*s; SVD(A) = U W V^T; M = U diag(1/(w_i^2 sc^2)) U^T
-// == (A A^T)^-1 / sc^2.  Evaluated in double, returned as float (the reference runs a
-// float Jacobi SVD; agreement ~1e-6 relative, acceptance tolerance 1e-4).
+// hesaff.cpp:115-123, statement by statement:
+//    float sc = mrSize * k.s;  SVD svd(A, FULL_UV);  d[i] = 1.0f/(d[i]*d[i]*sc*sc);
+//    A = svd.u * Mat::diag(svd.w) * svd.u.t();   ->  a = A(0,0), b = A(0,1), c = A(1,1)
+// cv::SVD (OpenCV's float Jacobi solver) is replaced by the closed-form symmetric
+// eigen-decomposition of A A^T evaluated in double; u and w are then stored as float like the
+// members of cv::SVD, d is the reference's float expression and the two matrix products
+// accumulate in double like cv::gemm does for CV_32F.  (a,b,c) carry the 1e-4 tolerance of
+// north_star; on SURVEY.md App. C's 640x480 input this form reproduces the md5 of the compiled
+// reference's output file.
 void hesaff_ellipse(const hesaff_keypoint *k, float mrSize, float *a, float *b, float *c)
 {
    const float sc = mrSize * k->s;
    const double a11 = k->a11, a12 = k->a12, a21 = k->a21, a22 = k->a22;
    const double m00 = a11 * a11 + a12 * a12, m01 = a11 * a21 + a12 * a22, m11 = a21 * a21 + a22 * a22;
-   const double det = m00 * m11 - m01 * m01;
-   const double sc2 = (double)sc * (double)sc;
-   *a = (float)(m11 / det / sc2);
-   *b = (float)(-m01 / det / sc2);
-   *c = (float)(m00 / det / sc2);
+   const double tr = m00 + m11, df = m00 - m11;
+   const double disc = std::sqrt(df * df + 4.0 * m01 * m01);
+   const double l1 = (tr + disc) / 2.0, l2 = (tr - disc) / 2.0;
+   // unit eigenvector of the larger eigenvalue: (l1 - m11, m01) or (m01, l1 - m00), the longer one
+   double vx = l1 - m11, vy = m01;
+   const double ux = m01, uy = l1 - m00;
+   if (ux * ux + uy * uy > vx * vx + vy * vy) { vx = ux; vy = uy; }
+   const double n = std::sqrt(vx * vx + vy * vy);
+   float cu = 1.0f, su = 0.0f;
+   if (n > 0) { cu = (float)(vx / n); su = (float)(vy / n); }
+   float w0 = (float)std::sqrt(l1), w1 = (float)std::sqrt(l2);
+   w0 = 1.0f / (w0 * w0 * sc * sc);
+   w1 = 1.0f / (w1 * w1 * sc * sc);
+   const float p00 = (float)((double)cu * w0), p01 = (float)(-(double)su * w1);
+   const float p10 = (float)((double)su * w0), p11 = (float)((double)cu * w1);
+   *a = (float)((double)p00 * cu + (double)p01 * -su);
+   *b = (float)((double)p00 * su + (double)p01 * cu);
+   *c = (float)((double)p10 * su + (double)p11 * cu);
 }
 
 int hesaff_format_sift(const hesaff_keypoint *keys, int n, float mrSize, char **out, size_t *len)

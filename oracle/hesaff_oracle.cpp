@@ -412,7 +412,11 @@ struct Oracle {
    bool detectOnly = false;                       // stop after Hessian keypoints
    long nCandidates = 0;
 
-   Oracle()
+   Oracle() { configure(); }
+
+   // derived constants and tables from `par` (the reference builds them in its constructors:
+   // pyramid.h:59-64, affine.h:63-75, siftdesc.h:40-49); called again by ho_set_params
+   void configure()
    {
       edgeScoreThreshold = (par.edgeEigenValueRatio + 1.0f) * (par.edgeEigenValueRatio + 1.0f) / par.edgeEigenValueRatio;
       finalThreshold = par.threshold * par.threshold;
@@ -725,19 +729,39 @@ struct Oracle {
    }
 };
 
-// hesaff.cpp:107-130 ; the reference runs cv::SVD (float Jacobi) on A and rebuilds
-// U diag(1/(w^2 sc^2)) U^T; the closed form (A A^T)^-1 / sc^2 is evaluated in double here
-// (agreement ~1e-6 relative; the acceptance tolerance on a,b,c is 1e-4).
+// hesaff.cpp:107-130 (exportKeypoints), the statements in the reference's order:
+//    float sc = mrSize * k.s;  SVD svd(A, FULL_UV);  d[i] = 1.0f/(d[i]*d[i]*sc*sc);
+//    A = svd.u * Mat::diag(svd.w) * svd.u.t();        print A(0,0), A(0,1), A(1,1)
+// cv::SVD is third-party (OpenCV, a float Jacobi solver): it is restated as the closed-form
+// symmetric eigen-decomposition of A A^T in double, with u and w then stored as float like the
+// members of cv::SVD; the reference's own float expression for d and the matrix product
+// (cv::gemm accumulates CV_32F products in double) follow as written.  With this form the
+// whole .hesaff.sift text of the SURVEY App. C inputs has the md5 the survey recorded from the
+// compiled reference (scripts/check_survey_probe.py).
 void ellipseOf(const Keypoint &k, float mrSize, float &ea, float &eb, float &ec)
 {
    const float sc = mrSize * k.s;
    const double a11 = k.a11, a12 = k.a12, a21 = k.a21, a22 = k.a22;
    const double m00 = a11 * a11 + a12 * a12, m01 = a11 * a21 + a12 * a22, m11 = a21 * a21 + a22 * a22;
-   const double det = m00 * m11 - m01 * m01;
-   const double sc2 = (double)sc * (double)sc;
-   ea = (float)(m11 / det / sc2);
-   eb = (float)(-m01 / det / sc2);
-   ec = (float)(m00 / det / sc2);
+   const double tr = m00 + m11, df = m00 - m11;
+   const double disc = std::sqrt(df * df + 4.0 * m01 * m01);
+   const double l1 = (tr + disc) / 2.0, l2 = (tr - disc) / 2.0;
+   // unit eigenvector of l1: (l1 - m11, m01) or (m01, l1 - m00), whichever is longer
+   double vx = l1 - m11, vy = m01;
+   const double wx = m01, wy = l1 - m00;
+   if (wx * wx + wy * wy > vx * vx + vy * vy) { vx = wx; vy = wy; }
+   const double n = std::sqrt(vx * vx + vy * vy);
+   float cu = 1.0f, su = 0.0f;
+   if (n > 0) { cu = (float)(vx / n); su = (float)(vy / n); }
+   float w0 = (float)std::sqrt(l1), w1 = (float)std::sqrt(l2);
+   w0 = 1.0f / (w0 * w0 * sc * sc);   // hesaff.cpp:120
+   w1 = 1.0f / (w1 * w1 * sc * sc);   // hesaff.cpp:121
+   // u = [cu -su; su cu];  u * diag(w) in double -> float, then * u^T in double -> float
+   const float p00 = (float)((double)cu * w0), p01 = (float)(-(double)su * w1);
+   const float p10 = (float)((double)su * w0), p11 = (float)((double)cu * w1);
+   ea = (float)((double)p00 * cu + (double)p01 * -su);
+   eb = (float)((double)p00 * su + (double)p01 * cu);
+   ec = (float)((double)p10 * su + (double)p11 * cu);
 }
 
 } // namespace
@@ -830,9 +854,42 @@ void ho_sift(float *patch, float *vec)
 
 // ---- full pipeline with a handle ----
 void *ho_create() { return new Oracle(); }
+// the stage functions above with the parameters of a handle (ho_set_params)
+int ho_h_find_affine_shape(void *h, const float *blur, int rows, int cols, float x, float y, float s, float pd, float *A, int *iters)
+{
+   Plane p(rows, cols);
+   memcpy(p.d.data(), blur, sizeof(float) * rows * cols);
+   const AffRes a = ((Oracle *)h)->findAffineShape(p, x, y, s, pd);
+   A[0] = a.a11; A[1] = a.a12; A[2] = a.a21; A[3] = a.a22; *iters = a.iters;
+   return a.converged;
+}
+int ho_h_normalize_affine(void *h, const float *img, int rows, int cols, float x, float y, float s, const float *A, float *patch)
+{
+   Plane p(rows, cols);
+   memcpy(p.d.data(), img, sizeof(float) * rows * cols);
+   return ((Oracle *)h)->normalizeAffine(p, x, y, s, A[0], A[1], A[2], A[3], patch) ? 1 : 0;
+}
+void ho_h_sift(void *h, float *patch, float *vec) { ((Oracle *)h)->computeSiftDescriptor(patch, vec); }
 void ho_destroy(void *h) { delete (Oracle *)h; }
 void ho_set_keep_planes(void *h, int keep) { ((Oracle *)h)->keepPlanes = keep != 0; }
 void ho_set_detect_only(void *h, int v) { ((Oracle *)h)->detectOnly = v != 0; }
+// Non-default parameters, the fields hesaff_params (include/hesaff_amd.h) exposes:
+// threshold pyramid.h:37 / hesaff.cpp:155, edgeEigenValueRatio pyramid.h:38, initialSigma pyramid.h:36,
+// maxIterations affine.h:39 / hesaff.cpp:158, convergenceThreshold affine.h:41, mrSize affine.h:44 /
+// hesaff.cpp:160, maxBinValue siftdesc.h:29, upscaleInputImage pyramid.h:34.
+void ho_set_params(void *h, float threshold, float edgeEigenValueRatio, float initialSigma, int maxIterations,
+                   float convergenceThreshold, float mrSize, float maxBinValue)
+{
+   Oracle *o = (Oracle *)h;
+   o->par.threshold = threshold;
+   o->par.edgeEigenValueRatio = edgeEigenValueRatio;
+   o->par.initialSigma = initialSigma;
+   o->par.maxIterations = maxIterations;
+   o->par.convergenceThreshold = convergenceThreshold;
+   o->par.mrSize = mrSize;
+   o->par.maxBinValue = maxBinValue;
+   o->configure();
+}
 void ho_detect(void *h, const float *gray, int rows, int cols)
 {
    Plane p(rows, cols);

@@ -59,6 +59,12 @@ def lib():
     L.ho_set_keep_planes.argtypes = [C.c_void_p, C.c_int]
     L.ho_set_detect_only.argtypes = [C.c_void_p, C.c_int]
     L.ho_detect.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int]
+    L.ho_set_params.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float]
+    L.ho_h_find_affine_shape.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int] + [C.c_float] * 4 + [f32p, i32p]
+    L.ho_h_find_affine_shape.restype = C.c_int
+    L.ho_h_normalize_affine.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int] + [C.c_float] * 3 + [f32p, f32p]
+    L.ho_h_normalize_affine.restype = C.c_int
+    L.ho_h_sift.argtypes = [C.c_void_p, f32p, f32p]
     for n in ("ho_num_hessian", "ho_num_keys", "ho_num_octaves"):
         getattr(L, n).argtypes = [C.c_void_p]; getattr(L, n).restype = C.c_int
     L.ho_num_candidates.argtypes = [C.c_void_p]; L.ho_num_candidates.restype = C.c_long
@@ -83,13 +89,52 @@ def gray_from_u8(img):
     return out
 
 
+def set_params(h, params):
+    """Copy the reference-side fields of a hesaff_params-like object (hesaff_amd.Params) into an oracle handle."""
+    lib().ho_set_params(h, params.threshold, params.edgeEigenValueRatio, params.initialSigma, int(params.maxIterations),
+                        params.convergenceThreshold, params.mrSize, params.maxBinValue)
+
+
+class OracleHandle:
+    """An oracle object with (optionally non-default) parameters, for the stage-level functions."""
+
+    def __init__(self, params=None):
+        self.h = lib().ho_create()
+        if params is not None:
+            set_params(self.h, params)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ho_destroy(self.h)
+            self.h = None
+
+    def normalize_affine(self, gray, x, y, s, A):
+        patch = np.zeros(41 * 41, np.float32)
+        rej = lib().ho_h_normalize_affine(self.h, gray, gray.shape[0], gray.shape[1], float(x), float(y), float(s),
+                                          np.ascontiguousarray(A, np.float32), patch)
+        return rej, patch.reshape(41, 41)
+
+    def find_affine_shape(self, blur, x, y, s, pd):
+        A = np.zeros(4, np.float32); it = np.zeros(1, np.int32)
+        conv = lib().ho_h_find_affine_shape(self.h, blur, blur.shape[0], blur.shape[1], float(x), float(y), float(s), float(pd), A, it)
+        return conv, A, int(it[0])
+
+    def sift(self, patch):
+        p = np.ascontiguousarray(patch, np.float32).reshape(-1).copy()
+        vec = np.zeros(128, np.float32)
+        lib().ho_h_sift(self.h, p, vec)
+        return vec.astype(np.uint8)
+
+
 class OracleRun:
     """Full reference-order pipeline on one float32 grey image."""
 
-    def __init__(self, gray, keep_planes=False, detect_only=False):
+    def __init__(self, gray, keep_planes=False, detect_only=False, params=None):
         L = lib()
         gray = np.ascontiguousarray(gray, dtype=np.float32)
         self.h = L.ho_create()
+        if params is not None:
+            set_params(self.h, params)
         L.ho_set_keep_planes(self.h, int(keep_planes))
         L.ho_set_detect_only(self.h, int(detect_only))
         L.ho_detect(self.h, gray, gray.shape[0], gray.shape[1])

@@ -5,8 +5,13 @@ WHAT THESE FIXTURES ARE: regression vectors produced by the repo's own CPU oracl
 (oracle/hesaff_oracle.cpp) on small deterministic images.  They are NOT outputs of the
 reference binary: perdoch/hesaff cannot be built in this image (all sources include
 OpenCV's <cv.h>, which is neither installed nor vendored) and it ships no golden vectors
-of its own, so the oracle is "parity unpinned" (DESIGN.md).  The fixtures pin the oracle
-against accidental change and give the GPU tests byte-exact files to reproduce.
+of its own.  The fixtures pin the oracle against accidental change and give the GPU tests
+byte-exact files to reproduce.
+
+The one fixture that ties the oracle to the COMPILED reference is probe_vga.pgm: the 640x480
+input of SURVEY.md Appendix C.3 (md5 74f828b5...), for which the survey recorded the md5 of the
+reference's own output file (e004ba88..., App. C.4) and its call counts (App. C.6).  The oracle
+reproduces both (tests/test_oracle.py::test_survey_probe_*, scripts/check_survey_probe.py).
 """
 import hashlib
 import json
@@ -56,6 +61,18 @@ def main():
         manifest[name] = {"width": w, "height": h, "seed": seed, "candidates": int(o.n_candidates), "hessian": int(o.n_hessian),
                           "descriptors": int(o.n_keys), "image_md5": hashlib.md5(img.tobytes()).hexdigest(),
                           "sift_md5": hashlib.md5(o.export_text()).hexdigest()}
+    # SURVEY.md App. C.3 input (640x480, seed 1234): committed as data, regenerated and compared by the tests
+    from scripts.check_survey_probe import PROBE, probe_image, pgm_bytes
+    h, w, seed, bands = PROBE["vga"][:4]
+    img = probe_image(h, w, seed, bands)
+    with open(os.path.join(HERE, "probe_vga.pgm"), "wb") as f:
+        f.write(pgm_bytes(img))
+    o = _oracle.OracleRun(_oracle.gray_from_u8(img))
+    manifest["probe_vga"] = {"width": w, "height": h, "seed": seed, "candidates": int(o.n_candidates), "hessian": int(o.n_hessian),
+                             "descriptors": int(o.n_keys), "pgm_md5": hashlib.md5(pgm_bytes(img)).hexdigest(),
+                             "sift_md5": hashlib.md5(o.export_text()).hexdigest(),
+                             "survey_recorded": {"pgm_md5_prefix": "74f828b5", "sift_md5_prefix": "e004ba88",
+                                                 "candidates": 5281, "hessian": 4763, "descriptors": 4183}}
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print(json.dumps(manifest, indent=1, sort_keys=True))
