@@ -109,7 +109,7 @@ def main():
         torch.cuda.synchronize()
 
     bh_ms = 0.0; bh_bytes = 0.0; bh_launches = 0
-    stage = {"pyramid_ms": 0.0, "detect_ms": 0.0, "affine_ms": 0.0, "patch_ms": 0.0, "sift_ms": 0.0}
+    stage = {"pyramid_ms": 0.0, "detect_ms": 0.0, "affine_ms": 0.0, "patch_ms": 0.0, "sift_ms": 0.0, "pack_ms": 0.0}
     n_desc = 0; n_hess = 0
     barrier()
     t0 = time.perf_counter()

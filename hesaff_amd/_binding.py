@@ -23,8 +23,10 @@ class Params(C.Structure):
         ("convergenceThreshold", C.c_float),
         ("mrSize", C.c_float),
         ("maxBinValue", C.c_float),
+        ("upscaleInputImage", C.c_int),
         ("max_batch", C.c_int),
         ("max_kpts_per_mpx", C.c_int),
+        ("fast", C.c_int),
     ]
 
 
@@ -35,7 +37,7 @@ class _Result(C.Structure):
 class Timings(C.Structure):
     _fields_ = [
         ("pyramid_ms", C.c_float), ("detect_ms", C.c_float), ("affine_ms", C.c_float), ("patch_ms", C.c_float),
-        ("sift_ms", C.c_float), ("total_ms", C.c_float), ("blur_hess_ms", C.c_float), ("blur_hess_launches", C.c_int32),
+        ("sift_ms", C.c_float), ("pack_ms", C.c_float), ("total_ms", C.c_float), ("blur_hess_ms", C.c_float), ("blur_hess_launches", C.c_int32),
         ("blur_hess_bytes", C.c_double), ("pyramid_bytes", C.c_double),
     ]
 

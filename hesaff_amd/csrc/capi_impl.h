@@ -21,18 +21,33 @@ int fail(hesaff_ctx *c, const HsError &e)
 
 void bind_device(hesaff_ctx *c) { HIP_TRY(hipSetDevice(c->device)); }
 
-// one-image float plane on the device for the stage API
-DPlane stage_plane(DevBuf &buf, int rows, int cols)
+bool finite_f(float v) { return v == v && v - v == 0.0f; }
+
+void validate_params(const hesaff_params &p)
 {
-   buf.ensure(std::max<size_t>((size_t)rows * cols * 4, 16));
-   return make_plane(buf.as<float>(), 1, rows, cols, cols);
+   if (!finite_f(p.threshold) || !finite_f(p.edgeEigenValueRatio) || !finite_f(p.initialSigma) || !finite_f(p.convergenceThreshold) ||
+       !finite_f(p.mrSize) || !finite_f(p.maxBinValue))
+      throw HsError(HESAFF_ERR_ARG, "non-finite parameter");
+   if (!(p.initialSigma > 0.0f)) throw HsError(HESAFF_ERR_ARG, "initialSigma must be positive");
+   if (!(p.mrSize > 0.0f)) throw HsError(HESAFF_ERR_ARG, "mrSize must be positive");
+   if (!(p.edgeEigenValueRatio > 0.0f)) throw HsError(HESAFF_ERR_ARG, "edgeEigenValueRatio must be positive");
+   if (p.maxIterations < 1 || p.maxIterations > 1000) throw HsError(HESAFF_ERR_ARG, "maxIterations out of range (1..1000)");
+   if (p.upscaleInputImage != 0) throw HsError(HESAFF_ERR_ARG, "upscaleInputImage is not supported by this build");
+   if (p.fast != 0) throw HsError(HESAFF_ERR_ARG, "fast mode is not supported by this build");
 }
 
 } // namespace
 
 extern "C" {
 
-const char *hesaff_version(void) { return "hesaff_amd 0.1 (gfx950)"; }
+const char *hesaff_version(void)
+{
+#ifdef HESAFF_TUNING
+   return "hesaff_amd 0.2 (gfx950, tuning build)";
+#else
+   return "hesaff_amd 0.2 (gfx950)";
+#endif
+}
 
 int hesaff_default_params(hesaff_params *p)
 {
@@ -44,8 +59,10 @@ int hesaff_default_params(hesaff_params *p)
    p->convergenceThreshold = 0.05f;
    p->mrSize = 3.0f * sqrtf(3.0f);
    p->maxBinValue = 0.2f;
+   p->upscaleInputImage = 0;
    p->max_batch = 16;
    p->max_kpts_per_mpx = 40000;
+   p->fast = 0;
    return HESAFF_OK;
 }
 
@@ -63,7 +80,7 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       if (p) c->par = *p; else hesaff_default_params(&c->par);
       if (c->par.max_batch < 1) c->par.max_batch = 1;
       if (c->par.max_kpts_per_mpx < 1000) c->par.max_kpts_per_mpx = 1000;
-      if (c->par.maxIterations < 1 || c->par.maxIterations > 1000) throw HsError(HESAFF_ERR_ARG, "maxIterations out of range");
+      validate_params(c->par);
       c->device = device;
       bind_device(c);
       hipDeviceProp_t prop;
@@ -85,27 +102,24 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
          HIP_TRY(hipEventCreateWithFlags(&c->ev_extract_done[i], hipEventDisableTiming));
          HIP_TRY(hipEventCreateWithFlags(&c->ev_sift_done[i], hipEventDisableTiming));
       }
-      if (const char *ov = getenv("HESAFF_OVERLAP")) c->no_overlap = atoi(ov) == 0;
+      set_kernel_attrs(c);
       build_tables(c);
       refresh_tables_struct(c);
       memset(&c->tm, 0, sizeof c->tm);
-      if (const char *ab = getenv("HESAFF_ABLATE")) c->ablate = atoi(ab) & ~1;
-      if (const char *pk = getenv("HESAFF_PYR")) { c->use_tile_kernel = strcmp(pk, "tile") == 0; c->use_glds = strcmp(pk, "glds") == 0; }
+#ifdef HESAFF_TUNING
+      // schedule knobs for A/B measurements (libhesaff_amd_tuning.so only); none of them changes a result
+      if (const char *ov = getenv("HESAFF_OVERLAP")) c->no_overlap = atoi(ov) == 0;
       if (const char *ab = getenv("HESAFF_AFF_BLOCKS")) c->aff_blocks_per_cu = std::max(1, atoi(ab));
       if (const char *sd = getenv("HESAFF_SIDE")) c->side_mask = atoi(sd);
-      if (const char *sm = getenv("HESAFF_SMALL")) c->old_small = strcmp(sm, "old") == 0;
-      if (const char *ex = getenv("HESAFF_EXTREMA")) c->use_tile_extrema = strcmp(ex, "tile") == 0;
-      if (const char *bd = getenv("HESAFF_BAND")) c->band_rows = std::max(8, atoi(bd));
-      c->debug = getenv("HESAFF_DEBUG") != nullptr;
-      if (const char *sf = getenv("HESAFF_SIFT")) c->fused_sift = strcmp(sf, "fused") == 0;
       if (const char *gk = getenv("HESAFF_GROUP")) c->sift_group_kpts = (uint32_t)std::max(1000, atoi(gk));
-      if (const char *sp = getenv("HESAFF_STOP")) c->stop_after_detect = strcmp(sp, "detect") == 0;
       if (const char *wv = getenv("HESAFF_BANDS")) c->force_bands = std::max(0, atoi(wv));
+      c->debug = getenv("HESAFF_DEBUG") != nullptr;
+#endif
    } catch (const HsError &e) {
-      delete c;
+      hesaff_destroy(c);
       return fail(nullptr, e);
    } catch (const std::exception &e) {
-      delete c;
+      hesaff_destroy(c);
       return fail(nullptr, HsError(HESAFF_ERR_NOMEM, e.what()));
    }
    *out = c;
@@ -120,8 +134,8 @@ void hesaff_destroy(hesaff_ctx *c)
    DevBuf *bufs[] = {&c->t_smm, &c->t_sift, &c->t_bin0, &c->t_bin1, &c->t_w0, &c->t_w1, &c->t_pyr_taps, &c->t_patch_taps,
                      &c->t_patch_off, &c->t_patch_k, &c->b_gray, &c->b_L, &c->b_L3, &c->b_R, &c->b_map, &c->b_bitmask, &c->b_prefix,
                      &c->b_blocksums, &c->b_counters, &c->b_cand, &c->b_rec_f, &c->b_rec_i, &c->b_rec_w, &c->b_hess_f, &c->b_hess_i,
-                     &c->b_aff, &c->b_pw, &c->b_bins, &c->b_rank, &c->b_desc, &c->b_out, &c->b_starts, &c->b_scratch, &c->b_patches,
-                     &c->b_stage, &c->b_input, &c->t_mask_idx, &c->b_rowprefix, &c->b_trows, &c->b_trows2, &c->b_trows3, &c->b_siftvec, &c->b_meanvar, &c->b_siftvo};
+                     &c->b_aff, &c->b_pw, &c->b_bins, &c->b_rank, &c->b_desc, &c->b_out, &c->b_starts, &c->b_patches,
+                     &c->b_stage, &c->b_input, &c->t_mask_idx, &c->b_rowprefix, &c->b_trows, &c->b_trows2, &c->b_trows3};
    for (DevBuf *b : bufs) b->release();
    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
    for (int i = 0; i < HS_NSIDE; i++) {
@@ -216,6 +230,7 @@ int hesaff_detect_batch(hesaff_ctx *c, int n, const uint8_t *const *images, cons
          for (int j = i; j < n; j++)
             if (!done[j] && widths[j] == W && heights[j] == H && (channels ? channels[j] : 1) == ch) {
                if (!images[j] || W < 1 || H < 1) throw HsError(HESAFF_ERR_ARG, "bad image");
+               if (strides && (long long)strides[j] < (long long)W * ch) throw HsError(HESAFF_ERR_ARG, "row stride smaller than width * channels");
                grp.push_back(j);
                done[j] = 1;
             }
@@ -306,28 +321,40 @@ int hesaff_detect_batch(hesaff_ctx *c, int n, const uint8_t *const *images, cons
 
 // ---------------------------------- stage entry points ----------------------------------
 
+// The stage entry points run the PRODUCTION kernels wherever the batch path has one for the operator:
+//   gaussianBlur     -> k_blur_hess_march<K> (K = 9, 11, 13, 15: every blur of the default pyramid), else the generic two-pass kernels
+//   hessianResponse  -> the fused R0 epilogue of k_blur_hess_march<9, .., WRITE_R0> (pyramid.cpp:230 on the batch path)
+//   SIFT             -> k_sift_meanvar / _grad / _hist / _quantize
+//   normalizeAffine  -> k_prepare_patch + the five window-size bin kernels
+//   findAffineShape  -> hs_affine_groups (k_affine's body)
+// halfImage has no stand-alone production kernel (the decimation is an epilogue of the K = 13 blur launch, checked
+// plane by plane through hesaff_stage_pyramid); k_half serves the operator here.
 int hesaff_stage_gaussian_blur(hesaff_ctx *c, const float *in, int rows, int cols, float sigma, float *out)
 {
-   if (!c || !in || !out || rows < 1 || cols < 1) return HESAFF_ERR_ARG;
+   if (!c || !in || !out || rows < 1 || cols < 1 || !(sigma > 0.0f)) return HESAFF_ERR_ARG;
    HS_API_BEGIN
    bind_device(c);
    const int K = hesaff::gauss_ksize(sigma);
-   const size_t n = (size_t)rows * cols;
+   const int pitch = round_up(cols, 64);   // like the batch planes: rows stay 16-byte aligned for the float4 stores
+   const size_t n = (size_t)rows * pitch;
    c->b_stage.ensure(n * 4 * 3 + (size_t)(K + 16) * 4);
    float *d_in = c->b_stage.as<float>(), *d_tmp = d_in + n, *d_out = d_tmp + n, *d_taps = d_out + n;
    std::vector<float> taps(K, 1.0f);
    if (K > 1) hesaff::gauss_taps(K, sigma, taps.data());
-   HIP_TRY(hipMemcpyAsync(d_in, in, n * 4, hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(hipMemcpy2DAsync(d_in, (size_t)pitch * 4, in, (size_t)cols * 4, (size_t)cols * 4, rows, hipMemcpyHostToDevice, c->stream));
    HIP_TRY(hipMemcpyAsync(d_taps, taps.data(), (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
+   DPlane pi = make_plane(d_in, rows, cols, pitch), pt = make_plane(d_tmp, rows, cols, pitch), po = make_plane(d_out, rows, cols, pitch);
+   const DPlane none = make_plane(nullptr, 0, 0, 0);
    if (K == 1) {
       HIP_TRY(hipMemcpyAsync(d_out, d_in, n * 4, hipMemcpyDeviceToDevice, c->stream));
+   } else if (K == 9 || K == 11 || K == 13 || K == 15) {
+      launch_blur_hess<true, false, false>(c, pi, po, none, none, d_taps, K, 0.0f, 1);
    } else {
-      DPlane pi = make_plane(d_in, 1, rows, cols, cols), pt = make_plane(d_tmp, 1, rows, cols, cols), po = make_plane(d_out, 1, rows, cols, cols);
       const dim3 grid((cols + 255) / 256, rows, 1);
       hipLaunchKernelGGL(k_blur_rows_generic, grid, dim3(256), 0, c->stream, pi, pt, (const float *)d_taps, K);
       hipLaunchKernelGGL(k_blur_cols_generic, grid, dim3(256), 0, c->stream, pt, po, (const float *)d_taps, K);
    }
-   HIP_TRY(hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipMemcpy2DAsync(out, (size_t)cols * 4, d_out, (size_t)pitch * 4, (size_t)cols * 4, rows, hipMemcpyDeviceToHost, c->stream));
    HIP_TRY(hipStreamSynchronize(c->stream));
    HIP_TRY(hipGetLastError());
    HS_API_END(c)
@@ -338,13 +365,19 @@ int hesaff_stage_hessian_response(hesaff_ctx *c, const float *in, int rows, int 
    if (!c || !in || !out || rows < 1 || cols < 1) return HESAFF_ERR_ARG;
    HS_API_BEGIN
    bind_device(c);
-   const size_t n = (size_t)rows * cols;
-   c->b_stage.ensure(n * 4 * 2);
-   float *d_in = c->b_stage.as<float>(), *d_out = d_in + n;
-   HIP_TRY(hipMemcpyAsync(d_in, in, n * 4, hipMemcpyHostToDevice, c->stream));
-   DPlane pi = make_plane(d_in, 1, rows, cols, cols), po = make_plane(d_out, 1, rows, cols, cols);
-   hipLaunchKernelGGL(k_hess, dim3((cols + 255) / 256, rows, 1), dim3(256), 0, c->stream, pi, po, norm * norm);
-   HIP_TRY(hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, c->stream));
+   const int pitch = round_up(cols, 64);
+   const size_t n = (size_t)rows * pitch;
+   c->b_stage.ensure(n * 4 * 4 + 64);
+   float *d_in = c->b_stage.as<float>(), *d_out = d_in + n, *d_l = d_out + n, *d_r = d_l + n, *d_taps = d_r + n;
+   HIP_TRY(hipMemcpy2DAsync(d_in, (size_t)pitch * 4, in, (size_t)cols * 4, (size_t)cols * 4, rows, hipMemcpyHostToDevice, c->stream));
+   DPlane pi = make_plane(d_in, rows, cols, pitch), po = make_plane(d_out, rows, cols, pitch);
+   // the batch path computes R0 in the epilogue of the first blur launch of an octave (K = 9 at the default sigmas)
+   std::vector<float> taps(9);
+   hesaff::gauss_taps(9, 1.2262737f, taps.data());
+   HIP_TRY(hipMemcpyAsync(d_taps, taps.data(), 9 * 4, hipMemcpyHostToDevice, c->stream));
+   launch_march<9, true, true, false, true>(c, pi, make_plane(d_l, rows, cols, pitch), make_plane(d_r, rows, cols, pitch), make_plane(nullptr, 0, 0, 0),
+                                            d_taps, 1.0f, 1, po, norm * norm);
+   HIP_TRY(hipMemcpy2DAsync(out, (size_t)cols * 4, d_out, (size_t)pitch * 4, (size_t)cols * 4, rows, hipMemcpyDeviceToHost, c->stream));
    HIP_TRY(hipStreamSynchronize(c->stream));
    HIP_TRY(hipGetLastError());
    HS_API_END(c)
@@ -360,7 +393,7 @@ int hesaff_stage_half_image(hesaff_ctx *c, const float *in, int rows, int cols, 
    c->b_stage.ensure(n * 4 * 2);
    float *d_in = c->b_stage.as<float>(), *d_out = d_in + n;
    HIP_TRY(hipMemcpyAsync(d_in, in, n * 4, hipMemcpyHostToDevice, c->stream));
-   DPlane pi = make_plane(d_in, 1, rows, cols, cols), po = make_plane(d_out, 1, r2, c2, c2);
+   DPlane pi = make_plane(d_in, rows, cols, cols), po = make_plane(d_out, r2, c2, c2);
    hipLaunchKernelGGL(k_half, dim3((c2 + 255) / 256, r2, 1), dim3(256), 0, c->stream, pi, po);
    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)r2 * c2 * 4, hipMemcpyDeviceToHost, c->stream));
    HIP_TRY(hipStreamSynchronize(c->stream));
@@ -449,7 +482,7 @@ int hesaff_stage_find_affine_shape(hesaff_ctx *c, const float *blur, int rows, i
    HIP_TRY(hipMemcpyAsync(d_plane, blur, np * 4, hipMemcpyHostToDevice, c->stream));
    HIP_TRY(hipMemcpyAsync(d_kp, kp, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
    AffineOut ao; ao.converged = d_conv; ao.iters = d_iters; ao.U = d_U;
-   DPlane P = make_plane(d_plane, 1, rows, cols, cols);
+   DPlane P = make_plane(d_plane, rows, cols, cols);
    hipLaunchKernelGGL(k_affine_stage, dim3(std::min((n + 3) / 4, 256 * 6)), dim3(64), 0, c->stream, P, (const float *)d_kp, n, c->tables, c->consts, ao);
    if (converged) HIP_TRY(hipMemcpyAsync(converged, d_conv, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
    if (iters) HIP_TRY(hipMemcpyAsync(iters, d_iters, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -490,7 +523,6 @@ int hesaff_stage_normalize_affine(hesaff_ctx *c, const float *img, int rows, int
    HIP_TRY(hipMemcpy2DAsync(c->gray.p, (size_t)c->gray.pitch * 4, img, (size_t)cols * 4, (size_t)cols * 4, rows, hipMemcpyHostToDevice, st));
    std::vector<float> x(n), y(n), sc(n);
    std::vector<int32_t> meta(n, 0), P0(n), alive(n);
-   std::vector<uint32_t> bins((size_t)HS_NBINS * n), bcount(HS_NBINS, 0);
    for (int i = 0; i < n; i++) { x[i] = kp[3 * i]; y[i] = kp[3 * i + 1]; sc[i] = kp[3 * i + 2]; }
    HIP_TRY(hipMemcpyAsync(s.hl.x, x.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
    HIP_TRY(hipMemcpyAsync(s.hl.y, y.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -506,11 +538,22 @@ int hesaff_stage_normalize_affine(hesaff_ctx *c, const float *img, int rows, int
                       c->consts, c->tables, s.pw);
    c->b_patches.ensure((size_t)n * HS_PATCH_PIX * 4);
    HIP_TRY(hipMemsetAsync(c->b_patches.p, 0, (size_t)n * HS_PATCH_PIX * 4, st));
-   run_patch_stage(c, s, c->gray, c->b_patches.as<float>(), 0, 0);
+   // T' rows of the huge windows: bounded by the sum of their sides
+   unsigned long long large_rows = 0;
+   for (int i = 0; i < n; i++) {
+      const float mrScale = ceilf(sc[i] * c->consts.mrSize);
+      const long long P = (mrScale < 1.0e6f) ? 2 * (long long)mrScale + 3 : 0;
+      if (P > HS_BIN3_PMAX && P <= c->max_p0 + 2) large_rows += (unsigned long long)P;
+   }
+   if (large_rows > 0xffffffffull) throw HsError(HESAFF_ERR_NOMEM, "too many huge windows in one call");
+   run_patch_stage(c, s, c->gray, c->b_patches.as<float>(), 0, (uint32_t)large_rows);
+   uint32_t ovf = 0;
+   HIP_TRY(hipMemcpyAsync(&ovf, s.counters + 6, 4, hipMemcpyDeviceToHost, st));
    HIP_TRY(hipMemcpyAsync(alive.data(), s.pw.alive, (size_t)n * 4, hipMemcpyDeviceToHost, st));
    if (patches) HIP_TRY(hipMemcpyAsync(patches, c->b_patches.p, (size_t)n * HS_PATCH_PIX * 4, hipMemcpyDeviceToHost, st));
    HIP_TRY(hipStreamSynchronize(st));
    HIP_TRY(hipGetLastError());
+   if (ovf) throw HsError(HESAFF_ERR_NOMEM, "large-window row buffer exceeded (internal bound violated)");
    if (rejected) for (int i = 0; i < n; i++) rejected[i] = alive[i] ? 0 : 1;
    HS_API_END(c)
 }
@@ -521,12 +564,21 @@ int hesaff_stage_sift(hesaff_ctx *c, int n, const float *patches, uint8_t *desc)
    HS_API_BEGIN
    bind_device(c);
    if (n == 0) return HESAFF_OK;
-   c->b_stage.ensure((size_t)n * (HS_PATCH_PIX * 4 + 128));
-   float *d_p = c->b_stage.as<float>();
-   uint8_t *d_d = (uint8_t *)(d_p + (size_t)n * HS_PATCH_PIX);
-   HIP_TRY(hipMemcpyAsync(d_p, patches, (size_t)n * HS_PATCH_PIX * 4, hipMemcpyHostToDevice, c->stream));
-   hipLaunchKernelGGL(k_sift_stage, dim3(std::min(n, 4096)), dim3(256), 0, c->stream, (const float *)d_p, n, c->tables, c->consts, d_d);
-   HIP_TRY(hipMemcpyAsync(desc, d_d, (size_t)n * 128, hipMemcpyDeviceToHost, c->stream));
+   const size_t N = (size_t)n;
+   // patches | alive flags | mean,var | histogram | descriptor bytes | (mask*grad, o) pairs
+   const size_t off_alive = N * HS_PATCH_PIX * 4, off_mv = off_alive + N * 4, off_vec = off_mv + N * 8, off_desc = off_vec + N * 128 * 4;
+   const size_t off_vo = (off_desc + N * 128 + 63) & ~(size_t)63, total = off_vo + N * HS_VO_PITCH * 8 + 64;
+   c->b_stage.ensure(total);
+   char *base = (char *)c->b_stage.p;
+   std::vector<int32_t> ones(N, 1);
+   HIP_TRY(hipMemcpyAsync(base, patches, N * HS_PATCH_PIX * 4, hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(hipMemcpyAsync(base + off_alive, ones.data(), N * 4, hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(hipMemsetAsync(base + off_vo, 0, N * HS_VO_PITCH * 8 + 64, c->stream));   // pairs outside the circular mask stay (0, 0)
+   SiftIO so;
+   so.patches = (const float *)base; so.alive = (const int32_t *)(base + off_alive); so.meanvar = (float *)(base + off_mv);
+   so.vec = (float *)(base + off_vec); so.desc = (uint8_t *)(base + off_desc); so.h_lo = 0; so.h_hi = (uint32_t)n;
+   launch_sift(c, c->stream, so, (uint32_t)n, (float2 *)(base + off_vo));
+   HIP_TRY(hipMemcpyAsync(desc, base + off_desc, N * 128, hipMemcpyDeviceToHost, c->stream));
    HIP_TRY(hipStreamSynchronize(c->stream));
    HIP_TRY(hipGetLastError());
    HS_API_END(c)

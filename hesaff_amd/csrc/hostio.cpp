@@ -10,6 +10,7 @@
 #include <atomic>
 #include <string>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <unordered_map>
 #include <utility>
@@ -83,6 +84,9 @@ int read_png_bytes(const std::vector<uint8_t> &f, uint8_t **data, int *width, in
    if (!depth_ok || (ctype == 3 && (plte.empty() || plte.size() % 3 != 0))) return HESAFF_ERR_IO;
    const size_t rowbytes = ((size_t)W * nch * depth + 7) / 8;
    const int bpp = std::max(1, nch * depth / 8);   // filter unit
+   // deflate expands by at most ~1032:1: an image the IDAT bytes cannot possibly produce is rejected before
+   // anything of its claimed size is allocated (a 60-byte file may claim 65535 x 65535 RGBA16)
+   if ((unsigned long long)H * (rowbytes + 1) > (unsigned long long)idat.size() * 1040ull + 4096ull) return HESAFF_ERR_IO;
    std::vector<uint8_t> raw((size_t)H * (rowbytes + 1));
    uLongf rawlen = (uLongf)raw.size();
    if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return HESAFF_ERR_IO;
@@ -296,7 +300,33 @@ char *format_rows(const hesaff_keypoint *keys, int i0, int i1, float mrSize, cha
    return p;
 }
 
+// Runs task(0..n_tasks-1) on up to `threads` host threads (the caller is one of them).  A thread that cannot be
+// created (std::system_error) is simply not used: the tasks it would have taken are picked up by the others.
+template <class F> void run_tasks(int n_tasks, int threads, F task)
+{
+   std::atomic<int> next(0);
+   auto work = [&] {
+      for (int i; (i = next.fetch_add(1)) < n_tasks;) task(i);
+   };
+   std::vector<std::thread> th;
+   try {
+      th.reserve((size_t)std::max(0, threads - 1));
+      for (int t = 1; t < threads; t++) th.emplace_back(work);
+   } catch (...) {
+   }
+   work();
+   for (auto &x : th) x.join();
+}
+
 } // namespace
+
+// No exception crosses the C ABI: allocation failures (std::bad_alloc) and thread-creation failures
+// (std::system_error) inside an entry point become error codes.
+#define HOSTIO_TRY try {
+#define HOSTIO_CATCH                                           \
+   }                                                           \
+   catch (const std::bad_alloc &) { return HESAFF_ERR_NOMEM; } \
+   catch (...) { return HESAFF_ERR_IO; }
 
 extern "C" {
 
@@ -342,11 +372,18 @@ int hesaff_read_png(const char *path, uint8_t **data, int *width, int *height, i
    if (!path || !data || !width || !height || !channels) return HESAFF_ERR_ARG;
    FILE *f = fopen(path, "rb");
    if (!f) return HESAFF_ERR_IO;
+   HOSTIO_TRY
    std::vector<uint8_t> bytes;
-   uint8_t chunk[1 << 16];
-   for (size_t n; (n = fread(chunk, 1, sizeof chunk, f)) > 0;) bytes.insert(bytes.end(), chunk, chunk + n);
+   try {
+      uint8_t chunk[1 << 16];
+      for (size_t n; (n = fread(chunk, 1, sizeof chunk, f)) > 0;) bytes.insert(bytes.end(), chunk, chunk + n);
+   } catch (...) {
+      fclose(f);
+      throw;
+   }
    fclose(f);
    return read_png_bytes(bytes, data, width, height, channels);
+   HOSTIO_CATCH
 }
 
 // the imread of hesaff.cpp:137 for the formats this library decodes itself: PGM/PPM and PNG, by magic number
@@ -423,15 +460,13 @@ int hesaff_format_sift_mt(const hesaff_keypoint *keys, int n, float mrSize, int 
    char *buf = big_alloc((size_t)hl + (size_t)n * kRowMax + 1);
    if (!buf) return HESAFF_ERR_NOMEM;
    memcpy(buf, head, (size_t)hl);
-   std::vector<size_t> plen((size_t)T, 0);
-   std::vector<std::thread> th;
-   for (int t = 0; t < T; t++)
-      th.emplace_back([&, t] {
-         const int i0 = (int)((long long)n * t / T), i1 = (int)((long long)n * (t + 1) / T);
-         char *dst = buf + hl + (size_t)i0 * kRowMax;
-         plen[t] = (size_t)(format_rows(keys, i0, i1, mrSize, dst) - dst);
-      });
-   for (auto &x : th) x.join();
+   std::vector<size_t> plen;
+   try { plen.assign((size_t)T, 0); } catch (...) { big_free(buf); return HESAFF_ERR_NOMEM; }
+   run_tasks(T, T, [&](int t) {
+      const int i0 = (int)((long long)n * t / T), i1 = (int)((long long)n * (t + 1) / T);
+      char *dst = buf + hl + (size_t)i0 * kRowMax;
+      plen[t] = (size_t)(format_rows(keys, i0, i1, mrSize, dst) - dst);
+   });
    size_t o = (size_t)hl + plen[0];
    for (int t = 1; t < T; t++) {
       const int i0 = (int)((long long)n * t / T);
@@ -471,23 +506,15 @@ int hesaff_write_sift_batch(int n_images, const char *const *paths, const hesaff
    if (n_images < 0 || (n_images > 0 && (!paths || !results))) return HESAFF_ERR_ARG;
    int T = threads > 0 ? threads : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
    T = std::max(1, std::min(T, n_images));
-   std::atomic<int> next(0), err(HESAFF_OK);
-   auto work = [&] {
-      for (;;) {
-         const int i = next.fetch_add(1);
-         if (i >= n_images) break;
-         if (!paths[i]) { err = HESAFF_ERR_ARG; continue; }
-         char *buf = nullptr;
-         size_t len = 0;
-         int rc = hesaff_format_sift_mt(results[i].keys, results[i].count_desc, mrSize, 1, &buf, &len);
-         if (rc == HESAFF_OK) { rc = write_file(paths[i], buf, len); big_free(buf); }
-         if (rc != HESAFF_OK) err = rc;
-      }
-   };
-   std::vector<std::thread> th;
-   for (int t = 1; t < T; t++) th.emplace_back(work);
-   work();
-   for (auto &x : th) x.join();
+   std::atomic<int> err(HESAFF_OK);
+   run_tasks(n_images, T, [&](int i) {
+      if (!paths[i]) { err = HESAFF_ERR_ARG; return; }
+      char *buf = nullptr;
+      size_t len = 0;
+      int rc = hesaff_format_sift_mt(results[i].keys, results[i].count_desc, mrSize, 1, &buf, &len);
+      if (rc == HESAFF_OK) { rc = write_file(paths[i], buf, len); big_free(buf); }
+      if (rc != HESAFF_OK) err = rc;
+   });
    return err.load();
 }
 

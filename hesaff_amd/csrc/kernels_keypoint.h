@@ -256,6 +256,20 @@ struct PatchWork {
    uint32_t cap;
 };
 
+// window side of normalizeAffine's smoothing branch from the scale alone (affine.cpp:106-109,120): 0 when P0 is out of range
+__device__ __forceinline__ int hs_window_p0(float s, float mrSize)
+{
+   const float mrScale = ceilf(s * mrSize);
+   // int(mrScale): saturate; the tap table bound rejects such a window anyway
+   const int m = (mrScale < 1.0e6f) ? (int)mrScale : 1000000;
+   return 2 * m + 1;
+}
+
+// Upper bound, per image, of the T' rows the huge windows (last bin) of its keypoints need: depends on the scales
+// only, so it is known right after detection and the host can size / group the patch stage without waiting for the
+// affine iteration.  rows[b] += P for every Hessian keypoint whose window falls into the last bin.
+__global__ __launch_bounds__(256) void k_image_large_rows(HessList hl, const uint32_t *__restrict__ n_ptr, float mrSize, uint32_t *__restrict__ rows);
+
 template <bool RECTIFY>
 __device__ __forceinline__ void hs_prepare_patch_body(const HessList &hl, uint32_t h_lo, uint32_t n, const AffineOut &aff, int imRows, int imCols,
                                                       const DConsts &k, const KpTables &tb, const PatchWork &pw)
@@ -273,11 +287,7 @@ __device__ __forceinline__ void hs_prepare_patch_body(const HessList &hl, uint32
          } else {
             a11 = pw.A[4 * h]; a12 = pw.A[4 * h + 1]; a21 = pw.A[4 * h + 2]; a22 = pw.A[4 * h + 3];
          }
-         const float s = hl.s[h];
-         const float mrScale = ceilf(s * k.mrSize);
-         // int(mrScale): saturate like the table bound below would reject anyway
-         const int m = (mrScale < 1.0e6f) ? (int)mrScale : 1000000;
-         P0 = 2 * m + 1;
+         P0 = hs_window_p0(hl.s[h], k.mrSize);
          const float scale = (float)P0 / (float)HS_PATCH;
          const bool rej = hs_check_borders(imRows, imCols, hl.x[h], hl.y[h], a11 * scale, a12 * scale, a21 * scale, a22 * scale);
          // P0 > max_p0: the P x P window cannot fit into the image (a11*a22 = 1), the
@@ -306,6 +316,17 @@ __device__ __forceinline__ void hs_prepare_patch_body(const HessList &hl, uint32
          base = __shfl(base, leader, 64);
          if (bin == bq) pw.bin_items[(size_t)bq * pw.cap + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = h;
       }
+   }
+}
+
+__global__ __launch_bounds__(256) void k_image_large_rows(HessList hl, const uint32_t *__restrict__ n_ptr, float mrSize, uint32_t *__restrict__ rows)
+{
+   const uint32_t n = min(*n_ptr, hl.cap);
+   for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < n; h += gridDim.x * blockDim.x) {
+      const int P0 = hs_window_p0(hl.s[h], mrSize);
+      const float scale = (float)P0 / (float)HS_PATCH;
+      const int P = ((double)scale > 0.4) ? P0 + 2 : 0;
+      if (hs_patch_bin(P) == HS_NBINS - 1 && P0 < (1 << 20)) atomicAdd(rows + (hl.meta[h] >> 8), (uint32_t)P);
    }
 }
 

@@ -23,11 +23,13 @@ __global__ __launch_bounds__(256) void k_gray(const uint8_t *__restrict__ src, i
 }
 
 // ---------------------------------------------------------------------------------------
-// k_blur_hess_tile (v1, LDS tile): separable Gaussian (pinned cv::GaussianBlur order, see
+// k_blur_hess_tile (LDS tile; the fallback for non-default initialSigma, i.e. tap counts K other
+// than 9, 11, 13, 15, which k_blur_hess_march is instantiated for): separable Gaussian (pinned cv::GaussianBlur order, see
 // DESIGN.md) of one 64x16 tile + 1-pixel halo, then the det-of-Hessian response of the
 // blurred tile (pyramid.cpp:63-114) and optionally the 2x decimated copy
 // (helpers.cpp:331-339).
-//   row pass   : t = k[0]*S[x-r]; t += k[j]*S[x-r+j], j = 1..K-1            (RowFilter)
+//   row pass   : t = k[0]*S[x-r]; t += k[j]*S[x-r+j], j = 1..K-1            (RowFilter, K > 5)
+//                S0*k0 + (S-1+S1)*k1 + (S-2+S2)*k2                            (SymmRowSmallFilter, K <= 5)
 //   column pass: d = k[r]*T[y];  d += k[r+j]*(T[y+j] + T[y-j]), j = 1..r     (SymmColumnFilter)
 // K <= 15 (pyramid sigmas give 9..15).  grid (ceil(cols/64), ceil(rows/16), B), block 256.
 // ---------------------------------------------------------------------------------------
@@ -66,8 +68,17 @@ __global__ __launch_bounds__(256) void k_blur_hess_tile(DPlane in, DPlane outL, 
    // row pass over inH rows x (TW+2) columns
    for (int idx = tid; idx < inH * (BH_TW + 2); idx += 256) {
       const int ly = idx / (BH_TW + 2), ox = idx - ly * (BH_TW + 2);
-      float t = s_k[0] * s_in[ly][ox];
-      for (int j = 1; j < K; j++) t += s_k[j] * s_in[ly][ox + j];
+      float t;
+      if (K == 1) t = s_in[ly][ox];   // ksize 1: cv::GaussianBlur copies
+      else if (K <= 5) {
+         // SymmRowSmallFilter (ksize 3 / 5): S0*k0 + (S-1 + S1)*k1 [+ (S-2 + S2)*k2]
+         const float *sp = &s_in[ly][ox + r];
+         t = sp[0] * s_k[r] + (sp[-1] + sp[1]) * s_k[r + 1];
+         if (K == 5) t = t + (sp[-2] + sp[2]) * s_k[r + 2];
+      } else {
+         t = s_k[0] * s_in[ly][ox];
+         for (int j = 1; j < K; j++) t += s_k[j] * s_in[ly][ox + j];
+      }
       s_row[ly][ox] = t;
    }
    __syncthreads();
@@ -162,52 +173,14 @@ __global__ __launch_bounds__(256) void k_blur_cols_generic(DPlane tmp, DPlane ou
    out.img(b)[(long long)y * out.pitch + x] = d;
 }
 
-// ---------------------------------------------------------------------------------------
-// k_extrema: findLevelKeypoints pyramid.cpp:206-222 + isMax/isMin :39-61 for one level.
-// A candidate passes when val > positiveThreshold and no neighbour in the 3x3x3 block is
-// strictly greater (resp. < negativeThreshold and none strictly smaller).  Appends
-// (img,level,r,c) to the octave's candidate list (unordered; order is restored by the
-// bitmask ranks in k_scatter_ordered).  grid (ceil(cols/64), ceil(rows/4), B), block (64,4)
-// ---------------------------------------------------------------------------------------
+// Candidates of one octave: findLevelKeypoints pyramid.cpp:206-222 appends (img,level,r,c) for every pixel that
+// passes isMax / isMin (:39-61); unordered here, the order is restored by the bitmask ranks in k_scatter_ordered.
 struct CandList {
    uint32_t *count;   // device counter
    uint2 *items;      // x = img<<2 | level, y = r<<16 | c
    uint32_t cap;
    uint32_t *overflow;   // set to 1 when a list ran out of capacity
 };
-
-__device__ __forceinline__ bool hs_is_ext(const float *__restrict__ p, int s, float val, bool wantMax)
-{
-   bool ok = true;
-#pragma unroll
-   for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-      for (int dx = -1; dx <= 1; dx++) {
-         const float v = p[dy * s + dx];
-         ok = ok && (wantMax ? !(v > val) : !(v < val));
-      }
-   return ok;
-}
-
-__global__ __launch_bounds__(256) void k_extrema(DPlane low, DPlane cur, DPlane high, int level, float posThr, float negThr,
-                                                 CandList cl)
-{
-   const int c = blockIdx.x * 64 + threadIdx.x;
-   const int r = blockIdx.y * 4 + threadIdx.y;
-   const int b = blockIdx.z;
-   const int rows = cur.rows, cols = cur.cols;
-   if (r < HS_BORDER || r >= rows - HS_BORDER || c < HS_BORDER || c >= cols - HS_BORDER) return;
-   const long long off = (long long)r * cur.pitch + c;
-   const float *pc = cur.img(b) + off;
-   const float val = *pc;
-   const bool isPos = val > posThr, isNeg = val < negThr;
-   if (!(isPos || isNeg)) return;
-   const float *pl = low.img(b) + off, *ph = high.img(b) + off;
-   const int s = cur.pitch;
-   if (!(hs_is_ext(pc, s, val, isPos) && hs_is_ext(pl, s, val, isPos) && hs_is_ext(ph, s, val, isPos))) return;
-   const uint32_t idx = atomicAdd(cl.count, 1u);
-   if (idx < cl.cap) cl.items[idx] = make_uint2(((uint32_t)b << 2) | (uint32_t)level, ((uint32_t)r << 16) | (uint32_t)c);
-}
 
 // ---------------------------------------------------------------------------------------
 // k_localize: localizeKeypoint pyramid.cpp:122-204 (without the order-dependent octaveMap
@@ -695,82 +668,7 @@ __global__ __launch_bounds__(256) void k_blur_hess_march(DPlane in, DPlane outL,
    }
 }
 
-// ---------------------------------------------------------------------------------------
-// k_extrema3: the three extrema scans of one octave (pyramid.cpp:245-250 for i = 2,3,4) in
-// one pass over the five response planes.  A block stages a 128 x 8 pixel tile (+1 halo) of
-// R0..R4 in LDS (each plane is read once from HBM/L2 instead of up to three times, and the
-// 27-neighbour tests hit LDS), then every thread tests its 4 pixels at the 3 levels.
-// Candidate = val > positiveThreshold and no strictly greater value among the 27 neighbours
-// (resp. < negativeThreshold and none strictly smaller), pyramid.cpp:39-61,211-218.
-// grid (ceil(cols/128), ceil(rows/8), B), block 256.
-// ---------------------------------------------------------------------------------------
-#define EX_TW 128
-#define EX_TH 8
-#define EX_LW (EX_TW + 2)
-#define EX_LH (EX_TH + 2)
-#define EX_LIST 768
-
 struct FivePlanes { DPlane R[5]; };
-
-__global__ __launch_bounds__(256) void k_extrema3(FivePlanes fp, float posThr, float negThr, CandList cl)
-{
-   __shared__ float s_r[5][EX_LH][EX_LW + 2];
-   const int tid = threadIdx.x, b = blockIdx.z;
-   const int x0 = blockIdx.x * EX_TW, y0 = blockIdx.y * EX_TH;
-   const int rows = fp.R[0].rows, cols = fp.R[0].cols, pitch = fp.R[0].pitch;
-   // stage: clamped coordinates (values outside the scanned region are never candidates' neighbours:
-   // the scan stays HS_BORDER pixels away from the frame)
-   for (int idx = tid; idx < 5 * EX_LH * EX_LW; idx += 256) {
-      const int p = idx / (EX_LH * EX_LW), rem = idx - p * (EX_LH * EX_LW);
-      const int ly = rem / EX_LW, lx = rem - ly * EX_LW;
-      const int gy = min(max(y0 - 1 + ly, 0), rows - 1), gx = min(max(x0 - 1 + lx, 0), cols - 1);
-      s_r[p][ly][lx] = fp.R[p].img(b)[(long long)gy * pitch + gx];
-   }
-   __shared__ uint2 s_list[EX_LIST];
-   __shared__ uint32_t s_n, s_base;
-   if (tid == 0) s_n = 0;
-   __syncthreads();
-   for (int k = 0; k < (EX_TW * EX_TH) / 256; k++) {
-      const int idx = tid + 256 * k;
-      const int ty = idx / EX_TW, tx = idx - ty * EX_TW;
-      const int r = y0 + ty, c = x0 + tx;
-      if (r < HS_BORDER || r >= rows - HS_BORDER || c < HS_BORDER || c >= cols - HS_BORDER) continue;
-#pragma unroll
-      for (int level = 0; level < 3; level++) {
-         const float val = s_r[level + 1][ty + 1][tx + 1];
-         const bool isPos = val > posThr, isNeg = val < negThr;
-         if (!(isPos || isNeg)) continue;
-         bool ok = true;
-#pragma unroll
-         for (int p = 0; p < 3; p++)
-#pragma unroll
-            for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-               for (int dx = 0; dx < 3; dx++) {
-                  const float v = s_r[level + p][ty + dy][tx + dx];
-                  ok = ok && (isPos ? !(v > val) : !(v < val));
-               }
-         if (!ok) continue;
-         const uint2 item = make_uint2(((uint32_t)b << 2) | (uint32_t)level, ((uint32_t)r << 16) | (uint32_t)c);
-         // one global atomic per BLOCK: candidates are collected in LDS first (a single global
-         // counter hit once per candidate serialises in L2: ~10 ns each, 0.9 ms per 4K image)
-         const uint32_t ls = atomicAdd(&s_n, 1u);
-         if (ls < EX_LIST) s_list[ls] = item;
-         else {
-            const uint32_t slot = atomicAdd(cl.count, 1u);
-            if (slot < cl.cap) cl.items[slot] = item;
-         }
-      }
-   }
-   __syncthreads();
-   const uint32_t n = min(s_n, (uint32_t)EX_LIST);
-   if (tid == 0 && n > 0) s_base = atomicAdd(cl.count, n);
-   __syncthreads();
-   for (uint32_t i = tid; i < n; i += 256) {
-      const uint32_t slot = s_base + i;
-      if (slot < cl.cap) cl.items[slot] = s_list[i];
-   }
-}
 
 // ---------------------------------------------------------------------------------------
 // k_extrema_march: the same three extrema scans, HBM-streaming form.  One wavefront marches

@@ -30,6 +30,7 @@ struct SiftIO {
 
 #define HS_VO_DIM 40                          // rows/columns of the patch that carry weight in samplePatch
 #define HS_VO_PITCH (HS_VO_DIM * HS_VO_DIM)   // float2 per keypoint in the gradient-pair buffer (rows 16-byte aligned)
+#define HS_SIFT_MSK_IT 5   // ceil(1245 / 256): pixels inside the circular mask per thread of a 256-thread block
 #define SM_TILE 64
 #define SM_STRIDE 65   // LDS row stride: lane k walking row k is conflict-free
 
@@ -96,9 +97,9 @@ __global__ __launch_bounds__(256) void k_sift_grad(SiftIO io, KpTables tb, float
    const int alive = io.alive[h];
    const float mean = io.meanvar[2 * (size_t)k], var = io.meanvar[2 * (size_t)k + 1];
    const float *gp = io.patches + (size_t)k * HS_PATCH_PIX;
-   float pv[HS_SIFT_PIX_IT];
+   float pv[HS_PATCH_PIX_IT];
 #pragma unroll
-   for (int q = 0; q < HS_SIFT_PIX_IT; q++) pv[q] = gp[min(tid + 256 * q, HS_PATCH_PIX - 1)];
+   for (int q = 0; q < HS_PATCH_PIX_IT; q++) pv[q] = gp[min(tid + 256 * q, HS_PATCH_PIX - 1)];
    // Only the pixels inside the circular mask (1245 of 1681, helpers.cpp:131) are evaluated: where
    // the mask is 0 the pair is (0, *) and samplePatch adds nothing; those entries of the buffer are
    // zero-filled once when it is allocated and never written.
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void k_sift_grad(SiftIO io, KpTables tb, float
    const bool norm = !((double)var < 0.0001);
    const float fac = 50.0f / var;
 #pragma unroll
-   for (int q = 0; q < HS_SIFT_PIX_IT; q++) {
+   for (int q = 0; q < HS_PATCH_PIX_IT; q++) {
       const int i = tid + 256 * q;
       if (i < HS_PATCH_PIX) {
          float v = pv[q];
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void k_sift_grad(SiftIO io, KpTables tb, float
 // The (mask*grad, o) rows are read straight from global memory, 8 x 16 bytes per cell row and
 // lane, the next row in flight while the current one is consumed.
 // grid-stride over groups of 4 keypoints, block 64.
-__global__ __launch_bounds__(64) void k_sift_hist(SiftIO io, KpTables tb, const float2 *__restrict__ vo, int flags)
+__global__ __launch_bounds__(64) void k_sift_hist(SiftIO io, KpTables tb, const float2 *__restrict__ vo)
 {
    __shared__ float s_acc[8 * 64];
    __shared__ float s_cw[64];   // [spatial bin][offset 0..15]
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(64) void k_sift_hist(SiftIO io, KpTables tb, const 
       const bool valid = k < n && io.alive[io.h_lo + min(k, n - 1)];
 #pragma unroll
       for (int b = 0; b < 8; b++) acc[64 * b] = 0.0f;
-      if (valid && !(flags & 2)) {
+      if (valid) {
          // float4 index of the cell's first pixel pair: rows are HS_VO_DIM float2 = 20 float4
          const float4 *g4 = reinterpret_cast<const float4 *>(vo + (size_t)k * HS_VO_PITCH) + (8 * cb_r) * (HS_VO_DIM / 2) + 4 * cb_c;
          float4 cur[8], nxt[8];

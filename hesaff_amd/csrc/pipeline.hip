@@ -4,9 +4,13 @@
 // The reference chains its stages depth-first through virtual callbacks, one keypoint at
 // a time (hesaff.cpp:66-105).  Here a batch of B equally sized images runs breadth-first:
 //   pyramid (per octave: R0, 4x blur+response, decimate)  ->  extrema + localise per octave
-//   -> order by bitmask rank -> affine iteration -> rectify/bin -> patch+SIFT -> pack.
+//   -> order by bitmask rank -> affine iteration -> rectify/bin -> patch -> SIFT -> pack.
 // The reference's output order (octave, level, raster of the initial extremum) is
 // reproduced by ranking survivors through a bitmask laid out in exactly that order.
+//
+// Nothing here reads the environment unless the library is built with -DHESAFF_TUNING
+// (`make tuning`, a second .so for A/B measurements): a drop-in library must not change its
+// schedule, let alone its results, because of an environment variable.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -31,7 +35,8 @@ OctaveSchedule make_schedule(float initialSigma)
    // pyramid.cpp:227 : powf(2, 1/numberOfScales) ; hm_pow2f == glibc powf(2,.) bit for bit
    const float sigmaStep = hm_pow2f(1.0f / (float)HS_NSCALES);
    float curSigma = initialSigma;
-   s.init_sigma = sqrtf(initialSigma * initialSigma - 0.5f * 0.5f);
+   // pyramid.cpp:276-280: the input is taken to be blurred by 0.5 already; no initial blur when initialSigma <= 0.5
+   s.init_sigma = initialSigma > 0.5f ? sqrtf(initialSigma * initialSigma - 0.5f * 0.5f) : 0.0f;
    s.level_sigma[0] = curSigma;
    s.blur_sigma[0] = 0.0f;
    {
@@ -50,7 +55,7 @@ OctaveSchedule make_schedule(float initialSigma)
 }
 } // namespace hesaff
 
-static std::string g_create_error;
+static thread_local std::string g_create_error;
 
 #define HIP_TRY(expr)                                                                         \
    do {                                                                                       \
@@ -68,19 +73,34 @@ struct HsError {
    HsError(int c, const std::string &m) : code(c), msg(m) {}
 };
 
+// A device buffer that only grows.  ensure() never leaves a dangling pointer behind: the new block
+// is allocated before the old one is released (when the device cannot hold both, the old block
+// is released first and the allocation retried); on failure the buffer is empty (p == nullptr,
+// bytes == 0) and HESAFF_ERR_NOMEM is thrown.
 struct DevBuf {
    void *p = nullptr;
    size_t bytes = 0;
    void ensure(size_t need)
    {
       if (need <= bytes) return;
-      if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
-      hipError_t e = hipMalloc(&p, need);
+      void *q = nullptr;
+      hipError_t e = hipMalloc(&q, need);
+      if (e != hipSuccess && p) {
+         (void)hipGetLastError();
+         (void)hipFree(p);
+         p = nullptr; bytes = 0;
+         e = hipMalloc(&q, need);
+      }
       if (e != hipSuccess) {
+         (void)hipGetLastError();
+         if (p) (void)hipFree(p);
+         p = nullptr; bytes = 0;
          char buf[256];
          snprintf(buf, sizeof buf, "hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(e));
          throw HsError(HESAFF_ERR_NOMEM, buf);
       }
+      if (p) (void)hipFree(p);
+      p = q;
       bytes = need;
    }
    void release()
@@ -111,8 +131,9 @@ struct hesaff_ctx {
 
    // tables
    DevBuf t_smm, t_sift, t_bin0, t_bin1, t_w0, t_w1, t_pyr_taps, t_patch_taps, t_patch_off, t_patch_k;
-   int pyr_K[5];          // [0] initial blur, [1..4] octave blurs
+   int pyr_K[5];          // [0] initial blur (0 = none), [1..4] octave blurs
    int pyr_tap_off[5];
+   bool pyr_march = false;   // the four octave blurs have K = 9, 11, 13, 15 (default initialSigma): marching kernel
    int max_p0 = 0;        // tap table covers odd P0 <= max_p0
    int n_masked = 0;
    KpTables tables;
@@ -128,10 +149,9 @@ struct hesaff_ctx {
    std::vector<DPlane> L;   // [octave*3 + level]
    DPlane gray, L3, R[5];
    // lists
-   DevBuf b_counters;       // uint32: [0] cand_count [1] rec_count [2] overflow [3] hess_total [4] desc_total
-                            //         [8..11] bin_count, [16..16+HS_MAX_OCTAVES) octave rec starts
-   DevBuf b_cand, b_rec_f, b_rec_i, b_rec_w, b_hess_f, b_hess_i, b_aff, b_pw, b_bins, b_rank, b_desc, b_out, b_starts, b_scratch,
-      b_patches, b_stage;
+   DevBuf b_counters;       // uint32: [0] cand_count [1] rec_count [2] overflow [3] hess_total [4] desc_total [5] group end
+                            //         [6] T' row overflow, [8..12] bin_count, [16..16+HS_MAX_OCTAVES) octave rec starts
+   DevBuf b_cand, b_rec_f, b_rec_i, b_rec_w, b_hess_f, b_hess_i, b_aff, b_pw, b_bins, b_rank, b_desc, b_out, b_starts, b_patches, b_stage;
    DevBuf b_input;          // staging for host images (stage API)
    // hesaff_detect_batch, host entry point: chunks of max_batch images are pipelined -- pinned
    // staging + H2D of chunk i+1 and D2H of chunk i-1 run beside the kernels of chunk i
@@ -154,16 +174,12 @@ struct hesaff_ctx {
    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_in_free[2] = {nullptr, nullptr}, ev_out_ready[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
    std::vector<int32_t> h_starts;
-   DevBuf t_mask_idx, b_rowprefix, b_trows, b_trows2, b_trows3, b_siftvec, b_meanvar, b_siftvo;
-   bool fused_sift = false;            // HESAFF_SIFT=fused: descriptor inside the patch kernels (v1 structure)
-   uint32_t sift_group_kpts = 0;       // keypoints per group of images (20 KB of patch + gradient-pair buffers each, two slots); 0 = by batch (HESAFF_GROUP)
-   uint32_t trows_budget = 4u << 20;   // rows of T' (82 floats each) per large-window round: 1.3 GB
+   DevBuf t_mask_idx, b_rowprefix, b_trows, b_trows2, b_trows3;
+   size_t rows_lds_set = 0;            // dynamic LDS opt-in of k_patch_large_rows on THIS device
+   uint32_t trows_rows = 4u << 20;     // rows of T' (82 floats each) the large-window buffer holds at least: 1.3 GB
 
    hesaff_timings tm;
    int profiling = 0;
-   bool use_glds = false;          // HESAFF_PYR=glds: LDS-DMA prefetch variant of the marching kernel
-   bool use_tile_kernel = false;   // HESAFF_PYR=tile: v1 LDS-tile pyramid kernel (cross-check / fallback)
-   int band_rows = 16;             // HESAFF_BAND: minimum rows per wavefront band of k_blur_hess_march
    hipStream_t side_streams[HS_NSIDE] = {nullptr, nullptr, nullptr, nullptr};
    hipStream_t sift_stream = nullptr;
    hipStream_t aff_stream = nullptr;      // affine shape of image group g+1 runs beside the patch extraction of group g
@@ -172,15 +188,13 @@ struct hesaff_ctx {
    hipEvent_t ev_extract_done[2] = {nullptr, nullptr}, ev_sift_done[2] = {nullptr, nullptr};
    DevBuf b_patches2[2], b_siftvec2[2], b_meanvar2[2], b_siftvo2[2];
    hipEvent_t ev_fork = nullptr, ev_join[HS_NSIDE] = {nullptr, nullptr, nullptr, nullptr};
-   bool no_overlap = false;        // HESAFF_OVERLAP=0: run the patch bins one after the other
-   bool stop_after_detect = false; // HESAFF_STOP=detect
+   // schedule knobs: fixed in the product build, environment-driven only under -DHESAFF_TUNING
+   bool no_overlap = false;        // HESAFF_OVERLAP=0: every kernel alone on the device (per-kernel profiling)
+   uint32_t sift_group_kpts = 0;   // HESAFF_GROUP: keypoints per image group; 0 = by batch
    int aff_blocks_per_cu = 6;      // HESAFF_AFF_BLOCKS: persistent k_affine blocks per CU (19 KB of LDS each)
    int side_mask = 15;             // HESAFF_SIDE: bit i = window-size bin i runs on its own side stream
-   bool old_small = false;         // HESAFF_SMALL=old: k_patch_small<BIN, false> instead of k_patch_extract_small<BIN>
-   bool use_tile_extrema = false;  // HESAFF_EXTREMA=tile: the LDS-tile extrema kernel (k_extrema3) instead of the marching one
+   int force_bands = 0;            // HESAFF_BANDS: force the band count of k_blur_hess_march
    bool debug = false;             // HESAFF_DEBUG=1: launch geometry on stderr
-   int force_bands = 0;            // HESAFF_BANDS: force the band count of k_blur_hess_march (tuning)
-   int ablate = 0;          // HESAFF_ABLATE: profiling-only ablation bits, breaks results when set
    std::vector<hipEvent_t> ev_pool;
    size_t ev_used = 0;
 };
@@ -224,13 +238,16 @@ void build_tables(hesaff_ctx *c)
    std::vector<float> taps;
    for (int i = 0; i < 5; i++) {
       const float sigma = i == 0 ? c->sched.init_sigma : c->sched.blur_sigma[i];
-      const int K = hesaff::gauss_ksize(sigma);
-      if (K > 2 * BH_RMAX + 1) throw HsError(HESAFF_ERR_ARG, "initialSigma too large for the tiled pyramid kernel (K > 15)");
-      c->pyr_K[i] = K;
       c->pyr_tap_off[i] = (int)taps.size();
       taps.resize(taps.size() + 16, 0.0f);
-      hesaff::gauss_taps(K, sigma, taps.data() + c->pyr_tap_off[i]);
+      if (i == 0 && !(c->par.initialSigma > 0.5f)) { c->pyr_K[0] = 0; continue; }   // pyramid.cpp:276: no initial blur
+      const int K = hesaff::gauss_ksize(sigma);
+      if (K > 2 * BH_RMAX + 1) throw HsError(HESAFF_ERR_ARG, "initialSigma too large for the pyramid kernels (a blur needs more than 15 taps)");
+      c->pyr_K[i] = K;
+      if (K == 1) taps[c->pyr_tap_off[i]] = 1.0f;
+      else hesaff::gauss_taps(K, sigma, taps.data() + c->pyr_tap_off[i]);
    }
+   c->pyr_march = c->pyr_K[1] == 9 && c->pyr_K[2] == 11 && c->pyr_K[3] == 13 && c->pyr_K[4] == 15;
    upload(c->t_pyr_taps, taps);
    const hesaff_params &p = c->par;
    DConsts &k = c->consts;
@@ -279,12 +296,48 @@ void refresh_tables_struct(hesaff_ctx *c)
    t.n_masked = c->n_masked;
 }
 
-DPlane make_plane(float *p, int B, int rows, int cols, int pitch)
+DPlane make_plane(float *p, int rows, int cols, int pitch)
 {
    DPlane d;
    d.p = p; d.rows = rows; d.cols = cols; d.pitch = pitch; d.img_stride = (long long)rows * pitch;
-   (void)B;
    return d;
+}
+
+template <class KERNEL> void set_dyn_lds(KERNEL kern, size_t lds)
+{
+   HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+}
+
+size_t small_extract_lds_bytes(int bin)
+{
+   const int PMAX = bin == 0 ? 41 : 64;
+   const int SSZ = (PMAX * (PMAX + 2 * HS_SMALL_RMAX) + 3) & ~3;
+   return (size_t)(SSZ + (PMAX + 2 * HS_SMALL_RMAX) * PMAX + 16) * 4;
+}
+size_t mid_lds_bytes() { return (size_t)(HS_PATCH_ARR + 32 + 4 * HS_MID_SROW) * 4; }
+size_t big_lds_bytes() { return (size_t)(HS_PATCH_ARR + HS_BIG_TAPS + 4 * HS_BIG_SROW) * 4; }
+
+// geometry of the large-window row kernel for windows up to pmax: LDS per wave = window row + replicated borders + taps
+struct LargeGeom { int srow_stride, tap_stride; size_t lds; };
+LargeGeom large_geom(int pmax)
+{
+   LargeGeom g;
+   // window row + r replicated border samples on each side, r = K/2 <= (6 * 1.5 * P0/41 + 2) / 2
+   g.srow_stride = round_up((int)(pmax * 1.23) + 16, 64);
+   g.tap_stride = round_up((int)(pmax * 0.22) + 8, 64);   // K = odd(int(6 * 1.5 * P0/41 + 1))
+   g.lds = (size_t)4 * (g.srow_stride + g.tap_stride) * 4;
+   return g;
+}
+
+// Dynamic-LDS opt-ins are per device: applied when a context is created on its device (hesaff_create) and, for the
+// large-window kernel whose need depends on the image size, in plan().
+void set_kernel_attrs(hesaff_ctx *c)
+{
+   (void)c;
+   set_dyn_lds(k_patch_extract_small<0>, small_extract_lds_bytes(0));
+   set_dyn_lds(k_patch_extract_small<1>, small_extract_lds_bytes(1));
+   set_dyn_lds(k_patch_mid<HS_MID_PMAX>, mid_lds_bytes());
+   set_dyn_lds(k_patch_mid<HS_BIN3_PMAX>, big_lds_bytes());
 }
 
 // Buffer plan for a batch of B images of H x W.
@@ -292,7 +345,10 @@ void plan(hesaff_ctx *c, int B, int H, int W)
 {
    if (B <= c->B && H == c->H && W == c->W) return;
    if (H < 1 || W < 1 || H > 65535 || W > 65535) throw HsError(HESAFF_ERR_ARG, "image size out of range (1..65535)");
+   // the cached geometry describes buffers that are about to be replaced: a failure below must not leave it valid
+   c->B = c->H = c->W = 0;
    c->oct.clear();
+   c->L.clear();
    long long words = 0;
    size_t L_floats = 0;
    {
@@ -314,14 +370,13 @@ void plan(hesaff_ctx *c, int B, int H, int W)
    const int pitch0 = round_up(W, 64);
    const size_t plane0 = (size_t)B * H * pitch0;
    c->b_gray.ensure(plane0 * 4);
-   c->gray = make_plane(c->b_gray.as<float>(), B, H, W, pitch0);
+   c->gray = make_plane(c->b_gray.as<float>(), H, W, pitch0);
    c->b_L.ensure(std::max<size_t>(L_floats * 4, 16));
-   c->L.clear();
    {
       float *p = c->b_L.as<float>();
       for (const OctGeom &g : c->oct)
          for (int l = 0; l < 3; l++) {
-            c->L.push_back(make_plane(p, B, g.rows, g.cols, g.pitch));
+            c->L.push_back(make_plane(p, g.rows, g.cols, g.pitch));
             p += (size_t)B * g.rows * g.pitch;
          }
    }
@@ -352,11 +407,19 @@ void plan(hesaff_ctx *c, int B, int H, int W)
    c->b_rank.ensure((cap + 1) * 4);
    c->b_desc.ensure(cap * 128);
    c->b_out.ensure(cap * sizeof(KeyRec));
-   c->b_starts.ensure((size_t)(B + 1) * 2 * 4);
-   // patch taps + BIN 3 scratch: P <= sqrt(W*H) + small (the det-1 window must fit)
+   c->b_starts.ensure((size_t)(B + 1) * 3 * 4);
+   // patch taps: P <= sqrt(W*H) + small (the det-1 window must fit)
    const int max_p0 = (int)std::floor(std::sqrt((double)W * (double)H)) + 3;
    ensure_patch_taps(c, max_p0);
    refresh_tables_struct(c);
+   // per-block T' slots of the row-streamed bins (persistent grids of fixed size)
+   c->b_trows2.ensure((size_t)HS_MID_BLOCKS * (HS_MID_PMAX + 2 * HS_MID_RPAD) * HS_NEED * 4);
+   c->b_trows3.ensure((size_t)HS_BIG_BLOCKS * (HS_BIN3_PMAX + 2 * HS_BIG_RPAD) * HS_NEED * 4);
+   {
+      const LargeGeom lg = large_geom(c->max_p0 + 2);
+      if (lg.lds > 160 * 1024) throw HsError(HESAFF_ERR_ARG, "image too large for the large-window row kernel");
+      if (lg.lds > c->rows_lds_set) { set_dyn_lds(k_patch_large_rows, lg.lds); c->rows_lds_set = lg.lds; }
+   }
    c->B = B; c->H = H; c->W = W;
 }
 
@@ -371,73 +434,55 @@ template <class LOAD> void exclusive_scan(hesaff_ctx *c, LOAD load, long long n,
    hipLaunchKernelGGL(k_scan_down<LOAD>, dim3(nb), dim3(256), 0, c->stream, load, n, bs, out);
 }
 
+// Stage timers: one HIP event pair per bracket, recorded on the stream the bracketed work is launched on.
 struct StageTimer {
    hesaff_ctx *c;
    std::vector<EvPair> pairs;
+   std::vector<hipStream_t> streams;
    explicit StageTimer(hesaff_ctx *ctx) : c(ctx) {}
-   int begin(int kind, double bytes = 0)
+   int begin(int kind, double bytes = 0, hipStream_t st = nullptr)
    {
       if (!c->profiling) return -1;
       if (kind >= 100 && c->profiling < 2) return -1;
+      if (!st) st = c->stream;
       EvPair p; p.a = get_event(c); p.b = get_event(c); p.kind = kind; p.bytes = bytes;
-      (void)hipEventRecord(p.a, c->stream);
+      (void)hipEventRecord(p.a, st);
       pairs.push_back(p);
+      streams.push_back(st);
       return (int)pairs.size() - 1;
    }
-   void end(int id) { if (id >= 0) (void)hipEventRecord(pairs[id].b, c->stream); }
+   void end(int id) { if (id >= 0) (void)hipEventRecord(pairs[id].b, streams[id]); }
 };
 
-enum { T_PYR = 0, T_DET = 1, T_AFF = 2, T_PATCH = 3, T_SIFT = 4, T_TOTAL = 5, T_BLURHESS = 100 };
+enum { T_PYR = 0, T_DET = 1, T_AFF = 2, T_PATCH = 3, T_SIFT = 4, T_TOTAL = 5, T_PACK = 6, T_BLURHESS = 100 };
 
-// Band height of k_blur_hess_march.  The kernel is VALU-bound and every wavefront does the
-// same amount of work per row, so a launch costs  rounds x steps:  rounds = how many times the
-// resident-block capacity (256 CUs x blocks per CU) is refilled, steps = rows a wavefront
-// marches through (band + K + 1 warm-up rows, padded to the unroll factor K + 1).  Pick the
-// band count that minimises it (ties: fewer, taller bands = less warm-up).
+// Band height of k_blur_hess_march: 16 bands per octave is the measured optimum for 16 x 4K at every octave
+// (sweeps in profiles/r01_notes.md); small batches get proportionally more bands to keep ~1000 blocks in flight.
 template <int K, bool WL, bool WR, bool WH, bool WR0 = false>
 void launch_march(hesaff_ctx *c, const DPlane &in, const DPlane &outL, const DPlane &outR, const DPlane &outHalf, const float *taps,
                   float norm2, int B, const DPlane &outR0 = DPlane(), float norm2_in = 0.0f)
 {
-   static int occ = 0;   // resident 256-thread blocks per CU for this instantiation
-   if (occ == 0) {
-      int nb = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_blur_hess_march<K, WL, WR, WH, WR0>, 256, 0) != hipSuccess || nb < 1) nb = 3;
-      occ = nb;
-   }
-   constexpr int U = K + 1;
    const int strips = (in.cols + BM_STRIP - 1) / BM_STRIP;
    const long long blocks_per_band = (long long)((strips + 3) / 4) * B;
-   const long long capacity = 256LL * occ;
-   // Measured on MI355X (16 x 4K): the launch is bandwidth/latency-bound, not issue-bound, once
-   // about 2/3 of the resident-block capacity is filled; beyond that more (shorter) bands only
-   // add warm-up rows.  So: blocks ~ 0.65 x capacity, bands at least 32 rows tall.
-   (void)capacity;
-   // 16 bands is the measured optimum for 16 x 4K at every octave (sweeps in profiles/r01_notes.md);
-   // small batches get proportionally more bands to keep ~1000 blocks in flight on octave 0.
    int best_nb = 16 * (int)std::max<long long>(1, std::min<long long>(4, 64 / std::max<long long>(1, blocks_per_band)));
    best_nb = std::max(1, std::min(best_nb, std::max(1, in.rows / 8)));
-   (void)U;
    if (c->force_bands > 0) best_nb = std::min(c->force_bands, in.rows);
    const int band = (in.rows + best_nb - 1) / best_nb;
-   if (c->debug) fprintf(stderr, "[hesaff] march K=%d %dx%d B=%d occ=%d bands=%d band=%d blocks=%lld\n", K, in.cols, in.rows, B, occ, best_nb, band, blocks_per_band * best_nb);
+   if (c->debug) fprintf(stderr, "[hesaff] march K=%d %dx%d B=%d bands=%d band=%d blocks=%lld\n", K, in.cols, in.rows, B, best_nb, band, blocks_per_band * best_nb);
    const dim3 grid((strips + 3) / 4, (in.rows + band - 1) / band, B);
    hipLaunchKernelGGL((k_blur_hess_march<K, WL, WR, WH, WR0>), grid, dim3(256), 0, c->stream, in, outL, outR, outHalf, taps, norm2, band, outR0, norm2_in);
 }
 
 template <bool WL, bool WR, bool WH>
-void launch_blur_hess(hesaff_ctx *c, const DPlane &in, const DPlane &outL, const DPlane &outR, const DPlane &outHalf, int tapIdx,
+void launch_blur_hess(hesaff_ctx *c, const DPlane &in, const DPlane &outL, const DPlane &outR, const DPlane &outHalf, const float *taps, int K,
                       float norm2, int B)
 {
-   const float *taps = c->t_pyr_taps.as<float>() + c->pyr_tap_off[tapIdx];
-   const int K = c->pyr_K[tapIdx];
-   if (!c->use_tile_kernel) {
-      switch (K) {
-         case 9: launch_march<9, WL, WR, WH>(c, in, outL, outR, outHalf, taps, norm2, B); return;
-         case 11: launch_march<11, WL, WR, WH>(c, in, outL, outR, outHalf, taps, norm2, B); return;
-         case 13: launch_march<13, WL, WR, WH>(c, in, outL, outR, outHalf, taps, norm2, B); return;
-         case 15: launch_march<15, WL, WR, WH>(c, in, outL, outR, outHalf, taps, norm2, B); return;
-         default: break;   // non-default initialSigma: generic tile kernel
-      }
+   switch (K) {
+      case 9: launch_march<9, WL, WR, WH>(c, in, outL, outR, outHalf, taps, norm2, B); return;
+      case 11: launch_march<11, WL, WR, WH>(c, in, outL, outR, outHalf, taps, norm2, B); return;
+      case 13: launch_march<13, WL, WR, WH>(c, in, outL, outR, outHalf, taps, norm2, B); return;
+      case 15: launch_march<15, WL, WR, WH>(c, in, outL, outR, outHalf, taps, norm2, B); return;
+      default: break;   // non-default initialSigma: generic tile kernel
    }
    const dim3 grid((in.cols + BH_TW - 1) / BH_TW, (in.rows + BH_TH - 1) / BH_TH, B);
    hipLaunchKernelGGL((k_blur_hess_tile<WL, WR, WH>), grid, dim3(256), 0, c->stream, in, outL, outR, outHalf, taps, K, norm2);
@@ -477,34 +522,10 @@ Lists make_lists(hesaff_ctx *c)
    return s;
 }
 
-template <class KERNEL> void set_dyn_lds(KERNEL kern, size_t lds)
-{
-   HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-}
-
-size_t small_extract_lds_bytes(int bin)
-{
-   const int PMAX = bin == 0 ? 41 : 64;
-   const int SSZ = (PMAX * (PMAX + 2 * HS_SMALL_RMAX) + 3) & ~3;
-   return (size_t)(SSZ + (PMAX + 2 * HS_SMALL_RMAX) * PMAX + 16) * 4;
-}
-
-size_t small_lds_bytes(int bin, bool fused = true)
-{
-   const int PMAX = bin == 0 ? 41 : 64;
-   const int WIN = (PMAX * PMAX + 3) & ~3;
-   if (!fused) return (size_t)(2 * WIN + 16) * 4;
-   const int REGION = std::max(2 * WIN, 2 * HS_SIFT_ARR);
-   return (size_t)(REGION + 128 + HS_SIFT_ARR + 8 + HS_SIFT_TAB + 16) * 4;
-}
-size_t mid_lds_bytes(bool fused) { return (size_t)(HS_MID_PMAX * HS_NEED + (fused ? 128 + HS_SIFT_TAB : 0) + HS_SIFT_ARR + 8 + 32 + 4 * HS_MID_SROW) * 4; }
-size_t mid_tpg_lds_bytes() { return (size_t)(HS_SIFT_ARR + 8 + 32 + 4 * HS_MID_SROW) * 4; }
-size_t big_lds_bytes(bool fused) { return (size_t)((fused ? 2 * HS_SIFT_ARR + 128 + HS_SIFT_TAB : 0) + HS_SIFT_ARR + 8 + HS_BIG_TAPS + 4 * HS_BIG_SROW) * 4; }
-
-// normalizeAffine + SIFT for every keypoint k_prepare_patch left alive.  The bin counts are
-// read back once (a ~20 us bubble per batch) so that every launch is sized exactly and the
-// large windows can be processed in rounds that fit the T' row buffer.
-void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *patches_out, uint32_t h_base, int flags)
+// normalizeAffine for every keypoint k_prepare_patch left alive and binned.  Every launch is a persistent grid of
+// fixed size that reads its work-list length from the device-side bin counters: the host never waits for them.
+// large_rows_bound: upper bound of the large bin's T' rows in this group (from k_image_large_rows).
+void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *patches_out, uint32_t h_base, uint32_t large_rows_bound)
 {
    hipStream_t st = c->stream;
    PatchIO io;
@@ -512,30 +533,11 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
    io.image = image;
    io.patches = patches_out;
    io.h_base = h_base;
-   io.desc = c->b_desc.as<uint8_t>();
-   uint32_t bins[HS_NBINS];
-   HIP_TRY(hipMemcpyAsync(bins, s.pw.bin_count, sizeof bins, hipMemcpyDeviceToHost, st));
-   HIP_TRY(hipStreamSynchronize(st));
-   if (c->debug) fprintf(stderr, "[hesaff] patch bins (P<=41, 64, 128, 512, larger): %u %u %u %u %u\n", bins[0], bins[1], bins[2], bins[3], bins[4]);
-   static bool attrs = false;
-   if (!attrs) {
-      set_dyn_lds((k_patch_small<0, true>), small_lds_bytes(0));
-      set_dyn_lds((k_patch_small<1, true>), small_lds_bytes(1));
-      set_dyn_lds(k_patch_extract_small<0>, small_extract_lds_bytes(0));
-      set_dyn_lds(k_patch_extract_small<1>, small_extract_lds_bytes(1));
-      set_dyn_lds((k_patch_small<0, false>), small_lds_bytes(0, false));
-      set_dyn_lds((k_patch_small<1, false>), small_lds_bytes(1, false));
-      set_dyn_lds(k_patch_mid<HS_MID_PMAX, true>, mid_lds_bytes(true));
-      set_dyn_lds(k_patch_mid<HS_BIN3_PMAX, true>, big_lds_bytes(true));
-      set_dyn_lds((k_patch_mid<HS_MID_PMAX, false, true>), mid_tpg_lds_bytes());
-      set_dyn_lds(k_patch_mid<HS_BIN3_PMAX, false>, big_lds_bytes(false));
-      attrs = true;
-   }
    // The bins are independent (disjoint keypoints) and each kernel leaves CU resources idle
-   // (LDS- or latency-bound), so they run concurrently on side streams; the large-window bins
-   // stay on the main stream (they need host round trips for their row prefix).
+   // (LDS- or latency-bound), so they run concurrently on side streams.
    hipStream_t s0 = st, s1 = st, s2 = st, s3 = st;
-   if (c->side_streams[0] && !c->no_overlap) {
+   const bool forked = c->side_streams[0] && !c->no_overlap;
+   if (forked) {
       HIP_TRY(hipEventRecord(c->ev_fork, st));
       for (int i = 0; i < HS_NSIDE; i++) HIP_TRY(hipStreamWaitEvent(c->side_streams[i], c->ev_fork, 0));
       if (c->side_mask & 1) s0 = c->side_streams[0];
@@ -543,80 +545,32 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
       if (c->side_mask & 4) s2 = c->side_streams[2];
       if (c->side_mask & 8) s3 = c->side_streams[3];
    }
-   if ((flags & 1) != 0) {
-      if (bins[0]) hipLaunchKernelGGL((k_patch_small<0, true>), dim3(std::min<uint32_t>(bins[0], 256 * 8)), dim3(256), small_lds_bytes(0), s0, s.hl, s.pw, io, c->tables, c->consts, flags);
-      if (bins[1]) hipLaunchKernelGGL((k_patch_small<1, true>), dim3(std::min<uint32_t>(bins[1], 256 * 4)), dim3(256), small_lds_bytes(1), s1, s.hl, s.pw, io, c->tables, c->consts, flags);
-   } else {
-      if (c->old_small) {
-         if (bins[0]) hipLaunchKernelGGL((k_patch_small<0, false>), dim3(std::min<uint32_t>(bins[0], 256 * 8)), dim3(256), small_lds_bytes(0, false), s0, s.hl, s.pw, io, c->tables, c->consts, flags);
-         if (bins[1]) hipLaunchKernelGGL((k_patch_small<1, false>), dim3(std::min<uint32_t>(bins[1], 256 * 4)), dim3(256), small_lds_bytes(1, false), s1, s.hl, s.pw, io, c->tables, c->consts, flags);
-      } else {
-         if (bins[0]) hipLaunchKernelGGL(k_patch_extract_small<0>, dim3(std::min<uint32_t>(bins[0], 256 * 8)), dim3(256), small_extract_lds_bytes(0), s0, s.hl, s.pw, io, c->tables, flags);
-         if (bins[1]) hipLaunchKernelGGL(k_patch_extract_small<1>, dim3(std::min<uint32_t>(bins[1], 256 * 4)), dim3(256), small_extract_lds_bytes(1), s1, s.hl, s.pw, io, c->tables, flags);
-      }
-   }
-   const bool fused = (flags & 1) != 0;
-   if (bins[2]) {
-      if (fused) hipLaunchKernelGGL((k_patch_mid<HS_MID_PMAX, true>), dim3(std::min<uint32_t>(bins[2], 256 * 3)), dim3(256), mid_lds_bytes(true), s2, s.hl, s.pw, io, c->tables, c->consts, flags);
-      else {
-         const uint32_t nblk = std::min<uint32_t>(bins[2], 256 * 7);
-         c->b_trows2.ensure((size_t)nblk * (HS_MID_PMAX + 2 * HS_MID_RPAD) * HS_NEED * 4);
-         PatchIO io2 = io;
-         io2.trows = c->b_trows2.as<float>();
-         hipLaunchKernelGGL((k_patch_mid<HS_MID_PMAX, false, true>), dim3(nblk), dim3(256), mid_tpg_lds_bytes(), s2, s.hl, s.pw, io2, c->tables, c->consts, flags);
-      }
-   }
-   if (bins[3]) {
-      // bin 3 (128 < P <= 512): same kernel, T' rows in a per-block HBM slot; on its own side stream so that the
-      // host round trip of the bin-4 row prefix below does not wait for it
-      const uint32_t nblk = std::min<uint32_t>(bins[3], 256 * (fused ? 4 : 8));
-      c->b_trows3.ensure((size_t)nblk * (HS_BIN3_PMAX + 2 * HS_BIG_RPAD) * HS_NEED * 4);
+   hipLaunchKernelGGL(k_patch_extract_small<0>, dim3(256 * 8), dim3(256), small_extract_lds_bytes(0), s0, s.hl, s.pw, io, c->tables);
+   hipLaunchKernelGGL(k_patch_extract_small<1>, dim3(256 * 4), dim3(256), small_extract_lds_bytes(1), s1, s.hl, s.pw, io, c->tables);
+   {
+      PatchIO io2 = io;
+      io2.trows = c->b_trows2.as<float>();
+      hipLaunchKernelGGL(k_patch_mid<HS_MID_PMAX>, dim3(HS_MID_BLOCKS), dim3(256), mid_lds_bytes(), s2, s.hl, s.pw, io2, c->tables);
       PatchIO io3 = io;
       io3.trows = c->b_trows3.as<float>();
-      if (fused) hipLaunchKernelGGL((k_patch_mid<HS_BIN3_PMAX, true>), dim3(nblk), dim3(256), big_lds_bytes(true), s3, s.hl, s.pw, io3, c->tables, c->consts, flags);
-      else hipLaunchKernelGGL((k_patch_mid<HS_BIN3_PMAX, false>), dim3(nblk), dim3(256), big_lds_bytes(false), s3, s.hl, s.pw, io3, c->tables, c->consts, flags);
+      hipLaunchKernelGGL(k_patch_mid<HS_BIN3_PMAX>, dim3(HS_BIG_BLOCKS), dim3(256), big_lds_bytes(), s3, s.hl, s.pw, io3, c->tables);
    }
-   const bool forked = c->side_streams[0] && !c->no_overlap;
-   if (forked) {
+   if (forked)
       for (int i = 0; i < HS_NSIDE; i++) HIP_TRY(hipEventRecord(c->ev_join[i], c->side_streams[i]));
-   }
-   // large windows: bin 3 (P <= 512, small LDS rows -> full occupancy) and bin 4 (the rare huge ones)
-   for (int lb = 4; lb <= 4; lb++) {
-      const uint32_t n3 = bins[lb];
-      if (!n3) continue;
-      // exclusive prefix of P over the bin -> row ids
-      c->b_rowprefix.ensure((size_t)(n3 + 1) * 4);
-      uint32_t *pre = c->b_rowprefix.as<uint32_t>();
-      LoadLargeP lp; lp.items = s.pw.bin_items + (size_t)lb * s.pw.cap; lp.P0 = s.pw.P0;
-      exclusive_scan(c, lp, (long long)n3, pre, pre + n3);
-      std::vector<uint32_t> hpre(n3 + 1);
-      HIP_TRY(hipMemcpyAsync(hpre.data(), pre, (size_t)(n3 + 1) * 4, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      // window row + r replicated border samples on each side, r = K/2 <= (6 * 1.5 * P0/41 + 2) / 2
-      const int pmax = lb == 3 ? HS_BIN3_PMAX : c->max_p0 + 2;
-      const int srow_stride = round_up((int)(pmax * 1.23) + 16, 64);
-      const int tap_stride = round_up((int)(pmax * 0.22) + 8, 64);   // K = odd(int(6 * 1.5 * P0/41 + 1))
-      const size_t rows_lds = (size_t)4 * (srow_stride + tap_stride) * 4;
-      if (rows_lds > 160 * 1024) throw HsError(HESAFF_ERR_ARG, "image too large for the large-window row kernel");
-      static size_t rows_lds_set = 0;
-      if (rows_lds > rows_lds_set) { set_dyn_lds(k_patch_large_rows, rows_lds); rows_lds_set = rows_lds; }
-      const uint32_t budget = c->trows_budget;
-      c->b_trows.ensure((size_t)budget * HS_NEED * 4);
+   // the rare huge windows (P > 512): row tasks over all of them, then one block per keypoint
+   if (large_rows_bound > 0) {
+      const uint32_t rows_cap = std::max(large_rows_bound, c->trows_rows);
+      c->b_trows.ensure((size_t)rows_cap * HS_NEED * 4);
+      c->b_rowprefix.ensure(((size_t)c->cap + 1) * 4);
+      const LargeGeom lg = large_geom(c->max_p0 + 2);
       io.trows = c->b_trows.as<float>();
-      io.row_prefix = pre;
-      io.bin = lb;
-      uint32_t k0 = 0;
-      while (k0 < n3) {
-         uint32_t k1 = k0 + 1;
-         while (k1 < n3 && hpre[k1 + 1] - hpre[k0] <= budget) k1++;
-         const uint32_t rows = hpre[k1] - hpre[k0];
-         if (rows > budget) throw HsError(HESAFF_ERR_NOMEM, "window larger than the T' row buffer");
-         io.item0 = k0; io.item1 = k1;
-         const uint32_t gblocks = std::min<uint32_t>((rows + 4 * HS_LARGE_CHUNK - 1) / (4 * HS_LARGE_CHUNK), 256 * 16);
-         hipLaunchKernelGGL(k_patch_large_rows, dim3(gblocks), dim3(256), rows_lds, st, s.hl, s.pw, io, c->tables, srow_stride, tap_stride, flags);
-         hipLaunchKernelGGL(k_patch_large_finish, dim3(std::min<uint32_t>(k1 - k0, 256 * 8)), dim3(256), 0, st, s.hl, s.pw, io, c->tables, c->consts, flags);
-         k0 = k1;
-      }
+      io.row_prefix = c->b_rowprefix.as<uint32_t>();
+      io.trows_cap = rows_cap;
+      io.overflow = s.counters + 6;
+      hipLaunchKernelGGL(k_large_prefix, dim3(1), dim3(256), 0, st, s.pw, c->b_rowprefix.as<uint32_t>());
+      const uint32_t gblocks = std::min<uint32_t>((large_rows_bound + 4 * HS_LARGE_CHUNK - 1) / (4 * HS_LARGE_CHUNK), 256 * 16);
+      hipLaunchKernelGGL(k_patch_large_rows, dim3(gblocks), dim3(256), lg.lds, st, s.hl, s.pw, io, c->tables, lg.srow_stride, lg.tap_stride);
+      hipLaunchKernelGGL(k_patch_large_finish, dim3(256 * 4), dim3(256), 0, st, s.pw, io, c->tables);
    }
    if (forked)
       for (int i = 0; i < HS_NSIDE; i++) HIP_TRY(hipStreamWaitEvent(st, c->ev_join[i], 0));
@@ -630,21 +584,23 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
    const hesaff::OctaveSchedule &sc = c->sched;
    hipStream_t st = c->stream;
    uint32_t *cnt = s.counters;
+   const float *ptaps = c->t_pyr_taps.as<float>();
    HIP_TRY(hipMemsetAsync(cnt, 0, 64 * 4, st));
    HIP_TRY(hipMemsetAsync(c->b_bitmask.p, 0, std::max<size_t>((size_t)B * c->words_per_image * 8, 8), st));
 
    int t = tm.begin(T_PYR);
+   DPlane none = make_plane(nullptr, 0, 0, 0);
    {
+      // grey conversion hesaff.cpp:138-148; without an initial blur (initialSigma <= 0.5) it writes the first level directly
+      const bool direct = c->pyr_K[0] == 0 && !c->oct.empty();
       const dim3 grid((c->W + 255) / 256, c->H, B);
-      DPlane g = c->gray;
-      hipLaunchKernelGGL(k_gray, grid, dim3(256), 0, st, d_src, channels, src_img_stride, src_row_stride, g);
+      hipLaunchKernelGGL(k_gray, grid, dim3(256), 0, st, d_src, channels, src_img_stride, src_row_stride, c->gray);
+      if (direct) HIP_TRY(hipMemcpyAsync(c->L[0].p, c->gray.p, (size_t)B * c->gray.img_stride * 4, hipMemcpyDeviceToDevice, st));
    }
-   DPlane none = make_plane(nullptr, B, 0, 0, 0);
-   if (!c->oct.empty()) {
-      // pyramid.cpp:276-280 initial blur 0.5 -> 1.6
-      DPlane L00 = c->L[0];
+   if (!c->oct.empty() && c->pyr_K[0] > 0) {
+      // pyramid.cpp:276-280 initial blur 0.5 -> initialSigma
       const int tb = tm.begin(T_BLURHESS, 0);   // initial blur: not counted in the 12N launches (bytes 0)
-      launch_blur_hess<true, false, false>(c, c->gray, L00, none, none, 0, 0.0f, B);
+      launch_blur_hess<true, false, false>(c, c->gray, c->L[0], none, none, ptaps + c->pyr_tap_off[0], c->pyr_K[0], 0.0f, B);
       tm.end(tb);
    }
    tm.end(t);
@@ -654,14 +610,14 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
       const size_t planeF = (size_t)B * g.rows * g.pitch;
       DPlane Lo[5], Ro[5];
       for (int l = 0; l < 3; l++) Lo[l] = c->L[o * 3 + l];
-      Lo[3] = make_plane(c->b_L3.as<float>(), B, g.rows, g.cols, g.pitch);
+      Lo[3] = make_plane(c->b_L3.as<float>(), g.rows, g.cols, g.pitch);
       Lo[4] = none;
-      if (keep_all_planes) Lo[4] = make_plane(c->b_stage.as<float>(), B, g.rows, g.cols, g.pitch);
-      for (int l = 0; l < 5; l++) Ro[l] = make_plane(c->b_R.as<float>() + l * planeF, B, g.rows, g.cols, g.pitch);
+      if (keep_all_planes) Lo[4] = make_plane(c->b_stage.as<float>(), g.rows, g.cols, g.pitch);
+      for (int l = 0; l < 5; l++) Ro[l] = make_plane(c->b_R.as<float>() + l * planeF, g.rows, g.cols, g.pitch);
       t = tm.begin(T_PYR);
       // R0 = hessianResponse(L0) (pyramid.cpp:230) is fused into the first blur launch when the
       // marching kernel handles it (default sigmas: K = 9); otherwise a separate pass.
-      const bool fuse_r0 = !c->use_tile_kernel && c->pyr_K[1] == 9;
+      const bool fuse_r0 = c->pyr_march;
       if (!fuse_r0) {
          const dim3 grid((g.cols + 255) / 256, g.rows, B);
          hipLaunchKernelGGL(k_hess, grid, dim3(256), 0, st, Lo[0], Ro[0], sc.norm2[0]);
@@ -673,17 +629,17 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
          double bytes = 12.0 * (double)B * g.rows * g.cols;
          if (i == 1 && fuse_r0) bytes += 8.0 * (double)B * g.rows * g.cols;
          if (i == 3 && has_next) bytes += 2.0 * (double)B * g.rows * g.cols;
+         const float *taps = ptaps + c->pyr_tap_off[i];
+         const int K = c->pyr_K[i];
          const int tb = tm.begin(T_BLURHESS, bytes);
-         if (i == 1 && fuse_r0)
-            launch_march<9, true, true, false, true>(c, Lo[0], Lo[1], Ro[1], none, c->t_pyr_taps.as<float>() + c->pyr_tap_off[1], sc.norm2[1], B,
-                                                     Ro[0], sc.norm2[0]);
-         else if (i < 3) launch_blur_hess<true, true, false>(c, Lo[i - 1], Lo[i], Ro[i], none, i, sc.norm2[i], B);
+         if (i == 1 && fuse_r0) launch_march<9, true, true, false, true>(c, Lo[0], Lo[1], Ro[1], none, taps, sc.norm2[1], B, Ro[0], sc.norm2[0]);
+         else if (i < 3) launch_blur_hess<true, true, false>(c, Lo[i - 1], Lo[i], Ro[i], none, taps, K, sc.norm2[i], B);
          else if (i == 3) {
-            if (has_next) launch_blur_hess<true, true, true>(c, Lo[2], Lo[3], Ro[3], c->L[(o + 1) * 3], 3, sc.norm2[3], B);
-            else launch_blur_hess<true, true, false>(c, Lo[2], Lo[3], Ro[3], none, 3, sc.norm2[3], B);
+            if (has_next) launch_blur_hess<true, true, true>(c, Lo[2], Lo[3], Ro[3], c->L[(o + 1) * 3], taps, K, sc.norm2[3], B);
+            else launch_blur_hess<true, true, false>(c, Lo[2], Lo[3], Ro[3], none, taps, K, sc.norm2[3], B);
          } else {
-            if (keep_all_planes) launch_blur_hess<true, true, false>(c, Lo[3], Lo[4], Ro[4], none, 4, sc.norm2[4], B);
-            else launch_blur_hess<false, true, false>(c, Lo[3], none, Ro[4], none, 4, sc.norm2[4], B);
+            if (keep_all_planes) launch_blur_hess<true, true, false>(c, Lo[3], Lo[4], Ro[4], none, taps, K, sc.norm2[4], B);
+            else launch_blur_hess<false, true, false>(c, Lo[3], none, Ro[4], none, taps, K, sc.norm2[4], B);
          }
          tm.end(tb);
       }
@@ -715,16 +671,11 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
       if (g.rows > 2 * HS_BORDER && g.cols > 2 * HS_BORDER) {
          FivePlanes fp;
          for (int l = 0; l < 5; l++) fp.R[l] = Ro[l];
-         if (c->use_tile_extrema) {
-            const dim3 grid((g.cols + EX_TW - 1) / EX_TW, (g.rows + EX_TH - 1) / EX_TH, B);
-            hipLaunchKernelGGL(k_extrema3, grid, dim3(256), 0, st, fp, c->consts.positiveThreshold, c->consts.negativeThreshold, s.cl);
-         } else {
-            // bands of 64 rows; 32 when that would leave the chip short of wavefronts
-            const int strips = (g.cols + EXM_STRIP - 1) / EXM_STRIP;
-            const int band = ((long long)strips * ((g.rows + 63) / 64) * B >= 4096) ? 64 : 32;
-            const dim3 grid(strips, (g.rows + band - 1) / band, B);
-            hipLaunchKernelGGL(k_extrema_march, grid, dim3(64), 0, st, fp, c->consts.positiveThreshold, c->consts.negativeThreshold, s.cl, band);
-         }
+         // bands of 64 rows; 32 when that would leave the chip short of wavefronts
+         const int strips = (g.cols + EXM_STRIP - 1) / EXM_STRIP;
+         const int band = ((long long)strips * ((g.rows + 63) / 64) * B >= 4096) ? 64 : 32;
+         const dim3 grid(strips, (g.rows + band - 1) / band, B);
+         hipLaunchKernelGGL(k_extrema_march, grid, dim3(64), 0, st, fp, c->consts.positiveThreshold, c->consts.negativeThreshold, s.cl, band);
          hipLaunchKernelGGL(k_localize, dim3(1024), dim3(256), 0, st, oc, s.cl, s.rl, c->consts);
          hipLaunchKernelGGL(k_dedupe, dim3(512), dim3(256), 0, st, oc, s.rl, (const uint32_t *)(cnt + 16 + o),
                             c->b_bitmask.as<unsigned long long>());
@@ -740,6 +691,10 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
                       (const uint32_t *)c->b_prefix.p, s.hl);
    hipLaunchKernelGGL(k_image_counts, dim3((B + 1 + 63) / 64), dim3(64), 0, st, (const uint32_t *)c->b_prefix.p,
                       c->words_per_image, B, (const uint32_t *)(cnt + 3), c->b_starts.as<int32_t>());
+   // per image: upper bound of the T' rows its huge windows (P > 512) need, known from the scales alone
+   HIP_TRY(hipMemsetAsync(c->b_starts.as<int32_t>() + 2 * (B + 1), 0, (size_t)(B + 1) * 4, st));
+   hipLaunchKernelGGL(k_image_large_rows, dim3(512), dim3(256), 0, st, s.hl, (const uint32_t *)(cnt + 3), c->consts.mrSize,
+                      c->b_starts.as<uint32_t>() + 2 * (B + 1));
    tm.end(t);
 }
 
@@ -765,6 +720,7 @@ void collect_timings(hesaff_ctx *c, StageTimer &tm, int B)
          case T_AFF: t.affine_ms += ms; break;
          case T_PATCH: t.patch_ms += ms; break;
          case T_SIFT: t.sift_ms += ms; break;
+         case T_PACK: t.pack_ms += ms; break;
          case T_TOTAL: t.total_ms += ms; break;
          case T_BLURHESS:
             if (p.bytes > 0) { t.blur_hess_ms += ms; t.blur_hess_launches++; t.blur_hess_bytes += p.bytes; }
@@ -774,6 +730,32 @@ void collect_timings(hesaff_ctx *c, StageTimer &tm, int B)
    double sumN = 0;
    for (const OctGeom &g : c->oct) sumN += (double)g.rows * g.cols;
    t.pyramid_bytes = (double)B * (5.0 * c->H * c->W + 58.0 * sumN);
+}
+
+// The descriptor kernels (kernels_sift.h) over n patches in HBM.
+void launch_sift(hesaff_ctx *c, hipStream_t ss, const SiftIO &so, uint32_t n, float2 *vo)
+{
+   const uint32_t nb64 = (n + 63) / 64;
+   hipLaunchKernelGGL(k_sift_meanvar, dim3(nb64), dim3(64), 0, ss, so, c->tables);
+   hipLaunchKernelGGL(k_sift_grad, dim3(n), dim3(256), 0, ss, so, c->tables, vo);
+   hipLaunchKernelGGL(k_sift_hist, dim3(std::min<uint32_t>((n + 3) / 4, 256 * 32)), dim3(64), 0, ss, so, c->tables, (const float2 *)vo);
+   hipLaunchKernelGGL(k_sift_quantize, dim3(nb64), dim3(64), 0, ss, so, c->consts);
+}
+
+// per-group patch / descriptor buffers (two slots): sized once per batch for the largest group
+void ensure_group_buffers(hesaff_ctx *c, uint32_t n)
+{
+   for (int slot = 0; slot < 2; slot++) {
+      c->b_patches2[slot].ensure((size_t)n * HS_PATCH_PIX * 4);
+      c->b_siftvec2[slot].ensure((size_t)n * 128 * 4);
+      c->b_meanvar2[slot].ensure((size_t)n * 2 * 4);
+      // the (mask*grad, o) pairs of pixels outside the circular mask stay (0, 0): zero-fill on (re)allocation
+      const void *before = c->b_siftvo2[slot].p;
+      const size_t bytes_before = c->b_siftvo2[slot].bytes;
+      c->b_siftvo2[slot].ensure((size_t)n * HS_VO_PITCH * 8 + 64);
+      if (c->b_siftvo2[slot].p != before || c->b_siftvo2[slot].bytes != bytes_before)
+         HIP_TRY(hipMemsetAsync(c->b_siftvo2[slot].p, 0, c->b_siftvo2[slot].bytes, c->stream));
+   }
 }
 
 // Whole hot path on a device-resident batch.  Leaves ordered KeyRec records in b_out and
@@ -788,47 +770,38 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
    uint32_t *cnt = s.counters;
    const int tt = tm.begin(T_TOTAL);
    run_detection(c, d_src, channels, src_img_stride, src_row_stride, B, s, tm, false, nullptr);
-   if (c->stop_after_detect) {
-      // HESAFF_STOP=detect (kernel tuning only): time the scale-space + detection part alone
-      tm.end(tt);
-      HIP_TRY(hipStreamSynchronize(st));
-      if (c->profiling) collect_timings(c, tm, B);
-      c->h_starts.assign(2 * (B + 1) + 8, 0);
-      return;
-   }
 
    int t;
    PlaneTab pt;
    memset(&pt, 0, sizeof pt);
    for (size_t o = 0; o < c->oct.size(); o++)
       for (int l = 0; l < 3; l++) pt.L[o][l] = c->L[o * 3 + l];
-   if (c->fused_sift) {
-      // one kernel per window-size bin does normalizeAffine + SIFT (HESAFF_SIFT=fused)
-      t = tm.begin(T_AFF);
-      hipLaunchKernelGGL(k_affine, dim3(256 * 6), dim3(64), 0, st, pt, s.hl, 0u, 0xffffffffu, (const uint32_t *)(cnt + 3), c->tables, c->consts, s.ao);
-      tm.end(t);
-      t = tm.begin(T_PATCH);
-      hipLaunchKernelGGL(k_prepare_patch, dim3(1024), dim3(256), 0, st, s.hl, 0u, (const uint32_t *)(cnt + 3), s.ao, H, W, c->consts,
-                         c->tables, s.pw);
-      run_patch_stage(c, s, c->gray, nullptr, 0, 1 | c->ablate);
-      tm.end(t);
-   } else {
-      // split form: the bin kernels only extract the 41x41 patches (to HBM), the descriptor runs
-      // as three kernels with the parallel axis each part wants (kernels_sift.h).  Images are
-      // processed in groups so that the patch buffer stays bounded.
-      std::vector<int32_t> hs(B + 1);
-      HIP_TRY(hipMemcpyAsync(hs.data(), c->b_starts.p, (size_t)(B + 1) * 4, hipMemcpyDeviceToHost, st));
+   {
+      // The one host round trip of a batch: per-image Hessian counts + large-window row bounds.  The bin kernels
+      // only extract the 41x41 patches (to HBM); the descriptor runs as four kernels with the parallel axis each
+      // part wants (kernels_sift.h).  Images are processed in groups so that the patch buffers stay bounded.
+      std::vector<int32_t> hs(3 * (B + 1));
+      HIP_TRY(hipMemcpyAsync(hs.data(), c->b_starts.p, (size_t)3 * (B + 1) * 4, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipEventRecord(c->ev_detect_done, st));
       HIP_TRY(hipStreamSynchronize(st));
       if ((uint32_t)hs[B] > c->cap) throw HsError(HESAFF_ERR_CAPACITY, "keypoint capacity exceeded; raise hesaff_params.max_kpts_per_mpx");
+      const uint32_t *lrows = (const uint32_t *)hs.data() + 2 * (B + 1);
       // image groups [h_lo, h_hi) of at most group_kpts keypoints: about 16 groups per batch keep the
-      // three-stage pipeline full, between 300 k (launch overheads) and 1.2 M keypoints (buffer size)
+      // three-stage pipeline full, between 300 k (launch overheads) and 1.2 M keypoints (buffer size);
+      // the T' rows of a group's huge windows must fit the row buffer (a single image may exceed it: the buffer grows)
       const uint32_t group_kpts = c->sift_group_kpts ? c->sift_group_kpts : std::min<uint32_t>(std::max<uint32_t>((uint32_t)hs[B] / 16u, 300000u), 1200000u);
-      std::vector<std::pair<uint32_t, uint32_t>> groups;
+      struct Group { uint32_t lo, hi, large_rows; };
+      std::vector<Group> groups;
+      uint32_t max_n = 0;
       for (int g0 = 0; g0 < B;) {
          int g1 = g0 + 1;
-         while (g1 < B && (uint32_t)(hs[g1 + 1] - hs[g0]) <= group_kpts) g1++;
-         if (hs[g1] > hs[g0]) groups.push_back({(uint32_t)hs[g0], (uint32_t)hs[g1]});
+         unsigned long long rows = lrows[g0];
+         while (g1 < B && (uint32_t)(hs[g1 + 1] - hs[g0]) <= group_kpts && rows + lrows[g1] <= c->trows_rows) { rows += lrows[g1]; g1++; }
+         if (rows > 0xffffffffull) throw HsError(HESAFF_ERR_NOMEM, "window rows of one image exceed 32 bits");
+         if (hs[g1] > hs[g0]) {
+            groups.push_back({(uint32_t)hs[g0], (uint32_t)hs[g1], (uint32_t)rows});
+            max_n = std::max(max_n, (uint32_t)(hs[g1] - hs[g0]));
+         }
          g0 = g1;
       }
       while (c->ev_aff.size() < groups.size()) {
@@ -836,6 +809,7 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
          HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
          c->ev_aff.push_back(e);
       }
+      if (max_n) ensure_group_buffers(c, max_n);
       // Three-deep software pipeline over image groups, one stream per stage:
       //   affine shape of group g+1 (aff_stream)  |  patch extraction of group g (main + side
       //   streams, latency-bound)  |  descriptor kernels of group g-1 (sift_stream).
@@ -843,64 +817,46 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       hipStream_t as = c->no_overlap ? st : c->aff_stream;
       if (as != st) HIP_TRY(hipStreamWaitEvent(as, c->ev_detect_done, 0));
       auto launch_affine = [&](size_t gi) {
-         hipLaunchKernelGGL(k_affine, dim3(std::min<uint32_t>((groups[gi].second - groups[gi].first + 3) / 4, 256 * c->aff_blocks_per_cu)), dim3(64), 0, as, pt, s.hl, groups[gi].first, groups[gi].second, (const uint32_t *)(cnt + 3),
+         const int ta = tm.begin(T_AFF, 0, as);
+         hipLaunchKernelGGL(k_affine, dim3(std::min<uint32_t>((groups[gi].hi - groups[gi].lo + 3) / 4, 256 * c->aff_blocks_per_cu)), dim3(64), 0, as, pt, s.hl, groups[gi].lo, groups[gi].hi, (const uint32_t *)(cnt + 3),
                             c->tables, c->consts, s.ao);
+         tm.end(ta);
          if (as != st) HIP_TRY(hipEventRecord(c->ev_aff[gi], as));
       };
-      t = tm.begin(T_AFF);
       if (!groups.empty()) launch_affine(0);
-      if (as != st && !groups.empty()) HIP_TRY(hipStreamWaitEvent(st, c->ev_aff[0], 0));
-      tm.end(t);
-      t = tm.begin(T_PATCH);
       bool slot_used[2] = {false, false};
       for (size_t gi = 0; gi < groups.size(); gi++) {
-         const uint32_t h_lo = groups[gi].first, h_hi = groups[gi].second, n = h_hi - h_lo;
+         const uint32_t h_lo = groups[gi].lo, h_hi = groups[gi].hi, n = h_hi - h_lo;
          if (gi + 1 < groups.size()) launch_affine(gi + 1);
-         if (as != st && gi > 0) HIP_TRY(hipStreamWaitEvent(st, c->ev_aff[gi], 0));
+         if (as != st) HIP_TRY(hipStreamWaitEvent(st, c->ev_aff[gi], 0));
          const int slot = (int)(gi & 1);
          if (slot_used[slot]) HIP_TRY(hipStreamWaitEvent(st, c->ev_sift_done[slot], 0));   // the slot's previous descriptors are finished
-         c->b_patches2[slot].ensure((size_t)n * HS_PATCH_PIX * 4);
-         c->b_siftvec2[slot].ensure((size_t)n * 128 * 4);
-         c->b_meanvar2[slot].ensure((size_t)n * 2 * 4);
-         {
-            // the (mask*grad, o) pairs of pixels outside the circular mask stay (0, 0): zero-fill on (re)allocation
-            const void *before = c->b_siftvo2[slot].p;
-            const size_t bytes_before = c->b_siftvo2[slot].bytes;
-            c->b_siftvo2[slot].ensure((size_t)n * HS_VO_PITCH * 8 + 64);
-            if (c->b_siftvo2[slot].p != before || c->b_siftvo2[slot].bytes != bytes_before)
-               HIP_TRY(hipMemsetAsync(c->b_siftvo2[slot].p, 0, c->b_siftvo2[slot].bytes, st));
-         }
+         t = tm.begin(T_PATCH);
          HIP_TRY(hipMemsetAsync(cnt + 8, 0, HS_NBINS * 4, st));
-         HIP_TRY(hipMemcpyAsync(cnt + 5, &h_hi, 4, hipMemcpyHostToDevice, st));
+         HIP_TRY(hipMemcpyAsync(cnt + 5, &groups[gi].hi, 4, hipMemcpyHostToDevice, st));
          hipLaunchKernelGGL(k_prepare_patch, dim3(1024), dim3(256), 0, st, s.hl, h_lo, (const uint32_t *)(cnt + 5), s.ao, H, W, c->consts,
                             c->tables, s.pw);
-         run_patch_stage(c, s, c->gray, c->b_patches2[slot].as<float>(), h_lo, c->ablate & ~1);
+         run_patch_stage(c, s, c->gray, c->b_patches2[slot].as<float>(), h_lo, groups[gi].large_rows);
+         tm.end(t);
          HIP_TRY(hipEventRecord(c->ev_extract_done[slot], st));
          hipStream_t ss = c->no_overlap ? st : c->sift_stream;
          if (ss != st) HIP_TRY(hipStreamWaitEvent(ss, c->ev_extract_done[slot], 0));
          SiftIO so;
          so.patches = c->b_patches2[slot].as<float>(); so.alive = s.pw.alive; so.meanvar = c->b_meanvar2[slot].as<float>();
          so.vec = c->b_siftvec2[slot].as<float>(); so.desc = c->b_desc.as<uint8_t>(); so.h_lo = h_lo; so.h_hi = h_hi;
-         const uint32_t nb64 = (n + 63) / 64;
-         hipLaunchKernelGGL(k_sift_meanvar, dim3(nb64), dim3(64), 0, ss, so, c->tables);
-         hipLaunchKernelGGL(k_sift_grad, dim3(n), dim3(256), 0, ss, so, c->tables, c->b_siftvo2[slot].as<float2>());
-         hipLaunchKernelGGL(k_sift_hist, dim3(std::min<uint32_t>((n + 3) / 4, 256 * 32)), dim3(64), 0, ss, so, c->tables, (const float2 *)c->b_siftvo2[slot].p, c->ablate);
-         hipLaunchKernelGGL(k_sift_quantize, dim3(nb64), dim3(64), 0, ss, so, c->consts);
+         const int ts = tm.begin(T_SIFT, 0, ss);
+         launch_sift(c, ss, so, n, c->b_siftvo2[slot].as<float2>());
+         tm.end(ts);
          HIP_TRY(hipEventRecord(c->ev_sift_done[slot], ss));
          slot_used[slot] = true;
       }
       for (int sl = 0; sl < 2; sl++)
          if (slot_used[sl]) HIP_TRY(hipStreamWaitEvent(st, c->ev_sift_done[sl], 0));
-      tm.end(t);
    }
-   t = tm.begin(T_SIFT);
-   // final stable compaction (hesaff.cpp:87: keys.push_back in detection order)
+   t = tm.begin(T_PACK);
+   // final stable compaction (hesaff.cpp:87: keys.push_back in detection order): exclusive scan of the alive
+   // flags over the whole capacity; alive[] is rewritten for h < n_hess each batch, the tail is cleared here
    LoadFlagI32 lf; lf.p = s.pw.alive;
-   // scan over cap entries would waste time: scan over n_hess only -> n is on the device, so
-   // scan `cap`-bounded by the host-known upper bound min(cap, candidates) = cap; alive[] of
-   // unused slots must be 0: k_prepare_patch only writes h < n, so clear the tail first.
-   // (cheap: 4 bytes per slot)
-   // NOTE: alive[] is fully rewritten for h < n_hess each batch; slots >= n_hess are zeroed here.
    hipLaunchKernelGGL(k_clear_tail, dim3(1024), dim3(256), 0, st, s.pw.alive, (const uint32_t *)(cnt + 3), c->cap);
    exclusive_scan(c, lf, (long long)c->cap, c->b_rank.as<uint32_t>(), cnt + 4);
    hipLaunchKernelGGL(k_pack, dim3(2048), dim3(256), 0, st, s.hl, (const uint32_t *)(cnt + 3), s.pw, (const uint32_t *)c->b_rank.p,
@@ -919,6 +875,7 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
    const int32_t *cn = c->h_starts.data() + 2 * (B + 1);
    if (cn[2] != 0 || (uint32_t)cn[1] > c->cap)
       throw HsError(HESAFF_ERR_CAPACITY, "keypoint capacity exceeded; raise hesaff_params.max_kpts_per_mpx");
+   if (cn[6] != 0) throw HsError(HESAFF_ERR_NOMEM, "large-window row buffer exceeded (internal bound violated)");
 }
 
 } // namespace

@@ -32,7 +32,7 @@ typedef struct hesaff_ctx hesaff_ctx;
  * PyramidParams pyramid.h:18-41, AffineShapeParams affine.h:17-46,
  * SIFTDescriptorParams siftdesc.h:19-32, HessianAffineParams hesaff.cpp:21-36.
  * patchSize (41), smmWindowSize (19), spatialBins (4), orientationBins (8),
- * numberOfScales (3), border (5) and upscaleInputImage (0) are fixed at the reference defaults. */
+ * numberOfScales (3) and border (5) are fixed at the reference defaults. */
 typedef struct hesaff_params {
    float threshold;            /* 16/3  pyramid.h:37, hesaff.cpp:30   */
    float edgeEigenValueRatio;  /* 10    pyramid.h:38                  */
@@ -41,9 +41,15 @@ typedef struct hesaff_params {
    float convergenceThreshold; /* 0.05  affine.h:41                   */
    float mrSize;               /* 3*sqrt(3) affine.h:44, hesaff.cpp:32 */
    float maxBinValue;          /* 0.2   siftdesc.h:29                 */
+   int upscaleInputImage;      /* 0     pyramid.h:34 (1: first octave on the 2x up-sampled image, helpers.cpp:297-329) */
    /* capacity knobs (no reference counterpart) */
    int max_batch;              /* images processed together on the device (default 16) */
    int max_kpts_per_mpx;       /* candidate/keypoint capacity per megapixel (default 40000) */
+   /* 0 (default): parity mode, results bit-identical to the reference's arithmetic.
+    * 1: fast mode: contracted multiply-adds, reassociated sums and approximate
+    *    division / square root / atan2 in the per-keypoint kernels; NOT bit-exact, see DESIGN.md for the
+    *    measured mismatch rate. */
+   int fast;
 } hesaff_params;
 
 /* One detected + described region = the reference's `struct Keypoint` hesaff.cpp:41-48,
@@ -65,17 +71,22 @@ typedef struct hesaff_result {
    const hesaff_keypoint *keys;
 } hesaff_result;
 
-/* Stage timings of the last device batch, milliseconds (HIP events on the ctx stream). */
+/* Stage timings of the last device batch, milliseconds.  Every bracket is a HIP event pair recorded on the
+ * stream its kernels are launched on.  pyramid / detect / pack run one after the other on the main stream; the
+ * affine, patch and descriptor stages run CONCURRENTLY on their own streams over groups of images (three-deep
+ * pipeline), so their three figures are per-stream busy times that overlap in wall-clock time: they add up to
+ * more than total_ms - pyramid_ms - detect_ms - pack_ms. */
 typedef struct hesaff_timings {
    float pyramid_ms;           /* grey + blur + Hessian + decimation (the roofline kernels) */
    float detect_ms;            /* extrema + localisation + ordering                          */
-   float affine_ms;            /* Baumberg iteration                                         */
-   float patch_ms;             /* rectify + normalizeAffine                                  */
-   float sift_ms;              /* descriptor + final compaction                              */
+   float affine_ms;            /* Baumberg iteration, sum over groups (affine stream)        */
+   float patch_ms;             /* rectify + normalizeAffine, sum over groups (main + bin streams) */
+   float sift_ms;              /* descriptor kernels, sum over groups (descriptor stream)    */
+   float pack_ms;              /* final stable compaction into hesaff_keypoint records       */
    float total_ms;
    float blur_hess_ms;         /* sum of the k_blur_hess launches only                       */
    int32_t blur_hess_launches;
-   double blur_hess_bytes;     /* algorithmic bytes of those launches (12 N each)            */
+   double blur_hess_bytes;     /* algorithmic bytes of those launches (12 N each, + 8 N with the fused R0, + 2 N with the fused decimation) */
    double pyramid_bytes;       /* algorithmic bytes B_pyr = 5 N0 + 58 sum N_k, whole batch   */
 } hesaff_timings;
 

@@ -44,6 +44,33 @@ def test_no_oracle_dependency_in_product():
                 assert "hesaff_oracle" not in src and "tests._oracle" not in src and "from tests" not in src, os.path.join(dirpath, f)
 
 
+def test_product_library_reads_no_environment():
+    """A drop-in library must not change its schedule or results because of an environment variable: the product
+    build imports no getenv (the schedule knobs exist only in the optional -DHESAFF_TUNING build)."""
+    out = subprocess.run(["nm", "-D", "--undefined-only", hesaff_amd.lib_path()], capture_output=True, text=True).stdout
+    assert "getenv" not in out
+    for f in ("capi_impl.h", "pipeline.hip", "hostio.cpp"):
+        src = open(os.path.join(ROOT, "hesaff_amd", "csrc", f)).read()
+        src = re.sub(r"#ifdef HESAFF_TUNING.*?#(else|endif)", "", src, flags=re.S)
+        assert "getenv" not in src, f
+
+
+def test_bad_png_header_is_an_error_not_an_abort(tmp_path):
+    """A tiny PNG claiming 65535 x 65535 RGBA16 (34 GB unpacked): HESAFF_ERR_IO, no allocation of that size, no abort."""
+    import struct
+    import zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 65535, 65535, 16, 6, 0, 0, 0)) + \
+        chunk(b"IDAT", zlib.compress(b"\0" * 16)) + chunk(b"IEND", b"")
+    p = tmp_path / "bomb.png"
+    p.write_bytes(png)
+    with pytest.raises(hesaff_amd.HesaffError) as e:
+        hesaff_amd.read_image(str(p))
+    assert e.value.code == -4
+
+
 def test_keypoint_layout_matches_reference_struct():
     # struct Keypoint hesaff.cpp:41-48: 8 floats, int, 128 bytes
     assert _binding.KEYPOINT_DTYPE.itemsize == 8 * 4 + 4 + 128
@@ -58,6 +85,7 @@ def test_default_params_are_reference_defaults():
     assert np.float32(p.convergenceThreshold) == np.float32(0.05)                   # affine.h:41
     assert np.float32(p.mrSize) == np.float32(3.0) * np.sqrt(np.float32(3.0))       # hesaff.cpp:32
     assert np.float32(p.maxBinValue) == np.float32(0.2)                             # siftdesc.h:29
+    assert p.upscaleInputImage == 0 and p.fast == 0                                 # pyramid.h:34 ; parity mode
 
 
 def test_create_fails_loudly_without_gpu():

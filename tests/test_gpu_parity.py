@@ -45,7 +45,7 @@ def test_device_math_matches_libm(ctx, oracle):
     assert_bit_equal(pw, refp, "powf(2,.)")
 
 
-@pytest.mark.parametrize("shape", [(61, 83), (128, 200), (7, 9)])
+@pytest.mark.parametrize("shape", [(61, 83), (128, 200), (7, 9), (33, 600)])
 @pytest.mark.parametrize("sigma", [0.62, 0.7, 0.9, 1.2262737, 1.5198685, 2.4525473, 4.3])
 def test_gaussian_blur(ctx, oracle, shape, sigma):
     rng = np.random.default_rng(11)
@@ -57,6 +57,12 @@ def test_gaussian_blur(ctx, oracle, shape, sigma):
 
 def test_hessian_and_half(ctx, oracle):
     rng = np.random.default_rng(12)
+    for shape in ((97, 131), (40, 700), (3, 3)):
+        im = (rng.random(shape) * 255).astype(np.float32)
+        r = np.empty_like(im)
+        oracle.lib().ho_hessian_response(im, shape[0], shape[1], 2.56, r)
+        # the frame of the reference's response plane is uninitialised memory (pyramid.cpp:70), the library writes 0
+        assert_bit_equal(ctx.hessian_response(im, 2.56)[1:-1, 1:-1], r[1:-1, 1:-1], "hessian %s" % (shape,))
     img = (rng.random((97, 131)) * 255).astype(np.float32)
     ref = np.empty_like(img)
     oracle.lib().ho_hessian_response(img, 97, 131, 2.56, ref)
@@ -276,30 +282,201 @@ def test_full_size_4k(ctx, oracle):
     assert np.abs(e - ref).max() <= 1e-4 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("env", ["HESAFF_EXTREMA=tile", "HESAFF_SMALL=old", "HESAFF_SIFT=fused", "HESAFF_OVERLAP=0",
-                                 "HESAFF_PYR=tile", "HESAFF_GROUP=2000", "HESAFF_SIDE=0", "HESAFF_AFF_BLOCKS=1"])
-def test_alternative_kernel_paths_agree(ctx, env):
-    """The library keeps earlier forms of several kernels behind environment switches (LDS-tile
-    extrema and pyramid kernels, fused patch+SIFT kernels, serial stream schedule, tiny image
-    groups).  They are independent implementations of the same contracts: every byte of the
-    result must be the same."""
+def _params(**kw):
     import hesaff_amd
-    imgs = [band_noise_image(480, 640, 77), band_noise_image(300, 500, 78, SMALL_BANDS)]
-    want = ctx.detect_batch(imgs)
-    k, v = env.split("=")
-    old = os.environ.get(k)
-    os.environ[k] = v
-    try:
-        with hesaff_amd.HesaffContext(device=0) as alt:
-            got = alt.detect_batch(imgs)
-    finally:
-        if old is None:
-            os.environ.pop(k)
-        else:
-            os.environ[k] = old
-    for (nh_w, keys_w), (nh_g, keys_g) in zip(want, got):
-        assert nh_w == nh_g and len(keys_w) == len(keys_g) and len(keys_w) > 500
-        assert keys_w.tobytes() == keys_g.tobytes(), env
+    p = hesaff_amd.default_params()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _assert_keys_equal_oracle(keys, n_hess, o, what=""):
+    g, t, d = o.keys()
+    assert n_hess == o.n_hessian and len(keys) == o.n_keys, (what, n_hess, o.n_hessian, len(keys), o.n_keys)
+    if len(keys):
+        assert np.array_equal(keys["desc"], d), what
+        assert np.array_equal(keys["type"], t), what
+        for j, name in enumerate(["x", "y", "s", "a11", "a12", "a21", "a22", "response"]):
+            assert_bit_equal(keys[name], g[:, j], "%s %s" % (what, name))
+
+
+# Non-default parameters (every reference-side field of hesaff_params): pyramid.h:18-41, affine.h:17-46,
+# siftdesc.h:19-32, hesaff.cpp:154-163.  mrSize = 1 sends every small keypoint through normalizeAffine's
+# direct branch (imageToPatchScale <= 0.4, affine.cpp:137-141); initialSigma 1.0 / 2.0 / 0.45 give blur tap
+# counts outside 9..15 (LDS-tile pyramid kernel, SymmRowSmallFilter order for K <= 5) and, at 0.45, no
+# initial blur at all (pyramid.cpp:276).
+NONDEFAULT = [
+    dict(threshold=9.0),
+    dict(threshold=2.5, edgeEigenValueRatio=4.0),
+    dict(mrSize=1.0),
+    dict(mrSize=2.0, maxBinValue=0.1),
+    dict(mrSize=9.0),
+    dict(maxIterations=3),
+    dict(maxIterations=40, convergenceThreshold=0.01),
+    dict(convergenceThreshold=0.2),
+    dict(initialSigma=1.0),
+    dict(initialSigma=2.0),
+    dict(initialSigma=0.45, threshold=3.0),
+    dict(maxBinValue=0.05),
+    dict(maxBinValue=1.0),
+]
+
+
+@pytest.mark.parametrize("kw", NONDEFAULT, ids=lambda kw: ",".join("%s=%g" % kv for kv in kw.items()))
+def test_non_default_parameters(oracle, kw):
+    import hesaff_amd
+    p = _params(**kw)
+    imgs = [band_noise_image(300, 420, 91), band_noise_image(200, 260, 92, SMALL_BANDS)]
+    with hesaff_amd.HesaffContext(p, device=0) as c2:
+        res = c2.detect_batch(imgs)
+        total = 0
+        for img, (n_hess, keys) in zip(imgs, res):
+            o = oracle.OracleRun(oracle.gray_from_u8(img), params=p)
+            _assert_keys_equal_oracle(keys, n_hess, o, str(kw))
+            assert hesaff_amd.format_sift(keys, p.mrSize) == o.export_text()
+            total += len(keys)
+        assert total > 30, "parameter set leaves too few keypoints for a meaningful comparison"
+
+
+def test_direct_branch_is_taken_with_small_mr_size(oracle):
+    """With mrSize = 1 the windows of the finest keypoints have imageToPatchScale = P0/41 <= 0.4 (P0 <= 15)."""
+    p = _params(mrSize=1.0)
+    o = oracle.OracleRun(oracle.gray_from_u8(band_noise_image(300, 420, 91)), params=p)
+    g, _, _ = o.keys()
+    P0 = 2 * np.ceil(g[:, 2] * np.float32(1.0)).astype(int) + 1
+    assert (P0 / 41.0 <= 0.4).sum() > 100 and (P0 / 41.0 > 0.4).sum() > 20
+
+
+def test_normalize_affine_direct_branch_stage(ctx, oracle):
+    """hesaff_stage_normalize_affine with scales small enough for affine.cpp:137-141 (no smoothing), anisotropic
+    shapes, next to keypoints that take the smoothing branch, against the oracle's normalizeAffine."""
+    rng = np.random.default_rng(77)
+    gray = oracle.gray_from_u8(band_noise_image(260, 340, 23))
+    n = 300
+    kp = np.zeros((n, 3), np.float32)
+    kp[:, 0] = rng.uniform(40, 300, n); kp[:, 1] = rng.uniform(40, 220, n)
+    kp[:, 2] = np.where(np.arange(n) % 3 == 0, rng.uniform(1.6, 4.0, n), rng.uniform(0.2, 1.5, n))   # s * mrSize <= 7 -> P0 <= 15
+    a11 = rng.uniform(0.6, 1.7, n).astype(np.float32)
+    A = np.stack([a11, np.zeros(n, np.float32), rng.uniform(-0.5, 0.5, n).astype(np.float32), (np.float32(1) / a11)], axis=1).astype(np.float32)
+    rej, patches = ctx.normalize_affine(gray, kp, A)
+    oh = oracle.OracleHandle()
+    n_direct = 0
+    for k in range(n):
+        r, ref = oh.normalize_affine(gray, kp[k, 0], kp[k, 1], kp[k, 2], A[k])
+        assert bool(rej[k]) == bool(r), k
+        if not r:
+            assert_bit_equal(patches[k], ref, "patch %d (s=%g)" % (k, kp[k, 2]))
+            P0 = 2 * int(np.ceil(np.float32(kp[k, 2]) * ctx.params.mrSize)) + 1
+            n_direct += P0 / 41.0 <= 0.4
+    assert n_direct > 100 and (rej == 0).sum() - n_direct > 50
+
+
+def test_stage_entry_points_with_non_default_sift_clip(oracle):
+    """computeSiftDescriptor with maxBinValue 0.08 / 0.5 through hesaff_stage_sift (production descriptor kernels)."""
+    import hesaff_amd
+    img = band_noise_image(200, 280, 24)
+    gray = oracle.gray_from_u8(img)
+    o = oracle.OracleRun(gray)
+    g, _, _ = o.keys()
+    oh0 = oracle.OracleHandle()
+    patches = np.stack([oh0.normalize_affine(gray, g[k, 0], g[k, 1], g[k, 2], g[k, 3:7])[1] for k in range(min(len(g), 200))])
+    for mbv in (0.08, 0.5):
+        p = _params(maxBinValue=mbv)
+        oh = oracle.OracleHandle(p)
+        with hesaff_amd.HesaffContext(p, device=0) as c2:
+            got = c2.sift(patches)
+        want = np.stack([oh.sift(pp) for pp in patches])
+        assert np.array_equal(got, want), mbv
+
+
+def _device_keys(dkeys, total):
+    """Copy `total` hesaff_keypoint records from the library's device buffer through torch's HIP runtime."""
+    import ctypes
+    import torch
+    import hesaff_amd
+    buf = torch.empty(max(total, 1) * 164, dtype=torch.uint8, device="cuda")
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    if total:
+        assert hip.hipMemcpy(ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(dkeys), ctypes.c_size_t(total * 164), 3) == 0
+    return np.frombuffer(buf.cpu().numpy().tobytes()[: total * 164], dtype=hesaff_amd.KEYPOINT_DTYPE)
+
+
+@pytest.mark.parametrize("width,height,name", [(1920, 1080, "BASELINE config 3: batch of 256 x 1920x1080"),
+                                               (3840, 2160, "per-GPU share of BASELINE config 4: 256 x 3840x2160")])
+def test_full_batch_configs(oracle, width, height, name):
+    """BASELINE.json's batch configurations through hesaff_detect_batch_device at their full size: size-independent
+    properties on the whole batch, and every field / byte of two sampled images against the oracle."""
+    import torch
+    import hesaff_amd
+    from hesaff_amd.synth import band_noise_batch_torch
+    B = 256
+    imgs = band_noise_batch_torch(B, height, width, seed=4321, device="cuda")
+    p = _params(max_batch=B)
+    with hesaff_amd.HesaffContext(p, device=0) as c2:
+        ch, cd, dkeys, total = c2.detect_batch_device(imgs.data_ptr(), B, width, height)
+        keys = _device_keys(dkeys, total).copy()
+        ch2, cd2, dkeys2, total2 = c2.detect_batch_device(imgs.data_ptr(), B, width, height)
+        assert total2 == total and np.array_equal(ch, ch2) and np.array_equal(cd, cd2)
+        assert _device_keys(dkeys2, total2).tobytes() == keys.tobytes(), "run-to-run determinism of the whole batch"
+    assert total == int(cd.sum()) and (cd <= ch).all() and (cd > 0.5 * ch).all()
+    mpx = width * height / 1e6
+    assert (cd > 5000 * mpx).all() and (cd < 40000 * mpx).all()
+    # rectified shapes: a12 == 0, det == 1 (helpers.cpp:95-96, affine.cpp:105); thresholded responses; clipped descriptors
+    assert not keys["a12"].any()
+    assert np.abs(keys["a11"].astype(np.float64) * keys["a22"] - 1).max() < 1e-5
+    assert (np.abs(keys["response"]) >= np.float32(16.0 / 3.0) ** 2).all() and set(np.unique(keys["type"])) <= {0, 1, 2}
+    assert (keys["x"] > 0).all() and (keys["x"] < width).all() and (keys["y"] > 0).all() and (keys["y"] < height).all()
+    nrm = np.sqrt((keys["desc"][::97].astype(np.float64) ** 2).sum(axis=1))
+    assert nrm.min() > 400 and nrm.max() < 520
+    starts = np.concatenate([[0], np.cumsum(cd)])
+    for b in (0, 171):
+        o = oracle.OracleRun(oracle.gray_from_u8(imgs[b].cpu().numpy()))
+        _assert_keys_equal_oracle(keys[starts[b]:starts[b + 1]], int(ch[b]), o, "%s, image %d" % (name, b))
+    del imgs
+    torch.cuda.empty_cache()
+
+
+def test_out_of_memory_is_recoverable(oracle):
+    """HESAFF_ERR_NOMEM in the middle of a buffer plan (a capacity request no device can hold) leaves the context
+    usable: the earlier geometry is planned afresh instead of running on half-replaced buffers."""
+    import hesaff_amd
+    img = band_noise_image(240, 320, 55, SMALL_BANDS)
+    p = _params(max_kpts_per_mpx=100_000_000)   # 16 Mpx x 1e8 = 1.6e9 candidates: ~700 GB of lists
+    with hesaff_amd.HesaffContext(device=0) as ref_ctx:
+        (n0, k0), = ref_ctx.detect_batch([img])
+    with hesaff_amd.HesaffContext(p, device=0) as c2:
+        small = np.full((64, 64), 7, np.uint8)
+        assert c2.detect_batch([small])[0][0] == 0
+        with pytest.raises(hesaff_amd.HesaffError) as e:
+            c2.detect_batch([np.zeros((4000, 4000), np.uint8)])
+        assert e.value.code == -5, e.value
+        assert c2.detect_batch([small])[0][0] == 0            # the geometry used before the failure
+        (n1, k1), = c2.detect_batch([img])                     # and a new one
+        assert n1 == n0 and k1.tobytes() == k0.tobytes()
+
+
+def test_bad_arguments_are_rejected():
+    import hesaff_amd
+    for kw in (dict(initialSigma=0.0), dict(initialSigma=float("nan")), dict(mrSize=-1.0), dict(maxIterations=0),
+               dict(threshold=float("inf")), dict(initialSigma=4.0)):
+        with pytest.raises(hesaff_amd.HesaffError) as e:
+            hesaff_amd.HesaffContext(_params(**kw), device=0)
+        assert e.value.code == -2, kw
+
+
+def test_survey_probe_output_md5_on_gpu(ctx):
+    """The product's .hesaff.sift of SURVEY App. C's 640x480 probe image has the md5 the survey recorded from the
+    COMPILED reference's output file (e004ba88...): 4183 rows, every coordinate, ellipse term and descriptor byte."""
+    import hashlib
+    import json
+    import hesaff_amd
+    man = json.load(open(os.path.join(GOLD, "manifest.json")))["probe_vga"]
+    img = hesaff_amd.read_pnm(os.path.join(GOLD, "probe_vga.pgm"))
+    (n_hess, keys), = ctx.detect_batch([img])
+    rec = man["survey_recorded"]
+    assert (n_hess, len(keys)) == (rec["hessian"], rec["descriptors"])
+    md5 = hashlib.md5(hesaff_amd.format_sift(keys, ctx.params.mrSize)).hexdigest()
+    assert md5.startswith(rec["sift_md5_prefix"]) and md5 == man["sift_md5"]
 
 
 def test_empty_and_featureless_inputs(ctx, oracle):
