@@ -145,7 +145,7 @@ struct hesaff_ctx {
    uint32_t cap = 0;      // keypoint / candidate capacity of a batch
 
    // planes
-   DevBuf b_gray, b_L, b_L3, b_R, b_map, b_bitmask, b_prefix, b_blocksums;
+   DevBuf b_gray, b_L, b_L3, b_R, b_map, b_bitmask, b_prefix, b_blocksums, b_generic;
    std::vector<DPlane> L;   // [octave*3 + level]
    DPlane gray, L3, R[5];
    // lists
@@ -239,10 +239,10 @@ void build_tables(hesaff_ctx *c)
    for (int i = 0; i < 5; i++) {
       const float sigma = i == 0 ? c->sched.init_sigma : c->sched.blur_sigma[i];
       c->pyr_tap_off[i] = (int)taps.size();
-      taps.resize(taps.size() + 16, 0.0f);
+      taps.resize(taps.size() + 256, 0.0f);
       if (i == 0 && !(c->par.initialSigma > 0.5f)) { c->pyr_K[0] = 0; continue; }   // pyramid.cpp:276: no initial blur
       const int K = hesaff::gauss_ksize(sigma);
-      if (K > 2 * BH_RMAX + 1) throw HsError(HESAFF_ERR_ARG, "initialSigma too large for the pyramid kernels (a blur needs more than 15 taps)");
+      if (K > 255) throw HsError(HESAFF_ERR_ARG, "initialSigma too large (a pyramid blur would need more than 255 taps)");
       c->pyr_K[i] = K;
       if (K == 1) taps[c->pyr_tap_off[i]] = 1.0f;
       else hesaff::gauss_taps(K, sigma, taps.data() + c->pyr_tap_off[i]);
@@ -482,10 +482,24 @@ void launch_blur_hess(hesaff_ctx *c, const DPlane &in, const DPlane &outL, const
       case 11: launch_march<11, WL, WR, WH>(c, in, outL, outR, outHalf, taps, norm2, B); return;
       case 13: launch_march<13, WL, WR, WH>(c, in, outL, outR, outHalf, taps, norm2, B); return;
       case 15: launch_march<15, WL, WR, WH>(c, in, outL, outR, outHalf, taps, norm2, B); return;
-      default: break;   // non-default initialSigma: generic tile kernel
+      default: break;   // non-default initialSigma
    }
-   const dim3 grid((in.cols + BH_TW - 1) / BH_TW, (in.rows + BH_TH - 1) / BH_TH, B);
-   hipLaunchKernelGGL((k_blur_hess_tile<WL, WR, WH>), grid, dim3(256), 0, c->stream, in, outL, outR, outHalf, taps, K, norm2);
+   if (K <= 2 * BH_RMAX + 1) {
+      // LDS-tile kernel: any tap count up to 15
+      const dim3 grid((in.cols + BH_TW - 1) / BH_TW, (in.rows + BH_TH - 1) / BH_TH, B);
+      hipLaunchKernelGGL((k_blur_hess_tile<WL, WR, WH>), grid, dim3(256), 0, c->stream, in, outL, outR, outHalf, taps, K, norm2);
+      return;
+   }
+   // any larger tap count (initialSigma above ~1.9): plain two-pass blur + stand-alone response / decimation kernels
+   const size_t planeF = (size_t)B * in.rows * in.pitch;
+   c->b_generic.ensure(planeF * 4 * 2);
+   const DPlane tmp = make_plane(c->b_generic.as<float>(), in.rows, in.cols, in.pitch);
+   const DPlane blurred = WL ? outL : make_plane(c->b_generic.as<float>() + planeF, in.rows, in.cols, in.pitch);
+   const dim3 grid((in.cols + 255) / 256, in.rows, B);
+   hipLaunchKernelGGL(k_blur_rows_generic, grid, dim3(256), 0, c->stream, in, tmp, taps, K);
+   hipLaunchKernelGGL(k_blur_cols_generic, grid, dim3(256), 0, c->stream, tmp, blurred, taps, K);
+   if (WR) hipLaunchKernelGGL(k_hess, grid, dim3(256), 0, c->stream, blurred, outR, norm2);
+   if (WH) hipLaunchKernelGGL(k_half, dim3((outHalf.cols + 255) / 256, outHalf.rows, B), dim3(256), 0, c->stream, blurred, outHalf);
 }
 
 struct Lists {

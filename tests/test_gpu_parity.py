@@ -303,8 +303,8 @@ def _assert_keys_equal_oracle(keys, n_hess, o, what=""):
 # Non-default parameters (every reference-side field of hesaff_params): pyramid.h:18-41, affine.h:17-46,
 # siftdesc.h:19-32, hesaff.cpp:154-163.  mrSize = 1 sends every small keypoint through normalizeAffine's
 # direct branch (imageToPatchScale <= 0.4, affine.cpp:137-141); initialSigma 1.0 / 2.0 / 0.45 give blur tap
-# counts outside 9..15 (LDS-tile pyramid kernel, SymmRowSmallFilter order for K <= 5) and, at 0.45, no
-# initial blur at all (pyramid.cpp:276).
+# counts outside 9..15 (LDS-tile pyramid kernel, SymmRowSmallFilter order for K <= 5; two-pass kernels above
+# 15 taps) and, at 0.45, no initial blur at all (pyramid.cpp:276).
 NONDEFAULT = [
     dict(threshold=9.0),
     dict(threshold=2.5, edgeEigenValueRatio=4.0),
@@ -458,7 +458,7 @@ def test_out_of_memory_is_recoverable(oracle):
 def test_bad_arguments_are_rejected():
     import hesaff_amd
     for kw in (dict(initialSigma=0.0), dict(initialSigma=float("nan")), dict(mrSize=-1.0), dict(maxIterations=0),
-               dict(threshold=float("inf")), dict(initialSigma=4.0)):
+               dict(threshold=float("inf")), dict(initialSigma=100.0)):
         with pytest.raises(hesaff_amd.HesaffError) as e:
             hesaff_amd.HesaffContext(_params(**kw), device=0)
         assert e.value.code == -2, kw
