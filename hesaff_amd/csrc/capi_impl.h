@@ -114,6 +114,7 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       if (const char *gk = getenv("HESAFF_GROUP")) c->sift_group_kpts = (uint32_t)std::max(1000, atoi(gk));
       if (const char *wv = getenv("HESAFF_BANDS")) c->force_bands = std::max(0, atoi(wv));
       c->debug = getenv("HESAFF_DEBUG") != nullptr;
+      if (const char *sg = getenv("HESAFF_SGRAD_GRID")) c->sgrad_grid = (uint32_t)std::max(0, atoi(sg));
 #endif
    } catch (const HsError &e) {
       hesaff_destroy(c);

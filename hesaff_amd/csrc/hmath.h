@@ -172,6 +172,56 @@ HM_HD float hm_atan2f_sel(float y, float x)
    return hm_u2f(hm_f2u(r) ^ ((uint32_t)hy & 0x80000000u));
 }
 
+// ---- atan2f a third time, table-driven: the per-interval constants of hm_atan2f_sel come from one 8-float row
+//      (HM_ATAN_TAB, staged in LDS by the device caller) instead of a tree of selects:
+//         num = c1*q + c0,   den = d1*q + d0,   z = hi - ((xr*(s1+s2) - lo) - xr),   xr = num/den
+//      which are fdlibm's expressions with the same roundings:
+//         |q| < 0.4375 : q / 1                    (c1, c0, d1, d0) = (1, 0, 0, 1)     1*q, q + 0, 0*q + 1 are exact
+//         < 0.6875     : (2q - 1) / (2 + q)                          (2, -1, 1, 2)
+//         < 1.1875     : (q - 1) / (q + 1)                           (1, -1, 1, 1)
+//         < 2.4375     : (q - 1.5) / (1 + 1.5q)                      (1, -1.5, 1.5, 1)
+//         otherwise    : -1 / q                                      (0, -1, 1, 0)    0*q - 1 = -1, q + 0 = q
+//      Row layout: c1, d1, c0, d0, hi, lo, 0, 0 (the (c1, d1) and (c0, d0) pairs feed packed operations).
+//      Everything else is hm_atan2f_sel's code; checked against it and libm in tests/test_host_side.py.
+#define HM_ATAN_TAB_FLOATS 40
+#define HM_ATAN_TAB_INIT                                                                                           \
+   {1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f,                                                               \
+    2.0f, 1.0f, -1.0f, 2.0f, 0x1.dac67p-2f /*3eed6338*/, 0x1.586ed2p-28f /*31ac3769*/, 0.0f, 0.0f,                  \
+    1.0f, 1.0f, -1.0f, 1.0f, 0x1.921fb4p-1f /*3f490fda*/, 0x1.4442dp-25f /*33222168*/, 0.0f, 0.0f,                  \
+    1.0f, 1.5f, -1.5f, 1.0f, 0x1.f730bcp-1f /*3f7b985e*/, 0x1.281f68p-25f /*33140fb4*/, 0.0f, 0.0f,                 \
+    0.0f, 1.0f, -1.0f, 0.0f, 0x1.921fb4p+0f /*3fc90fda*/, 0x1.4442dp-24f /*33a22168*/, 0.0f, 0.0f}
+
+HM_HD float hm_atan2f_tab(float y, float x, const float *tab)
+{
+   const float pi_o_2 = hm_u2f(0x3fc90fdbu), pi = hm_u2f(0x40490fdbu), pi_lo = hm_u2f(0xb3bbbd2eu);
+   const int32_t hx = (int32_t)hm_f2u(x), hy = (int32_t)hm_f2u(y);
+   const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+   const int32_t k = (iy - ix) >> 23;
+   if ((ix >= 0x7f800000) | (iy >= 0x7f800000) | ((iy != 0) & (ix != 0) & ((k > 60) | (k < -60)))) return hm_atan2f(y, x);
+   const float q = hm_fabsf(y / x);   // NaN for 0/0, +inf for y/0: both replaced below
+   const int32_t iq = (int32_t)hm_f2u(q);
+   const int id = (int)(iq >= 0x3ee00000) + (int)(iq >= 0x3f300000) + (int)(iq >= 0x3f980000) + (int)(iq >= 0x401c0000);
+   const float *row = tab + 8 * id;
+   const float num = row[0] * q + row[2];
+   const float den = row[1] * q + row[3];
+   const float hi = row[4], lo = row[5];
+   const float xr = num / den;
+   const float z = xr * xr;
+   const float w = z * z;
+   const float aT0 = hm_u2f(0x3eaaaaabu), aT1 = hm_u2f(0xbe4ccccdu), aT2 = hm_u2f(0x3e124925u),
+               aT3 = hm_u2f(0xbde38e38u), aT4 = hm_u2f(0x3dba2e6eu), aT5 = hm_u2f(0xbd9d8795u),
+               aT6 = hm_u2f(0x3d886b35u), aT7 = hm_u2f(0xbd6ef16bu), aT8 = hm_u2f(0x3d4bda59u),
+               aT9 = hm_u2f(0xbd15a221u), aT10 = hm_u2f(0x3c8569d7u);
+   const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+   const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+   float za = hi - ((xr * (s1 + s2) - lo) - xr);
+   za = (iq >= 0x4c000000) ? hm_u2f(0x3fc90fdau) + hm_u2f(0x33a22168u) : za;   // |q| >= 2^25
+   float r = (hx < 0) ? pi - (za - pi_lo) : za;
+   // x == 0: +-pi/2 (pi_o_2 + tiny), or, with y == 0 too, y itself / +-pi by the sign of x
+   r = (ix == 0) ? ((iy == 0) ? ((hx < 0) ? pi : 0.0f) : pi_o_2) : r;
+   return hm_u2f(hm_f2u(r) ^ ((uint32_t)hy & 0x80000000u));
+}
+
 // ---- powf(2.0f, y) for |y| < 126 (no overflow/underflow handling needed on this path:
 //      callers pass y = b/3 with |b| <= 1.5, or 1/numberOfScales) ----
 // log2(2.0f) evaluates to exactly 1.0 in glibc's log2_inline (table entry for z == 1 has

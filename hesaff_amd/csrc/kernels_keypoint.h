@@ -210,7 +210,10 @@ __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, con
    }
 }
 
-__global__ __launch_bounds__(64) void k_affine(PlaneTab pt, HessList hl, uint32_t h_lo, uint32_t h_hi, const uint32_t *__restrict__ n_ptr,
+#ifndef HS_AFF_WAVES
+#define HS_AFF_WAVES 0   // tuning: wavefronts per SIMD to hold the register allocation to (0: the compiler's choice)
+#endif
+__global__ __launch_bounds__(64, HS_AFF_WAVES) void k_affine(PlaneTab pt, HessList hl, uint32_t h_lo, uint32_t h_hi, const uint32_t *__restrict__ n_ptr,
                                                KpTables tb, DConsts k, AffineOut out)
 {
    const uint32_t n = min(min(*n_ptr, hl.cap), h_hi);   // keypoints [h_lo, h_hi) of the list
@@ -270,6 +273,28 @@ __device__ __forceinline__ int hs_window_p0(float s, float mrSize)
 // affine iteration.  rows[b] += P for every Hessian keypoint whose window falls into the last bin.
 __global__ __launch_bounds__(256) void k_image_large_rows(HessList hl, const uint32_t *__restrict__ n_ptr, float mrSize, uint32_t *__restrict__ rows);
 
+// interpolate()'s return flag ("some tap fell outside the image", helpers.cpp:209-244) for the P x P window of
+// normalizeAffine's smoothing branch (affine.cpp:126), without visiting the P^2 taps.  The tap coordinate
+//    w(j, i) = fl(fl(ofs + fl(j * a_row)) + fl(i * a_col))        j, i in [-half, half]
+// is monotone in i for fixed j and in j for fixed i (a float product or sum with one operand fixed is monotone under
+// round-to-nearest), so over the grid it takes its extremes at the four corners; a tap is inside iff
+// 0 <= floor(w) < limit, i.e. 0 <= w < limit for the integer limits cols - 1 / rows - 1.  Hence "some tap outside" <=>
+// "some corner outside".  Non-finite values: an infinite product at an inner index is also infinite at the corner of the
+// same sign, and a NaN operand makes every coordinate NaN, so a corner fails whenever any tap would.
+__device__ inline bool hs_window_outside(int imRows, int imCols, float ofsx, float ofsy, float a11, float a12, float a21, float a22, int half)
+{
+   const float width = (float)(imCols - 1), height = (float)(imRows - 1);
+   bool outside = false;
+#pragma unroll
+   for (int q = 0; q < 4; q++) {
+      const int j = (q & 1) ? half : -half, i = (q & 2) ? half : -half;
+      const float rx = ofsx + (float)j * a12, ry = ofsy + (float)j * a22;
+      const float fx = floorf(rx + (float)i * a11), fy = floorf(ry + (float)i * a21);
+      outside = outside || !(fx >= 0.0f && fy >= 0.0f && fx < width && fy < height);
+   }
+   return outside;
+}
+
 template <bool RECTIFY>
 __device__ __forceinline__ void hs_prepare_patch_body(const HessList &hl, uint32_t h_lo, uint32_t n, const AffineOut &aff, int imRows, int imCols,
                                                       const DConsts &k, const KpTables &tb, const PatchWork &pw)
@@ -289,9 +314,11 @@ __device__ __forceinline__ void hs_prepare_patch_body(const HessList &hl, uint32
          }
          P0 = hs_window_p0(hl.s[h], k.mrSize);
          const float scale = (float)P0 / (float)HS_PATCH;
-         const bool rej = hs_check_borders(imRows, imCols, hl.x[h], hl.y[h], a11 * scale, a12 * scale, a21 * scale, a22 * scale);
-         // P0 > max_p0: the P x P window cannot fit into the image (a11*a22 = 1), the
-         // reference rejects it in interpolate(); no taps are tabulated for it.
+         bool rej = hs_check_borders(imRows, imCols, hl.x[h], hl.y[h], a11 * scale, a12 * scale, a21 * scale, a22 * scale);
+         // smoothing branch (affine.cpp:114-135): a window that leaves the image rejects the keypoint
+         if (!rej && (double)scale > 0.4) rej = hs_window_outside(imRows, imCols, hl.x[h], hl.y[h], a11, a12, a21, a22, (P0 + 2) >> 1);
+         // P0 > max_p0: the P x P window cannot fit into the image (a11*a22 = 1), the window test has
+         // rejected it; no taps are tabulated for it.
          alive = (!rej && P0 <= tb.max_p0) ? 1 : 0;
       }
       if (valid) {

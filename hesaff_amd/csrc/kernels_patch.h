@@ -15,6 +15,15 @@
 //   row   : t = k[0]*S[x-r]; t += k[j]*S[x-r+j]  (j ascending)       K > 5
 //           S0*k0 + (S-1+S1)*k1 + (S-2+S2)*k2                         K <= 5
 //   column: d = k[r]*T[y];  d += k[r+j]*(T[y+j] + T[y-j])
+//
+// What keeps the instruction count down:
+//   * k_prepare_patch already decided whether the P x P window leaves the image (hs_window_outside:
+//     the corner test is exactly interpolate()'s return flag), so no tap of these kernels tests bounds
+//     and no kernel has a reject path;
+//   * tap coordinates come from two small tables per window, R[row] = (ofsx + j*a12, ofsy + j*a22) and
+//     C[col] = (i*a11, i*a21): (wx, wy) = R + C is the reference's rx + i*a11, ry + i*a21 in one packed add;
+//   * both blur passes work on PAIRS of adjacent outputs with packed FP32 (v_pk_mul_f32 / v_pk_add_f32:
+//     two IEEE products / sums per instruction, same rounding as the scalar forms, no FMA).
 #pragma once
 #include "kernels_keypoint.h"
 
@@ -31,6 +40,39 @@ struct PatchIO {
    uint32_t trows_cap;           // large bin: rows the T' buffer holds
    uint32_t *overflow;           // set when the large bin's rows exceed trows_cap (reported as an error by the host)
 };
+
+// ---- helpers.cpp:227-240 : one bilinear tap that is known to lie inside the image ----
+// (0 <= floor(w) < cols-1 / rows-1 was established for the whole window by hs_window_outside; the buffer
+// resource still bounds every load to the plane.)
+__device__ __forceinline__ float hs_tap_inside(const HsPlaneBuf &im, float wx, float wy)
+{
+   const float fx = floorf(wx), fy = floorf(wy);
+   wx -= fx;
+   wy -= fy;
+   const uint32_t off = ((uint32_t)(int)fy * im.pitch + (uint32_t)(int)fx) * 4u;
+   const hs_v2u r0 = __builtin_amdgcn_raw_buffer_load_b64(im.rsrc, (int)off, 0, 0);
+   const hs_v2u r1 = __builtin_amdgcn_raw_buffer_load_b64(im.rsrc, (int)off, (int)im.pitch_bytes, 0);
+   const float p00 = __uint_as_float(r0.x), p01 = __uint_as_float(r0.y), p10 = __uint_as_float(r1.x), p11 = __uint_as_float(r1.y);
+   return (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + (wy) * ((1.0f - wx) * p10 + wx * p11);
+}
+
+// Coordinate tables of one window: interpolate() (helpers.cpp:209-244) evaluates, for output (j, i),
+//    rx = ofsx + j*a12;  ry = ofsy + j*a22;  wx = rx + i*a11;  wy = ry + i*a21        (j, i ints promoted to float)
+// R[jj] = (rx, ry) for j = jj - half and C[ii] = (i*a11, i*a21) for i = ii - half hold the same roundings.
+__device__ __forceinline__ v2f hs_row_coord(float ofsx, float ofsy, float a12, float a22, int j)
+{
+   v2f r;
+   r.x = ofsx + (float)j * a12;
+   r.y = ofsy + (float)j * a22;
+   return r;
+}
+__device__ __forceinline__ v2f hs_col_coord(float a11, float a21, int i)
+{
+   v2f c;
+   c.x = (float)i * a11;
+   c.y = (float)i * a21;
+   return c;
+}
 
 // resample of affine.cpp:131 from the blurred window, separable bookkeeping: the sample
 // coordinate of output (jj, ii) is (c0 + (ii - 20) * scale, c0 + (jj - 20) * scale) (the cross
@@ -50,58 +92,74 @@ __device__ __forceinline__ void hs_resample_table(int P, float scale, int *tab_i
    }
 }
 
-__device__ __forceinline__ void hs_resample_full_tab(const float *S, int P, const int *tab_i, const float *tab_f, float *out)
+__device__ __forceinline__ int hs_div_small(int idx, float inv)   // floor(idx / P) for idx < 2^16, P < 2^8, inv = 1.0f / P
+{
+   return (int)(((float)idx + 0.5f) * inv);
+}
+
+// S: blurred window with row pitch `pitch`
+__device__ __forceinline__ void hs_resample_full_tab(const float *S, int pitch, const int *tab_i, const float *tab_f, float *out)
 {
    for (int idx = threadIdx.x; idx < HS_PATCH_PIX; idx += 256) {
-      const int jj = idx / HS_PATCH, ii = idx - jj * HS_PATCH;
+      const int jj = hs_div_small(idx, 1.0f / (float)HS_PATCH), ii = idx - jj * HS_PATCH;
       const int xi = tab_i[ii], yi = tab_i[jj];
       const float wx = tab_f[ii], wy = tab_f[jj];
       const bool in = (xi | yi) >= 0;
-      const float *p = S + (in ? yi * P + xi : 0);
-      const float p00 = p[0], p01 = p[1], p10 = p[P], p11 = p[P + 1];
+      const float *p = S + (in ? yi * pitch + xi : 0);
+      const float p00 = p[0], p01 = p[1], p10 = p[pitch], p11 = p[pitch + 1];
       const float v = (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + (wy) * ((1.0f - wx) * p10 + wx * p11);
       out[idx] = in ? v : 0.0f;
    }
 }
 
 // ---------------------------------------------------------------------------------------
-// k_patch_extract_small<BIN>: the extraction-only form of k_patch_small (the descriptor runs in
-// kernels_sift.h): warp -> blur -> resample for windows P <= 43 (BIN 0) / 66 (BIN 1), result
-// straight to io.patches.  Same arithmetic, cheaper addressing:
+// k_patch_extract_small<BIN>: warp -> blur -> resample for windows P <= 41 (BIN 0) / 63 (BIN 1),
+// result straight to io.patches.
 //   * the window S is stored with r replicated columns on either side and the row-pass plane
 //     T with r replicated rows above and below (BORDER_REPLICATE materialised), so no tap
 //     needs an index clamp;
-//   * the tap count K is a template parameter (K = 5..15 here, affine.cpp:129): the loops
-//     are unrolled, taps sit in registers and all LDS reads of an output are in flight together
-//     (the rolled loop waited one LDS round trip per tap);
+//   * the tap count K is a template parameter (K = 3..15 here, affine.cpp:129): the loops
+//     are unrolled, taps sit in registers and all LDS reads of an output are in flight together;
+//   * a thread computes the outputs of two adjacent columns at once (packed FP32); all row pitches
+//     are even so that the pairs of the column pass are aligned 8-byte LDS accesses;
 //   * idx -> (row, column) uses a float reciprocal (exact for these sizes) instead of the
 //     ~20-instruction integer division.
-// LDS: S[PMAX][PMAX + 14] | T[PMAX + 14][PMAX] | taps  (18 KB / 40 KB: 8 / 4 blocks per CU).
+// LDS: S[PMAX][SPITCH] | T[PMAX + 14][TPITCH] | taps | R | C   (19 KB / 40 KB: 8 / 4 blocks per CU).
 // ---------------------------------------------------------------------------------------
 #define HS_SMALL_RMAX 7
-#ifndef HS_WNIT1
-#define HS_WNIT1 6
-#endif
-#ifndef HS_WNIT0
 #define HS_WNIT0 4
+#define HS_WNIT1 6
+#ifndef HS_SMALL_WAVES
+#define HS_SMALL_WAVES 0   // tuning: wavefronts per SIMD to hold the register allocation to (0: the compiler's choice)
+#endif
+#ifndef HS_MID_WAVES
+#define HS_MID_WAVES 0
 #endif
 
-__device__ __forceinline__ int hs_div_small(int idx, float inv)   // floor(idx / P) for idx < 2^16, P < 2^8, inv = 1.0f / P
-{
-   return (int)(((float)idx + 0.5f) * inv);
-}
+template <int BIN> struct SmallGeom {
+   static constexpr int PMAX = BIN == 0 ? 41 : 63;   // largest window of the bin: the bins are cut on P = P0 + 2 <= 41 | 64, P is odd
+   // even pitches; one spare column each for the second output of an odd window's last column pair:
+   // the row pass of column pair (P - 1, P) reads S up to index P + 2 r, and writes T / the blurred S up to column P
+   static constexpr int SPITCH = (PMAX + 2 * HS_SMALL_RMAX + 2) & ~1;   // 56 | 78
+   static constexpr int TPITCH = (PMAX + 2) & ~1;                       // 42 | 64
+   static constexpr int SSZ = PMAX * SPITCH;
+   static constexpr int TSZ = (PMAX + 2 * HS_SMALL_RMAX) * TPITCH;
+   static constexpr int FLOATS = SSZ + TSZ + 16 + 4 * (PMAX + 1);       // + taps + R and C tables (float2 each)
+   static_assert(SPITCH % 2 == 0 && TPITCH % 2 == 0 && SSZ % 2 == 0 && TSZ % 2 == 0, "pairs must stay 8-byte aligned");
+   static_assert(SPITCH >= PMAX + 2 * HS_SMALL_RMAX + 1 && TPITCH >= PMAX + 1, "spare column");
+};
 
+// both blur passes of one window; KT = 0: run-time tap count (any odd K <= 15)
 template <int KT, int SPITCH, int TPITCH>
 __device__ __forceinline__ void hs_small_blur(float *S, float *T, int P, const float *s_taps, int Krt)
 {
    const int K = KT ? KT : Krt, r = K >> 1;
    const int tid = threadIdx.x;
-   const float invP = 1.0f / (float)P;
    float kk[KT ? KT : 2 * HS_SMALL_RMAX + 1];
 #pragma unroll
    for (int j = 0; j < (KT ? KT : 2 * HS_SMALL_RMAX + 1); j++) kk[j] = (j < K) ? s_taps[j] : 0.0f;
    // replicated border columns of S
-   {
+   if (r > 0) {
       const float inv2r = 1.0f / (float)(2 * r);
       for (int i = tid; i < 2 * r * P; i += 256) {
          const int yy = hs_div_small(i, inv2r), m = i - yy * 2 * r;
@@ -111,47 +169,51 @@ __device__ __forceinline__ void hs_small_blur(float *S, float *T, int P, const f
       }
    }
    __syncthreads();
+   const int PC = (P + 1) >> 1;                 // column pairs per row (an odd window's last pair computes one spare output)
+   const float invPC = 1.0f / (float)PC;
    // row pass: T[r + y][x]; rows y = 0 and y = P-1 are also written into the r border rows
-   for (int idx = tid; idx < P * P; idx += 256) {
-      const int yy = hs_div_small(idx, invP), xx = idx - yy * P;
-      const float *sp = S + yy * SPITCH + xx;   // sp[j] = S[clamp(xx - r + j)]
-      float t;
-      if (K <= 5) {
-         t = sp[r] * kk[r] + (sp[r - 1] + sp[r + 1]) * kk[r + 1];
-         if (K == 5) t = t + (sp[r - 2] + sp[r + 2]) * kk[r + 2];
+   for (int idx = tid; idx < P * PC; idx += 256) {
+      const int yy = hs_div_small(idx, invPC), xx = 2 * (idx - yy * PC);
+      const float *sp = S + yy * SPITCH + xx;   // sp[j] = S[clamp(xx - r + j)], sp[j + 1] the same for column xx + 1
+      v2f t;
+      auto G = [&](int j) { v2f g; g.x = sp[j]; g.y = sp[j + 1]; return g; };
+      if (K == 1) t = G(0);
+      else if (K <= 5) {
+         t = G(r) * kk[r] + (G(r - 1) + G(r + 1)) * kk[r + 1];
+         if (K == 5) t = t + (G(r - 2) + G(r + 2)) * kk[r + 2];
       } else {
-         t = kk[0] * sp[0];
+         t = kk[0] * G(0);
 #pragma unroll
-         for (int j = 1; j < K; j++) t += kk[j] * sp[j];
+         for (int j = 1; j < K; j++) t += kk[j] * G(j);
       }
-      T[(r + yy) * TPITCH + xx] = t;
+      *reinterpret_cast<v2f *>(T + (r + yy) * TPITCH + xx) = t;
       if (yy == 0)
-         for (int j = 0; j < r; j++) T[j * TPITCH + xx] = t;
+         for (int j = 0; j < r; j++) *reinterpret_cast<v2f *>(T + j * TPITCH + xx) = t;
       if (yy == P - 1)
-         for (int j = 0; j < r; j++) T[(r + P + j) * TPITCH + xx] = t;
+         for (int j = 0; j < r; j++) *reinterpret_cast<v2f *>(T + (r + P + j) * TPITCH + xx) = t;
    }
    __syncthreads();
-   // column pass, blurred window back into S with pitch P
-   for (int idx = tid; idx < P * P; idx += 256) {
-      const int yy = hs_div_small(idx, invP), xx = idx - yy * P;
+   // column pass, blurred window back into S with pitch SPITCH
+   for (int idx = tid; idx < P * PC; idx += 256) {
+      const int yy = hs_div_small(idx, invPC), xx = 2 * (idx - yy * PC);
       const float *tp = T + (r + yy) * TPITCH + xx;
-      float d = kk[r] * tp[0];
+      auto TT = [&](int j) { return *reinterpret_cast<const v2f *>(tp + j * TPITCH); };
+      v2f d = kk[r] * TT(0);
 #pragma unroll
-      for (int j = 1; j <= r; j++) d += kk[r + j] * (tp[j * TPITCH] + tp[-j * TPITCH]);
-      S[idx] = d;
+      for (int j = 1; j <= r; j++) d += kk[r + j] * (TT(j) + TT(-j));
+      *reinterpret_cast<v2f *>(S + yy * SPITCH + xx) = d;
    }
    __syncthreads();
 }
 
 template <int BIN>
-__global__ __launch_bounds__(256) void k_patch_extract_small(HessList hl, PatchWork pw, PatchIO io, KpTables tb)
+__global__ __launch_bounds__(256, HS_SMALL_WAVES) void k_patch_extract_small(HessList hl, PatchWork pw, PatchIO io, KpTables tb)
 {
    extern __shared__ __attribute__((aligned(16))) float smem[];
-   constexpr int PMAX = BIN == 0 ? 41 : 64;   // the bins are cut on P = P0 + 2 (hs_patch_bin)
-   constexpr int SPITCH = PMAX + 2 * HS_SMALL_RMAX, TPITCH = PMAX;
-   constexpr int SSZ = (PMAX * SPITCH + 3) & ~3;
-   float *S = smem, *T = smem + SSZ, *s_taps = T + (PMAX + 2 * HS_SMALL_RMAX) * TPITCH;
-   __shared__ int s_flag;
+   typedef SmallGeom<BIN> GM;
+   constexpr int PMAX = GM::PMAX, SPITCH = GM::SPITCH, TPITCH = GM::TPITCH;
+   float *S = smem, *T = smem + GM::SSZ, *s_taps = T + GM::TSZ;
+   v2f *s_R = reinterpret_cast<v2f *>(s_taps + 16), *s_C = s_R + (PMAX + 1);
    __shared__ int s_tab_i[HS_PATCH];
    __shared__ float s_tab_f[HS_PATCH];
 
@@ -171,10 +233,10 @@ __global__ __launch_bounds__(256) void k_patch_extract_small(HessList hl, PatchW
       float *out = io.patches + (size_t)(h - io.h_base) * HS_PATCH_PIX;
       const HsPlaneBuf pbuf = hs_plane_buf(img, imRows, imPitch);
       if (!((double)scale > 0.4)) {
-         // direct branch, affine.cpp:137-141
+         // direct branch, affine.cpp:137-141: the taps keep their bounds test (interpolateCheckBorders only
+         // looked at the patch corners; the reference asserts that nothing is outside)
          const float b11 = a11 * scale, b12 = a12 * scale, b21 = a21 * scale, b22 = a22 * scale;
-         // 7 taps per thread in two batches (4 + 3): one batch of 7 costs 23 more VGPRs and with them
-         // three of the eight wavefronts a SIMD can hold
+         // 7 taps per thread in two batches (4 + 3): one batch of 7 costs 23 more VGPRs
 #pragma unroll
          for (int h0 = 0; h0 < HS_PATCH_PIX_IT; h0 += 4) {
             float dv[4];
@@ -204,13 +266,13 @@ __global__ __launch_bounds__(256) void k_patch_extract_small(HessList hl, PatchW
       const int P = P0 + 2, half = P >> 1;
       const int K = tb.patch_tap_k[(P0 - 1) >> 1], r = K >> 1;
       const float *taps_g = tb.patch_taps + tb.patch_tap_off[(P0 - 1) >> 1];
-      if (tid == 0) s_flag = 0;
       if (tid < K) s_taps[tid] = taps_g[tid];
+      if (tid < P) s_R[tid] = hs_row_coord(x, y, a12, a22, tid - half);
+      else if (tid >= 128 && tid - 128 < P) s_C[tid - 128] = hs_col_coord(a11, a21, tid - 128 - half);
       hs_resample_table(P, scale, s_tab_i, s_tab_f);
       __syncthreads();
-      // 1. warp, affine.cpp:126 ; touching the image boundary rejects the keypoint.  All gathers of
-      // a batch are issued before the first use (clamped index, branch-free tap).
-      bool outside = false;
+      // 1. warp, affine.cpp:126 (the window lies inside the image: k_prepare_patch).  All gathers of a
+      // batch are issued before the first use.
       constexpr int WNIT = BIN == 0 ? HS_WNIT0 : HS_WNIT1;
       const int PP = P * P;
       const float invP = 1.0f / (float)P;
@@ -220,10 +282,8 @@ __global__ __launch_bounds__(256) void k_patch_extract_small(HessList hl, PatchW
          for (int it = 0; it < WNIT; it++) {
             const int idx = min(ib + tid + 256 * it, PP - 1);
             const int jj = hs_div_small(idx, invP), ii = idx - jj * P;
-            const int j = jj - half, i = ii - half;
-            const float rx = x + (float)j * a12, ry = y + (float)j * a22;
-            const float wx = rx + (float)i * a11, wy = ry + (float)i * a21;
-            wv[it] = hs_bilinear_buf(pbuf, width, height, wx, wy, outside);
+            const v2f w = s_R[jj] + s_C[ii];
+            wv[it] = hs_tap_inside(pbuf, w.x, w.y);
          }
 #pragma unroll
          for (int it = 0; it < WNIT; it++) HS_KEEP(wv[it]);
@@ -236,13 +296,7 @@ __global__ __launch_bounds__(256) void k_patch_extract_small(HessList hl, PatchW
             }
          }
       }
-      if (outside) s_flag = 1;
       __syncthreads();
-      if (s_flag != 0) {
-         if (tid == 0) pw.alive[h] = 0;
-         __syncthreads();
-         continue;
-      }
       // 2. blur, affine.cpp:129 (pinned cv::GaussianBlur order, see the file header)
       switch (K) {
          case 3: hs_small_blur<3, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
@@ -255,33 +309,34 @@ __global__ __launch_bounds__(256) void k_patch_extract_small(HessList hl, PatchW
          default: hs_small_blur<0, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
       }
       // 3. resample, affine.cpp:131
-      hs_resample_full_tab(S, P, s_tab_i, s_tab_f, out);
+      hs_resample_full_tab(S, SPITCH, s_tab_i, s_tab_f, out);
       __syncthreads();
    }
 }
 
-// The same four column-pass sums with the loads batched: the two chains share their rows (row
-// y0 + j of chain (y0) is row (y0 + 1) + (j - 1) of chain (y0 + 1)), and the loads of JC tap steps
-// are issued together - the plane is read through L2 / HBM, where a load per tap step followed
-// by its use is a full round trip per step.  CLAMP = false: T points at window row 0 of a plane
+// The four column-pass sums an output of the 41x41 resample needs, from the row-pass plane T[rows][82] that holds
+// only the needed columns: window rows y0 (chain a) and y0 + 1 (chain b), needed columns q and q + 1 (one aligned pair).
+// Each sum keeps the SymmColumnFilter order d = k[r]*T[y]; d += k[r+j]*(T[y+j]+T[y-j]); the two chains share their
+// rows (row y0 + j of chain a is row (y0 + 1) + (j - 1) of chain b), the loads of JC tap steps are issued together -
+// the plane is read through L2 / HBM, where a load per tap step followed by its use is a full round trip per step -
+// and the two columns of a row ride in one packed operation.  CLAMP = false: T points at window row 0 of a plane
 // stored with r replicated rows above and below (k_patch_mid's HBM slot), no index clamps.
-//   chain a = window row y0, chain b = window row y0 + 1, columns q and q + 1.
 template <int JC, bool CLAMP>
 __device__ __forceinline__ void hs_colpass4_rows(const float *__restrict__ T, int y0, int q, int pm, const float *__restrict__ taps, int r,
-                                                 float &p00, float &p01, float &p10, float &p11)
+                                                 v2f &pa, v2f &pb)
 {
-   // row y of the window -> float2 at T[row][q]; CLAMP: BORDER_REPLICATE by index clamp (unpadded plane)
+   // row y of the window -> pair at T[row][q]; CLAMP: BORDER_REPLICATE by index clamp (unpadded plane)
    auto ld = [&](int y) {
       const int row = CLAMP ? min(max(y, 0), pm) : y;
-      return *reinterpret_cast<const float2 *>(T + row * HS_NEED + q);
+      return *reinterpret_cast<const v2f *>(T + row * HS_NEED + q);
    };
-   const float2 c0 = ld(y0), c1 = ld(y0 + 1);
+   const v2f c0 = ld(y0), c1 = ld(y0 + 1);
    const float kc = taps[r];
-   float d00 = kc * c0.x, d01 = kc * c0.y, d10 = kc * c1.x, d11 = kc * c1.y;
-   float2 pj = c1;   // row y0 + j      (j = 1)
-   float2 mj = c0;   // row y0 + 1 - j  (j = 1)
+   v2f da = kc * c0, db = kc * c1;
+   v2f pj = c1;   // row y0 + j      (j = 1)
+   v2f mj = c0;   // row y0 + 1 - j  (j = 1)
    for (int j0 = 1; j0 <= r; j0 += JC) {
-      float2 pn[JC], mn[JC];   // rows y0 + j + 1 and y0 - j
+      v2f pn[JC], mn[JC];   // rows y0 + j + 1 and y0 - j
 #pragma unroll
       for (int u = 0; u < JC; u++) {
          const int j = min(j0 + u, r);   // steps past r re-read step r's rows, unused
@@ -293,14 +348,16 @@ __device__ __forceinline__ void hs_colpass4_rows(const float *__restrict__ T, in
          const int j = j0 + u;
          if (j <= r) {   // block-uniform
             const float kj = taps[r + j];
-            const float s00 = pj.x + mn[u].x, s01 = pj.y + mn[u].y, s10 = pn[u].x + mj.x, s11 = pn[u].y + mj.y;
-            d00 += kj * s00; d01 += kj * s01; d10 += kj * s10; d11 += kj * s11;
+            const v2f sa = pj + mn[u], sb = pn[u] + mj;
+            da += kj * sa;
+            db += kj * sb;
             pj = pn[u];
             mj = mn[u];
          }
       }
    }
-   p00 = d00; p01 = d01; p10 = d10; p11 = d11;
+   pa = da;
+   pb = db;
 }
 
 // resample of affine.cpp:131 from the row-pass plane at the 82 needed columns (PADDED: T points at
@@ -311,16 +368,16 @@ __device__ __forceinline__ void hs_resample_reduced_batched(const float *__restr
 {
    const float c0 = (float)(P >> 1);
    for (int idx = threadIdx.x; idx < HS_PATCH_PIX; idx += 256) {
-      const int jj = idx / HS_PATCH, ii = idx - jj * HS_PATCH;
+      const int jj = hs_div_small(idx, 1.0f / (float)HS_PATCH), ii = idx - jj * HS_PATCH;
       const int j = jj - (HS_PATCH >> 1), i = ii - (HS_PATCH >> 1);
       const float rx = c0 + (float)j * 0.0f, ry = c0 + (float)j * scale;
       float wx = rx + (float)i * scale, wy = ry + (float)i * 0.0f;
       const float fx = floorf(wx), fy = floorf(wy);
       wx -= fx; wy -= fy;
       const int y0 = min(max((int)fy, 0), P - 2);   // always inside: |j * scale| < P0 / 2
-      float p00, p01, p10, p11;
-      hs_colpass4_rows<8, !PADDED>(T, y0, 2 * ii, P - 1, taps, r, p00, p01, p10, p11);
-      s_patch[idx] = (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + (wy) * ((1.0f - wx) * p10 + wx * p11);
+      v2f pa, pb;   // (p00, p01), (p10, p11)
+      hs_colpass4_rows<8, !PADDED>(T, y0, 2 * ii, P - 1, taps, r, pa, pb);
+      s_patch[idx] = (1.0f - wy) * ((1.0f - wx) * pa.x + wx * pa.y) + (wy) * ((1.0f - wx) * pb.x + wx * pb.y);
    }
 }
 
@@ -328,26 +385,24 @@ __device__ __forceinline__ void hs_resample_reduced_batched(const float *__restr
 // needed columns.  Called by all 64 lanes of a wave.  The LDS row is stored with r replicated
 // border samples on either side (BORDER_REPLICATE), so the tap loop has no index clamps:
 //   srow[r + x] = S[x],  srow[0..r) = S[0],  srow[r+P .. r+P+r) = S[P-1]     (needs P + 2r floats)
-// The image gathers of NIT x 64 window pixels are issued together (branch-free taps, clamped
-// index) before any of them is used; taps are read from LDS (`taps`, broadcast reads).
-// Lane i < 41 owns the output pair (2i, 2i + 1); the two accumulation chains share their reads.
+// The image gathers of NIT x 64 window pixels are issued together before any of them is used; taps are read from
+// LDS (`taps`, broadcast reads).  ctab: the window's column table C[ii] = (i*a11, i*a21) in LDS, or nullptr
+// (huge windows: computed per tap).
+// Lane i < 41 owns the output pair (2i, 2i + 1); the two accumulation chains run as one packed chain.
 template <int NIT>
-__device__ __forceinline__ void hs_row_stream(const HsPlaneBuf &img, int width, int height, float x, float y,
-                                              float a11, float a12, float a21, float a22, int P, int yy, float scale,
-                                              const float *__restrict__ taps, int K, float *__restrict__ srow, float *__restrict__ out82,
-                                              bool &outside, int pad_r = 0)
+__device__ __forceinline__ void hs_row_stream(const HsPlaneBuf &img, float x, float y, float a11, float a12, float a21, float a22, int P, int yy,
+                                              float scale, const v2f *__restrict__ ctab, const float *__restrict__ taps, int K,
+                                              float *__restrict__ srow, float *__restrict__ out82, int pad_r = 0)
 {
    const int lane = threadIdx.x & 63, half = P >> 1, pm = P - 1, r = K >> 1;
-   const int j = yy - half;
-   const float rx = x + (float)j * a12, ry = y + (float)j * a22;
+   const v2f rc = hs_row_coord(x, y, a12, a22, yy - half);
    for (int xb = 0; xb < P; xb += 64 * NIT) {
       float v[NIT];
 #pragma unroll
       for (int it = 0; it < NIT; it++) {
          const int xx = min(xb + lane + 64 * it, pm);   // lanes past the row re-sample its last pixel (not stored)
-         const int i = xx - half;
-         const float wx = rx + (float)i * a11, wy = ry + (float)i * a21;
-         v[it] = hs_bilinear_buf(img, width, height, wx, wy, outside);
+         const v2f w = rc + (ctab ? ctab[xx] : hs_col_coord(a11, a21, xx - half));
+         v[it] = hs_tap_inside(img, w.x, w.y);
       }
 #pragma unroll
       for (int it = 0; it < NIT; it++) HS_KEEP(v[it]);
@@ -364,42 +419,33 @@ __device__ __forceinline__ void hs_row_stream(const HsPlaneBuf &img, int width, 
    }
    HS_WAVE_LDS_SYNC();
    // Lane i < 41 owns the output pair q = 2i, 2i + 1: the two blurred columns floor(w) and floor(w) + 1
-   // that output pixel i of the 41x41 resample reads.  Their tap windows overlap in all but one
-   // sample, so the pair costs K + 1 LDS reads instead of 2K.  (0 <= floor(w) <= P - 2 always:
-   // |(i - 20) * scale| < P0 / 2.)
+   // that output pixel i of the 41x41 resample reads.  (0 <= floor(w) <= P - 2 always: |(i - 20) * scale| < P0 / 2.)
    if (lane < HS_PATCH) {
       const float c0 = (float)half;
       const float w = c0 + (float)(lane - 20) * scale;
       const int x0 = min(max((int)floorf(w), 0), pm - 1);
       const float *s = srow + x0;   // s[jt] = S[clamp(x0 - r + jt)],  s[jt + 1] = S[clamp(x0 + 1 - r + jt)]
-      float prev = s[1];
-      float t0 = taps[0] * s[0], t1 = taps[0] * prev;
+      auto G = [&](int jt) { v2f g; g.x = s[jt]; g.y = s[jt + 1]; return g; };
+      // RowFilter order; a window of this path has P0 >= 63, i.e. K = odd(int(9 * P0 / 41 + 1)) >= 15 (never the K <= 5 form)
+      v2f t = taps[0] * G(0);
 #pragma unroll 8
-      for (int jt = 1; jt < K; jt++) {
-         const float k = taps[jt];
-         const float nxt = s[jt + 1];
-         const float p0 = k * prev, p1 = k * nxt;
-         t0 += p0;
-         t1 += p1;
-         prev = nxt;
-      }
-      if (out82) {
-         float2 *o = reinterpret_cast<float2 *>(out82) + lane;
-         *o = make_float2(t0, t1);
-         // padded T' plane: the first / last window row is replicated pad_r times above / below (wave-uniform)
-         if (pad_r > 0 && (yy == 0 || yy == pm)) {
-            const int step = (yy == 0) ? -(HS_NEED / 2) : (HS_NEED / 2);
-            for (int jr = 1; jr <= pad_r; jr++) o[jr * step] = make_float2(t0, t1);
-         }
+      for (int jt = 1; jt < K; jt++) t += taps[jt] * G(jt);
+      v2f *o = reinterpret_cast<v2f *>(out82) + lane;
+      *o = t;
+      // padded T' plane: the first / last window row is replicated pad_r times above / below (wave-uniform)
+      if (pad_r > 0 && (yy == 0 || yy == pm)) {
+         const int step = (yy == 0) ? -(HS_NEED / 2) : (HS_NEED / 2);
+         for (int jr = 1; jr <= pad_r; jr++) o[jr * step] = t;
       }
    }
    HS_WAVE_LDS_SYNC();
 }
 
 // ---------------------------------------------------------------------------------------
-// k_patch_mid: 64 < P <= 128.  Each of the 4 waves streams window rows (warp -> row pass at
-// the 82 needed columns) into Tp[P][82] in LDS; then the resample evaluates the column
-// pass where it reads.  LDS ~52 KB -> 3 blocks per CU.
+// k_patch_mid: 64 < P <= 128 (bin 2) and 128 < P <= 512 (bin 3).  Each of the 4 waves streams window rows
+// (warp -> row pass at the 82 needed columns) into T' (P x 82, padded with K/2 replicated rows above and below) in a
+// per-block slot of HBM scratch (io.trows), written and re-read by the same block (L2-hot); then the resample
+// evaluates the column pass where it reads.
 // ---------------------------------------------------------------------------------------
 #define HS_MID_PMAX 128
 #define HS_MID_SROW 160   // 128 + 2 x 14 border samples, padded
@@ -410,27 +456,31 @@ __device__ __forceinline__ void hs_row_stream(const HsPlaneBuf &img, int width, 
 #define HS_MID_BLOCKS (256 * 7)   // persistent grids of the row-streamed bins: one T' slot per block
 #define HS_BIG_BLOCKS (256 * 8)
 
-// PMAX = 128: bin 2; PMAX = 512: bin 3.  T' (P x 82, padded with K/2 replicated rows above and below) lives in
-// a per-block slot of HBM scratch (io.trows), written and re-read by the same block (L2-hot).
+template <int PMAX> struct MidGeom {
+   static constexpr bool BIG = PMAX > HS_MID_PMAX;
+   static constexpr int SROW = BIG ? HS_BIG_SROW : HS_MID_SROW;
+   static constexpr int NTAP = BIG ? HS_BIG_TAPS : 32;
+   static constexpr int RPAD = BIG ? HS_BIG_RPAD : HS_MID_RPAD;
+   // s_patch | taps | C table (float2 x (PMAX + 2)) | 4 wave rows
+   static constexpr int FLOATS = HS_PATCH_ARR + NTAP + 2 * (PMAX + 2) + 4 * SROW;
+};
+
 template <int PMAX>
-__global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, PatchIO io, KpTables tb)
+__global__ __launch_bounds__(256, HS_MID_WAVES) void k_patch_mid(HessList hl, PatchWork pw, PatchIO io, KpTables tb)
 {
-   constexpr bool BIG = PMAX > HS_MID_PMAX;
-   constexpr int BIN = BIG ? 3 : 2;
-   constexpr int SROW = BIG ? HS_BIG_SROW : HS_MID_SROW;
-   constexpr int NTAP = BIG ? HS_BIG_TAPS : 32;
-   constexpr int NIT = BIG ? 4 : 2;
+   typedef MidGeom<PMAX> GM;
+   constexpr int BIN = GM::BIG ? 3 : 2;
+   constexpr int NIT = GM::BIG ? 4 : 2;
    extern __shared__ __attribute__((aligned(16))) float smem[];
    float *s_patch = smem;
    float *s_taps = s_patch + HS_PATCH_ARR;
-   float *s_srow = s_taps + NTAP;                      // 4 waves x SROW
-   __shared__ int s_flag;
-   constexpr int RPAD = BIG ? HS_BIG_RPAD : HS_MID_RPAD;
-   float *Tp = io.trows + (size_t)blockIdx.x * ((size_t)(PMAX + 2 * RPAD) * HS_NEED);
+   v2f *s_C = reinterpret_cast<v2f *>(s_taps + GM::NTAP);
+   float *s_srow = reinterpret_cast<float *>(s_C + (PMAX + 2));   // 4 waves x SROW
+   float *Tp = io.trows + (size_t)blockIdx.x * ((size_t)(PMAX + 2 * GM::RPAD) * HS_NEED);
 
    const int tid = threadIdx.x, wave = tid >> 6;
    const uint32_t cnt = min(pw.bin_count[BIN], pw.cap);
-   const int imPitch = io.image.pitch, width = io.image.cols - 1, height = io.image.rows - 1;
+   const int imPitch = io.image.pitch;
 
    for (uint32_t wi = blockIdx.x; wi < cnt; wi += gridDim.x) {
       const uint32_t h = pw.bin_items[(size_t)BIN * pw.cap + wi];
@@ -438,25 +488,18 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
       const HsPlaneBuf ib = hs_plane_buf(io.image.img(b), io.image.rows, imPitch);
       const float x = hl.x[h], y = hl.y[h];
       const float a11 = pw.A[4 * h], a12 = pw.A[4 * h + 1], a21 = pw.A[4 * h + 2], a22 = pw.A[4 * h + 3];
-      const int P0 = pw.P0[h], P = P0 + 2;
+      const int P0 = pw.P0[h], P = P0 + 2, half = P >> 1;
       const float scale = (float)P0 / (float)HS_PATCH;
       const int K = tb.patch_tap_k[(P0 - 1) >> 1];
       const float *taps_g = tb.patch_taps + tb.patch_tap_off[(P0 - 1) >> 1];
-      if (tid == 0) s_flag = 0;
       if (tid < K) s_taps[tid] = taps_g[tid];
+      for (int m = tid; m < P; m += 256) s_C[m] = hs_col_coord(a11, a21, m - half);
       __syncthreads();
-      bool outside = false;
 #pragma unroll 1
       for (int yy = wave; yy < P; yy += 4)
-         hs_row_stream<NIT>(ib, width, height, x, y, a11, a12, a21, a22, P, yy, scale, s_taps, K, s_srow + wave * SROW,
-                            Tp + (size_t)(yy + (K >> 1)) * HS_NEED, outside, K >> 1);
-      if (outside) s_flag = 1;
+         hs_row_stream<NIT>(ib, x, y, a11, a12, a21, a22, P, yy, scale, s_C, s_taps, K, s_srow + wave * GM::SROW,
+                            Tp + (size_t)(yy + (K >> 1)) * HS_NEED, K >> 1);
       __syncthreads();   // workgroup-scope release/acquire: the T' rows of all four waves are visible
-      if (s_flag != 0) {
-         if (tid == 0) pw.alive[h] = 0;
-         __syncthreads();
-         continue;
-      }
       hs_resample_reduced_batched<true>(Tp + (K >> 1) * HS_NEED, P, scale, s_taps, K >> 1, s_patch);
       __syncthreads();
       for (int i = tid; i < HS_PATCH_PIX; i += 256) io.patches[(size_t)(h - io.h_base) * HS_PATCH_PIX + i] = s_patch[i];
@@ -465,10 +508,13 @@ __global__ __launch_bounds__(256) void k_patch_mid(HessList hl, PatchWork pw, Pa
 }
 
 // ---------------------------------------------------------------------------------------
-// Large windows (P > 128, ~2 % of the keypoints, most of the blur work).
-// k_patch_large_rows: grid-stride over ALL window rows of the round's keypoints, one
-//   wavefront per row (binary search of the row id in the prefix of P); writes T' rows to HBM.
+// Large windows (P > 512: well under 1 % of the keypoints, ~15 % of all window pixels).
+// k_large_prefix: exclusive prefix of the window sides over the bin's items = first T' row of every item.
+// k_patch_large_rows: grid-stride over ALL window rows of the group's huge keypoints, one wavefront per chunk
+//   of rows (binary search of the row id in the prefix); writes T' rows to HBM.
 // k_patch_large_finish: one block per keypoint: column pass at the resample taps.
+// The item count and the prefix stay on the device; the host only supplies an upper bound of the rows
+// (k_image_large_rows) to size the T' buffer.
 // ---------------------------------------------------------------------------------------
 #define HS_LARGE_CHUNK 16   // consecutive window rows per wavefront task
 
@@ -487,7 +533,7 @@ __global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork
       if (threadIdx.x == 0 && blockIdx.x == 0) *io.overflow = 1u;
       return;
    }
-   const int imPitch = io.image.pitch, width = io.image.cols - 1, height = io.image.rows - 1;
+   const int imPitch = io.image.pitch;
    const uint32_t ntasks = (row_hi + HS_LARGE_CHUNK - 1) / HS_LARGE_CHUNK;
    for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
       uint32_t row = task * HS_LARGE_CHUNK;
@@ -514,11 +560,9 @@ __global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork
          // this item's taps -> the wave's LDS tap buffer (broadcast reads in the tap loop)
          for (int i = threadIdx.x & 63; i < K; i += 64) stap[i] = taps[i];
          HS_WAVE_LDS_SYNC();
-         bool outside = false;
          for (; row < it_rows_end; row++)
-            hs_row_stream<8>(ib, width, height, kx, ky, a11, a12, a21, a22, P, (int)(row - first), scale, stap, K, srow,
-                             io.trows + (size_t)row * HS_NEED, outside);
-         if (outside) pw.alive[h] = 0;   // every writer stores the same value
+            hs_row_stream<8>(ib, kx, ky, a11, a12, a21, a22, P, (int)(row - first), scale, nullptr, stap, K, srow,
+                             io.trows + (size_t)row * HS_NEED);
          it++;
       }
    }
@@ -529,9 +573,9 @@ __global__ __launch_bounds__(256) void k_patch_large_finish(PatchWork pw, PatchI
    __shared__ float s_patch[HS_PATCH_ARR];
    const uint32_t *pre = io.row_prefix;
    const uint32_t n_items = min(pw.bin_count[HS_NBINS - 1], pw.cap);
+   if (n_items == 0 || pre[n_items] > io.trows_cap) return;
    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
       const uint32_t h = pw.bin_items[(size_t)(HS_NBINS - 1) * pw.cap + it];
-      if (!pw.alive[h]) continue;   // uniform for the block
       const int P0 = pw.P0[h], P = P0 + 2;
       const float scale = (float)P0 / (float)HS_PATCH;
       const int K = tb.patch_tap_k[(P0 - 1) >> 1];

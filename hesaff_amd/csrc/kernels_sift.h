@@ -75,74 +75,105 @@ __global__ __launch_bounds__(64) void k_sift_meanvar(SiftIO io, KpTables tb)
 }
 
 // k_sift_grad: photometric normalisation (helpers.cpp:269-280) + gradient magnitude and
-// orientation (siftdesc.cpp:123-137) + the per-pixel factors of samplePatch.  One block per
-// keypoint: every pixel is normalised once into LDS, then one thread per pixel takes the
-// gradient stencil from LDS.  Output: vo[k][r][c] = (mask*grad, o), r, c < 40, with
-// o = float(8 * (atan2f + 2 pi) / (2 pi)) evaluated in double like the reference.  Row and
-// column 40 are not produced: their spatial weights are zero (bin0 and bin1 both clamped,
-// siftdesc.cpp:33-44) so samplePatch adds nothing for them; neither are the pixels outside the
+// orientation (siftdesc.cpp:123-137) + the per-pixel factors of samplePatch.  Every pixel of a patch is
+// normalised once into LDS, then one thread per pixel takes the gradient stencil from LDS.
+// Output: vo[k][r][c] = (mask*grad, o), r, c < 40, with o = float(8 * (atan2f + 2 pi) / (2 pi)) evaluated in
+// double like the reference.  Row and column 40 are not produced: their spatial weights are zero (bin0 and bin1
+// both clamped, siftdesc.cpp:33-44) so samplePatch adds nothing for them; neither are the pixels outside the
 // circular mask (mask*grad = 0 adds nothing either).
-// All per-pixel math is select-based (hm_atan2f_sel): no divergence inside a wavefront.
-// grid n, block 256.
-__global__ __launch_bounds__(256) void k_sift_grad(SiftIO io, KpTables tb, float2 *__restrict__ vo)
+// This kernel is bound by VALU issue (correctly rounded sqrt and two divisions, fdlibm atan2f, a double-precision
+// quotient per pixel), so everything that does not depend on the keypoint is computed ONCE per thread: blocks are
+// persistent (grid-stride over keypoints), a thread owns the same five pixels of every patch and keeps their
+// neighbour addresses, output offset and mask value in registers; the interval constants of atanf come from an
+// LDS table (hm_atan2f_tab: no select trees, no divergence).  The next keypoint's pixels are requested before
+// the current one is evaluated.
+// grid: min(n, 256 * 8) blocks of 256 threads.
+#ifndef HS_SGRAD_WAVES
+#define HS_SGRAD_WAVES 0   // tuning: wavefronts per SIMD to hold the register allocation to (0: the compiler's choice)
+#endif
+__global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, KpTables tb, float2 *__restrict__ vo)
 {
    __shared__ float s_p[HS_PATCH_PIX];
-   const uint32_t k = blockIdx.x;
-   const uint32_t h = io.h_lo + k;
+   __shared__ float s_at[HM_ATAN_TAB_FLOATS];
    const int tid = threadIdx.x;
-   // Everything the block reads from global memory is requested up front, in two dependent rounds
-   // (the second one only for the mask values): a block lives for little more than its memory
-   // round trips, so a chain of dependent loads (alive -> mean -> pixels -> index -> mask) is
-   // what it would spend its time on.
-   const int alive = io.alive[h];
-   const float mean = io.meanvar[2 * (size_t)k], var = io.meanvar[2 * (size_t)k + 1];
-   const float *gp = io.patches + (size_t)k * HS_PATCH_PIX;
-   float pv[HS_PATCH_PIX_IT];
-#pragma unroll
-   for (int q = 0; q < HS_PATCH_PIX_IT; q++) pv[q] = gp[min(tid + 256 * q, HS_PATCH_PIX - 1)];
-   // Only the pixels inside the circular mask (1245 of 1681, helpers.cpp:131) are evaluated: where
-   // the mask is 0 the pair is (0, *) and samplePatch adds nothing; those entries of the buffer are
-   // zero-filled once when it is allocated and never written.
+   const uint32_t n = io.h_hi - io.h_lo;
+   {
+      const float at_init[HM_ATAN_TAB_FLOATS] = HM_ATAN_TAB_INIT;
+      if (tid < HM_ATAN_TAB_FLOATS) s_at[tid] = at_init[tid];
+   }
+   // this thread's pixels inside the circular mask (1245 of 1681, helpers.cpp:131): LDS byte addresses of the
+   // stencil neighbours (affine.cpp:14-33 convention: one-sided differences at the patch border), output slot, mask
    const int nm = tb.n_masked;
-   int mi[HS_SIFT_MSK_IT];
+   int a_l[HS_SIFT_MSK_IT], a_r[HS_SIFT_MSK_IT], a_u[HS_SIFT_MSK_IT], a_d[HS_SIFT_MSK_IT], o_off[HS_SIFT_MSK_IT];
    float mv[HS_SIFT_MSK_IT];
 #pragma unroll
-   for (int q = 0; q < HS_SIFT_MSK_IT; q++) mi[q] = tb.mask_idx[min(tid + 256 * q, nm - 1)];
-#pragma unroll
-   for (int q = 0; q < HS_SIFT_MSK_IT; q++) mv[q] = tb.sift_mask[mi[q]];
-   if (!alive) return;
-   const bool norm = !((double)var < 0.0001);
-   const float fac = 50.0f / var;
-#pragma unroll
-   for (int q = 0; q < HS_PATCH_PIX_IT; q++) {
-      const int i = tid + 256 * q;
-      if (i < HS_PATCH_PIX) {
-         float v = pv[q];
-         if (norm) { v = 128 + fac * (v - mean); v = v > 255 ? 255.0f : v; v = v < 0 ? 0.0f : v; }
-         s_p[i] = v;
-      }
-   }
-#pragma unroll
-   for (int q = 0; q < HS_SIFT_MSK_IT; q++) HS_KEEP(mv[q]);
-   __syncthreads();
-   float2 *out = vo + (size_t)k * HS_VO_PITCH;
-#pragma unroll
    for (int q = 0; q < HS_SIFT_MSK_IT; q++) {
-      const int i = mi[q];
+      const int slot = tid + 256 * q;
+      const int i = tb.mask_idx[min(slot, nm - 1)];
       const int r = i / HS_PATCH, c = i - r * HS_PATCH;
-      if (tid + 256 * q < nm && r < HS_VO_DIM && c < HS_VO_DIM) {
-         // the four (or three) patch values the gradient stencil reads, affine.cpp:14-33 convention
-         const int il = (c == 0) ? i : i - 1, ir = i + 1;                  // c <= 39 < patchSize - 1
-         const int iu = (r == 0) ? i : i - HS_PATCH, id = i + HS_PATCH;    // r <= 39
-         const float gx = s_p[ir] - s_p[il], gy = s_p[id] - s_p[iu];
-         const float grad = sqrtf(gx * gx + gy * gy);
-         const float ori = hm_atan2f_sel(gy, gx);
-         const float o = hm_sift_orient_coord(ori);
-         out[r * HS_VO_DIM + c] = make_float2(mv[q] * grad, o);
+      const bool valid = slot < nm && r < HS_VO_DIM && c < HS_VO_DIM;
+      a_l[q] = (c == 0) ? i : i - 1;                  // c <= 39 < patchSize - 1 for valid pixels
+      a_r[q] = i + 1;
+      a_u[q] = (r == 0) ? i : i - HS_PATCH;
+      a_d[q] = i + HS_PATCH;
+      o_off[q] = valid ? r * HS_VO_DIM + c : -1;
+      mv[q] = tb.sift_mask[i];
+      if (!valid) { a_l[q] = a_r[q] = a_u[q] = a_d[q] = 0; }
+   }
+   uint32_t k = blockIdx.x;
+   if (k >= n) return;
+   // first keypoint's operands
+   float pv[HS_PATCH_PIX_IT];
+   int alive = io.alive[io.h_lo + k];
+   float mean = io.meanvar[2 * (size_t)k], var = io.meanvar[2 * (size_t)k + 1];
+   {
+      const float *gp = io.patches + (size_t)k * HS_PATCH_PIX;
+#pragma unroll
+      for (int q = 0; q < HS_PATCH_PIX_IT; q++) pv[q] = gp[min(tid + 256 * q, HS_PATCH_PIX - 1)];
+   }
+   for (; k < n; k += gridDim.x) {
+      const bool cur_alive = alive != 0;
+      // normalise this keypoint's pixels into LDS (helpers.cpp:269-280: ALL pixels, not only the masked ones)
+      if (cur_alive) {
+         const bool norm = !((double)var < 0.0001);
+         const float fac = 50.0f / var;
+#pragma unroll
+         for (int q = 0; q < HS_PATCH_PIX_IT; q++) {
+            const int i = tid + 256 * q;
+            if (i < HS_PATCH_PIX) {
+               float v = pv[q];
+               if (norm) { v = 128 + fac * (v - mean); v = v > 255 ? 255.0f : v; v = v < 0 ? 0.0f : v; }
+               s_p[i] = v;
+            }
+         }
       }
-      // the loop is unrolled only so that mi[q] / mv[q] are registers; do not let the scheduler
-      // interleave the iterations (five atan2 bodies in flight cost ~60 VGPRs)
-      __builtin_amdgcn_sched_barrier(0);
+      // request the next keypoint's operands before evaluating this one
+      const uint32_t kn = k + gridDim.x;
+      if (kn < n) {
+         alive = io.alive[io.h_lo + kn];
+         mean = io.meanvar[2 * (size_t)kn]; var = io.meanvar[2 * (size_t)kn + 1];
+         const float *gp = io.patches + (size_t)kn * HS_PATCH_PIX;
+#pragma unroll
+         for (int q = 0; q < HS_PATCH_PIX_IT; q++) pv[q] = gp[min(tid + 256 * q, HS_PATCH_PIX - 1)];
+      }
+      __syncthreads();
+      if (cur_alive) {
+         float2 *out = vo + (size_t)k * HS_VO_PITCH;
+#pragma unroll
+         for (int q = 0; q < HS_SIFT_MSK_IT; q++) {
+            if (o_off[q] >= 0) {
+               const float gx = s_p[a_r[q]] - s_p[a_l[q]], gy = s_p[a_d[q]] - s_p[a_u[q]];
+               const float grad = sqrtf(gx * gx + gy * gy);
+               const float ori = hm_atan2f_tab(gy, gx, s_at);
+               const float o = hm_sift_orient_coord(ori);
+               out[o_off[q]] = make_float2(mv[q] * grad, o);
+            }
+            // the loop is unrolled only so that the per-pixel constants are registers; do not let the scheduler
+            // interleave the iterations (five atan2 bodies in flight cost ~60 VGPRs)
+            __builtin_amdgcn_sched_barrier(0);
+         }
+      }
+      __syncthreads();
    }
 }
 
@@ -155,7 +186,10 @@ __global__ __launch_bounds__(256) void k_sift_grad(SiftIO io, KpTables tb, float
 // The (mask*grad, o) rows are read straight from global memory, 8 x 16 bytes per cell row and
 // lane, the next row in flight while the current one is consumed.
 // grid-stride over groups of 4 keypoints, block 64.
-__global__ __launch_bounds__(64) void k_sift_hist(SiftIO io, KpTables tb, const float2 *__restrict__ vo)
+#ifndef HS_HIST_WAVES
+#define HS_HIST_WAVES 0   // tuning: wavefronts per SIMD to hold the register allocation to (0: the compiler's choice)
+#endif
+__global__ __launch_bounds__(64, HS_HIST_WAVES) void k_sift_hist(SiftIO io, KpTables tb, const float2 *__restrict__ vo)
 {
    __shared__ float s_acc[8 * 64];
    __shared__ float s_cw[64];   // [spatial bin][offset 0..15]

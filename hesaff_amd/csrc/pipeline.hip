@@ -191,10 +191,11 @@ struct hesaff_ctx {
    // schedule knobs: fixed in the product build, environment-driven only under -DHESAFF_TUNING
    bool no_overlap = false;        // HESAFF_OVERLAP=0: every kernel alone on the device (per-kernel profiling)
    uint32_t sift_group_kpts = 0;   // HESAFF_GROUP: keypoints per image group; 0 = by batch
-   int aff_blocks_per_cu = 6;      // HESAFF_AFF_BLOCKS: persistent k_affine blocks per CU (19 KB of LDS each)
+   int aff_blocks_per_cu = 8;      // HESAFF_AFF_BLOCKS: persistent k_affine blocks per CU (19 KB of LDS each, 2 wavefronts per SIMD at 244 VGPRs)
    int side_mask = 15;             // HESAFF_SIDE: bit i = window-size bin i runs on its own side stream
    int force_bands = 0;            // HESAFF_BANDS: force the band count of k_blur_hess_march
    bool debug = false;             // HESAFF_DEBUG=1: launch geometry on stderr
+   uint32_t sgrad_grid = 0;        // HESAFF_SGRAD_GRID: persistent grid of k_sift_grad (0: one block per keypoint)
    std::vector<hipEvent_t> ev_pool;
    size_t ev_used = 0;
 };
@@ -308,14 +309,9 @@ template <class KERNEL> void set_dyn_lds(KERNEL kern, size_t lds)
    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 }
 
-size_t small_extract_lds_bytes(int bin)
-{
-   const int PMAX = bin == 0 ? 41 : 64;
-   const int SSZ = (PMAX * (PMAX + 2 * HS_SMALL_RMAX) + 3) & ~3;
-   return (size_t)(SSZ + (PMAX + 2 * HS_SMALL_RMAX) * PMAX + 16) * 4;
-}
-size_t mid_lds_bytes() { return (size_t)(HS_PATCH_ARR + 32 + 4 * HS_MID_SROW) * 4; }
-size_t big_lds_bytes() { return (size_t)(HS_PATCH_ARR + HS_BIG_TAPS + 4 * HS_BIG_SROW) * 4; }
+size_t small_extract_lds_bytes(int bin) { return (size_t)(bin == 0 ? SmallGeom<0>::FLOATS : SmallGeom<1>::FLOATS) * 4; }
+size_t mid_lds_bytes() { return (size_t)MidGeom<HS_MID_PMAX>::FLOATS * 4; }
+size_t big_lds_bytes() { return (size_t)MidGeom<HS_BIN3_PMAX>::FLOATS * 4; }
 
 // geometry of the large-window row kernel for windows up to pmax: LDS per wave = window row + replicated borders + taps
 struct LargeGeom { int srow_stride, tap_stride; size_t lds; };
@@ -751,7 +747,7 @@ void launch_sift(hesaff_ctx *c, hipStream_t ss, const SiftIO &so, uint32_t n, fl
 {
    const uint32_t nb64 = (n + 63) / 64;
    hipLaunchKernelGGL(k_sift_meanvar, dim3(nb64), dim3(64), 0, ss, so, c->tables);
-   hipLaunchKernelGGL(k_sift_grad, dim3(n), dim3(256), 0, ss, so, c->tables, vo);
+   hipLaunchKernelGGL(k_sift_grad, dim3(c->sgrad_grid ? std::min(n, c->sgrad_grid) : n), dim3(256), 0, ss, so, c->tables, vo);
    hipLaunchKernelGGL(k_sift_hist, dim3(std::min<uint32_t>((n + 3) / 4, 256 * 32)), dim3(64), 0, ss, so, c->tables, (const float2 *)vo);
    hipLaunchKernelGGL(k_sift_quantize, dim3(nb64), dim3(64), 0, ss, so, c->consts);
 }
