@@ -255,6 +255,7 @@ struct PatchWork {
    int32_t *P0;         // 2*int(mrScale)+1 ; 0 = dead before the patch stage
    int32_t *alive;      // 1 while the keypoint is still a candidate for output
    uint32_t *bin_count; // [HS_NBINS]
+   uint32_t *bin_work;  // [HS_NBINS] next unclaimed item of each bin's list (dynamic scheduling of the patch kernels)
    uint32_t *bin_items; // [HS_NBINS][cap]
    uint32_t cap;
 };

@@ -130,8 +130,8 @@ __device__ __forceinline__ void hs_resample_full_tab(const float *S, int pitch, 
 #define HS_WNIT0 4
 #define HS_WNIT1 6
 #ifndef HS_SMALL_WAVES
-#define HS_SMALL_WAVES 0   // tuning: wavefronts per SIMD to hold the register allocation to (0: the compiler's choice)
-#endif
+#define HS_SMALL_WAVES 6   // wavefronts per SIMD the register allocation of bin 0 is held to (0: the compiler's choice, 4);
+#endif                     // measured: 17.0 / 15.7 / 14.3 ms per 32 UHD images at 4 / 5 / 6; bin 1 spills at 6 and stays at the compiler's choice
 #ifndef HS_MID_WAVES
 #define HS_MID_WAVES 0
 #endif
@@ -207,7 +207,7 @@ __device__ __forceinline__ void hs_small_blur(float *S, float *T, int P, const f
 }
 
 template <int BIN>
-__global__ __launch_bounds__(256, HS_SMALL_WAVES) void k_patch_extract_small(HessList hl, PatchWork pw, PatchIO io, KpTables tb)
+__global__ __launch_bounds__(256, (BIN == 0 ? HS_SMALL_WAVES : 0)) void k_patch_extract_small(HessList hl, PatchWork pw, PatchIO io, KpTables tb)
 {
    extern __shared__ __attribute__((aligned(16))) float smem[];
    typedef SmallGeom<BIN> GM;
@@ -222,6 +222,8 @@ __global__ __launch_bounds__(256, HS_SMALL_WAVES) void k_patch_extract_small(Hes
    const int imCols = io.image.cols, imRows = io.image.rows, imPitch = io.image.pitch;
    const int width = imCols - 1, height = imRows - 1;
 
+   // static striding: the windows of these two bins cost about the same, and a claim per item on one counter
+   // (2 M items per batch) would serialise in L2
    for (uint32_t wi = blockIdx.x; wi < cnt; wi += gridDim.x) {
       const uint32_t h = pw.bin_items[(size_t)BIN * pw.cap + wi];
       const int b = hl.meta[h] >> 8;
@@ -441,6 +443,66 @@ __device__ __forceinline__ void hs_row_stream(const HsPlaneBuf &img, float x, fl
    HS_WAVE_LDS_SYNC();
 }
 
+// Two window rows at once (rows yyA and yyB of the same window, one LDS row each): the gathers of both rows are in
+// flight together and the two row-pass chains interleave, so that neither the memory round trip nor the dependent
+// accumulation of one row leaves the wavefront without work.  Same operations per row as hs_row_stream.
+template <int NIT>
+__device__ __forceinline__ void hs_row_stream2(const HsPlaneBuf &img, float x, float y, float a12, float a22, int P, int yyA, int yyB,
+                                               float scale, const v2f *__restrict__ ctab, const float *__restrict__ taps, int K,
+                                               float *__restrict__ srowA, float *__restrict__ srowB, float *__restrict__ outA, float *__restrict__ outB, int pad_r)
+{
+   const int lane = threadIdx.x & 63, half = P >> 1, pm = P - 1, r = K >> 1;
+   const v2f rcA = hs_row_coord(x, y, a12, a22, yyA - half), rcB = hs_row_coord(x, y, a12, a22, yyB - half);
+   for (int xb = 0; xb < P; xb += 64 * NIT) {
+      float vA[NIT], vB[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+         const int xx = min(xb + lane + 64 * it, pm);   // lanes past the row re-sample its last pixel (not stored)
+         const v2f c = ctab[xx];
+         const v2f wA = rcA + c, wB = rcB + c;
+         vA[it] = hs_tap_inside(img, wA.x, wA.y);
+         vB[it] = hs_tap_inside(img, wB.x, wB.y);
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; it++) { HS_KEEP(vA[it]); HS_KEEP(vB[it]); }
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+         const int xx = xb + lane + 64 * it;
+         if (xx < P) { srowA[r + xx] = vA[it]; srowB[r + xx] = vB[it]; }
+      }
+   }
+   HS_WAVE_LDS_SYNC();
+   {
+      const float fA = srowA[r], lA = srowA[r + pm], fB = srowB[r], lB = srowB[r + pm];
+      for (int i = lane; i < r; i += 64) { srowA[i] = fA; srowA[r + P + i] = lA; srowB[i] = fB; srowB[r + P + i] = lB; }
+   }
+   HS_WAVE_LDS_SYNC();
+   if (lane < HS_PATCH) {
+      const float c0 = (float)half;
+      const float w = c0 + (float)(lane - 20) * scale;
+      const int x0 = min(max((int)floorf(w), 0), pm - 1);
+      const float *sA = srowA + x0, *sB = srowB + x0;
+      auto GA = [&](int jt) { v2f g; g.x = sA[jt]; g.y = sA[jt + 1]; return g; };
+      auto GB = [&](int jt) { v2f g; g.x = sB[jt]; g.y = sB[jt + 1]; return g; };
+      v2f tA = taps[0] * GA(0), tB = taps[0] * GB(0);
+#pragma unroll 4
+      for (int jt = 1; jt < K; jt++) {
+         const float k = taps[jt];
+         tA += k * GA(jt);
+         tB += k * GB(jt);
+      }
+      v2f *oA = reinterpret_cast<v2f *>(outA) + lane, *oB = reinterpret_cast<v2f *>(outB) + lane;
+      *oA = tA;
+      *oB = tB;
+      // padded T' plane: the first / last window row is replicated pad_r times above / below (wave-uniform)
+      if (pad_r > 0 && yyA == 0)
+         for (int jr = 1; jr <= pad_r; jr++) oA[-jr * (HS_NEED / 2)] = tA;
+      if (pad_r > 0 && yyB == pm)
+         for (int jr = 1; jr <= pad_r; jr++) oB[jr * (HS_NEED / 2)] = tB;
+   }
+   HS_WAVE_LDS_SYNC();
+}
+
 // ---------------------------------------------------------------------------------------
 // k_patch_mid: 64 < P <= 128 (bin 2) and 128 < P <= 512 (bin 3).  Each of the 4 waves streams window rows
 // (warp -> row pass at the 82 needed columns) into T' (P x 82, padded with K/2 replicated rows above and below) in a
@@ -461,8 +523,8 @@ template <int PMAX> struct MidGeom {
    static constexpr int SROW = BIG ? HS_BIG_SROW : HS_MID_SROW;
    static constexpr int NTAP = BIG ? HS_BIG_TAPS : 32;
    static constexpr int RPAD = BIG ? HS_BIG_RPAD : HS_MID_RPAD;
-   // s_patch | taps | C table (float2 x (PMAX + 2)) | 4 wave rows
-   static constexpr int FLOATS = HS_PATCH_ARR + NTAP + 2 * (PMAX + 2) + 4 * SROW;
+   // s_patch | taps | C table (float2 x (PMAX + 2)) | 4 waves x 2 rows
+   static constexpr int FLOATS = HS_PATCH_ARR + NTAP + 2 * (PMAX + 2) + 8 * SROW;
 };
 
 template <int PMAX>
@@ -475,14 +537,22 @@ __global__ __launch_bounds__(256, HS_MID_WAVES) void k_patch_mid(HessList hl, Pa
    float *s_patch = smem;
    float *s_taps = s_patch + HS_PATCH_ARR;
    v2f *s_C = reinterpret_cast<v2f *>(s_taps + GM::NTAP);
-   float *s_srow = reinterpret_cast<float *>(s_C + (PMAX + 2));   // 4 waves x SROW
+   float *s_srow = reinterpret_cast<float *>(s_C + (PMAX + 2));   // 4 waves x 2 rows x SROW
    float *Tp = io.trows + (size_t)blockIdx.x * ((size_t)(PMAX + 2 * GM::RPAD) * HS_NEED);
 
    const int tid = threadIdx.x, wave = tid >> 6;
    const uint32_t cnt = min(pw.bin_count[BIN], pw.cap);
    const int imPitch = io.image.pitch;
 
-   for (uint32_t wi = blockIdx.x; wi < cnt; wi += gridDim.x) {
+   // Dynamic scheduling: a block claims the next item of the bin's list when it is free, so blocks that draw cheap
+   // windows (the cost of an item grows with P^2: 16x across a bin) take more of them instead of idling at the end of
+   // the launch.  (The two LDS-window bins stride statically: uniform cost, and 2 M claims on one counter would serialise.)
+   __shared__ uint32_t s_item;
+   for (;;) {
+      if (tid == 0) s_item = atomicAdd(pw.bin_work + BIN, 1u);
+      __syncthreads();
+      const uint32_t wi = s_item;
+      if (wi >= cnt) break;
       const uint32_t h = pw.bin_items[(size_t)BIN * pw.cap + wi];
       const int b = hl.meta[h] >> 8;
       const HsPlaneBuf ib = hs_plane_buf(io.image.img(b), io.image.rows, imPitch);
@@ -495,10 +565,17 @@ __global__ __launch_bounds__(256, HS_MID_WAVES) void k_patch_mid(HessList hl, Pa
       if (tid < K) s_taps[tid] = taps_g[tid];
       for (int m = tid; m < P; m += 256) s_C[m] = hs_col_coord(a11, a21, m - half);
       __syncthreads();
+      float *srowA = s_srow + wave * 2 * GM::SROW, *srowB = srowA + GM::SROW;
 #pragma unroll 1
-      for (int yy = wave; yy < P; yy += 4)
-         hs_row_stream<NIT>(ib, x, y, a11, a12, a21, a22, P, yy, scale, s_C, s_taps, K, s_srow + wave * GM::SROW,
-                            Tp + (size_t)(yy + (K >> 1)) * HS_NEED, K >> 1);
+      for (int yy = wave; yy < P; yy += 8) {
+         // rows yy and yy + 4 of this wavefront together; a last single row alone
+         if (yy + 4 < P)
+            hs_row_stream2<NIT>(ib, x, y, a12, a22, P, yy, yy + 4, scale, s_C, s_taps, K, srowA, srowB,
+                                Tp + (size_t)(yy + (K >> 1)) * HS_NEED, Tp + (size_t)(yy + 4 + (K >> 1)) * HS_NEED, K >> 1);
+         else
+            hs_row_stream<NIT>(ib, x, y, a11, a12, a21, a22, P, yy, scale, s_C, s_taps, K, srowA,
+                               Tp + (size_t)(yy + (K >> 1)) * HS_NEED, K >> 1);
+      }
       __syncthreads();   // workgroup-scope release/acquire: the T' rows of all four waves are visible
       hs_resample_reduced_batched<true>(Tp + (K >> 1) * HS_NEED, P, scale, s_taps, K >> 1, s_patch);
       __syncthreads();

@@ -150,7 +150,8 @@ struct hesaff_ctx {
    DPlane gray, L3, R[5];
    // lists
    DevBuf b_counters;       // uint32: [0] cand_count [1] rec_count [2] overflow [3] hess_total [4] desc_total [5] group end
-                            //         [6] T' row overflow, [8..12] bin_count, [16..16+HS_MAX_OCTAVES) octave rec starts
+                            //         [6] T' row overflow, [8..12] bin_count, [24..28] bin work counters,
+                            //         [32..32+HS_MAX_OCTAVES) octave rec starts
    DevBuf b_cand, b_rec_f, b_rec_i, b_rec_w, b_hess_f, b_hess_i, b_aff, b_pw, b_bins, b_rank, b_desc, b_out, b_starts, b_patches, b_stage;
    DevBuf b_input;          // staging for host images (stage API)
    // hesaff_detect_batch, host entry point: chunks of max_batch images are pipelined -- pinned
@@ -528,7 +529,7 @@ Lists make_lists(hesaff_ctx *c)
    s.ao.converged = ai; s.ao.iters = ai + cap; s.ao.U = (float *)(ai + 2 * cap);
    int32_t *pi = c->b_pw.as<int32_t>();
    s.pw.P0 = pi; s.pw.alive = pi + cap; s.pw.A = (float *)(pi + 2 * cap);
-   s.pw.bin_count = cnt + 8; s.pw.bin_items = c->b_bins.as<uint32_t>(); s.pw.cap = c->cap;
+   s.pw.bin_count = cnt + 8; s.pw.bin_work = cnt + 24; s.pw.bin_items = c->b_bins.as<uint32_t>(); s.pw.cap = c->cap;
    return s;
 }
 
@@ -669,7 +670,7 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
       t = tm.begin(T_DET);
       HIP_TRY(hipMemsetAsync(c->b_map.p, 0xFF, (size_t)B * g.rows * g.cols * 4, st));
       HIP_TRY(hipMemsetAsync(cnt + 0, 0, 4, st));
-      HIP_TRY(hipMemcpyAsync(cnt + 16 + o, cnt + 1, 4, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpyAsync(cnt + 32 + o, cnt + 1, 4, hipMemcpyDeviceToDevice, st));
       OctaveCtx oc;
       for (int l = 0; l < 5; l++) { oc.R[l] = Ro[l]; oc.L[l] = Lo[l]; oc.sigma[l] = sc.level_sigma[l]; }
       oc.pixelDistance = (float)(1 << o);
@@ -687,7 +688,7 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
          const dim3 grid(strips, (g.rows + band - 1) / band, B);
          hipLaunchKernelGGL(k_extrema_march, grid, dim3(64), 0, st, fp, c->consts.positiveThreshold, c->consts.negativeThreshold, s.cl, band);
          hipLaunchKernelGGL(k_localize, dim3(1024), dim3(256), 0, st, oc, s.cl, s.rl, c->consts);
-         hipLaunchKernelGGL(k_dedupe, dim3(512), dim3(256), 0, st, oc, s.rl, (const uint32_t *)(cnt + 16 + o),
+         hipLaunchKernelGGL(k_dedupe, dim3(512), dim3(256), 0, st, oc, s.rl, (const uint32_t *)(cnt + 32 + o),
                             c->b_bitmask.as<unsigned long long>());
       }
       tm.end(t);
@@ -842,7 +843,7 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
          const int slot = (int)(gi & 1);
          if (slot_used[slot]) HIP_TRY(hipStreamWaitEvent(st, c->ev_sift_done[slot], 0));   // the slot's previous descriptors are finished
          t = tm.begin(T_PATCH);
-         HIP_TRY(hipMemsetAsync(cnt + 8, 0, HS_NBINS * 4, st));
+         HIP_TRY(hipMemsetAsync(cnt + 8, 0, 24 * 4, st));   // bin counts [8..13) and work counters [24..29)
          HIP_TRY(hipMemcpyAsync(cnt + 5, &groups[gi].hi, 4, hipMemcpyHostToDevice, st));
          hipLaunchKernelGGL(k_prepare_patch, dim3(1024), dim3(256), 0, st, s.hl, h_lo, (const uint32_t *)(cnt + 5), s.ao, H, W, c->consts,
                             c->tables, s.pw);
