@@ -3,18 +3,27 @@
 
 A "step" is one pass of the whole hot path (grey -> pyramid + det-Hessian -> extrema ->
 affine -> patch -> SIFT -> ordered records) over one batch of synthetic 3840x2160 8-bit
-images that are already resident in HBM.  One process per GPU; images shard across ranks
-with no data-path collective, one all-gather of counts at the end (RCCL).
+images.  One process per GPU; images shard across ranks with no data-path collective, one
+all-gather of counts at the end (RCCL).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant pyramid kernel
-(k_blur_hess: Gaussian + det-of-Hessian), timed live with HIP events on the library's
-stream; `cpu_baseline` is the CPU oracle (a port of the reference, 1 thread) on a bounded
-sample of the same images.
+Prints ONE JSON line (rank 0):
+  value         descriptors/s with the batch already resident in HBM when the timed region starts and the
+                records left in HBM (hesaff_detect_batch_device) -- the harness contract for `value`;
+  host_path     the same batch through hesaff_detect_batch: host images in -> H2D -> kernels -> D2H -> host
+                records out, chunks pipelined (SURVEY.md 8d: "H2D -> D2H inclusive"), in the same run;
+  text_export   hesaff_write_sift_batch (exportKeypoints hesaff.cpp:107-130 for every image) to a RAM disk on a
+                bounded subset, and the end-to-end rate with the export of batch i beside the detection of i+1;
+  roofline      the dominant pyramid kernel (k_blur_hess_march: Gaussian + det-of-Hessian), timed live with HIP
+                events on the library's stream;
+  cpu_baseline  the CPU oracle (a port of the reference, 1 thread) on a bounded sample of the same images;
+                cpu_baseline_multicore: one oracle process per physical core.
 """
 import argparse
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -46,6 +55,40 @@ def _cpu_oracle_worker(img):
     return o.n_keys, time.perf_counter() - t0
 
 
+def host_cpu_info():
+    """CPU model, logical / physical core counts and SMT state of this host (for the CPU baseline legs)."""
+    info = {"logical_cpus": os.cpu_count()}
+    try:
+        model = None
+        cores = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        info["model"] = model
+        if cores:
+            info["physical_cores"] = len(cores)
+    except OSError:
+        pass
+    try:
+        info["smt"] = open("/sys/devices/system/cpu/smt/active").read().strip() == "1"
+    except OSError:
+        pass
+    try:
+        info["usable_cpus"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -55,9 +98,12 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=1, help="images of the batch timed on the CPU oracle")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-inclusive and text-export legs")
+    ap.add_argument("--host-chunk", type=int, default=32, help="images per pipelined chunk of the host path (hesaff_params.max_batch)")
+    ap.add_argument("--export-images", type=int, default=32, help="images of the batch written as .hesaff.sift text (RAM disk)")
+    ap.add_argument("--cpu-images", type=int, default=2, help="images of the batch timed on the CPU oracle, 1 thread (about 14 s each)")
     ap.add_argument("--cpu-workers", type=int, default=-1,
-                    help="worker processes of the multi-core CPU baseline, one image each (-1: min(32, host cpus / 4); 0: skip)")
+                    help="worker processes of the multi-core CPU baseline, one image each (-1: one per physical core, at most the batch; 0: skip)")
     args = ap.parse_args()
 
     import torch
@@ -109,7 +155,7 @@ def main():
         torch.cuda.synchronize()
 
     bh_ms = 0.0; bh_bytes = 0.0; bh_launches = 0
-    stage = {"pyramid_ms": 0.0, "detect_ms": 0.0, "affine_ms": 0.0, "patch_ms": 0.0, "sift_ms": 0.0, "pack_ms": 0.0}
+    stage = {"pyramid_ms": 0.0, "detect_ms": 0.0, "affine_ms": 0.0, "patch_ms": 0.0, "sift_ms": 0.0, "pack_ms": 0.0, "total_ms": 0.0}
     n_desc = 0; n_hess = 0
     barrier()
     t0 = time.perf_counter()
@@ -129,9 +175,70 @@ def main():
     from hesaff_amd.shard import gather_counts
     counts = gather_counts([n_hess, n_desc, B * args.steps], device=coll_dev if world > 1 else None)
     tot_hess, tot_desc, tot_imgs = [int(v) for v in counts.sum(axis=0)]
+    ctx.close()
+
+    # ---- host-inclusive leg: host images -> hesaff_detect_batch -> host records, + text export ----
+    host_path = None
+    text_export = None
+    if not args.no_host_path:
+        hp = hesaff_amd.default_params()
+        hp.max_batch = max(1, min(args.host_chunk, B))
+        hctx = hesaff_amd.HesaffContext(hp, device=local_rank)
+        host_imgs = list(imgs.cpu().numpy())           # B pageable host images; the library stages them through pinned memory
+        del imgs
+        torch.cuda.empty_cache()
+        hctx.detect_batch(host_imgs[: 2 * hp.max_batch])   # warm-up: buffers of both pipeline slots
+        hsteps = max(1, min(args.steps, 2))
+        barrier()
+        t1 = time.perf_counter()
+        hdesc = 0
+        res = None
+        for _ in range(hsteps):
+            res = hctx.detect_batch_raw(host_imgs)
+            hdesc += sum(r.count_desc for r in res)
+        barrier()
+        hdt = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([hdt], device=coll_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            hdt = float(t.item())
+        hc = gather_counts([hdesc, B * hsteps], device=coll_dev if world > 1 else None).sum(axis=0)
+        host_path = {"value": float(hc[0]) / hdt, "unit": "keypoints/s", "images_per_s": float(hc[1]) / hdt, "steps": hsteps,
+                     "ms_per_step": hdt / hsteps * 1e3, "chunk_images": int(hp.max_batch),
+                     "what": "hesaff_detect_batch: pageable host images -> pinned staging -> H2D -> kernels -> D2H -> pinned host records; "
+                             "chunks of %d images, H2D of chunk i+1 and D2H of chunk i-1 beside the kernels of chunk i" % hp.max_batch,
+                     "h2d_bytes_per_step": B * H * W, "d2h_bytes_per_step": int(hdesc // hsteps) * 164}
+        # text export (exportKeypoints for every image) on a bounded subset, to a RAM disk when there is one
+        if rank == 0 and args.export_images > 0:
+            ne = min(args.export_images, B)
+            base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+            tmp = tempfile.mkdtemp(prefix="hesaff_bench_", dir=base)
+            try:
+                paths = [os.path.join(tmp, "img%04d.hesaff.sift" % i) for i in range(ne)]
+                hctx.write_sift_batch_raw(paths, res[:ne], hp.mrSize, 0)            # warm-up (page cache, thread pool)
+                t2 = time.perf_counter()
+                hctx.write_sift_batch_raw(paths, res[:ne], hp.mrSize, 0)
+                edt = time.perf_counter() - t2
+                rows = sum(r.count_desc for r in res[:ne])
+                nbytes = sum(os.path.getsize(q) for q in paths)
+                exp_img_s = ne / edt
+                det_img_s = host_path["images_per_s"] / max(world, 1)   # per rank
+                text_export = {"images": ne, "rows_per_s": rows / edt, "images_per_s": exp_img_s, "text_GB_per_s": nbytes / edt / 1e9,
+                               "bytes_per_image": nbytes / ne, "threads": "auto (one per core, at most 64)", "target": tmp.rsplit("/", 1)[0],
+                               # the export of batch i runs on host threads beside the detection of batch i+1: the slower of the two sets the rate
+                               "end_to_end_images_per_s_pipelined": min(exp_img_s, det_img_s),
+                               "end_to_end_images_per_s_sequential": 1.0 / (1.0 / exp_img_s + 1.0 / det_img_s),
+                               "what": "hesaff_write_sift_batch (the reference's text format, hesaff.cpp:107-130) of %d images of the batch" % ne}
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+        cpu_sample = host_imgs
+        hctx.close()
+    else:
+        cpu_sample = None
 
     if rank == 0:
         achieved = (bh_bytes / 1e9) / (bh_ms / 1e3) if bh_ms > 0 else 0.0
+        st = {k: v / args.steps for k, v in stage.items()}
         out = {
             "metric": "keypoints/sec (descriptors written), 4K grayscale batch",
             "value": tot_desc / dt,
@@ -149,45 +256,61 @@ def main():
             "data": "synthetic",
             "config": {"workload": "batch of %d x %dx%d 8-bit grey images per GPU per step, band-noise synthetic, default params" % (B, W, H),
                        "images_per_gpu_per_step": B, "width": W, "height": H, "sharding": "image-level, %d rank(s)" % world,
-                       "descriptors_per_image": tot_desc / max(tot_imgs, 1)},
-            "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
+                       "descriptors_per_image": tot_desc / max(tot_imgs, 1),
+                       "value_is": "device-resident: inputs in HBM before the timed region, records left in HBM (hesaff_detect_batch_device)"},
+            "host_path": host_path,
+            "text_export": text_export,
+            "stage_ms_per_step": {"serial_on_main_stream": {"pyramid_ms": st["pyramid_ms"], "detect_ms": st["detect_ms"], "pack_ms": st["pack_ms"]},
+                                  "concurrent_stream_busy_time": {"affine_ms": st["affine_ms"], "patch_ms": st["patch_ms"], "sift_ms": st["sift_ms"]},
+                                  "device_total_ms": st["total_ms"],
+                                  "note": "affine / patch / sift run concurrently on three streams over groups of images (three-deep pipeline): "
+                                          "each figure is the sum of that stage's own event brackets on its own stream, they overlap in "
+                                          "wall-clock time and add up to more than device_total_ms minus the serial stages"},
             "roofline": {"bound": "hbm",
                          "kernel": "k_blur_hess_march (Gaussian + det-of-Hessian; 4 launches per octave = 58 B/px algorithmic: "
                                    "12 B/px each + 8 B/px for the fused R0 + 2 B/px for the fused decimation)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(B, W, H, bh_launches // max(args.steps, 1)), "launches": bh_launches,
-                         "avg_launch_ms": bh_ms / max(bh_launches, 1), "bytes_per_launch_avg": bh_bytes / max(bh_launches, 1)},
+                         "avg_launch_ms": bh_ms / max(bh_launches, 1), "bytes_per_launch_avg": bh_bytes / max(bh_launches, 1),
+                         "stage": {"what": "whole pyramid stage incl. grey conversion and initial blur: B_pyr = 5 N0 + 58 sum N_k per image (SURVEY.md 8d)",
+                                   "achieved": (tm.pyramid_bytes / 1e9) / (st["pyramid_ms"] / 1e3) if st["pyramid_ms"] > 0 else 0.0,
+                                   "frac": ((tm.pyramid_bytes / 1e9) / (st["pyramid_ms"] / 1e3)) / HBM_PEAK_GBS if st["pyramid_ms"] > 0 else 0.0}},
         }
         if not args.no_cpu_baseline and world == 1:
             from tests import _oracle
-            host = imgs[: args.cpu_images].cpu().numpy()
+            if cpu_sample is None:
+                cpu_sample = list(imgs.cpu().numpy())
+            cpu = host_cpu_info()
+            host = cpu_sample[: max(1, args.cpu_images)]
             t1 = time.perf_counter()
             nk = 0
-            for i in range(len(host)):
-                o = _oracle.OracleRun(_oracle.gray_from_u8(host[i]))
+            for im in host:
+                o = _oracle.OracleRun(_oracle.gray_from_u8(im))
                 nk += o.n_keys
             cdt = time.perf_counter() - t1
             out["cpu_baseline"] = {"value": nk / cdt, "unit": "keypoints/s", "cores": 1, "kind": "port",
                                    "images_per_s": len(host) / cdt,
                                    "sample": "%d of the %d batch images (%dx%d), oracle/libhesaff_oracle.so, 1 thread, %.1f s"
                                              % (len(host), B, W, H, cdt),
-                                   "host_cpus": os.cpu_count()}
-            # the same oracle, one worker process per image over W cores
-            nw = args.cpu_workers if args.cpu_workers >= 0 else min(32, max(1, (os.cpu_count() or 4) // 4))
-            nw = min(nw, B)
+                                   "cpu": cpu}
+            # the same oracle, one worker process per physical core, one image each (>= 8 images)
+            phys = cpu.get("physical_cores") or max(1, (cpu.get("logical_cpus") or 4) // 2)
+            usable = cpu.get("usable_cpus") or cpu.get("logical_cpus") or phys
+            nw = args.cpu_workers if args.cpu_workers >= 0 else min(phys, usable)
+            nw = min(nw, len(cpu_sample))
             if nw > 1:
                 import multiprocessing as mp
-                sample = [imgs[i].cpu().numpy() for i in range(nw)]
+                sample = cpu_sample[:nw]
                 t1 = time.perf_counter()
                 with mp.get_context("spawn").Pool(nw) as pool:
                     res = pool.map(_cpu_oracle_worker, sample)
                 mdt = time.perf_counter() - t1
                 out["cpu_baseline_multicore"] = {"value": sum(r[0] for r in res) / mdt, "unit": "keypoints/s", "cores": nw, "kind": "port",
                                                  "images_per_s": nw / mdt,
-                                                 "sample": "%d of the %d batch images, one oracle process each, %.1f s wall (slowest worker %.1f s)"
-                                                           % (nw, B, mdt, max(r[1] for r in res))}
+                                                 "sample": "%d of the %d batch images, one oracle process per physical core (%d workers), one image each, "
+                                                           "%.1f s wall (slowest worker %.1f s)" % (nw, B, nw, mdt, max(r[1] for r in res)),
+                                                 "cpu": cpu}
         print(json.dumps(out))
-    ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

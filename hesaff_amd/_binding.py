@@ -110,6 +110,7 @@ def load_library():
     L.hesaff_stage_normalize_affine.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _i32p, _f32p]
     L.hesaff_stage_sift.argtypes = [vp, C.c_int, _f32p, _u8p]
     L.hesaff_stage_math.argtypes = [vp, C.c_int, _f32p, _f32p, _f32p, _f32p]
+    L.hesaff_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.hesaff_table_gauss_mask.argtypes = [C.c_int, _f32p]
     L.hesaff_table_circ_gauss_mask.argtypes = [C.c_int, _f32p]
     L.hesaff_table_sift_bins.argtypes = [_i32p, _i32p, _f32p, _f32p]
@@ -127,7 +128,7 @@ ABI_SYMBOLS = [
     "hesaff_stage_find_affine_shape", "hesaff_stage_rectify", "hesaff_stage_normalize_affine", "hesaff_stage_sift",
     "hesaff_stage_math", "hesaff_table_gauss_mask", "hesaff_table_circ_gauss_mask", "hesaff_table_sift_bins",
     "hesaff_table_gauss_kernel", "hesaff_format_sift_mt", "hesaff_write_sift_batch", "hesaff_test_fmt_g",
-    "hesaff_read_png", "hesaff_read_image",
+    "hesaff_read_png", "hesaff_read_image", "hesaff_device_count", "hesaff_shard_range",
 ]
 
 
@@ -294,6 +295,29 @@ class HesaffContext:
                 keys = np.zeros(0, KEYPOINT_DTYPE)
             out.append((r.count_hessian, keys))
         return out
+
+    def detect_batch_raw(self, images):
+        """hesaff_detect_batch without copying the records out: -> ctypes array of hesaff_result whose `keys` point into
+        library-owned pinned memory (valid until the next call on this context)."""
+        n = len(images)
+        imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        ws = (C.c_int * n)(*[im.shape[1] for im in imgs])
+        hs = (C.c_int * n)(*[im.shape[0] for im in imgs])
+        chs = (C.c_int * n)(*[1 if im.ndim == 2 else 3 for im in imgs])
+        st = (C.c_int * n)(*[im.shape[1] * (1 if im.ndim == 2 else 3) for im in imgs])
+        res = (_Result * n)()
+        self._check(self.L.hesaff_detect_batch(self.h, n, ptrs, ws, hs, st, chs, res))
+        return res
+
+    def write_sift_batch_raw(self, paths, results, mr_size, threads=0):
+        """hesaff_write_sift_batch on hesaff_result records (e.g. a slice of detect_batch_raw's return value)."""
+        n = len(paths)
+        arr = (_Result * n)(*[results[i] for i in range(n)])
+        cp = (C.c_char_p * n)(*[os.fsencode(q) for q in paths])
+        rc = self.L.hesaff_write_sift_batch(n, cp, arr, C.c_float(mr_size), threads)
+        if rc != 0:
+            raise HesaffError(rc, "hesaff_write_sift_batch")
 
     def detect_batch_device(self, d_ptr, n, width, height):
         """Inputs resident in HBM (uint8 [n,H,W], raw device pointer).  -> (count_hessian[n], count_desc[n], d_keys, total)."""

@@ -49,6 +49,21 @@ const char *hesaff_version(void)
 #endif
 }
 
+int hesaff_device_count(void)
+{
+   int n = 0;
+   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+   return n;
+}
+
+int hesaff_shard_range(int n, int rank, int world, int *lo, int *hi)
+{
+   if (n < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi) return HESAFF_ERR_ARG;
+   *lo = (int)(((long long)n * rank + world - 1) / world);
+   *hi = (int)(((long long)n * (rank + 1) + world - 1) / world);
+   return HESAFF_OK;
+}
+
 int hesaff_default_params(hesaff_params *p)
 {
    if (!p) return HESAFF_ERR_ARG;

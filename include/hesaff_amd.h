@@ -194,6 +194,13 @@ int hesaff_table_circ_gauss_mask(int size, float *mask);
 int hesaff_table_sift_bins(int32_t *bin0, int32_t *bin1, float *w0, float *w1);
 int hesaff_table_gauss_kernel(float sigma, int cap, float *taps, int *ksize);
 
+/* ---- multi-GPU: images of a batch shard across the devices of a node, no data-path collective ---- */
+/* number of visible HIP devices (0 when there is none / no runtime) */
+int hesaff_device_count(void);
+/* contiguous block [*lo, *hi) of n items owned by `rank` of `world`: item i belongs to rank floor(i * world / n);
+ * the same rule as hesaff_amd/shard.py:shard_range (bench.py, one process per GPU) */
+int hesaff_shard_range(int n, int rank, int world, int *lo, int *hi);
+
 const char *hesaff_version(void);
 
 #ifdef __cplusplus

@@ -209,6 +209,70 @@ def test_cli_batch_mode(tmp_path):
         assert open(n + ".hesaff.sift", "rb").read() == want and len(want) > 1000
 
 
+def test_cli_multi_device_shards_and_isolates_bad_files(tmp_path):
+    """`hesaff --batch list --devices 0,0`: two device contexts on two host threads of one process, the list split into
+    contiguous shards (hesaff_shard_range) -- every .hesaff.sift byte equals the single-context run; an unreadable file
+    is reported and skipped without losing the rest of the batch."""
+    exe = os.path.join(ROOT, "hesaff_amd", "bin", "hesaff")
+    names = []
+    for i, (h, w, seed) in enumerate(((120, 160, 5), (131, 77, 7), (120, 160, 6), (200, 140, 8), (96, 96, 9), (120, 160, 10), (77, 131, 11))):
+        img = band_noise_image(h, w, seed, SMALL_BANDS)
+        q = tmp_path / ("m%d.pgm" % i)
+        q.write_bytes(b"P5\n%d %d\n255\n" % (w, h) + img.tobytes())
+        names.append(str(q))
+    bad = tmp_path / "broken.pgm"
+    bad.write_bytes(b"P5\n10 10\n255\nshort")
+    lst = tmp_path / "list.txt"
+    lst.write_text("\n".join(names[:3] + [str(bad)] + names[3:]) + "\n")
+
+    def run(devs):
+        for n in names:
+            if os.path.exists(n + ".hesaff.sift"):
+                os.remove(n + ".hesaff.sift")
+        r = subprocess.run([exe, "--batch", str(lst), "--devices", devs], capture_output=True, text=True)
+        assert r.returncode == 1, (r.stdout, r.stderr)               # the broken file
+        assert "broken.pgm" in r.stderr and "skipped" in r.stderr
+        m = re.search(r"Detected (\d+) keypoints and (\d+) affine shapes in 7 images", r.stdout)
+        assert m, r.stdout
+        return [open(n + ".hesaff.sift", "rb").read() for n in names], (int(m.group(1)), int(m.group(2)))
+    one, tot1 = run("0")
+    two, tot2 = run("0,0")
+    three, tot3 = run("0,0,0")
+    assert tot1 == tot2 == tot3 and tot1[1] > 300
+    assert one == two == three and all(len(b) > 100 for b in one)
+    r = subprocess.run([exe, "--batch", str(lst), "--devices", "0-99"], capture_output=True, text=True)
+    assert r.returncode == 1 and "--devices" in r.stderr
+
+
+def test_two_contexts_on_two_threads_shard_a_batch(ctx):
+    """Image-level sharding inside one process: two contexts driven by two host threads, contiguous blocks
+    from shard_range, results identical to one context over the whole list."""
+    import threading
+    import hesaff_amd
+    from hesaff_amd.shard import shard_range
+    imgs = [band_noise_image(150 + 10 * (i % 3), 200 + 8 * (i % 2), 60 + i, SMALL_BANDS) for i in range(9)]
+    want = ctx.detect_batch(imgs)
+    got = [None] * len(imgs)
+    errs = []
+
+    def worker(rank):
+        try:
+            lo, hi = shard_range(len(imgs), rank, 2)
+            with hesaff_amd.HesaffContext(device=0) as c2:
+                for k, r in enumerate(c2.detect_batch(imgs[lo:hi])):
+                    got[lo + k] = r
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for (nw, kw), (ng, kg) in zip(want, got):
+        assert nw == ng and kw.tobytes() == kg.tobytes()
+
+
 def test_batch_and_mixed_sizes(ctx):
     a = band_noise_image(200, 300, 31, SMALL_BANDS)
     b = band_noise_image(200, 300, 32, SMALL_BANDS)

@@ -26,6 +26,21 @@ def test_shard_range_partitions():
         shard_range(4, 4, 4)
 
 
+def test_c_abi_shard_range_equals_python():
+    """hesaff_shard_range (C ABI, used by `hesaff --batch --devices`) is the same partition as shard.py's."""
+    import ctypes as C
+    import hesaff_amd
+    L = hesaff_amd.load_library()
+    lo = C.c_int(); hi = C.c_int()
+    for n in [0, 1, 7, 8, 255, 256, 2048, 100003]:
+        for world in [1, 2, 3, 4, 8]:
+            for r in range(world):
+                assert L.hesaff_shard_range(n, r, world, C.byref(lo), C.byref(hi)) == 0
+                assert (lo.value, hi.value) == shard_range(n, r, world)
+    assert L.hesaff_shard_range(4, 4, 4, C.byref(lo), C.byref(hi)) == -2
+    assert L.hesaff_device_count() >= 0
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
