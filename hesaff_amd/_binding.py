@@ -100,6 +100,7 @@ def load_library():
     L.hesaff_read_pnm.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.hesaff_read_png.argtypes = L.hesaff_read_pnm.argtypes
     L.hesaff_read_image.argtypes = L.hesaff_read_pnm.argtypes
+    L.hesaff_read_jpeg.argtypes = L.hesaff_read_pnm.argtypes
     L.hesaff_stage_gaussian_blur.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_float, _f32p]
     L.hesaff_stage_hessian_response.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_float, _f32p]
     L.hesaff_stage_half_image.argtypes = [vp, _f32p, C.c_int, C.c_int, _f32p]
@@ -128,7 +129,7 @@ ABI_SYMBOLS = [
     "hesaff_stage_find_affine_shape", "hesaff_stage_rectify", "hesaff_stage_normalize_affine", "hesaff_stage_sift",
     "hesaff_stage_math", "hesaff_table_gauss_mask", "hesaff_table_circ_gauss_mask", "hesaff_table_sift_bins",
     "hesaff_table_gauss_kernel", "hesaff_format_sift_mt", "hesaff_write_sift_batch", "hesaff_test_fmt_g",
-    "hesaff_read_png", "hesaff_read_image", "hesaff_device_count", "hesaff_shard_range",
+    "hesaff_read_png", "hesaff_read_image", "hesaff_device_count", "hesaff_shard_range", "hesaff_read_jpeg",
 ]
 
 

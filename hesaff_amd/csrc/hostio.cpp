@@ -386,7 +386,7 @@ int hesaff_read_png(const char *path, uint8_t **data, int *width, int *height, i
    HOSTIO_CATCH
 }
 
-// the imread of hesaff.cpp:137 for the formats this library decodes itself: PGM/PPM and PNG, by magic number
+// the imread of hesaff.cpp:137 for the formats this library decodes itself: PGM/PPM, PNG and baseline JPEG, by magic number
 int hesaff_read_image(const char *path, uint8_t **data, int *width, int *height, int *channels)
 {
    if (!path || !data || !width || !height || !channels) return HESAFF_ERR_ARG;
@@ -396,6 +396,7 @@ int hesaff_read_image(const char *path, uint8_t **data, int *width, int *height,
    fclose(f);
    if (c1 == 'P' && (c2 == '5' || c2 == '6')) return hesaff_read_pnm(path, data, width, height, channels);
    if (c1 == 0x89 && c2 == 'P') return hesaff_read_png(path, data, width, height, channels);
+   if (c1 == 0xFF && c2 == 0xD8) return hesaff_read_jpeg(path, data, width, height, channels);
    return HESAFF_ERR_IO;
 }
 

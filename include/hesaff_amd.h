@@ -145,7 +145,12 @@ int hesaff_read_pnm(const char *path, uint8_t **data, int *width, int *height, i
  * channel, alpha dropped, 16-bit samples reduced to the high byte, palette / 1-2-4-bit grey expanded;
  * channels = 1 for grey files, 3 (R,G,B order) otherwise.  Interlaced files: HESAFF_ERR_IO. */
 int hesaff_read_png(const char *path, uint8_t **data, int *width, int *height, int *channels);
-/* PGM/PPM or PNG by magic number (JPEG is not decoded: decoder-dependent pixels) */
+/* baseline (sequential Huffman, 8-bit, grey or YCbCr) JPEG: the integer algorithms of libjpeg at cv::imread's settings
+ * (JDCT_ISLOW inverse DCT, "fancy" chroma up-sampling, JFIF colour conversion), pixel for pixel the bytes libjpeg /
+ * libjpeg-turbo return; channels = 1 for grey files, 3 (R,G,B order) otherwise.  Progressive, arithmetic-coded,
+ * 12-bit and CMYK files: HESAFF_ERR_IO. */
+int hesaff_read_jpeg(const char *path, uint8_t **data, int *width, int *height, int *channels);
+/* PGM/PPM, PNG or JPEG by magic number */
 int hesaff_read_image(const char *path, uint8_t **data, int *width, int *height, int *channels);
 
 /* ---- stage entry points (host pointers in/out; used by the parity tests and by callers

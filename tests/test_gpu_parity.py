@@ -586,6 +586,20 @@ def test_cli_reads_png(tmp_path):
     assert (tmp_path / "img.png.hesaff.sift").read_bytes() == open(os.path.join(GOLD, "band_160x120.hesaff.sift"), "rb").read()
 
 
+def test_cli_reads_jpeg(tmp_path):
+    """`hesaff img.jpg`: the baseline JPEG decoder feeds the detector the pixels libjpeg decodes (committed fixture + the
+    PPM of its libjpeg-turbo decode): both files give the same .hesaff.sift."""
+    exe = os.path.join(ROOT, "hesaff_amd", "bin", "hesaff")
+    outs = []
+    for name in ("jpeg_420_q85.jpg", "jpeg_420_q85.ppm"):
+        dst = tmp_path / name
+        shutil.copy(os.path.join(GOLD, name), dst)
+        r = subprocess.run([exe, str(dst)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append((tmp_path / (name + ".hesaff.sift")).read_bytes())
+    assert outs[0] == outs[1] and len(outs[0]) > 5000
+
+
 def test_bench_two_ranks_on_one_gpu():
     """bench.py's multi-rank path (barriers, max-over-ranks time, count gather) with two ranks sharing
     this box's GPU: BENCH_DIST_BACKEND=gloo moves the three small collectives to CPU tensors; the

@@ -269,3 +269,63 @@ def test_read_png_matches_imread_semantics(tmp_path):
     (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0" + bytes(100))
     with pytest.raises(hesaff_amd.HesaffError):
         hesaff_amd.read_image(str(tmp_path / "x.jpg"))
+
+
+# ------------------------------------------------------------------------------------------
+# JPEG: hesaff_read_jpeg restates libjpeg's integer algorithms at cv::imread's settings
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["jpeg_gray_q90", "jpeg_420_q85", "jpeg_422_q70_rst"])
+def test_read_jpeg_golden_pixels(name):
+    """Committed JPEG files and the pixels libjpeg-turbo (Pillow 12.2) decoded them to when the fixtures were made."""
+    import hesaff_amd
+    got = hesaff_amd.read_image(os.path.join(GOLD, name + ".jpg"))
+    ref_path = os.path.join(GOLD, name + (".pgm" if got.ndim == 2 else ".ppm"))
+    assert np.array_equal(got, hesaff_amd.read_pnm(ref_path))
+
+
+def test_read_jpeg_equals_libjpeg_on_many_encodings(tmp_path):
+    """Every pixel equals libjpeg-turbo's (through Pillow, when installed): JDCT_ISLOW, fancy up-sampling, JFIF colour
+    conversion -- 4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1, grey; odd sizes down to 1x1; restart intervals; optimised tables."""
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    import hesaff_amd
+    rng = np.random.default_rng(3)
+
+    def synth(h, w, color):
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = np.stack([127 + 100 * np.sin(xx / 7.0 + yy / 11.0), 127 + 100 * np.cos(xx / 5.0 - yy / 13.0),
+                         127 + 90 * np.sin(xx / 3.0) * np.cos(yy / 4.0)], -1) + rng.normal(0, 25, (h, w, 3))
+        a = np.clip(base, 0, 255).astype(np.uint8)
+        return a if color else a[..., 0]
+    n = 0
+    p = str(tmp_path / "t.jpg")
+    for (h, w) in [(64, 64), (61, 83), (7, 9), (1, 1), (17, 3), (120, 211), (33, 2)]:
+        for sub in [0, 1, 2, "4:4:0", "4:1:1", "gray"]:
+            for q, extra in [(30, {}), (75, {"restart_marker_blocks": 3}), (95, {"optimize": True}), (100, {})]:
+                im = Image.fromarray(synth(h, w, sub != "gray"))
+                kw = dict(quality=q, **extra)
+                if sub != "gray":
+                    kw["subsampling"] = sub
+                buf = io.BytesIO()
+                try:
+                    im.save(buf, "JPEG", **kw)
+                except Exception:   # noqa: BLE001  (an encoder option this Pillow does not know)
+                    continue
+                open(p, "wb").write(buf.getvalue())
+                ref = np.asarray(Image.open(p))
+                got = hesaff_amd.read_image(p)
+                assert got.shape == ref.shape and np.array_equal(got, ref), (h, w, sub, q, extra)
+                n += 1
+    assert n > 100
+    # progressive files are refused, not mis-decoded
+    Image.fromarray(synth(40, 40, True)).save(p, "JPEG", progressive=True)
+    with pytest.raises(hesaff_amd.HesaffError):
+        hesaff_amd.read_image(p)
+    # truncated / corrupt files: an error or an image, never a crash
+    raw = open(os.path.join(GOLD, "jpeg_420_q85.jpg"), "rb").read()
+    for cut in (2, 20, 200, len(raw) // 2, len(raw) - 3):
+        open(p, "wb").write(raw[:cut])
+        try:
+            hesaff_amd.read_image(p)
+        except hesaff_amd.HesaffError:
+            pass
