@@ -32,7 +32,6 @@ void validate_params(const hesaff_params &p)
    if (!(p.mrSize > 0.0f)) throw HsError(HESAFF_ERR_ARG, "mrSize must be positive");
    if (!(p.edgeEigenValueRatio > 0.0f)) throw HsError(HESAFF_ERR_ARG, "edgeEigenValueRatio must be positive");
    if (p.maxIterations < 1 || p.maxIterations > 1000) throw HsError(HESAFF_ERR_ARG, "maxIterations out of range (1..1000)");
-   if (p.upscaleInputImage != 0) throw HsError(HESAFF_ERR_ARG, "upscaleInputImage is not supported by this build");
    if (p.fast != 0) throw HsError(HESAFF_ERR_ARG, "fast mode is not supported by this build");
 }
 
@@ -148,7 +147,7 @@ void hesaff_destroy(hesaff_ctx *c)
    (void)hipSetDevice(c->device);
    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
    DevBuf *bufs[] = {&c->t_smm, &c->t_sift, &c->t_bin0, &c->t_bin1, &c->t_w0, &c->t_w1, &c->t_pyr_taps, &c->t_patch_taps,
-                     &c->t_patch_off, &c->t_patch_k, &c->b_gray, &c->b_L, &c->b_L3, &c->b_R, &c->b_map, &c->b_bitmask, &c->b_prefix,
+                     &c->t_patch_off, &c->t_patch_k, &c->b_gray, &c->b_up, &c->b_L, &c->b_L3, &c->b_R, &c->b_map, &c->b_bitmask, &c->b_prefix,
                      &c->b_blocksums, &c->b_generic, &c->b_counters, &c->b_cand, &c->b_rec_f, &c->b_rec_i, &c->b_rec_w, &c->b_hess_f, &c->b_hess_i,
                      &c->b_aff, &c->b_pw, &c->b_bins, &c->b_rank, &c->b_desc, &c->b_out, &c->b_starts, &c->b_patches,
                      &c->b_stage, &c->b_input, &c->t_mask_idx, &c->b_rowprefix, &c->b_trows, &c->b_trows2, &c->b_trows3};
@@ -475,7 +474,7 @@ int hesaff_stage_hessian_keypoints(hesaff_ctx *c, const uint8_t *gray, int rows,
          const int octave = (meta[i] >> 4) & 15, level = (meta[i] >> 2) & 3, type = meta[i] & 3;
          const OctGeom &g = c->oct[octave];
          const uint32_t pix = (uint32_t)key[i] % (uint32_t)(g.rows * g.cols);
-         f[5 * i] = x[i]; f[5 * i + 1] = y[i]; f[5 * i + 2] = sc[i]; f[5 * i + 3] = (float)(1 << octave); f[5 * i + 4] = resp[i];
+         f[5 * i] = x[i]; f[5 * i + 1] = y[i]; f[5 * i + 2] = sc[i]; f[5 * i + 3] = c->consts.pd0 * (float)(1 << octave); f[5 * i + 4] = resp[i];
          iv[5 * i] = type; iv[5 * i + 1] = octave; iv[5 * i + 2] = level; iv[5 * i + 3] = (int32_t)(pix / g.cols); iv[5 * i + 4] = (int32_t)(pix % g.cols);
       }
    }

@@ -33,6 +33,7 @@ struct DConsts {
    float mrSize;                // affine.h:44
    float maxBinValue;           // siftdesc.h:29
    int maxIterations;           // affine.h:39
+   float pd0;                   // pixelDistance of octave 0: 1, or 0.5 with upscaleInputImage (pyramid.cpp:264,270)
 };
 
 // Pins a value: everything it depends on (in particular its global loads) is issued before this

@@ -88,6 +88,6 @@ struct OctaveSchedule {
    float level_sigma[5];    // [0] = initialSigma, [i] = curSigma * step
    float norm2[5];          // (sigma*sigma)^2 handed to hessianResponse (pyramid.cpp:76)
 };
-OctaveSchedule make_schedule(float initialSigma);
+OctaveSchedule make_schedule(float initialSigma, bool upscale);
 
 } // namespace hesaff

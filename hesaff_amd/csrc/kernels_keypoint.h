@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64, HS_AFF_WAVES) void k_affine(PlaneTab pt, HessLi
       const DPlane &P = pt.L[octave][level];
       AffKp q;
       q.blur = P.img(b); q.rows = P.rows; q.cols = P.cols; q.pitch = P.pitch;
-      q.x = hl.x[h]; q.y = hl.y[h]; q.s = hl.s[h]; q.pd = (float)(1 << octave);
+      q.x = hl.x[h]; q.y = hl.y[h]; q.s = hl.s[h]; q.pd = k.pd0 * (float)(1 << octave);
       return q;
    });
 }

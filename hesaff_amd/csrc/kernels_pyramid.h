@@ -130,6 +130,29 @@ __global__ __launch_bounds__(256) void k_hess(DPlane in, DPlane out, float norm2
    out.img(b)[(long long)y * out.pitch + x] = resp;
 }
 
+// k_double: doubleImage helpers.cpp:297-329, the 2x bilinear up-sampling of the upscaleInputImage path
+// (pyramid.cpp:267-271).  The reference's loops index the source with its BYTE stride (in[input.step]) and leave the
+// last row / column of the result unwritten; this is the evident intent with the same float expressions:
+//    n(2r,   2c)   = in(r, c)
+//    n(2r+1, 2c)   = 0.5f  * (in(r, c) + in(r+1, c))
+//    n(2r,   2c+1) = 0.5f  * (in(r, c) + in(r, c+1))
+//    n(2r+1, 2c+1) = 0.25f * (((in(r, c) + in(r, c+1)) + in(r+1, c)) + in(r+1, c+1))
+// with r+1 / c+1 clamped to the last row / column (replicated edge).  grid (ceil(outcols/256), outrows, B)
+__global__ __launch_bounds__(256) void k_double(DPlane in, DPlane out)
+{
+   const int x = blockIdx.x * 256 + threadIdx.x;
+   const int y = blockIdx.y, b = blockIdx.z;
+   if (x >= out.cols) return;
+   const int r = y >> 1, c = x >> 1, r1 = min(r + 1, in.rows - 1), c1 = min(c + 1, in.cols - 1);
+   const float *p = in.img(b);
+   const float v00 = p[(long long)r * in.pitch + c], v01 = p[(long long)r * in.pitch + c1];
+   const float v10 = p[(long long)r1 * in.pitch + c], v11 = p[(long long)r1 * in.pitch + c1];
+   float v;
+   if ((y & 1) == 0) v = (x & 1) == 0 ? v00 : 0.5f * (v00 + v01);
+   else v = (x & 1) == 0 ? 0.5f * (v00 + v10) : 0.25f * (v00 + v01 + v10 + v11);
+   out.img(b)[(long long)y * out.pitch + x] = v;
+}
+
 // k_half: halfImage helpers.cpp:331-339 ; grid (ceil(outcols/256), outrows, B)
 __global__ __launch_bounds__(256) void k_half(DPlane in, DPlane out)
 {

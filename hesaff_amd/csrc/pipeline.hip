@@ -29,14 +29,16 @@
 #include "kernels_pyramid.h"
 
 namespace hesaff {
-OctaveSchedule make_schedule(float initialSigma)
+OctaveSchedule make_schedule(float initialSigma, bool upscale)
 {
    OctaveSchedule s;
    // pyramid.cpp:227 : powf(2, 1/numberOfScales) ; hm_pow2f == glibc powf(2,.) bit for bit
    const float sigmaStep = hm_pow2f(1.0f / (float)HS_NSCALES);
    float curSigma = initialSigma;
-   // pyramid.cpp:276-280: the input is taken to be blurred by 0.5 already; no initial blur when initialSigma <= 0.5
-   s.init_sigma = initialSigma > 0.5f ? sqrtf(initialSigma * initialSigma - 0.5f * 0.5f) : 0.0f;
+   // pyramid.cpp:263-280: the input is taken to be blurred by 0.5 already (1.0 after the 2x up-sampling);
+   // no initial blur when initialSigma does not exceed that
+   const float inputSigma = upscale ? 0.5f * 2.0f : 0.5f;
+   s.init_sigma = initialSigma > inputSigma ? sqrtf(initialSigma * initialSigma - inputSigma * inputSigma) : 0.0f;
    s.level_sigma[0] = curSigma;
    s.blur_sigma[0] = 0.0f;
    {
@@ -138,16 +140,17 @@ struct hesaff_ctx {
    int n_masked = 0;
    KpTables tables;
 
-   // geometry of the current buffer plan
+   // geometry of the current buffer plan (H x W: the images; the pyramid starts at (H << up) x (W << up))
+   int up = 0;            // upscaleInputImage, pyramid.h:34
    int B = 0, H = 0, W = 0;
    std::vector<OctGeom> oct;
    long long words_per_image = 0;
    uint32_t cap = 0;      // keypoint / candidate capacity of a batch
 
    // planes
-   DevBuf b_gray, b_L, b_L3, b_R, b_map, b_bitmask, b_prefix, b_blocksums, b_generic;
+   DevBuf b_gray, b_up, b_L, b_L3, b_R, b_map, b_bitmask, b_prefix, b_blocksums, b_generic;
    std::vector<DPlane> L;   // [octave*3 + level]
-   DPlane gray, L3, R[5];
+   DPlane gray, upimg, L3, R[5];
    // lists
    DevBuf b_counters;       // uint32: [0] cand_count [1] rec_count [2] overflow [3] hess_total [4] desc_total [5] group end
                             //         [6] T' row overflow, [8..12] bin_count, [24..28] bin work counters,
@@ -236,13 +239,14 @@ void build_tables(hesaff_ctx *c)
       upload(c->t_mask_idx, midx);
    }
    upload(c->t_smm, smm); upload(c->t_sift, sm); upload(c->t_bin0, b0); upload(c->t_bin1, b1); upload(c->t_w0, w0); upload(c->t_w1, w1);
-   c->sched = hesaff::make_schedule(c->par.initialSigma);
+   c->up = c->par.upscaleInputImage > 0 ? 1 : 0;
+   c->sched = hesaff::make_schedule(c->par.initialSigma, c->up != 0);
    std::vector<float> taps;
    for (int i = 0; i < 5; i++) {
       const float sigma = i == 0 ? c->sched.init_sigma : c->sched.blur_sigma[i];
       c->pyr_tap_off[i] = (int)taps.size();
       taps.resize(taps.size() + 256, 0.0f);
-      if (i == 0 && !(c->par.initialSigma > 0.5f)) { c->pyr_K[0] = 0; continue; }   // pyramid.cpp:276: no initial blur
+      if (i == 0 && !(c->sched.init_sigma > 0.0f)) { c->pyr_K[0] = 0; continue; }   // pyramid.cpp:276: no initial blur
       const int K = hesaff::gauss_ksize(sigma);
       if (K > 255) throw HsError(HESAFF_ERR_ARG, "initialSigma too large (a pyramid blur would need more than 255 taps)");
       c->pyr_K[i] = K;
@@ -263,6 +267,7 @@ void build_tables(hesaff_ctx *c)
    k.mrSize = p.mrSize;
    k.maxBinValue = p.maxBinValue;
    k.maxIterations = p.maxIterations;
+   k.pd0 = c->up ? 0.5f : 1.0f;   // pixelDistance of octave 0, pyramid.cpp:264,270
 }
 
 // taps of the per-keypoint patch blur (affine.cpp:129: sigma = 1.5f * P0/41) for odd P0
@@ -341,7 +346,8 @@ void set_kernel_attrs(hesaff_ctx *c)
 void plan(hesaff_ctx *c, int B, int H, int W)
 {
    if (B <= c->B && H == c->H && W == c->W) return;
-   if (H < 1 || W < 1 || H > 65535 || W > 65535) throw HsError(HESAFF_ERR_ARG, "image size out of range (1..65535)");
+   if (H < 1 || W < 1 || (H << c->up) > 65535 || (W << c->up) > 65535) throw HsError(HESAFF_ERR_ARG, "image size out of range (1..65535 at the first pyramid level)");
+   const int PH = H << c->up, PW = W << c->up;   // first pyramid level
    // the cached geometry describes buffers that are about to be replaced: a failure below must not leave it valid
    c->B = c->H = c->W = 0;
    c->oct.clear();
@@ -349,7 +355,7 @@ void plan(hesaff_ctx *c, int B, int H, int W)
    long long words = 0;
    size_t L_floats = 0;
    {
-      int r = H, cc = W;
+      int r = PH, cc = PW;
       const int minSize = 2 * HS_BORDER + 2;   // pyramid.cpp:283
       while (r > minSize && cc > minSize) {
          OctGeom g;
@@ -377,13 +383,19 @@ void plan(hesaff_ctx *c, int B, int H, int W)
             p += (size_t)B * g.rows * g.pitch;
          }
    }
-   c->b_L3.ensure(plane0 * 4);
-   c->b_R.ensure(plane0 * 4 * 5);
-   c->b_map.ensure(std::max<size_t>((size_t)B * H * W * 4, 16));
+   const int ppitch0 = round_up(PW, 64);
+   const size_t pplane0 = (size_t)B * PH * ppitch0;
+   if (c->up) {
+      c->b_up.ensure(pplane0 * 4);
+      c->upimg = make_plane(c->b_up.as<float>(), PH, PW, ppitch0);
+   }
+   c->b_L3.ensure(pplane0 * 4);
+   c->b_R.ensure(pplane0 * 4 * 5);
+   c->b_map.ensure(std::max<size_t>((size_t)B * PH * PW * 4, 16));
    const long long total_words = (long long)B * words;
    c->b_bitmask.ensure(std::max<size_t>((size_t)total_words * 8, 16));
    c->b_prefix.ensure(std::max<size_t>((size_t)(total_words + 1) * 4, 16));
-   double mpx = (double)B * H * W / 1.0e6;
+   double mpx = (double)B * PH * PW / 1.0e6;   // capacity per megapixel of the first pyramid level
    double capd = mpx * (double)c->par.max_kpts_per_mpx;
    if (capd < 4096) capd = 4096;
    if (capd > 2.0e9) throw HsError(HESAFF_ERR_ARG, "batch too large for 32-bit keypoint indices");
@@ -606,12 +618,18 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
       const bool direct = c->pyr_K[0] == 0 && !c->oct.empty();
       const dim3 grid((c->W + 255) / 256, c->H, B);
       hipLaunchKernelGGL(k_gray, grid, dim3(256), 0, st, d_src, channels, src_img_stride, src_row_stride, c->gray);
-      if (direct) HIP_TRY(hipMemcpyAsync(c->L[0].p, c->gray.p, (size_t)B * c->gray.img_stride * 4, hipMemcpyDeviceToDevice, st));
+      if (c->up) {
+         // pyramid.cpp:267-271: the first level is the 2x up-sampled image (doubleImage, helpers.cpp:297-329)
+         const dim3 g2((c->upimg.cols + 255) / 256, c->upimg.rows, B);
+         hipLaunchKernelGGL(k_double, g2, dim3(256), 0, st, c->gray, c->upimg);
+      }
+      const DPlane &first = c->up ? c->upimg : c->gray;
+      if (direct) HIP_TRY(hipMemcpyAsync(c->L[0].p, first.p, (size_t)B * first.img_stride * 4, hipMemcpyDeviceToDevice, st));
    }
    if (!c->oct.empty() && c->pyr_K[0] > 0) {
       // pyramid.cpp:276-280 initial blur 0.5 -> initialSigma
       const int tb = tm.begin(T_BLURHESS, 0);   // initial blur: not counted in the 12N launches (bytes 0)
-      launch_blur_hess<true, false, false>(c, c->gray, c->L[0], none, none, ptaps + c->pyr_tap_off[0], c->pyr_K[0], 0.0f, B);
+      launch_blur_hess<true, false, false>(c, c->up ? c->upimg : c->gray, c->L[0], none, none, ptaps + c->pyr_tap_off[0], c->pyr_K[0], 0.0f, B);
       tm.end(tb);
    }
    tm.end(t);
@@ -673,7 +691,7 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
       HIP_TRY(hipMemcpyAsync(cnt + 32 + o, cnt + 1, 4, hipMemcpyDeviceToDevice, st));
       OctaveCtx oc;
       for (int l = 0; l < 5; l++) { oc.R[l] = Ro[l]; oc.L[l] = Lo[l]; oc.sigma[l] = sc.level_sigma[l]; }
-      oc.pixelDistance = (float)(1 << o);
+      oc.pixelDistance = c->consts.pd0 * (float)(1 << o);   // pyramid.cpp:288: doubles per octave
       oc.octave = (int)o;
       oc.map = c->b_map.as<uint32_t>();
       oc.word_base = g.word_base;
@@ -740,7 +758,7 @@ void collect_timings(hesaff_ctx *c, StageTimer &tm, int B)
    }
    double sumN = 0;
    for (const OctGeom &g : c->oct) sumN += (double)g.rows * g.cols;
-   t.pyramid_bytes = (double)B * (5.0 * c->H * c->W + 58.0 * sumN);
+   t.pyramid_bytes = (double)B * (5.0 * c->H * c->W + 58.0 * sumN);   // (+ the up-sampling pass when upscaleInputImage is set: not counted)
 }
 
 // The descriptor kernels (kernels_sift.h) over n patches in HBM.

@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <malloc.h>
 #include <string>
 #include <vector>
 
@@ -59,6 +60,7 @@ struct Params {
    int spatialBins = 4;
    int orientationBins = 8;
    float maxBinValue = 0.2f;
+   int upscaleInputImage = 0;            // pyramid.h:34
 };
 
 // ----------------------------------------------------------------------------------------
@@ -140,6 +142,26 @@ void gaussianBlur(const Plane &in, float sigma, Plane &out)
       }
    }
    out = res;
+}
+
+// helpers.cpp:297-329 doubleImage.  The reference indexes the source with its byte stride (`in[input.step]`, reading four
+// rows below) and never writes the last row and column of the result; it is dead code at the defaults
+// (upscaleInputImage = 0) and cannot be restated literally without undefined behaviour.  This is the evident intent,
+// the same float expressions with the row below / column to the right clamped at the image edge (shared definition of
+// the oracle and the product; SURVEY.md 8f rank 4 "fix stride bug").
+void doubleImage(const Plane &in, Plane &out)
+{
+   Plane n(in.rows * 2, in.cols * 2);
+   for (int y = 0; y < n.rows; y++)
+      for (int x = 0; x < n.cols; x++) {
+         const int r = y >> 1, c = x >> 1, r1 = r + 1 < in.rows ? r + 1 : in.rows - 1, c1 = c + 1 < in.cols ? c + 1 : in.cols - 1;
+         const float v00 = in.at(r, c), v01 = in.at(r, c1), v10 = in.at(r1, c), v11 = in.at(r1, c1);
+         float v;
+         if ((y & 1) == 0) v = (x & 1) == 0 ? v00 : 0.5f * (v00 + v01);
+         else v = (x & 1) == 0 ? 0.5f * (v00 + v10) : 0.25f * (v00 + v01 + v10 + v11);
+         n.at(y, x) = v;
+      }
+   out = n;
 }
 
 // helpers.cpp:331-339
@@ -713,6 +735,11 @@ struct Oracle {
       float curSigma = 0.5f;
       float pixelDistance = 1.0f;
       Plane firstLevel = image;
+      if (par.upscaleInputImage > 0) {   // pyramid.cpp:267-271
+         doubleImage(image, firstLevel);
+         pixelDistance *= 0.5f;
+         curSigma *= 2.0f;
+      }
       if (par.initialSigma > curSigma) {
          const float sigma = sqrtf(par.initialSigma * par.initialSigma - curSigma * curSigma);
          gaussianBlur(firstLevel, sigma, firstLevel);
@@ -788,6 +815,13 @@ void ho_hessian_response(const float *in, int rows, int cols, float norm, float 
    hessianResponse(p, norm, o);
    memcpy(out, o.d.data(), sizeof(float) * rows * cols);
 }
+void ho_double_image(const float *in, int rows, int cols, float *out)
+{
+   Plane p(rows, cols), o;
+   memcpy(p.d.data(), in, sizeof(float) * rows * cols);
+   doubleImage(p, o);
+   memcpy(out, o.d.data(), sizeof(float) * o.rows * o.cols);
+}
 void ho_half_image(const float *in, int rows, int cols, float *out)
 {
    Plane p(rows, cols), o;
@@ -853,7 +887,15 @@ void ho_sift(float *patch, float *vec)
 }
 
 // ---- full pipeline with a handle ----
-void *ho_create() { return new Oracle(); }
+void *ho_create()
+{
+   // The reference warps every patch into ONE growing workspace (affine.cpp:120-124); this restatement allocates its
+   // planes per call.  Keep freed blocks inside the heap instead of returning them to the kernel each time, so that the
+   // timed baseline measures arithmetic and not page faults (a 3840x2160 image: system time 0.7 s instead of tens of seconds).
+   static const int once = (mallopt(M_MMAP_THRESHOLD, 1 << 30), mallopt(M_TRIM_THRESHOLD, 1 << 30), 0);
+   (void)once;
+   return new Oracle();
+}
 // the stage functions above with the parameters of a handle (ho_set_params)
 int ho_h_find_affine_shape(void *h, const float *blur, int rows, int cols, float x, float y, float s, float pd, float *A, int *iters)
 {
@@ -890,6 +932,7 @@ void ho_set_params(void *h, float threshold, float edgeEigenValueRatio, float in
    o->par.maxBinValue = maxBinValue;
    o->configure();
 }
+void ho_set_upscale(void *h, int upscale) { ((Oracle *)h)->par.upscaleInputImage = upscale; }
 void ho_detect(void *h, const float *gray, int rows, int cols)
 {
    Plane p(rows, cols);

@@ -37,6 +37,7 @@ def lib():
     L.ho_gaussian_blur.argtypes = [f32p, C.c_int, C.c_int, C.c_float, f32p]
     L.ho_hessian_response.argtypes = [f32p, C.c_int, C.c_int, C.c_float, f32p]
     L.ho_half_image.argtypes = [f32p, C.c_int, C.c_int, f32p]
+    L.ho_double_image.argtypes = [f32p, C.c_int, C.c_int, f32p]
     L.ho_gray_from_u8.argtypes = [u8p, C.c_int, C.c_int, f32p]
     L.ho_interpolate.argtypes = [f32p, C.c_int, C.c_int] + [C.c_float] * 6 + [f32p, C.c_int, C.c_int]
     L.ho_interpolate.restype = C.c_int
@@ -60,6 +61,7 @@ def lib():
     L.ho_set_detect_only.argtypes = [C.c_void_p, C.c_int]
     L.ho_detect.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int]
     L.ho_set_params.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float]
+    L.ho_set_upscale.argtypes = [C.c_void_p, C.c_int]
     L.ho_h_find_affine_shape.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int] + [C.c_float] * 4 + [f32p, i32p]
     L.ho_h_find_affine_shape.restype = C.c_int
     L.ho_h_normalize_affine.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int] + [C.c_float] * 3 + [f32p, f32p]
@@ -93,6 +95,7 @@ def set_params(h, params):
     """Copy the reference-side fields of a hesaff_params-like object (hesaff_amd.Params) into an oracle handle."""
     lib().ho_set_params(h, params.threshold, params.edgeEigenValueRatio, params.initialSigma, int(params.maxIterations),
                         params.convergenceThreshold, params.mrSize, params.maxBinValue)
+    lib().ho_set_upscale(h, int(getattr(params, "upscaleInputImage", 0)))
 
 
 class OracleHandle:

@@ -383,6 +383,8 @@ NONDEFAULT = [
     dict(initialSigma=0.45, threshold=3.0),
     dict(maxBinValue=0.05),
     dict(maxBinValue=1.0),
+    dict(upscaleInputImage=1),                       # pyramid.cpp:267-271: first octave on the 2x up-sampled image, pixelDistance 0.5
+    dict(upscaleInputImage=1, initialSigma=0.9),     # ... and no initial blur (initialSigma <= 2 * 0.5)
 ]
 
 
