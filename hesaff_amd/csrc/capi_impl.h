@@ -32,7 +32,7 @@ void validate_params(const hesaff_params &p)
    if (!(p.mrSize > 0.0f)) throw HsError(HESAFF_ERR_ARG, "mrSize must be positive");
    if (!(p.edgeEigenValueRatio > 0.0f)) throw HsError(HESAFF_ERR_ARG, "edgeEigenValueRatio must be positive");
    if (p.maxIterations < 1 || p.maxIterations > 1000) throw HsError(HESAFF_ERR_ARG, "maxIterations out of range (1..1000)");
-   if (p.fast != 0) throw HsError(HESAFF_ERR_ARG, "fast mode is not supported by this build");
+   if (p.fast != 0 && p.fast != 1) throw HsError(HESAFF_ERR_ARG, "fast must be 0 (parity mode) or 1");
 }
 
 } // namespace
@@ -96,6 +96,7 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       if (c->par.max_kpts_per_mpx < 1000) c->par.max_kpts_per_mpx = 1000;
       validate_params(c->par);
       c->device = device;
+      c->fast = c->par.fast == 1;
       bind_device(c);
       hipDeviceProp_t prop;
       HIP_TRY(hipGetDeviceProperties(&prop, device));

@@ -16,6 +16,13 @@
 #pragma once
 #include <stdint.h>
 
+// HS_FAST: the translation unit of the fast mode (kernels_fast.hip, hesaff_params.fast = 1): contraction and approximate
+// division / square root are allowed by its compiler flags and the functions below may be replaced by cheaper ones.
+// Parity mode (the default, pipeline.hip) never defines it.
+#ifndef HS_FAST
+#define HS_FAST 0
+#endif
+
 #if defined(__HIPCC__)
 #define HM_HD __host__ __device__ __forceinline__
 #else
@@ -281,3 +288,9 @@ HM_HD float hm_sift_orient_coord(float ori)
    const double q2 = __builtin_fma(r, inv_twopi, q);
    return (float)q2;
 }
+
+#if HS_FAST && defined(__HIPCC__)
+// fast mode: the device math library's atan2f (about 1 ulp, no interval tables) and the orientation coordinate in float
+__device__ __forceinline__ float hm_fast_atan2f(float y, float x) { return atan2f(y, x); }
+__device__ __forceinline__ float hm_fast_orient_coord(float ori) { return 8.0f * (ori + 6.2831855f) * 0.15915494f; }
+#endif

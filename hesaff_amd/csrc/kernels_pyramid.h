@@ -503,15 +503,32 @@ __device__ __forceinline__ v2f hs_hessian2(v2f ul, v2f uc, v2f ur, v2f ml, v2f m
 // WRITE_R0: additionally emit the response of the INPUT plane (R0 = hessianResponse(L0),
 // pyramid.cpp:230) from the input rows that pass through LDS anyway; used by the first blur
 // of every octave so that L0 is read from HBM once instead of twice.
-template <int K, bool WRITE_L, bool WRITE_R, bool WRITE_HALF, bool WRITE_R0 = false>
-__global__ __launch_bounds__(256) void k_blur_hess_march(DPlane in, DPlane outL, DPlane outR, DPlane outHalf,
+// SRC8: the input rows are taken from the 8-bit source images and converted on the fly (hesaff.cpp:145, k_gray's
+// expression); the float grey plane normalizeAffine samples later is written from the same registers.  Used by the
+// initial blur (pyramid.cpp:276-280): the image is read once as bytes instead of once as bytes and once as floats.
+struct GraySrc {
+   const uint8_t *p;
+   int channels;             // 1 or 3 interleaved
+   long long img_stride;     // bytes between images
+   int row_stride;           // bytes between rows
+};
+
+#ifndef HS_MARCH15_WAVES
+#define HS_MARCH15_WAVES 0   // tuning: wavefronts per SIMD the K = 15 instantiation (144 VGPRs) is held to (0: the compiler's choice, 3)
+#endif
+template <int K, bool WRITE_L, bool WRITE_R, bool WRITE_HALF, bool WRITE_R0 = false, bool SRC8 = false>
+__global__ __launch_bounds__(256, (K == 15 ? HS_MARCH15_WAVES : 0)) void k_blur_hess_march(DPlane in, DPlane outL, DPlane outR, DPlane outHalf,
                                                           const float *__restrict__ taps, float norm2, int band_rows,
-                                                          DPlane outR0 = DPlane(), float norm2_in = 0.0f)
+                                                          DPlane outR0 = DPlane(), float norm2_in = 0.0f, GraySrc gs = GraySrc(), DPlane outGray = DPlane())
 {
    constexpr int R = K >> 1;
    constexpr int U = K + 1;                      // ring size and unroll factor (even: static prefetch parity)
    constexpr int W0 = 8 - R;                     // row-buffer float of column x-R, relative to 4*lane
-   constexpr int NB = WRITE_R0 ? 3 : 2;          // input rows kept in LDS
+#ifndef HS_R0_LDS3
+#define HS_R0_LDS3 0   // tuning: 1 = the R0 epilogue re-reads its three input rows from LDS instead of carrying two of them in registers
+#endif
+   constexpr bool R0L3 = WRITE_R0 && HS_R0_LDS3;
+   constexpr int NB = R0L3 ? 3 : 2;              // input rows kept in LDS (the row being filtered, the row being staged [, one more])
    __shared__ __attribute__((aligned(16))) float s_rows[4][NB][BM_ROWBUF];
 
    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -546,10 +563,36 @@ __global__ __launch_bounds__(256) void k_blur_hess_march(DPlane in, DPlane outL,
    v2f P2[5], P1[5];
 #pragma unroll
    for (int i = 0; i < 5; i++) { P2[i] = (v2f)(0.0f); P1[i] = (v2f)(0.0f); }
+   // WRITE_R0: the two previous INPUT rows in the same form (registers, like P2 / P1)
+   v2f Q0[5], Q1[5];
+#pragma unroll
+   for (int i = 0; i < 5; i++) { Q0[i] = (v2f)(0.0f); Q1[i] = (v2f)(0.0f); }
 
    float pre[2][5];
    auto load_row = [&](int t, float *dst5) {
-      const int y = min(max(yh0 - 1 - R + t, 0), rows - 1);
+      const int yu = yh0 - 1 - R + t;
+      const int y = min(max(yu, 0), rows - 1);
+      if (SRC8) {
+         const uint8_t *rp = gs.p + (long long)b * gs.img_stride + (long long)y * gs.row_stride;
+#pragma unroll
+         for (int m = 0; m < 5; m++) {
+            const uint8_t *q = rp + (long long)cx[m] * gs.channels;
+            const float c0 = (float)q[0];
+            const float c1 = (float)(gs.channels == 3 ? q[1] : q[0]);
+            const float c2 = (float)(gs.channels == 3 ? q[2] : q[0]);
+            dst5[m] = (c0 + c1 + c2) / 3.0f;   // hesaff.cpp:145
+         }
+         // the band's own rows x the strip's own columns (row-buffer floats 12 .. 259): each grey pixel is written exactly once
+         if (yu >= yh0 && yu < yh1) {
+            float *go = outGray.img(b) + (long long)y * outGray.pitch + (xs - 12);
+#pragma unroll
+            for (int m = 0; m < 5; m++) {
+               const int f = lane + 64 * m;
+               if (f >= 12 && f < 12 + BM_STRIP && xs - 12 + f < cols) go[f] = dst5[m];
+            }
+         }
+         return;
+      }
       const float *rp = src + (long long)y * pitch;
 #pragma unroll
       for (int m = 0; m < 4; m++) dst5[m] = rp[cx[m]];
@@ -575,7 +618,7 @@ __global__ __launch_bounds__(256) void k_blur_hess_march(DPlane in, DPlane outL,
          load_row(t + 2, pre[u & 1]);    // row t's registers are free (staged during step t-1)
          // ---- row pass of input row t: acc = k[0]*S[x-R]; acc += k[j]*S[x-R+j], two columns per op ----
          {
-            const float *rb = s_rows[wave][WRITE_R0 ? (t % 3) : (u & 1)] + 4 * lane + W0;
+            const float *rb = s_rows[wave][R0L3 ? (t % 3) : (u & 1)] + 4 * lane + W0;
             v2f G[K + 2];                // G[i] = (S[x-R+i], S[x-R+i+1]), x = this lane's first column
 #pragma unroll
             for (int i = 0; i < K + 2; i++) {
@@ -655,25 +698,27 @@ __global__ __launch_bounds__(256) void k_blur_hess_march(DPlane in, DPlane outL,
 #pragma unroll
             for (int i = 0; i < 5; i++) { P2[i] = P1[i]; P1[i] = P0[i]; }
          }
-         // ---- response of the input plane: row y(t-1) from the input rows t-2, t-1, t in LDS ----
+         // ---- response of the input plane: row y(t-1) from the input rows t-2, t-1 (registers) and t (LDS) ----
+         // Every lane reads its four columns of row t as one aligned float4 (conflict-free); the columns x-1 and x+4 come
+         // from the neighbouring lanes by shuffle instead of two more LDS reads at a 16-byte lane stride (4-way conflicts).
          if (WRITE_R0) {
+            auto row_pairs = [&](int buf, v2f *Q) {
+               const float4 m = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(s_rows[wave][buf] + 4 * lane + 8, 16));
+               const float e0 = __shfl_up(m.w, 1, 64), e5 = __shfl_down(m.x, 1, 64);
+               Q[0].x = e0; Q[0].y = m.x;
+               Q[1].x = m.x; Q[1].y = m.y;
+               Q[2].x = m.y; Q[2].y = m.z;
+               Q[3].x = m.z; Q[3].y = m.w;
+               Q[4].x = m.w; Q[4].y = e5;
+            };
+            v2f Q2[5];
+            if (R0L3) { row_pairs((t + 1) % 3, Q0); row_pairs((t + 2) % 3, Q1); row_pairs(t % 3, Q2); }
+            else row_pairs(u & 1, Q2);
             const int yr = yh0 - 1 - R + (t - 1);
             if (yr >= yh0 && yr < yh1 && store_lane) {
-               v2f Q[3][5];
-#pragma unroll
-               for (int k = 0; k < 3; k++) {
-                  const float *rr = s_rows[wave][(t + 1 + k) % 3] + 4 * lane + 7;   // rows t-2, t-1, t ; column x-1
-                  const float e0 = rr[0], e5 = rr[5];
-                  const float4 m = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(rr + 1, 16));
-                  Q[k][0].x = e0; Q[k][0].y = m.x;
-                  Q[k][1].x = m.x; Q[k][1].y = m.y;
-                  Q[k][2].x = m.y; Q[k][2].y = m.z;
-                  Q[k][3].x = m.z; Q[k][3].y = m.w;
-                  Q[k][4].x = m.w; Q[k][4].y = e5;
-               }
                const bool yin = yr > 0 && yr < rows - 1;
-               const v2f ra = hs_hessian2(Q[0][0], Q[0][1], Q[0][2], Q[1][0], Q[1][1], Q[1][2], Q[2][0], Q[2][1], Q[2][2], norm2_in);
-               const v2f rbv = hs_hessian2(Q[0][2], Q[0][3], Q[0][4], Q[1][2], Q[1][3], Q[1][4], Q[2][2], Q[2][3], Q[2][4], norm2_in);
+               const v2f ra = hs_hessian2(Q0[0], Q0[1], Q0[2], Q1[0], Q1[1], Q1[2], Q2[0], Q2[1], Q2[2], norm2_in);
+               const v2f rbv = hs_hessian2(Q0[2], Q0[3], Q0[4], Q1[2], Q1[3], Q1[4], Q2[2], Q2[3], Q2[4], norm2_in);
                const float r0 = (yin && cin0) ? ra.x : 0.0f, r1 = (yin && cin1) ? ra.y : 0.0f;
                const float r2 = (yin && cin2) ? rbv.x : 0.0f, r3 = (yin && cin3) ? rbv.y : 0.0f;
                float *o = outR0.img(b) + (long long)yr * outR0.pitch + xl;
@@ -684,9 +729,13 @@ __global__ __launch_bounds__(256) void k_blur_hess_march(DPlane in, DPlane outL,
                      if (xl + c < cols) o[c] = v[c];
                }
             }
+            if (!R0L3) {
+#pragma unroll
+               for (int i = 0; i < 5; i++) { Q0[i] = Q1[i]; Q1[i] = Q2[i]; }
+            }
          }
          // ---- stage row t+1 (loaded during step t-1) for the next step ----
-         stage_row(WRITE_R0 ? ((t + 1) % 3) : ((u + 1) & 1), pre[(u + 1) & 1]);
+         stage_row(R0L3 ? ((t + 1) % 3) : ((u + 1) & 1), pre[(u + 1) & 1]);
       }
    }
 }

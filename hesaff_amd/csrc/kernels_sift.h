@@ -106,6 +106,9 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
    const int nm = tb.n_masked;
    int a_l[HS_SIFT_MSK_IT], a_r[HS_SIFT_MSK_IT], a_u[HS_SIFT_MSK_IT], a_d[HS_SIFT_MSK_IT], o_off[HS_SIFT_MSK_IT];
    float mv[HS_SIFT_MSK_IT];
+#if HS_FAST
+   int m_i[HS_SIFT_MSK_IT];
+#endif
 #pragma unroll
    for (int q = 0; q < HS_SIFT_MSK_IT; q++) {
       const int slot = tid + 256 * q;
@@ -118,6 +121,9 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
       a_d[q] = i + HS_PATCH;
       o_off[q] = valid ? r * HS_VO_DIM + c : -1;
       mv[q] = tb.sift_mask[i];
+#if HS_FAST
+      m_i[q] = i;
+#endif
       if (!valid) { a_l[q] = a_r[q] = a_u[q] = a_d[q] = 0; }
    }
    uint32_t k = blockIdx.x;
@@ -125,7 +131,11 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
    // first keypoint's operands
    float pv[HS_PATCH_PIX_IT];
    int alive = io.alive[io.h_lo + k];
+#if HS_FAST
+   float mean = 0.0f, var = 0.0f;
+#else
    float mean = io.meanvar[2 * (size_t)k], var = io.meanvar[2 * (size_t)k + 1];
+#endif
    {
       const float *gp = io.patches + (size_t)k * HS_PATCH_PIX;
 #pragma unroll
@@ -133,6 +143,32 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
    }
    for (; k < n; k += gridDim.x) {
       const bool cur_alive = alive != 0;
+#if HS_FAST
+      // fast mode: photometric mean / variance by a block reduction right here (no k_sift_meanvar pass, the patch is read
+      // once); sums are re-associated, NOT bit-exact
+      {
+         __shared__ float s_red[8];
+#pragma unroll
+         for (int q = 0; q < HS_PATCH_PIX_IT; q++) { const int i = tid + 256 * q; if (i < HS_PATCH_PIX) s_p[i] = pv[q]; }
+         __syncthreads();
+         float ps = 0.0f;
+#pragma unroll
+         for (int q = 0; q < HS_SIFT_MSK_IT; q++) if (tid + 256 * q < nm) ps += s_p[m_i[q]];
+#pragma unroll
+         for (int d = 32; d >= 1; d >>= 1) ps += __shfl_xor(ps, d, 64);
+         if ((tid & 63) == 0) s_red[tid >> 6] = ps;
+         __syncthreads();
+         mean = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (float)nm;
+         float pq = 0.0f;
+#pragma unroll
+         for (int q = 0; q < HS_SIFT_MSK_IT; q++) if (tid + 256 * q < nm) { const float dd = mean - s_p[m_i[q]]; pq += dd * dd; }
+#pragma unroll
+         for (int d = 32; d >= 1; d >>= 1) pq += __shfl_xor(pq, d, 64);
+         if ((tid & 63) == 0) s_red[4 + (tid >> 6)] = pq;
+         __syncthreads();
+         var = sqrtf((s_red[4] + s_red[5] + s_red[6] + s_red[7]) / (float)nm);
+      }
+#endif
       // normalise this keypoint's pixels into LDS (helpers.cpp:269-280: ALL pixels, not only the masked ones)
       if (cur_alive) {
          const bool norm = !((double)var < 0.0001);
@@ -151,7 +187,9 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
       const uint32_t kn = k + gridDim.x;
       if (kn < n) {
          alive = io.alive[io.h_lo + kn];
+#if !HS_FAST
          mean = io.meanvar[2 * (size_t)kn]; var = io.meanvar[2 * (size_t)kn + 1];
+#endif
          const float *gp = io.patches + (size_t)kn * HS_PATCH_PIX;
 #pragma unroll
          for (int q = 0; q < HS_PATCH_PIX_IT; q++) pv[q] = gp[min(tid + 256 * q, HS_PATCH_PIX - 1)];
@@ -164,8 +202,12 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
             if (o_off[q] >= 0) {
                const float gx = s_p[a_r[q]] - s_p[a_l[q]], gy = s_p[a_d[q]] - s_p[a_u[q]];
                const float grad = sqrtf(gx * gx + gy * gy);
+#if HS_FAST
+               const float o = hm_fast_orient_coord(hm_fast_atan2f(gy, gx));
+#else
                const float ori = hm_atan2f_tab(gy, gx, s_at);
                const float o = hm_sift_orient_coord(ori);
+#endif
                out[o_off[q]] = make_float2(mv[q] * grad, o);
             }
             // the loop is unrolled only so that the per-pixel constants are registers; do not let the scheduler

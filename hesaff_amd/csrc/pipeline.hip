@@ -27,6 +27,7 @@
 #include "kernels_patch.h"
 #include "kernels_sift.h"
 #include "kernels_pyramid.h"
+#include "fast_api.h"
 
 namespace hesaff {
 OctaveSchedule make_schedule(float initialSigma, bool upscale)
@@ -180,6 +181,10 @@ struct hesaff_ctx {
    std::vector<int32_t> h_starts;
    DevBuf t_mask_idx, b_rowprefix, b_trows, b_trows2, b_trows3;
    size_t rows_lds_set = 0;            // dynamic LDS opt-in of k_patch_large_rows on THIS device
+   // persistent grids of the LDS-window kernels: exactly as many blocks as the device holds at once (CUs x resident
+   // blocks per CU), so that every block takes the same share of a bin's list; queried per device at hesaff_create
+   int n_cu = 256;
+   uint32_t g_small0 = 256 * 6, g_small1 = 256 * 4, g_mid = HS_MID_BLOCKS, g_big = HS_BIG_BLOCKS, g_lfin = 256 * 4, g_shist = 256 * 32;
    uint32_t trows_rows = 4u << 20;     // rows of T' (82 floats each) the large-window buffer holds at least: 1.3 GB
 
    hesaff_timings tm;
@@ -192,6 +197,7 @@ struct hesaff_ctx {
    hipEvent_t ev_extract_done[2] = {nullptr, nullptr}, ev_sift_done[2] = {nullptr, nullptr};
    DevBuf b_patches2[2], b_siftvec2[2], b_meanvar2[2], b_siftvo2[2];
    hipEvent_t ev_fork = nullptr, ev_join[HS_NSIDE] = {nullptr, nullptr, nullptr, nullptr};
+   bool fast = false;              // hesaff_params.fast: per-keypoint stages on the kernels of kernels_fast.hip (not bit-exact)
    // schedule knobs: fixed in the product build, environment-driven only under -DHESAFF_TUNING
    bool no_overlap = false;        // HESAFF_OVERLAP=0: every kernel alone on the device (per-kernel profiling)
    uint32_t sift_group_kpts = 0;   // HESAFF_GROUP: keypoints per image group; 0 = by batch
@@ -333,13 +339,36 @@ LargeGeom large_geom(int pmax)
 
 // Dynamic-LDS opt-ins are per device: applied when a context is created on its device (hesaff_create) and, for the
 // large-window kernel whose need depends on the image size, in plan().
+template <class KERNEL> uint32_t resident_grid(hesaff_ctx *c, KERNEL kern, int threads, size_t dyn_lds, uint32_t fallback_per_cu)
+{
+   int nb = 0;
+   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, threads, dyn_lds) != hipSuccess || nb < 1) {
+      (void)hipGetLastError();
+      nb = (int)fallback_per_cu;
+   }
+   return (uint32_t)c->n_cu * (uint32_t)nb;
+}
+
 void set_kernel_attrs(hesaff_ctx *c)
 {
-   (void)c;
    set_dyn_lds(k_patch_extract_small<0>, small_extract_lds_bytes(0));
    set_dyn_lds(k_patch_extract_small<1>, small_extract_lds_bytes(1));
    set_dyn_lds(k_patch_mid<HS_MID_PMAX>, mid_lds_bytes());
    set_dyn_lds(k_patch_mid<HS_BIN3_PMAX>, big_lds_bytes());
+   hipDeviceProp_t prop;
+   HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+   c->n_cu = std::max(1, prop.multiProcessorCount);
+   c->g_small0 = resident_grid(c, k_patch_extract_small<0>, 256, small_extract_lds_bytes(0), 6);
+   c->g_small1 = resident_grid(c, k_patch_extract_small<1>, 256, small_extract_lds_bytes(1), 4);
+   // the row-streamed bins claim their items dynamically: any grid that fills the device works; one T' slot per block
+   c->g_mid = std::min<uint32_t>(resident_grid(c, k_patch_mid<HS_MID_PMAX>, 256, mid_lds_bytes(), 6), HS_MID_BLOCKS);
+   c->g_big = std::min<uint32_t>(resident_grid(c, k_patch_mid<HS_BIN3_PMAX>, 256, big_lds_bytes(), 4), HS_BIG_BLOCKS);
+   c->g_lfin = resident_grid(c, k_patch_large_finish, 256, 0, 4);
+   c->g_shist = resident_grid(c, k_sift_hist, 64, 0, 32);
+   if (c->fast) {
+      const size_t lds[4] = {small_extract_lds_bytes(0), small_extract_lds_bytes(1), mid_lds_bytes(), big_lds_bytes()};
+      hsfast_set_attrs(lds, 0);
+   }
 }
 
 // Buffer plan for a batch of B images of H x W.
@@ -427,7 +456,14 @@ void plan(hesaff_ctx *c, int B, int H, int W)
    {
       const LargeGeom lg = large_geom(c->max_p0 + 2);
       if (lg.lds > 160 * 1024) throw HsError(HESAFF_ERR_ARG, "image too large for the large-window row kernel");
-      if (lg.lds > c->rows_lds_set) { set_dyn_lds(k_patch_large_rows, lg.lds); c->rows_lds_set = lg.lds; }
+      if (lg.lds > c->rows_lds_set) {
+         set_dyn_lds(k_patch_large_rows, lg.lds);
+         if (c->fast) {
+            const size_t lds[4] = {small_extract_lds_bytes(0), small_extract_lds_bytes(1), mid_lds_bytes(), big_lds_bytes()};
+            hsfast_set_attrs(lds, lg.lds);
+         }
+         c->rows_lds_set = lg.lds;
+      }
    }
    c->B = B; c->H = H; c->W = W;
 }
@@ -467,9 +503,9 @@ enum { T_PYR = 0, T_DET = 1, T_AFF = 2, T_PATCH = 3, T_SIFT = 4, T_TOTAL = 5, T_
 
 // Band height of k_blur_hess_march: 16 bands per octave is the measured optimum for 16 x 4K at every octave
 // (sweeps in profiles/r01_notes.md); small batches get proportionally more bands to keep ~1000 blocks in flight.
-template <int K, bool WL, bool WR, bool WH, bool WR0 = false>
+template <int K, bool WL, bool WR, bool WH, bool WR0 = false, bool SRC8 = false>
 void launch_march(hesaff_ctx *c, const DPlane &in, const DPlane &outL, const DPlane &outR, const DPlane &outHalf, const float *taps,
-                  float norm2, int B, const DPlane &outR0 = DPlane(), float norm2_in = 0.0f)
+                  float norm2, int B, const DPlane &outR0 = DPlane(), float norm2_in = 0.0f, const GraySrc &gs = GraySrc(), const DPlane &outGray = DPlane())
 {
    const int strips = (in.cols + BM_STRIP - 1) / BM_STRIP;
    const long long blocks_per_band = (long long)((strips + 3) / 4) * B;
@@ -479,7 +515,7 @@ void launch_march(hesaff_ctx *c, const DPlane &in, const DPlane &outL, const DPl
    const int band = (in.rows + best_nb - 1) / best_nb;
    if (c->debug) fprintf(stderr, "[hesaff] march K=%d %dx%d B=%d bands=%d band=%d blocks=%lld\n", K, in.cols, in.rows, B, best_nb, band, blocks_per_band * best_nb);
    const dim3 grid((strips + 3) / 4, (in.rows + band - 1) / band, B);
-   hipLaunchKernelGGL((k_blur_hess_march<K, WL, WR, WH, WR0>), grid, dim3(256), 0, c->stream, in, outL, outR, outHalf, taps, norm2, band, outR0, norm2_in);
+   hipLaunchKernelGGL((k_blur_hess_march<K, WL, WR, WH, WR0, SRC8>), grid, dim3(256), 0, c->stream, in, outL, outR, outHalf, taps, norm2, band, outR0, norm2_in, gs, outGray);
 }
 
 template <bool WL, bool WR, bool WH>
@@ -545,6 +581,21 @@ Lists make_lists(hesaff_ctx *c)
    return s;
 }
 
+FastArgs fast_args(const hesaff_ctx *c, const Lists &s, const PatchIO *io, const PlaneTab *pt, const SiftIO *so)
+{
+   FastArgs a;
+   memset(&a, 0, sizeof a);
+   a.hl = &s.hl; a.sz_hl = sizeof s.hl;
+   a.pw = &s.pw; a.sz_pw = sizeof s.pw;
+   a.ao = &s.ao; a.sz_ao = sizeof s.ao;
+   a.tb = &c->tables; a.sz_tb = sizeof c->tables;
+   a.kc = &c->consts; a.sz_kc = sizeof c->consts;
+   a.io = io; a.sz_io = sizeof(PatchIO);
+   a.pt = pt; a.sz_pt = sizeof(PlaneTab);
+   a.so = so; a.sz_so = sizeof(SiftIO);
+   return a;
+}
+
 // normalizeAffine for every keypoint k_prepare_patch left alive and binned.  Every launch is a persistent grid of
 // fixed size that reads its work-list length from the device-side bin counters: the host never waits for them.
 // large_rows_bound: upper bound of the large bin's T' rows in this group (from k_image_large_rows).
@@ -568,15 +619,21 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
       if (c->side_mask & 4) s2 = c->side_streams[2];
       if (c->side_mask & 8) s3 = c->side_streams[3];
    }
-   hipLaunchKernelGGL(k_patch_extract_small<0>, dim3(256 * 8), dim3(256), small_extract_lds_bytes(0), s0, s.hl, s.pw, io, c->tables);
-   hipLaunchKernelGGL(k_patch_extract_small<1>, dim3(256 * 4), dim3(256), small_extract_lds_bytes(1), s1, s.hl, s.pw, io, c->tables);
    {
       PatchIO io2 = io;
       io2.trows = c->b_trows2.as<float>();
-      hipLaunchKernelGGL(k_patch_mid<HS_MID_PMAX>, dim3(HS_MID_BLOCKS), dim3(256), mid_lds_bytes(), s2, s.hl, s.pw, io2, c->tables);
       PatchIO io3 = io;
       io3.trows = c->b_trows3.as<float>();
-      hipLaunchKernelGGL(k_patch_mid<HS_BIN3_PMAX>, dim3(HS_BIG_BLOCKS), dim3(256), big_lds_bytes(), s3, s.hl, s.pw, io3, c->tables);
+      if (c->fast) {
+         const uint32_t grids[4] = {c->g_small0, c->g_small1, c->g_mid, c->g_big};
+         const size_t lds[4] = {small_extract_lds_bytes(0), small_extract_lds_bytes(1), mid_lds_bytes(), big_lds_bytes()};
+         hsfast_patch_bins(s0, s1, s2, s3, fast_args(c, s, &io, nullptr, nullptr), &io2, &io3, grids, lds);
+      } else {
+         hipLaunchKernelGGL(k_patch_extract_small<0>, dim3(c->g_small0), dim3(256), small_extract_lds_bytes(0), s0, s.hl, s.pw, io, c->tables);
+         hipLaunchKernelGGL(k_patch_extract_small<1>, dim3(c->g_small1), dim3(256), small_extract_lds_bytes(1), s1, s.hl, s.pw, io, c->tables);
+         hipLaunchKernelGGL(k_patch_mid<HS_MID_PMAX>, dim3(c->g_mid), dim3(256), mid_lds_bytes(), s2, s.hl, s.pw, io2, c->tables);
+         hipLaunchKernelGGL(k_patch_mid<HS_BIN3_PMAX>, dim3(c->g_big), dim3(256), big_lds_bytes(), s3, s.hl, s.pw, io3, c->tables);
+      }
    }
    if (forked)
       for (int i = 0; i < HS_NSIDE; i++) HIP_TRY(hipEventRecord(c->ev_join[i], c->side_streams[i]));
@@ -590,10 +647,13 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
       io.row_prefix = c->b_rowprefix.as<uint32_t>();
       io.trows_cap = rows_cap;
       io.overflow = s.counters + 6;
-      hipLaunchKernelGGL(k_large_prefix, dim3(1), dim3(256), 0, st, s.pw, c->b_rowprefix.as<uint32_t>());
       const uint32_t gblocks = std::min<uint32_t>((large_rows_bound + 4 * HS_LARGE_CHUNK - 1) / (4 * HS_LARGE_CHUNK), 256 * 16);
-      hipLaunchKernelGGL(k_patch_large_rows, dim3(gblocks), dim3(256), lg.lds, st, s.hl, s.pw, io, c->tables, lg.srow_stride, lg.tap_stride);
-      hipLaunchKernelGGL(k_patch_large_finish, dim3(256 * 4), dim3(256), 0, st, s.pw, io, c->tables);
+      if (c->fast) hsfast_patch_large(st, fast_args(c, s, &io, nullptr, nullptr), c->b_rowprefix.as<uint32_t>(), gblocks, lg.lds, lg.srow_stride, lg.tap_stride, c->g_lfin);
+      else {
+         hipLaunchKernelGGL(k_large_prefix, dim3(1), dim3(256), 0, st, s.pw, c->b_rowprefix.as<uint32_t>());
+         hipLaunchKernelGGL(k_patch_large_rows, dim3(gblocks), dim3(256), lg.lds, st, s.hl, s.pw, io, c->tables, lg.srow_stride, lg.tap_stride);
+         hipLaunchKernelGGL(k_patch_large_finish, dim3(c->g_lfin), dim3(256), 0, st, s.pw, io, c->tables);
+      }
    }
    if (forked)
       for (int i = 0; i < HS_NSIDE; i++) HIP_TRY(hipStreamWaitEvent(st, c->ev_join[i], 0));
@@ -613,8 +673,17 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
 
    int t = tm.begin(T_PYR);
    DPlane none = make_plane(nullptr, 0, 0, 0);
-   {
-      // grey conversion hesaff.cpp:138-148; without an initial blur (initialSigma <= 0.5) it writes the first level directly
+   // Default parameters: grey conversion (hesaff.cpp:138-148) fused into the initial blur 0.5 -> 1.6 (pyramid.cpp:276-280,
+   // K = 11): the 8-bit images are read once, the float grey plane (normalizeAffine's input) and L0 are written.
+   const bool fused_gray = !c->oct.empty() && c->pyr_K[0] == 11 && !c->up;
+   if (fused_gray) {
+      GraySrc gs;
+      gs.p = d_src; gs.channels = channels; gs.img_stride = src_img_stride; gs.row_stride = src_row_stride;
+      const int tb = tm.begin(T_BLURHESS, 0);   // not one of the 58 B/px launches (bytes 0)
+      launch_march<11, true, false, false, false, true>(c, c->gray, c->L[0], none, none, ptaps + c->pyr_tap_off[0], 0.0f, B, DPlane(), 0.0f, gs, c->gray);
+      tm.end(tb);
+   } else {
+      // grey conversion; without an initial blur (initialSigma <= the input's own blur) it is the first level directly
       const bool direct = c->pyr_K[0] == 0 && !c->oct.empty();
       const dim3 grid((c->W + 255) / 256, c->H, B);
       hipLaunchKernelGGL(k_gray, grid, dim3(256), 0, st, d_src, channels, src_img_stride, src_row_stride, c->gray);
@@ -625,12 +694,12 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
       }
       const DPlane &first = c->up ? c->upimg : c->gray;
       if (direct) HIP_TRY(hipMemcpyAsync(c->L[0].p, first.p, (size_t)B * first.img_stride * 4, hipMemcpyDeviceToDevice, st));
-   }
-   if (!c->oct.empty() && c->pyr_K[0] > 0) {
-      // pyramid.cpp:276-280 initial blur 0.5 -> initialSigma
-      const int tb = tm.begin(T_BLURHESS, 0);   // initial blur: not counted in the 12N launches (bytes 0)
-      launch_blur_hess<true, false, false>(c, c->up ? c->upimg : c->gray, c->L[0], none, none, ptaps + c->pyr_tap_off[0], c->pyr_K[0], 0.0f, B);
-      tm.end(tb);
+      if (!c->oct.empty() && c->pyr_K[0] > 0) {
+         // pyramid.cpp:276-280 initial blur 0.5 -> initialSigma
+         const int tb = tm.begin(T_BLURHESS, 0);   // initial blur: not counted in the 12N launches (bytes 0)
+         launch_blur_hess<true, false, false>(c, first, c->L[0], none, none, ptaps + c->pyr_tap_off[0], c->pyr_K[0], 0.0f, B);
+         tm.end(tb);
+      }
    }
    tm.end(t);
    float *pout = planes_out;
@@ -764,10 +833,16 @@ void collect_timings(hesaff_ctx *c, StageTimer &tm, int B)
 // The descriptor kernels (kernels_sift.h) over n patches in HBM.
 void launch_sift(hesaff_ctx *c, hipStream_t ss, const SiftIO &so, uint32_t n, float2 *vo)
 {
+   if (c->fast) {
+      Lists none;
+      memset(&none, 0, sizeof none);
+      hsfast_sift(ss, fast_args(c, none, nullptr, nullptr, &so), n, vo, c->n_cu * 6u, c->g_shist);
+      return;
+   }
    const uint32_t nb64 = (n + 63) / 64;
    hipLaunchKernelGGL(k_sift_meanvar, dim3(nb64), dim3(64), 0, ss, so, c->tables);
    hipLaunchKernelGGL(k_sift_grad, dim3(c->sgrad_grid ? std::min(n, c->sgrad_grid) : n), dim3(256), 0, ss, so, c->tables, vo);
-   hipLaunchKernelGGL(k_sift_hist, dim3(std::min<uint32_t>((n + 3) / 4, 256 * 32)), dim3(64), 0, ss, so, c->tables, (const float2 *)vo);
+   hipLaunchKernelGGL(k_sift_hist, dim3(std::min<uint32_t>((n + 3) / 4, c->g_shist)), dim3(64), 0, ss, so, c->tables, (const float2 *)vo);
    hipLaunchKernelGGL(k_sift_quantize, dim3(nb64), dim3(64), 0, ss, so, c->consts);
 }
 
@@ -847,8 +922,9 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       if (as != st) HIP_TRY(hipStreamWaitEvent(as, c->ev_detect_done, 0));
       auto launch_affine = [&](size_t gi) {
          const int ta = tm.begin(T_AFF, 0, as);
-         hipLaunchKernelGGL(k_affine, dim3(std::min<uint32_t>((groups[gi].hi - groups[gi].lo + 3) / 4, 256 * c->aff_blocks_per_cu)), dim3(64), 0, as, pt, s.hl, groups[gi].lo, groups[gi].hi, (const uint32_t *)(cnt + 3),
-                            c->tables, c->consts, s.ao);
+         const uint32_t agrid = std::min<uint32_t>((groups[gi].hi - groups[gi].lo + 3) / 4, (uint32_t)c->n_cu * c->aff_blocks_per_cu);
+         if (c->fast) hsfast_affine(as, std::min<uint32_t>((groups[gi].hi - groups[gi].lo + 3) / 4, (uint32_t)c->n_cu * 16u), fast_args(c, s, nullptr, &pt, nullptr), groups[gi].lo, groups[gi].hi, (const uint32_t *)(cnt + 3));
+         else hipLaunchKernelGGL(k_affine, dim3(agrid), dim3(64), 0, as, pt, s.hl, groups[gi].lo, groups[gi].hi, (const uint32_t *)(cnt + 3), c->tables, c->consts, s.ao);
          tm.end(ta);
          if (as != st) HIP_TRY(hipEventRecord(c->ev_aff[gi], as));
       };

@@ -1,8 +1,6 @@
+# usage (through gpurun): bash scripts/gpu_pyr.sh <lib> ...   roofline numbers of the pyramid kernels for several builds (bench --batch 64, 3 steps)
 cd $GRAFT_REPO_ROOT
-for v in "$@"; do
-  HESAFF_PYR=$v timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "pyramid or golden or end_to_end" 2>&1 | tail -1
-  HESAFF_PYR=$v timeout 600 python bench.py --steps 3 --warmup 1 --batch 16 --no-cpu-baseline 2>/dev/null | python -c "
-import sys, json
-d = json.loads(sys.stdin.read()); r = d['roofline']
-print('PYR=$v', 'achieved %.0f GB/s frac %.3f avg_launch_ms %.4f' % (r['achieved'], r['frac'], r['avg_launch_ms']), 'pyr_ms %.2f' % d['stage_ms_per_step']['pyramid_ms'], 'kp/s %.0f' % d['value'])"
+for lib in "$@"; do
+  HESAFF_AMD_LIB=$GRAFT_REPO_ROOT/hesaff_amd/$lib python bench.py --batch 64 --steps 3 --warmup 1 --no-cpu-baseline --no-host-path 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$lib', 'ms/step', round(d['ms_per_step'],1), 'kernel frac', round(r['frac'],3), 'stage frac', round(r['stage']['frac'],3), 'pyramid_ms', round(d['stage_ms_per_step']['serial_on_main_stream']['pyramid_ms'],2))"
 done

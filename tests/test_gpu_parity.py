@@ -530,6 +530,27 @@ def test_bad_arguments_are_rejected():
         assert e.value.code == -2, kw
 
 
+def test_fast_mode_is_close_to_parity_mode(ctx):
+    """hesaff_params.fast = 1 is NOT bit-exact; it must stay a faithful approximation: the same
+    Hessian keypoints, nearly all described regions reproduced within 0.01 px, descriptors within a few quantisation
+    steps.  (The measured rates on the bench images are in profiles/r02_fast_mode.json.)"""
+    import hesaff_amd
+    from tools.fast_mode_report import compare
+    imgs = [band_noise_image(480, 640, 77), band_noise_image(300, 500, 78, SMALL_BANDS)]
+    want = ctx.detect_batch(imgs)
+    p = _params(fast=1)
+    with hesaff_amd.HesaffContext(p, device=0) as fctx:
+        got = fctx.detect_batch(imgs)
+        again = fctx.detect_batch(imgs)
+    for (nh_w, kw), (nh_g, kg), (_, k2) in zip(want, got, again):
+        assert nh_w == nh_g                                   # detection is shared by both modes
+        assert kg.tobytes() == k2.tobytes()                   # fast mode is deterministic too
+        c = compare(kw, kg)
+        assert c["matched_within_0.01px"] > 0.97 * len(kw) and abs(len(kg) - len(kw)) < 0.02 * len(kw), c
+        assert c["rows_with_delta_le_4"] > 0.97 * c["matched_within_0.01px"], c
+        assert c["shape_rel_delta_p50_p99_max"][0] < 1e-4, c
+
+
 def test_survey_probe_output_md5_on_gpu(ctx):
     """The product's .hesaff.sift of SURVEY App. C's 640x480 probe image has the md5 the survey recorded from the
     COMPILED reference's output file (e004ba88...): 4183 rows, every coordinate, ellipse term and descriptor byte."""
