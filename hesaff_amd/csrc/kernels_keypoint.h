@@ -20,6 +20,11 @@ struct KpTables {   // device tables built on the host once per context
    const float *sift_mask;   // 41x41 computeCircularGaussMask, helpers.cpp:131
    const int32_t *mask_idx;  // raster-ordered indices of the pixels with sift_mask > 0
    int n_masked;
+   // per masked pixel (slot order = mask_idx order, padded to 1280): the constants k_sift_grad needs for it, so that a
+   // thread fetches them in one round of loads: {left, right, up, down} stencil neighbours as LDS byte offsets into the
+   // patch, and {output slot r * 40 + c (or -1: row / column 40, no weight), mask value bits}
+   const int4 *sgrad_nb;
+   const int2 *sgrad_om;
    const int32_t *bin0, *bin1;   // precomputeBinsAndWeights siftdesc.cpp:18 (already x8)
    const float *w0, *w1;
    const float *patch_taps;      // Gaussian taps of every odd P0, concatenated

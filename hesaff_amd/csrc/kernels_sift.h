@@ -101,31 +101,18 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
       const float at_init[HM_ATAN_TAB_FLOATS] = HM_ATAN_TAB_INIT;
       if (tid < HM_ATAN_TAB_FLOATS) s_at[tid] = at_init[tid];
    }
-   // this thread's pixels inside the circular mask (1245 of 1681, helpers.cpp:131): LDS byte addresses of the
-   // stencil neighbours (affine.cpp:14-33 convention: one-sided differences at the patch border), output slot, mask
+   // this thread's pixels inside the circular mask (1245 of 1681, helpers.cpp:131): stencil neighbours (LDS byte offsets),
+   // output slot and mask value come from one table row per pixel (KpTables::sgrad_*), all requested in one round
    const int nm = tb.n_masked;
-   int a_l[HS_SIFT_MSK_IT], a_r[HS_SIFT_MSK_IT], a_u[HS_SIFT_MSK_IT], a_d[HS_SIFT_MSK_IT], o_off[HS_SIFT_MSK_IT];
-   float mv[HS_SIFT_MSK_IT];
+   int4 nbq[HS_SIFT_MSK_IT];
+   int2 omq[HS_SIFT_MSK_IT];
+#pragma unroll
+   for (int q = 0; q < HS_SIFT_MSK_IT; q++) { nbq[q] = tb.sgrad_nb[tid + 256 * q]; omq[q] = tb.sgrad_om[tid + 256 * q]; }
 #if HS_FAST
    int m_i[HS_SIFT_MSK_IT];
-#endif
 #pragma unroll
-   for (int q = 0; q < HS_SIFT_MSK_IT; q++) {
-      const int slot = tid + 256 * q;
-      const int i = tb.mask_idx[min(slot, nm - 1)];
-      const int r = i / HS_PATCH, c = i - r * HS_PATCH;
-      const bool valid = slot < nm && r < HS_VO_DIM && c < HS_VO_DIM;
-      a_l[q] = (c == 0) ? i : i - 1;                  // c <= 39 < patchSize - 1 for valid pixels
-      a_r[q] = i + 1;
-      a_u[q] = (r == 0) ? i : i - HS_PATCH;
-      a_d[q] = i + HS_PATCH;
-      o_off[q] = valid ? r * HS_VO_DIM + c : -1;
-      mv[q] = tb.sift_mask[i];
-#if HS_FAST
-      m_i[q] = i;
+   for (int q = 0; q < HS_SIFT_MSK_IT; q++) m_i[q] = tb.mask_idx[min(tid + 256 * q, nm - 1)];
 #endif
-      if (!valid) { a_l[q] = a_r[q] = a_u[q] = a_d[q] = 0; }
-   }
    uint32_t k = blockIdx.x;
    if (k >= n) return;
    // first keypoint's operands
@@ -199,8 +186,10 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
          float2 *out = vo + (size_t)k * HS_VO_PITCH;
 #pragma unroll
          for (int q = 0; q < HS_SIFT_MSK_IT; q++) {
-            if (o_off[q] >= 0) {
-               const float gx = s_p[a_r[q]] - s_p[a_l[q]], gy = s_p[a_d[q]] - s_p[a_u[q]];
+            if (omq[q].x >= 0) {
+               const char *sp = reinterpret_cast<const char *>(s_p);
+               const float gx = *reinterpret_cast<const float *>(sp + nbq[q].y) - *reinterpret_cast<const float *>(sp + nbq[q].x);
+               const float gy = *reinterpret_cast<const float *>(sp + nbq[q].w) - *reinterpret_cast<const float *>(sp + nbq[q].z);
                const float grad = sqrtf(gx * gx + gy * gy);
 #if HS_FAST
                const float o = hm_fast_orient_coord(hm_fast_atan2f(gy, gx));
@@ -208,7 +197,7 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
                const float ori = hm_atan2f_tab(gy, gx, s_at);
                const float o = hm_sift_orient_coord(ori);
 #endif
-               out[o_off[q]] = make_float2(mv[q] * grad, o);
+               out[omq[q].x] = make_float2(__int_as_float(omq[q].y) * grad, o);
             }
             // the loop is unrolled only so that the per-pixel constants are registers; do not let the scheduler
             // interleave the iterations (five atan2 bodies in flight cost ~60 VGPRs)

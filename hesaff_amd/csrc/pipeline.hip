@@ -179,7 +179,7 @@ struct hesaff_ctx {
    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_in_free[2] = {nullptr, nullptr}, ev_out_ready[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
    std::vector<int32_t> h_starts;
-   DevBuf t_mask_idx, b_rowprefix, b_trows, b_trows2, b_trows3;
+   DevBuf t_mask_idx, t_sgrad_nb, t_sgrad_om, b_rowprefix, b_trows, b_trows2, b_trows3;
    size_t rows_lds_set = 0;            // dynamic LDS opt-in of k_patch_large_rows on THIS device
    // persistent grids of the LDS-window kernels: exactly as many blocks as the device holds at once (CUs x resident
    // blocks per CU), so that every block takes the same share of a bin's list; queried per device at hesaff_create
@@ -243,6 +243,22 @@ void build_tables(hesaff_ctx *c)
          if (sm[i] > 0) midx.push_back(i);
       c->n_masked = (int)midx.size();
       upload(c->t_mask_idx, midx);
+      // k_sift_grad's per-pixel constants (affine.cpp:14-33 stencil convention: one-sided differences at the patch border)
+      std::vector<int32_t> nb(4 * 1280, 0), om(2 * 1280, 0);
+      for (size_t s = 0; s < 1280; s++) {
+         const bool used = s < midx.size();
+         const int i = used ? midx[s] : 0, r = i / HS_PATCH, cc = i - r * HS_PATCH;
+         const bool valid = used && r < HS_PATCH - 1 && cc < HS_PATCH - 1;   // row / column 40 carry no weight in samplePatch
+         if (valid) {
+            nb[4 * s + 0] = 4 * (cc == 0 ? i : i - 1);
+            nb[4 * s + 1] = 4 * (i + 1);
+            nb[4 * s + 2] = 4 * (r == 0 ? i : i - HS_PATCH);
+            nb[4 * s + 3] = 4 * (i + HS_PATCH);
+         }
+         om[2 * s + 0] = valid ? r * (HS_PATCH - 1) + cc : -1;
+         memcpy(&om[2 * s + 1], &sm[i], 4);
+      }
+      upload(c->t_sgrad_nb, nb); upload(c->t_sgrad_om, om);
    }
    upload(c->t_smm, smm); upload(c->t_sift, sm); upload(c->t_bin0, b0); upload(c->t_bin1, b1); upload(c->t_w0, w0); upload(c->t_w1, w1);
    c->up = c->par.upscaleInputImage > 0 ? 1 : 0;
@@ -306,6 +322,7 @@ void refresh_tables_struct(hesaff_ctx *c)
    t.patch_taps = c->t_patch_taps.as<float>(); t.patch_tap_off = c->t_patch_off.as<int32_t>(); t.patch_tap_k = c->t_patch_k.as<int32_t>();
    t.max_p0 = c->max_p0;
    t.mask_idx = c->t_mask_idx.as<int32_t>();
+   t.sgrad_nb = c->t_sgrad_nb.as<int4>(); t.sgrad_om = c->t_sgrad_om.as<int2>();
    t.n_masked = c->n_masked;
 }
 

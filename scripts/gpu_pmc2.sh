@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc2_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export HESAFF_AMD_LIB=$LIB HESAFF_OVERLAP=0
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $OUT -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --batch $BATCH --no-cpu-baseline > $OUT/bench.json 2> $OUT/log.txt
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --batch $BATCH --no-cpu-baseline --no-host-path > $OUT/bench.json 2> $OUT/log.txt
 cd $GRAFT_REPO_ROOT
 python3 - $OUT <<'PY'
 import csv, sys, glob, collections
@@ -21,15 +21,18 @@ f = glob.glob(out + '/**/p_kernel_trace.csv', recursive=True)[0]
 for r in csv.DictReader(open(f)):
     n = r['Kernel_Name'].split('(')[0].replace('void ', '')[:40]
     dur[n] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6; calls[n] += 1
-print('| %-40s | %5s | %8s | %9s | %6s | %7s | %7s | %7s | %6s |' % ('kernel', 'calls', 'ms', 'VALU inst', 'VALU %', 'parked%', 'stall%', 'active%', 'waves/SIMD'))
-print('|---|---|---|---|---|---|---|---|---|')
+print('| %-40s | %5s | %8s | %9s | %6s | %7s | %7s | %7s | %6s | %5s |' % ('kernel', 'calls', 'ms', 'VALU inst', 'VALU %', 'parked%', 'stall%', 'active%', 'waves/SIMD', 'GHz'))
+print('|---|---|---|---|---|---|---|---|---|---|')
 for n in sorted(dur, key=lambda k: -dur[k])[:16]:
     if not n.startswith('k_'): continue
     a = agg[n]; ms = dur[n]
     wc = max(a['SQ_WAVE_CYCLES'], 1.0)
-    valu_pct = 100.0 * a['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * 2.4e6 * ms) if ms else 0
+    # GRBM_GUI_ACTIVE: shader-clock cycles the GPU was busy during the kernel (summed over its launches) -> effective clock
+    cyc = a['GRBM_GUI_ACTIVE'] if a['GRBM_GUI_ACTIVE'] > 0 else 2.4e6 * ms
+    ghz = cyc / (ms * 1e6) if ms else 0
+    valu_pct = 100.0 * a['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * cyc) if cyc else 0
     # average resident waves per SIMD = wave quad-cycles * 4 / (SIMD cycles of the kernel)
-    occ = a['SQ_WAVE_CYCLES'] * 4 / (1024 * 2.4e6 * ms) if ms else 0
-    print('| %-40s | %5d | %8.2f | %9.3g | %6.1f | %7.1f | %7.1f | %7.1f | %6.2f |' % (n, calls[n], ms, a['SQ_INSTS_VALU'], valu_pct,
-          100 * a['SQ_WAIT_ANY'] / wc, 100 * a['SQ_WAIT_INST_ANY'] / wc, 100 * a['SQ_ACTIVE_INST_ANY'] / wc, occ))
+    occ = a['SQ_WAVE_CYCLES'] * 4 / (1024 * cyc) if cyc else 0
+    print('| %-40s | %5d | %8.2f | %9.3g | %6.1f | %7.1f | %7.1f | %7.1f | %6.2f | %5.2f |' % (n, calls[n], ms, a['SQ_INSTS_VALU'], valu_pct,
+          100 * a['SQ_WAIT_ANY'] / wc, 100 * a['SQ_WAIT_INST_ANY'] / wc, 100 * a['SQ_ACTIVE_INST_ANY'] / wc, occ, ghz))
 PY
