@@ -574,13 +574,17 @@ __global__ __launch_bounds__(256, (K == 15 ? HS_MARCH15_WAVES : 0)) void k_blur_
       const int y = min(max(yu, 0), rows - 1);
       if (SRC8) {
          const uint8_t *rp = gs.p + (long long)b * gs.img_stride + (long long)y * gs.row_stride;
+         if (gs.channels == 1) {
+            // grey input: cv::imread replicates the byte into B, G, R and (float(c) + c + c) / 3.0f == float(c) exactly
+            // (3c <= 765 is exact, and so is its quotient by 3): no arithmetic needed
 #pragma unroll
-         for (int m = 0; m < 5; m++) {
-            const uint8_t *q = rp + (long long)cx[m] * gs.channels;
-            const float c0 = (float)q[0];
-            const float c1 = (float)(gs.channels == 3 ? q[1] : q[0]);
-            const float c2 = (float)(gs.channels == 3 ? q[2] : q[0]);
-            dst5[m] = (c0 + c1 + c2) / 3.0f;   // hesaff.cpp:145
+            for (int m = 0; m < 5; m++) dst5[m] = (float)rp[cx[m]];
+         } else {
+#pragma unroll
+            for (int m = 0; m < 5; m++) {
+               const uint8_t *q = rp + (long long)cx[m] * 3;
+               dst5[m] = ((float)q[0] + (float)q[1] + (float)q[2]) / 3.0f;   // hesaff.cpp:145
+            }
          }
          // the band's own rows x the strip's own columns (row-buffer floats 12 .. 259): each grey pixel is written exactly once
          if (yu >= yh0 && yu < yh1) {
