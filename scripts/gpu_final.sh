@@ -1,0 +1,10 @@
+# usage (through gpurun): bash scripts/gpu_final.sh <tag>
+# round-end evidence: GPU test suite, default bench line, rocprofv3 stats + HBM traffic of the bench command, per-kernel PMC table
+cd $GRAFT_REPO_ROOT
+TAG=$1
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_tests.log 2>&1; tail -4 gpurun_out/${TAG}_tests.log
+(time timeout 1200 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err); tail -4 gpurun_out/${TAG}_bench.err
+bash scripts/gpu_profile_round.sh ${TAG}_prof > gpurun_out/${TAG}_prof.log 2>&1; tail -20 gpurun_out/${TAG}_prof.log | cut -c1-400
+bash scripts/gpu_pmc2.sh ${TAG} 8 > gpurun_out/${TAG}_pmc.md 2>&1; cat gpurun_out/${TAG}_pmc.md
+python scripts/hbm_probe.py > gpurun_out/${TAG}_hbm_probe.txt 2>&1; tail -5 gpurun_out/${TAG}_hbm_probe.txt

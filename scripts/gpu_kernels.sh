@@ -29,3 +29,4 @@ try:
 except Exception as e:
     print(e)
 PY
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete

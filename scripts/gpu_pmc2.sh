@@ -28,7 +28,8 @@ for n in sorted(dur, key=lambda k: -dur[k])[:16]:
     a = agg[n]; ms = dur[n]
     wc = max(a['SQ_WAVE_CYCLES'], 1.0)
     # GRBM_GUI_ACTIVE: shader-clock cycles the GPU was busy during the kernel (summed over its launches) -> effective clock
-    cyc = a['GRBM_GUI_ACTIVE'] if a['GRBM_GUI_ACTIVE'] > 0 else 2.4e6 * ms
+    # (the counter is kept per XCD and rocprofv3 sums the eight of them)
+    cyc = a['GRBM_GUI_ACTIVE'] / 8.0 if a['GRBM_GUI_ACTIVE'] > 0 else 2.4e6 * ms
     ghz = cyc / (ms * 1e6) if ms else 0
     valu_pct = 100.0 * a['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * cyc) if cyc else 0
     # average resident waves per SIMD = wave quad-cycles * 4 / (SIMD cycles of the kernel)
@@ -36,3 +37,4 @@ for n in sorted(dur, key=lambda k: -dur[k])[:16]:
     print('| %-40s | %5d | %8.2f | %9.3g | %6.1f | %7.1f | %7.1f | %7.1f | %6.2f | %5.2f |' % (n, calls[n], ms, a['SQ_INSTS_VALU'], valu_pct,
           100 * a['SQ_WAIT_ANY'] / wc, 100 * a['SQ_WAIT_INST_ANY'] / wc, 100 * a['SQ_ACTIVE_INST_ANY'] / wc, occ, ghz))
 PY
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete

@@ -39,3 +39,5 @@ for r in rows[:14]:
     print('%-70s calls=%5s total=%9.3f ms avg=%9.1f us' % (r['Name'].split('(')[0][:70], r['Calls'], float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3))
 PY
 cat $OUT/bench_under_rocprof.json | head -c 1500
+# raw traces are large (gpurun merges at most 64 MiB back): keep the summaries only
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
