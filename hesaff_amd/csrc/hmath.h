@@ -198,13 +198,21 @@ HM_HD float hm_atan2f_sel(float y, float x)
     1.0f, 1.5f, -1.5f, 1.0f, 0x1.f730bcp-1f /*3f7b985e*/, 0x1.281f68p-25f /*33140fb4*/, 0.0f, 0.0f,                 \
     0.0f, 1.0f, -1.0f, 0.0f, 0x1.921fb4p+0f /*3fc90fda*/, 0x1.4442dp-24f /*33a22168*/, 0.0f, 0.0f}
 
+// the operands the select / table forms hand over (NaN, infinities, exponent gaps above 60) are rare: keep fdlibm's
+// branchy general form out of line on the device so that it does not bloat every call site
+#if defined(__HIPCC__)
+__host__ __device__ __attribute__((noinline)) inline float hm_atan2f_rare(float y, float x) { return hm_atan2f(y, x); }
+#else
+inline float hm_atan2f_rare(float y, float x) { return hm_atan2f(y, x); }
+#endif
+
 HM_HD float hm_atan2f_tab(float y, float x, const float *tab)
 {
    const float pi_o_2 = hm_u2f(0x3fc90fdbu), pi = hm_u2f(0x40490fdbu), pi_lo = hm_u2f(0xb3bbbd2eu);
    const int32_t hx = (int32_t)hm_f2u(x), hy = (int32_t)hm_f2u(y);
    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
    const int32_t k = (iy - ix) >> 23;
-   if ((ix >= 0x7f800000) | (iy >= 0x7f800000) | ((iy != 0) & (ix != 0) & ((k > 60) | (k < -60)))) return hm_atan2f(y, x);
+   if ((ix >= 0x7f800000) | (iy >= 0x7f800000) | ((iy != 0) & (ix != 0) & ((k > 60) | (k < -60)))) return hm_atan2f_rare(y, x);
    const float q = hm_fabsf(y / x);   // NaN for 0/0, +inf for y/0: both replaced below
    const int32_t iq = (int32_t)hm_f2u(q);
    const int id = (int)(iq >= 0x3ee00000) + (int)(iq >= 0x3f300000) + (int)(iq >= 0x3f980000) + (int)(iq >= 0x401c0000);

@@ -5,7 +5,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 C=$R/hesaff_amd/csrc; B=$R/hesaff_amd/build; V=$R/hesaff_amd/variants
 name=$1; shift
 mkdir -p $B $V
-FP="-ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero"
+FP="-ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize"
 make -s -C $C $B/kernels_fast.o $B/hostio.o $B/jpeg_decode.o >/dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $FP -Wno-unused-result -DHESAFF_TUNING "$@" -c -o $B/p_$name.o $C/pipeline.hip
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $V/$name.so $B/p_$name.o $B/kernels_fast.o $B/hostio.o $B/jpeg_decode.o -lz
