@@ -97,6 +97,9 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       validate_params(c->par);
       c->device = device;
       c->fast = c->par.fast == 1;
+#ifdef HESAFF_TUNING
+      if (const char *fm = getenv("HESAFF_FAST")) c->fast = atoi(fm) == 1;   // profile the fast kernels under bench.py
+#endif
       bind_device(c);
       hipDeviceProp_t prop;
       HIP_TRY(hipGetDeviceProperties(&prop, device));

@@ -17,7 +17,7 @@ tot = 0.0
 lines = []
 for r in rows:
     n = r['Name'].split('(')[0].replace('void ', '')
-    if not n.startswith('k_'): continue
+    if not (n.startswith('k_') or n.startswith('hsfast::k_')): continue
     ms = float(r['TotalDurationNs']) / 1e6 / 3.0   # per step (2 timed + 1 warm-up)
     tot += ms
     lines.append((ms, n, int(r['Calls']) // 3))
