@@ -86,6 +86,14 @@ def host_cpu_info():
         info["usable_cpus"] = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         pass
+    # a container's CPU bandwidth limit (cgroup v2 cpu.max = "<quota> <period>" or "max <period>"): the number of
+    # CPUs' worth of time this process tree may use, whatever the affinity mask says
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            info["cgroup_cpu_quota"] = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
     return info
 
 
@@ -224,7 +232,7 @@ def main():
                 exp_img_s = ne / edt
                 det_img_s = host_path["images_per_s"] / max(world, 1)   # per rank
                 text_export = {"images": ne, "rows_per_s": rows / edt, "images_per_s": exp_img_s, "text_GB_per_s": nbytes / edt / 1e9,
-                               "bytes_per_image": nbytes / ne, "threads": "auto (one per core, at most 64)", "target": tmp.rsplit("/", 1)[0],
+                               "bytes_per_image": nbytes / ne, "threads": int(hctx.L.hesaff_host_threads()), "target": tmp.rsplit("/", 1)[0],
                                # the export of batch i runs on host threads beside the detection of batch i+1: the slower of the two sets the rate
                                "end_to_end_images_per_s_pipelined": min(exp_img_s, det_img_s),
                                "end_to_end_images_per_s_sequential": 1.0 / (1.0 / exp_img_s + 1.0 / det_img_s),
@@ -296,7 +304,11 @@ def main():
             # the same oracle, one worker process per physical core, one image each (>= 8 images)
             phys = cpu.get("physical_cores") or max(1, (cpu.get("logical_cpus") or 4) // 2)
             usable = cpu.get("usable_cpus") or cpu.get("logical_cpus") or phys
-            nw = args.cpu_workers if args.cpu_workers >= 0 else min(phys, usable)
+            quota = cpu.get("cgroup_cpu_quota")
+            auto = min(phys, usable)
+            if quota:       # more workers than the CPU-time limit only time-slice (measured: 128 workers on a 16-CPU quota
+                auto = max(8, min(auto, int(quota)))    # are slower in aggregate than 32); never fewer than 8 images
+            nw = args.cpu_workers if args.cpu_workers >= 0 else auto
             nw = min(nw, len(cpu_sample))
             if nw > 1:
                 import multiprocessing as mp
@@ -307,8 +319,9 @@ def main():
                 mdt = time.perf_counter() - t1
                 out["cpu_baseline_multicore"] = {"value": sum(r[0] for r in res) / mdt, "unit": "keypoints/s", "cores": nw, "kind": "port",
                                                  "images_per_s": nw / mdt,
-                                                 "sample": "%d of the %d batch images, one oracle process per physical core (%d workers), one image each, "
-                                                           "%.1f s wall (slowest worker %.1f s)" % (nw, B, nw, mdt, max(r[1] for r in res)),
+                                                 "sample": "%d of the %d batch images, %d oracle worker processes (one per physical core, capped by the "
+                                                           "container's CPU quota of %s CPUs), one image each, %.1f s wall (slowest worker %.1f s)"
+                                                           % (nw, B, nw, ("%g" % quota) if quota else "unlimited", mdt, max(r[1] for r in res)),
                                                  "cpu": cpu}
         print(json.dumps(out))
     if world > 1:

@@ -94,6 +94,8 @@ def load_library():
     L.hesaff_write_sift.argtypes = [C.c_char_p, vp, C.c_int, C.c_float]
     L.hesaff_format_sift.argtypes = [vp, C.c_int, C.c_float, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.hesaff_format_sift_mt.argtypes = [vp, C.c_int, C.c_float, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.hesaff_host_threads.argtypes = []
+    L.hesaff_host_threads.restype = C.c_int
     L.hesaff_write_sift_batch.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(_Result), C.c_float, C.c_int]
     L.hesaff_test_fmt_g.argtypes = [_f32p, C.c_int]
     L.hesaff_free.argtypes = [vp]; L.hesaff_free.restype = None
@@ -130,6 +132,7 @@ ABI_SYMBOLS = [
     "hesaff_stage_math", "hesaff_table_gauss_mask", "hesaff_table_circ_gauss_mask", "hesaff_table_sift_bins",
     "hesaff_table_gauss_kernel", "hesaff_format_sift_mt", "hesaff_write_sift_batch", "hesaff_test_fmt_g",
     "hesaff_read_png", "hesaff_read_image", "hesaff_device_count", "hesaff_shard_range", "hesaff_read_jpeg",
+    "hesaff_host_threads",
 ]
 
 

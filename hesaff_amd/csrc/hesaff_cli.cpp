@@ -87,7 +87,7 @@ int run_batch_mode(const char *list_path, const char *devices_spec)
             imgs[i].ok = hesaff_read_image(names[i].c_str(), &imgs[i].data, &imgs[i].w, &imgs[i].h, &imgs[i].ch) == HESAFF_OK;
       };
       std::vector<std::thread> th;
-      const int T = std::max(1, std::min<int>(n_all, std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u)));
+      const int T = std::max(1, std::min<int>(n_all, std::min(hesaff_host_threads(), 16)));
       for (int t = 1; t < T; t++) th.emplace_back(work);
       work();
       for (auto &x : th) x.join();
@@ -144,7 +144,7 @@ int run_batch_mode(const char *list_path, const char *devices_spec)
          outp[k] = outs[k].c_str();
       }
       // the result records live in the context's pinned memory: write this shard's files before the context goes away
-      const int T = std::max(1, (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()) / (unsigned)world, 64u));
+      const int T = std::max(1, hesaff_host_threads() / world);
       if (hesaff_write_sift_batch(m, outp.data(), res.data() + lo, mrSize, T) != HESAFF_OK) errs[rank] = "cannot write the output files";
       {
          std::lock_guard<std::mutex> g(out_mutex);

@@ -16,6 +16,7 @@
 #include <utility>
 #include <vector>
 
+#include <sched.h>
 #include <zlib.h>
 
 #include "../../include/hesaff_amd.h"
@@ -439,11 +440,33 @@ int hesaff_format_sift(const hesaff_keypoint *keys, int n, float mrSize, char **
    return hesaff_format_sift_mt(keys, n, mrSize, 1, out, len);
 }
 
+// Worker threads when the caller says "auto": CPUs of the affinity mask, no more than the cgroup's CPU-time limit
+// (threads beyond it only time-slice: a 256-CPU host with a 16-CPU quota formats fastest on 16), 1..64.
+int hesaff_host_threads(void)
+{
+   static const int cached = [] {
+      unsigned n = std::max(1u, std::thread::hardware_concurrency());
+      cpu_set_t set;
+      if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned)std::max(1, CPU_COUNT(&set));
+      if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+         char q[32] = {0};
+         double period = 0;
+         if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const double cpus = atof(q) / period;
+            if (cpus >= 1.0 && cpus < (double)n) n = (unsigned)cpus;
+         }
+         fclose(f);
+      }
+      return (int)std::min(std::max(n, 1u), 64u);
+   }();
+   return cached;
+}
+
 // Rows are formatted by `threads` workers into one buffer.
 int hesaff_format_sift_mt(const hesaff_keypoint *keys, int n, float mrSize, int threads, char **out, size_t *len)
 {
    if (n < 0 || (n > 0 && !keys) || !out || !len) return HESAFF_ERR_ARG;
-   int T = threads > 0 ? threads : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+   int T = threads > 0 ? threads : hesaff_host_threads();
    T = std::max(1, std::min(T, n / 4096 + 1));   // below ~4 k rows a thread costs more than it saves
    char head[64];
    const int hl = snprintf(head, sizeof head, "%d\n%d\n", 128, n);
@@ -505,7 +528,7 @@ int hesaff_write_sift(const char *path, const hesaff_keypoint *keys, int n, floa
 int hesaff_write_sift_batch(int n_images, const char *const *paths, const hesaff_result *results, float mrSize, int threads)
 {
    if (n_images < 0 || (n_images > 0 && (!paths || !results))) return HESAFF_ERR_ARG;
-   int T = threads > 0 ? threads : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+   int T = threads > 0 ? threads : hesaff_host_threads();
    T = std::max(1, std::min(T, n_images));
    std::atomic<int> err(HESAFF_OK);
    run_tasks(n_images, T, [&](int i) {

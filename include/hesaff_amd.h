@@ -134,6 +134,10 @@ int hesaff_format_sift_mt(const hesaff_keypoint *keys, int n, float mrSize, int 
 /* replaces: the per-image exportKeypoints + ofstream of main() (hesaff.cpp:170-176) for a whole
  * batch: results[i] -> paths[i], images spread over `threads` host threads (0 = auto) */
 int hesaff_write_sift_batch(int n_images, const char *const *paths, const hesaff_result *results, float mrSize, int threads);
+/* what "threads = 0" means above: the CPUs this process may run on (affinity mask), capped by the
+ * container's CPU-time limit (cgroup v2 cpu.max) when there is one, at most 64, at least 1.
+ * (No counterpart in the reference, which is single-threaded: hesaff.cpp:133-180.) */
+int hesaff_host_threads(void);
 /* test hook: number of inputs on which the fast "%g" formatter and snprintf disagree (must be 0) */
 int hesaff_test_fmt_g(const float *v, int n);
 void hesaff_free(void *p);
