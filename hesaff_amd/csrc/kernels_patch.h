@@ -147,6 +147,10 @@ template <int BIN> struct SmallGeom {
    static constexpr int FLOATS = SSZ + TSZ + 16 + 4 * (PMAX + 1);       // + taps + R and C tables (float2 each)
    static_assert(SPITCH % 2 == 0 && TPITCH % 2 == 0 && SSZ % 2 == 0 && TSZ % 2 == 0, "pairs must stay 8-byte aligned");
    static_assert(SPITCH >= PMAX + 2 * HS_SMALL_RMAX + 1 && TPITCH >= PMAX + 1, "spare column");
+   // the register-blocked passes read up to 3 floats past the last row of S (into T) and up to 3 rows past T (into the
+   // tap / table area): values that only feed outputs which are not stored, but the addresses must stay inside the block's LDS
+   static_assert(((PMAX + 3) & ~3) + 2 * HS_SMALL_RMAX - (PMAX + 2 * HS_SMALL_RMAX) <= 3, "rows read past T");
+   static_assert(FLOATS - SSZ - TSZ >= 3 * TPITCH || BIN == 1, "overshoot stays inside the allocation");
 };
 
 // both blur passes of one window; KT = 0: run-time tap count (any odd K <= 15)
@@ -169,6 +173,74 @@ __device__ __forceinline__ void hs_small_blur(float *S, float *T, int P, const f
       }
    }
    __syncthreads();
+   if (KT >= 7) {
+      // Register-blocked form (the tap counts these bins really see).  The plain form below reads K + 1 dwords of S
+      // per two row-pass outputs and K pairs of T per two column-pass outputs; the LDS pipe (not the VALU) then sets
+      // the pace.  Here a lane produces 4 adjacent columns of a row from K + 3 dwords, and 4 consecutive rows of a
+      // column pair from K + 3 pairs: 2.5 x fewer LDS bytes per output; every output is still its own sequential chain.
+      constexpr int KK = KT ? KT : 1, RR = KK >> 1;
+      const int PQ = (P + 3) >> 2;                 // column quads per row / row quads per column pair
+      const float invPQ = 1.0f / (float)PQ;
+      for (int idx = tid; idx < P * PQ; idx += 256) {
+         const int yy = hs_div_small(idx, invPQ), xx = 4 * (idx - yy * PQ);
+         const float *sp = S + yy * SPITCH + xx;   // sp[j] = S[clamp(xx - r + j)]; outputs past column P - 1 read what follows the row, not stored
+         float g[KK + 3];
+#pragma unroll
+         for (int j = 0; j < KK + 3; j += 2) {
+            const v2f q = *reinterpret_cast<const v2f *>(sp + j);
+            g[j] = q.x;
+            g[j + 1] = q.y;
+         }
+         float t[4];
+#pragma unroll
+         for (int m = 0; m < 4; m++) {
+            float a = kk[0] * g[m];
+#pragma unroll
+            for (int j = 1; j < KK; j++) a += kk[j] * g[m + j];
+            t[m] = a;
+         }
+         v2f t01, t23;
+         t01.x = t[0]; t01.y = t[1]; t23.x = t[2]; t23.y = t[3];
+         const bool second = xx + 2 < P;           // pair (xx + 2, xx + 3) holds a window column (column P is the spare one)
+         float *tq = T + (RR + yy) * TPITCH + xx;
+         *reinterpret_cast<v2f *>(tq) = t01;
+         if (second) *reinterpret_cast<v2f *>(tq + 2) = t23;
+         if (yy == 0)
+            for (int j = 0; j < RR; j++) {
+               *reinterpret_cast<v2f *>(T + j * TPITCH + xx) = t01;
+               if (second) *reinterpret_cast<v2f *>(T + j * TPITCH + xx + 2) = t23;
+            }
+         if (yy == P - 1)
+            for (int j = 0; j < RR; j++) {
+               *reinterpret_cast<v2f *>(T + (RR + P + j) * TPITCH + xx) = t01;
+               if (second) *reinterpret_cast<v2f *>(T + (RR + P + j) * TPITCH + xx + 2) = t23;
+            }
+      }
+      __syncthreads();
+      const int PC = (P + 1) >> 1;
+      const float invPC = 1.0f / (float)PC;
+      for (int idx = tid; idx < PQ * PC; idx += 256) {
+         const int yb = hs_div_small(idx, invPC), xx = 2 * (idx - yb * PC), y0 = 4 * yb;
+         const float *tp = T + y0 * TPITCH + xx;   // T row y0 + j = window row y0 + j - r; rows past the plane (last block only) feed unstored outputs
+         v2f c[KK + 3];
+#pragma unroll
+         for (int j = 0; j < KK + 3; j++) c[j] = *reinterpret_cast<const v2f *>(tp + j * TPITCH);
+#pragma unroll
+         for (int m = 0; m < 4; m++) {
+            float dx = kk[RR] * c[m + RR].x, dy = kk[RR] * c[m + RR].y;
+#pragma unroll
+            for (int j = 1; j <= RR; j++) {
+               dx += kk[RR + j] * (c[m + RR + j].x + c[m + RR - j].x);
+               dy += kk[RR + j] * (c[m + RR + j].y + c[m + RR - j].y);
+            }
+            v2f d;
+            d.x = dx; d.y = dy;
+            if (y0 + m < P) *reinterpret_cast<v2f *>(S + (y0 + m) * SPITCH + xx) = d;
+         }
+      }
+      __syncthreads();
+      return;
+   }
    const int PC = (P + 1) >> 1;                 // column pairs per row (an odd window's last pair computes one spare output)
    const float invPC = 1.0f / (float)PC;
    // row pass: T[r + y][x]; rows y = 0 and y = P-1 are also written into the r border rows
@@ -503,6 +575,86 @@ __device__ __forceinline__ void hs_row_stream2(const HsPlaneBuf &img, float x, f
    HS_WAVE_LDS_SYNC();
 }
 
+// Three window rows at once: the row pass produces 41 output pairs per row, i.e. 41 of a wavefront's 64 lanes in
+// hs_row_stream / hs_row_stream2.  Three rows are 123 pair tasks = two per lane at 96 % lane use: task t = lane + 64 s
+// (s = 0, 1) is pair t % 41 of row t / 41.  Every task is the same RowFilter chain as before (one lane, ascending taps);
+// only the assignment of chains to lanes changes.  srow: three LDS rows `sstride` floats apart; out[i]: T' row of window
+// row yy[i].
+template <int NIT>
+__device__ __forceinline__ void hs_row_stream3(const HsPlaneBuf &img, float x, float y, float a12, float a22, int P, int yy0, int yy1, int yy2,
+                                               float scale, const v2f *__restrict__ ctab, const float *__restrict__ taps, int K,
+                                               float *__restrict__ srow, int sstride, float *__restrict__ out0, float *__restrict__ out1,
+                                               float *__restrict__ out2, int pad_r)
+{
+   const int lane = threadIdx.x & 63, half = P >> 1, pm = P - 1, r = K >> 1;
+   const v2f rc0 = hs_row_coord(x, y, a12, a22, yy0 - half), rc1 = hs_row_coord(x, y, a12, a22, yy1 - half),
+             rc2 = hs_row_coord(x, y, a12, a22, yy2 - half);
+   float *srow1 = srow + sstride, *srow2 = srow + 2 * sstride;
+   for (int xb = 0; xb < P; xb += 64 * NIT) {
+      float v0[NIT], v1[NIT], v2[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+         const int xx = min(xb + lane + 64 * it, pm);   // lanes past the row re-sample its last pixel (not stored)
+         const v2f c = ctab[xx];
+         const v2f w0 = rc0 + c, w1 = rc1 + c, w2 = rc2 + c;
+         v0[it] = hs_tap_inside(img, w0.x, w0.y);
+         v1[it] = hs_tap_inside(img, w1.x, w1.y);
+         v2[it] = hs_tap_inside(img, w2.x, w2.y);
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; it++) { HS_KEEP(v0[it]); HS_KEEP(v1[it]); HS_KEEP(v2[it]); }
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+         const int xx = xb + lane + 64 * it;
+         if (xx < P) { srow[r + xx] = v0[it]; srow1[r + xx] = v1[it]; srow2[r + xx] = v2[it]; }
+      }
+   }
+   HS_WAVE_LDS_SYNC();
+   {
+      const float f0 = srow[r], l0 = srow[r + pm], f1 = srow1[r], l1 = srow1[r + pm], f2 = srow2[r], l2 = srow2[r + pm];
+      for (int i = lane; i < r; i += 64) {
+         srow[i] = f0; srow[r + P + i] = l0;
+         srow1[i] = f1; srow1[r + P + i] = l1;
+         srow2[i] = f2; srow2[r + P + i] = l2;
+      }
+   }
+   HS_WAVE_LDS_SYNC();
+   {
+      // slot A: task lane (rows 0 and 1); slot B: task 64 + lane (rows 1 and 2; lanes 59..63 repeat task 122, not stored)
+      const int tA = lane, tB = min(64 + lane, 3 * HS_PATCH - 1);
+      const int rowA = tA >= HS_PATCH ? 1 : 0, rowB = tB >= 2 * HS_PATCH ? 2 : 1;
+      const int colA = tA - HS_PATCH * rowA, colB = tB - HS_PATCH * rowB;
+      const float c0 = (float)half;
+      const float wA = c0 + (float)(colA - 20) * scale, wB = c0 + (float)(colB - 20) * scale;
+      const int xA = min(max((int)floorf(wA), 0), pm - 1), xB = min(max((int)floorf(wB), 0), pm - 1);
+      const float *sA = srow + rowA * sstride + xA, *sB = srow + rowB * sstride + xB;
+      auto GA = [&](int jt) { v2f g; g.x = sA[jt]; g.y = sA[jt + 1]; return g; };
+      auto GB = [&](int jt) { v2f g; g.x = sB[jt]; g.y = sB[jt + 1]; return g; };
+      v2f tA2 = taps[0] * GA(0), tB2 = taps[0] * GB(0);
+#pragma unroll 4
+      for (int jt = 1; jt < K; jt++) {
+         const float k = taps[jt];
+         tA2 += k * GA(jt);
+         tB2 += k * GB(jt);
+      }
+      const int yA = rowA ? yy1 : yy0, yB = rowB == 2 ? yy2 : yy1;
+      v2f *oA = reinterpret_cast<v2f *>(rowA ? out1 : out0) + colA;
+      v2f *oB = reinterpret_cast<v2f *>(rowB == 2 ? out2 : out1) + colB;
+      *oA = tA2;
+      if (64 + lane < 3 * HS_PATCH) *oB = tB2;
+      // padded T' plane: the first / last window row is replicated pad_r times above / below
+      if (pad_r > 0) {
+         if (yA == 0) for (int jr = 1; jr <= pad_r; jr++) oA[-jr * (HS_NEED / 2)] = tA2;
+         if (yA == pm) for (int jr = 1; jr <= pad_r; jr++) oA[jr * (HS_NEED / 2)] = tA2;
+         if (64 + lane < 3 * HS_PATCH) {
+            if (yB == 0) for (int jr = 1; jr <= pad_r; jr++) oB[-jr * (HS_NEED / 2)] = tB2;
+            if (yB == pm) for (int jr = 1; jr <= pad_r; jr++) oB[jr * (HS_NEED / 2)] = tB2;
+         }
+      }
+   }
+   HS_WAVE_LDS_SYNC();
+}
+
 // ---------------------------------------------------------------------------------------
 // k_patch_mid: 64 < P <= 128 (bin 2) and 128 < P <= 512 (bin 3).  Each of the 4 waves streams window rows
 // (warp -> row pass at the 82 needed columns) into T' (P x 82, padded with K/2 replicated rows above and below) in a
@@ -511,10 +663,13 @@ __device__ __forceinline__ void hs_row_stream2(const HsPlaneBuf &img, float x, f
 // ---------------------------------------------------------------------------------------
 #define HS_MID_PMAX 128
 #define HS_MID_SROW 160   // 128 + 2 x 14 border samples, padded
-#define HS_BIG_SROW 704   // 512 + 2 x 57 border samples, padded
+#define HS_BIG_SROW 640   // 514 + 2 x 57 border samples, padded
 #define HS_BIG_TAPS 128   // K <= 113 for P <= 512
 #define HS_MID_RPAD 14    // K / 2 for P <= 128
 #define HS_BIG_RPAD 57    // K / 2 for P <= 512
+#ifndef HS_MID_NIT3_BIG
+#define HS_MID_NIT3_BIG 2
+#endif
 #define HS_MID_BLOCKS (256 * 7)   // persistent grids of the row-streamed bins: one T' slot per block
 #define HS_BIG_BLOCKS (256 * 8)
 
@@ -523,8 +678,8 @@ template <int PMAX> struct MidGeom {
    static constexpr int SROW = BIG ? HS_BIG_SROW : HS_MID_SROW;
    static constexpr int NTAP = BIG ? HS_BIG_TAPS : 32;
    static constexpr int RPAD = BIG ? HS_BIG_RPAD : HS_MID_RPAD;
-   // s_patch | taps | C table (float2 x (PMAX + 2)) | 4 waves x 2 rows
-   static constexpr int FLOATS = HS_PATCH_ARR + NTAP + 2 * (PMAX + 2) + 8 * SROW;
+   // s_patch | taps | C table (float2 x (PMAX + 2)) | 4 waves x 3 rows
+   static constexpr int FLOATS = HS_PATCH_ARR + NTAP + 2 * (PMAX + 2) + 12 * SROW;
 };
 
 template <int PMAX>
@@ -533,11 +688,12 @@ __global__ __launch_bounds__(256, HS_MID_WAVES) void k_patch_mid(HessList hl, Pa
    typedef MidGeom<PMAX> GM;
    constexpr int BIN = GM::BIG ? 3 : 2;
    constexpr int NIT = GM::BIG ? 4 : 2;
+   constexpr int NIT3 = GM::BIG ? HS_MID_NIT3_BIG : 2;   // gathers in flight per row of the three-row form
    extern __shared__ __attribute__((aligned(16))) float smem[];
    float *s_patch = smem;
    float *s_taps = s_patch + HS_PATCH_ARR;
    v2f *s_C = reinterpret_cast<v2f *>(s_taps + GM::NTAP);
-   float *s_srow = reinterpret_cast<float *>(s_C + (PMAX + 2));   // 4 waves x 2 rows x SROW
+   float *s_srow = reinterpret_cast<float *>(s_C + (PMAX + 2));   // 4 waves x 3 rows x SROW
    float *Tp = io.trows + (size_t)blockIdx.x * ((size_t)(PMAX + 2 * GM::RPAD) * HS_NEED);
 
    const int tid = threadIdx.x, wave = tid >> 6;
@@ -565,11 +721,15 @@ __global__ __launch_bounds__(256, HS_MID_WAVES) void k_patch_mid(HessList hl, Pa
       if (tid < K) s_taps[tid] = taps_g[tid];
       for (int m = tid; m < P; m += 256) s_C[m] = hs_col_coord(a11, a21, m - half);
       __syncthreads();
-      float *srowA = s_srow + wave * 2 * GM::SROW, *srowB = srowA + GM::SROW;
+      float *srowA = s_srow + wave * 3 * GM::SROW, *srowB = srowA + GM::SROW;
 #pragma unroll 1
-      for (int yy = wave; yy < P; yy += 8) {
-         // rows yy and yy + 4 of this wavefront together; a last single row alone
-         if (yy + 4 < P)
+      for (int yy = wave; yy < P; yy += 12) {
+         // rows yy, yy + 4 and yy + 8 of this wavefront together; the last one or two rows in the narrower forms
+         const int rr = K >> 1;
+         if (yy + 8 < P)
+            hs_row_stream3<NIT3>(ib, x, y, a12, a22, P, yy, yy + 4, yy + 8, scale, s_C, s_taps, K, srowA, GM::SROW,
+                                 Tp + (size_t)(yy + rr) * HS_NEED, Tp + (size_t)(yy + 4 + rr) * HS_NEED, Tp + (size_t)(yy + 8 + rr) * HS_NEED, rr);
+         else if (yy + 4 < P)
             hs_row_stream2<NIT>(ib, x, y, a12, a22, P, yy, yy + 4, scale, s_C, s_taps, K, srowA, srowB,
                                 Tp + (size_t)(yy + (K >> 1)) * HS_NEED, Tp + (size_t)(yy + 4 + (K >> 1)) * HS_NEED, K >> 1);
          else
