@@ -25,6 +25,7 @@
 //   * both blur passes work on PAIRS of adjacent outputs with packed FP32 (v_pk_mul_f32 / v_pk_add_f32:
 //     two IEEE products / sums per instruction, same rounding as the scalar forms, no FMA).
 #pragma once
+#include <type_traits>
 #include "kernels_keypoint.h"
 
 #define HS_PATCH_ARR 1684  // 1681 rounded up to a multiple of 4 floats
@@ -132,6 +133,9 @@ __device__ __forceinline__ void hs_resample_full_tab(const float *S, int pitch, 
 #ifndef HS_SMALL_WAVES
 #define HS_SMALL_WAVES 6   // wavefronts per SIMD the register allocation of bin 0 is held to (0: the compiler's choice, 4);
 #endif                     // measured: 17.0 / 15.7 / 14.3 ms per 32 UHD images at 4 / 5 / 6; bin 1 spills at 6 and stays at the compiler's choice
+#ifndef HS_SMALL_BLK_BIN
+#define HS_SMALL_BLK_BIN 1   // first bin whose blur runs register-blocked (measured: bin 1 -7 %, bin 0 +3 %: its windows waste more of a quad)
+#endif
 #ifndef HS_MID_WAVES
 #define HS_MID_WAVES 0
 #endif
@@ -154,7 +158,7 @@ template <int BIN> struct SmallGeom {
 };
 
 // both blur passes of one window; KT = 0: run-time tap count (any odd K <= 15)
-template <int KT, int SPITCH, int TPITCH>
+template <int KT, int SPITCH, int TPITCH, bool BLK>
 __device__ __forceinline__ void hs_small_blur(float *S, float *T, int P, const float *s_taps, int Krt)
 {
    const int K = KT ? KT : Krt, r = K >> 1;
@@ -173,7 +177,7 @@ __device__ __forceinline__ void hs_small_blur(float *S, float *T, int P, const f
       }
    }
    __syncthreads();
-   if (KT >= 7) {
+   if (BLK && KT >= 7) {
       // Register-blocked form (the tap counts these bins really see).  The plain form below reads K + 1 dwords of S
       // per two row-pass outputs and K pairs of T per two column-pass outputs; the LDS pipe (not the VALU) then sets
       // the pace.  Here a lane produces 4 adjacent columns of a row from K + 3 dwords, and 4 consecutive rows of a
@@ -348,39 +352,62 @@ __global__ __launch_bounds__(256, (BIN == 0 ? HS_SMALL_WAVES : 0)) void k_patch_
       // 1. warp, affine.cpp:126 (the window lies inside the image: k_prepare_patch).  All gathers of a
       // batch are issued before the first use.
       constexpr int WNIT = BIN == 0 ? HS_WNIT0 : HS_WNIT1;
+      constexpr bool BLK = BIN >= HS_SMALL_BLK_BIN;
       const int PP = P * P;
       const float invP = 1.0f / (float)P;
-      for (int ib = 0; ib < PP; ib += 256 * WNIT) {
-         float wv[WNIT];
+      // The P x P taps are taken in slots of 256 (one per thread), up to WNIT slots per batch with all gathers of a
+      // batch issued before the first use.  The batch size is a compile-time constant picked per window (a switch on a
+      // block-uniform value): a fixed WNIT would evaluate 1024 taps for a window of 23 x 23 = 529, and a test per slot
+      // inside the batch would serialise the gathers (measured: slower than the waste).
+      auto warp_batch = [&](auto nbc, int ib) {
+         constexpr int NB = decltype(nbc)::value;
+         float wv[NB];
 #pragma unroll
-         for (int it = 0; it < WNIT; it++) {
+         for (int it = 0; it < NB; it++) {
             const int idx = min(ib + tid + 256 * it, PP - 1);
             const int jj = hs_div_small(idx, invP), ii = idx - jj * P;
             const v2f w = s_R[jj] + s_C[ii];
             wv[it] = hs_tap_inside(pbuf, w.x, w.y);
          }
 #pragma unroll
-         for (int it = 0; it < WNIT; it++) HS_KEEP(wv[it]);
+         for (int it = 0; it < NB; it++) HS_KEEP(wv[it]);
 #pragma unroll
-         for (int it = 0; it < WNIT; it++) {
+         for (int it = 0; it < NB; it++) {
             const int idx = ib + tid + 256 * it;
             if (idx < PP) {
                const int jj = hs_div_small(idx, invP), ii = idx - jj * P;
                S[jj * SPITCH + r + ii] = wv[it];
             }
          }
+      };
+      {
+         int ib = 0;
+         for (int rem = (PP + 255) >> 8; rem > 0;) {
+            const int nbatch = (rem + WNIT - 1) / WNIT;   // batches left; this one takes an even share of the slots
+            const int nb = (rem + nbatch - 1) / nbatch;
+            switch (nb) {
+               case 1: warp_batch(std::integral_constant<int, 1>{}, ib); break;
+               case 2: warp_batch(std::integral_constant<int, 2>{}, ib); break;
+               case 3: warp_batch(std::integral_constant<int, 3>{}, ib); break;
+               case 4: warp_batch(std::integral_constant<int, 4>{}, ib); break;
+               case 5: if (WNIT >= 5) warp_batch(std::integral_constant<int, (WNIT >= 5 ? 5 : 1)>{}, ib); break;
+               default: if (WNIT >= 6) warp_batch(std::integral_constant<int, (WNIT >= 6 ? 6 : 1)>{}, ib); break;
+            }
+            ib += 256 * nb;
+            rem -= nb;
+         }
       }
       __syncthreads();
       // 2. blur, affine.cpp:129 (pinned cv::GaussianBlur order, see the file header)
       switch (K) {
-         case 3: hs_small_blur<3, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
-         case 5: hs_small_blur<5, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
-         case 7: hs_small_blur<7, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
-         case 9: hs_small_blur<9, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
-         case 11: hs_small_blur<11, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
-         case 13: hs_small_blur<13, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
-         case 15: hs_small_blur<15, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
-         default: hs_small_blur<0, SPITCH, TPITCH>(S, T, P, s_taps, K); break;
+         case 3: hs_small_blur<3, SPITCH, TPITCH, BLK>(S, T, P, s_taps, K); break;
+         case 5: hs_small_blur<5, SPITCH, TPITCH, BLK>(S, T, P, s_taps, K); break;
+         case 7: hs_small_blur<7, SPITCH, TPITCH, BLK>(S, T, P, s_taps, K); break;
+         case 9: hs_small_blur<9, SPITCH, TPITCH, BLK>(S, T, P, s_taps, K); break;
+         case 11: hs_small_blur<11, SPITCH, TPITCH, BLK>(S, T, P, s_taps, K); break;
+         case 13: hs_small_blur<13, SPITCH, TPITCH, BLK>(S, T, P, s_taps, K); break;
+         case 15: hs_small_blur<15, SPITCH, TPITCH, BLK>(S, T, P, s_taps, K); break;
+         default: hs_small_blur<0, SPITCH, TPITCH, BLK>(S, T, P, s_taps, K); break;
       }
       // 3. resample, affine.cpp:131
       hs_resample_full_tab(S, SPITCH, s_tab_i, s_tab_f, out);
@@ -455,6 +482,56 @@ __device__ __forceinline__ void hs_resample_reduced_batched(const float *__restr
    }
 }
 
+// Gathers of NB x 64 consecutive window pixels (columns xb + lane + 64 it) of NR rows of one window, all issued before
+// the first use, then stored into the rows' LDS lines (row i at srow + i * sstride, r border samples to the left).
+// rc[i]: the row term of the tap coordinate; ctab: the window's column table in LDS, or nullptr (computed per tap).
+template <int NR, int NB>
+__device__ __forceinline__ void hs_gather_slots(const HsPlaneBuf &img, const v2f *rc, const v2f *__restrict__ ctab, float a11, float a21, int half,
+                                                int xb, int P, int r, float *__restrict__ srow, int sstride)
+{
+   const int lane = threadIdx.x & 63, pm = P - 1;
+   float v[NR][NB];
+#pragma unroll
+   for (int it = 0; it < NB; it++) {
+      const int xx = min(xb + lane + 64 * it, pm);   // lanes past the row re-sample its last pixel (not stored)
+      const v2f c = ctab ? ctab[xx] : hs_col_coord(a11, a21, xx - half);
+#pragma unroll
+      for (int i = 0; i < NR; i++) {
+         const v2f w = rc[i] + c;
+         v[i][it] = hs_tap_inside(img, w.x, w.y);
+      }
+   }
+#pragma unroll
+   for (int it = 0; it < NB; it++)
+#pragma unroll
+      for (int i = 0; i < NR; i++) HS_KEEP(v[i][it]);
+#pragma unroll
+   for (int it = 0; it < NB; it++) {
+      const int xx = xb + lane + 64 * it;
+      if (xx < P) {
+#pragma unroll
+         for (int i = 0; i < NR; i++) srow[i * sstride + r + xx] = v[i][it];
+      }
+   }
+}
+
+// all P pixels of NR rows: batches of NIT slots, and a last batch of exactly the slots that are left (a batch size is a
+// compile-time constant: the remainder goes by its binary digits, at most three narrower batches; a test per slot inside
+// one batch would serialise its gathers)
+template <int NR, int NIT>
+__device__ __forceinline__ void hs_gather_rows(const HsPlaneBuf &img, const v2f *rc, const v2f *__restrict__ ctab, float a11, float a21, int half,
+                                               int P, int r, float *__restrict__ srow, int sstride)
+{
+   static_assert(NIT == 1 || NIT == 2 || NIT == 4 || NIT == 8, "power of two");
+   int xb = 0;
+   for (; ((P - xb + 63) >> 6) >= NIT; xb += 64 * NIT)
+      hs_gather_slots<NR, NIT>(img, rc, ctab, a11, a21, half, xb, P, r, srow, sstride);
+   const int rem = (P - xb + 63) >> 6;   // slots left, < NIT (wave-uniform)
+   if (NIT > 4 && (rem & 4)) { hs_gather_slots<NR, 4>(img, rc, ctab, a11, a21, half, xb, P, r, srow, sstride); xb += 256; }
+   if (NIT > 2 && (rem & 2)) { hs_gather_slots<NR, 2>(img, rc, ctab, a11, a21, half, xb, P, r, srow, sstride); xb += 128; }
+   if (NIT > 1 && (rem & 1)) { hs_gather_slots<NR, 1>(img, rc, ctab, a11, a21, half, xb, P, r, srow, sstride); }
+}
+
 // one window row: warp (affine.cpp:126) into the wave's LDS row, then the row pass at the 82
 // needed columns.  Called by all 64 lanes of a wave.  The LDS row is stored with r replicated
 // border samples on either side (BORDER_REPLICATE), so the tap loop has no index clamps:
@@ -470,22 +547,7 @@ __device__ __forceinline__ void hs_row_stream(const HsPlaneBuf &img, float x, fl
 {
    const int lane = threadIdx.x & 63, half = P >> 1, pm = P - 1, r = K >> 1;
    const v2f rc = hs_row_coord(x, y, a12, a22, yy - half);
-   for (int xb = 0; xb < P; xb += 64 * NIT) {
-      float v[NIT];
-#pragma unroll
-      for (int it = 0; it < NIT; it++) {
-         const int xx = min(xb + lane + 64 * it, pm);   // lanes past the row re-sample its last pixel (not stored)
-         const v2f w = rc + (ctab ? ctab[xx] : hs_col_coord(a11, a21, xx - half));
-         v[it] = hs_tap_inside(img, w.x, w.y);
-      }
-#pragma unroll
-      for (int it = 0; it < NIT; it++) HS_KEEP(v[it]);
-#pragma unroll
-      for (int it = 0; it < NIT; it++) {
-         const int xx = xb + lane + 64 * it;
-         if (xx < P) srow[r + xx] = v[it];
-      }
-   }
+   hs_gather_rows<1, NIT>(img, &rc, ctab, a11, a21, half, P, r, srow, 0);
    HS_WAVE_LDS_SYNC();
    {
       const float first = srow[r], last = srow[r + pm];
@@ -524,25 +586,8 @@ __device__ __forceinline__ void hs_row_stream2(const HsPlaneBuf &img, float x, f
                                                float *__restrict__ srowA, float *__restrict__ srowB, float *__restrict__ outA, float *__restrict__ outB, int pad_r)
 {
    const int lane = threadIdx.x & 63, half = P >> 1, pm = P - 1, r = K >> 1;
-   const v2f rcA = hs_row_coord(x, y, a12, a22, yyA - half), rcB = hs_row_coord(x, y, a12, a22, yyB - half);
-   for (int xb = 0; xb < P; xb += 64 * NIT) {
-      float vA[NIT], vB[NIT];
-#pragma unroll
-      for (int it = 0; it < NIT; it++) {
-         const int xx = min(xb + lane + 64 * it, pm);   // lanes past the row re-sample its last pixel (not stored)
-         const v2f c = ctab[xx];
-         const v2f wA = rcA + c, wB = rcB + c;
-         vA[it] = hs_tap_inside(img, wA.x, wA.y);
-         vB[it] = hs_tap_inside(img, wB.x, wB.y);
-      }
-#pragma unroll
-      for (int it = 0; it < NIT; it++) { HS_KEEP(vA[it]); HS_KEEP(vB[it]); }
-#pragma unroll
-      for (int it = 0; it < NIT; it++) {
-         const int xx = xb + lane + 64 * it;
-         if (xx < P) { srowA[r + xx] = vA[it]; srowB[r + xx] = vB[it]; }
-      }
-   }
+   const v2f rc[2] = {hs_row_coord(x, y, a12, a22, yyA - half), hs_row_coord(x, y, a12, a22, yyB - half)};
+   hs_gather_rows<2, NIT>(img, rc, ctab, 0.0f, 0.0f, half, P, r, srowA, (int)(srowB - srowA));
    HS_WAVE_LDS_SYNC();
    {
       const float fA = srowA[r], lA = srowA[r + pm], fB = srowB[r], lB = srowB[r + pm];
@@ -587,28 +632,10 @@ __device__ __forceinline__ void hs_row_stream3(const HsPlaneBuf &img, float x, f
                                                float *__restrict__ out2, int pad_r)
 {
    const int lane = threadIdx.x & 63, half = P >> 1, pm = P - 1, r = K >> 1;
-   const v2f rc0 = hs_row_coord(x, y, a12, a22, yy0 - half), rc1 = hs_row_coord(x, y, a12, a22, yy1 - half),
-             rc2 = hs_row_coord(x, y, a12, a22, yy2 - half);
+   const v2f rc[3] = {hs_row_coord(x, y, a12, a22, yy0 - half), hs_row_coord(x, y, a12, a22, yy1 - half),
+                      hs_row_coord(x, y, a12, a22, yy2 - half)};
    float *srow1 = srow + sstride, *srow2 = srow + 2 * sstride;
-   for (int xb = 0; xb < P; xb += 64 * NIT) {
-      float v0[NIT], v1[NIT], v2[NIT];
-#pragma unroll
-      for (int it = 0; it < NIT; it++) {
-         const int xx = min(xb + lane + 64 * it, pm);   // lanes past the row re-sample its last pixel (not stored)
-         const v2f c = ctab[xx];
-         const v2f w0 = rc0 + c, w1 = rc1 + c, w2 = rc2 + c;
-         v0[it] = hs_tap_inside(img, w0.x, w0.y);
-         v1[it] = hs_tap_inside(img, w1.x, w1.y);
-         v2[it] = hs_tap_inside(img, w2.x, w2.y);
-      }
-#pragma unroll
-      for (int it = 0; it < NIT; it++) { HS_KEEP(v0[it]); HS_KEEP(v1[it]); HS_KEEP(v2[it]); }
-#pragma unroll
-      for (int it = 0; it < NIT; it++) {
-         const int xx = xb + lane + 64 * it;
-         if (xx < P) { srow[r + xx] = v0[it]; srow1[r + xx] = v1[it]; srow2[r + xx] = v2[it]; }
-      }
-   }
+   hs_gather_rows<3, NIT>(img, rc, ctab, 0.0f, 0.0f, half, P, r, srow, sstride);
    HS_WAVE_LDS_SYNC();
    {
       const float f0 = srow[r], l0 = srow[r + pm], f1 = srow1[r], l1 = srow1[r + pm], f2 = srow2[r], l2 = srow2[r + pm];
@@ -670,6 +697,9 @@ __device__ __forceinline__ void hs_row_stream3(const HsPlaneBuf &img, float x, f
 #ifndef HS_MID_NIT3_BIG
 #define HS_MID_NIT3_BIG 2
 #endif
+#ifndef HS_MID_NIT3_SMALL
+#define HS_MID_NIT3_SMALL 1
+#endif
 #define HS_MID_BLOCKS (256 * 7)   // persistent grids of the row-streamed bins: one T' slot per block
 #define HS_BIG_BLOCKS (256 * 8)
 
@@ -688,7 +718,7 @@ __global__ __launch_bounds__(256, HS_MID_WAVES) void k_patch_mid(HessList hl, Pa
    typedef MidGeom<PMAX> GM;
    constexpr int BIN = GM::BIG ? 3 : 2;
    constexpr int NIT = GM::BIG ? 4 : 2;
-   constexpr int NIT3 = GM::BIG ? HS_MID_NIT3_BIG : 2;   // gathers in flight per row of the three-row form
+   constexpr int NIT3 = GM::BIG ? HS_MID_NIT3_BIG : HS_MID_NIT3_SMALL;   // gathers in flight per row of the three-row form
    extern __shared__ __attribute__((aligned(16))) float smem[];
    float *s_patch = smem;
    float *s_taps = s_patch + HS_PATCH_ARR;
