@@ -105,6 +105,19 @@ const uint8_t kZigZag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4
 
 inline uint8_t clamp8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
+// Two's-complement arithmetic that wraps: what libjpeg's INT32 does on every real target.  The IDCT of a legal stream
+// never leaves 32 bits; a damaged one can, and signed overflow would be undefined behaviour here.
+struct W32 {
+   uint32_t u;
+   W32() = default;
+   explicit W32(int32_t v) : u((uint32_t)v) {}
+   int32_t s() const { return (int32_t)u; }
+   friend W32 operator+(W32 a, W32 b) { W32 r; r.u = a.u + b.u; return r; }
+   friend W32 operator-(W32 a, W32 b) { W32 r; r.u = a.u - b.u; return r; }
+   friend W32 operator*(W32 a, W32 b) { W32 r; r.u = a.u * b.u; return r; }
+   friend W32 operator>>(W32 a, int n) { return W32(a.s() >> n); }
+};
+
 // jidctint.c (jpeg_idct_islow): coef in natural order, quant table in natural order, output 8 rows of 8 samples
 void idct_islow(const int16_t *coef, const uint16_t *quant, uint8_t *out, int out_stride)
 {
@@ -112,29 +125,29 @@ void idct_islow(const int16_t *coef, const uint16_t *quant, uint8_t *out, int ou
    constexpr int32_t FIX_0_298631336 = 2446, FIX_0_390180644 = 3196, FIX_0_541196100 = 4433, FIX_0_765366865 = 6270, FIX_0_899976223 = 7373,
                      FIX_1_175875602 = 9633, FIX_1_501321110 = 12299, FIX_1_847759065 = 15137, FIX_1_961570560 = 16069, FIX_2_053119869 = 16819,
                      FIX_2_562915447 = 20995, FIX_3_072711026 = 25172;
-   auto descale = [](int32_t x, int n) { return (x + (1 << (n - 1))) >> n; };
-   int32_t ws[64];
+   auto descale = [](W32 x, int n) { return (x + W32(1 << (n - 1))) >> n; };
+   W32 ws[64];
    for (int c = 0; c < 8; c++) {
       const int16_t *in = coef + c;
       const uint16_t *q = quant + c;
-      int32_t *w = ws + c;
-      auto D = [&](int r) { return (int32_t)in[8 * r] * (int32_t)q[8 * r]; };
-      int32_t z2 = D(2), z3 = D(6);
-      int32_t z1 = (z2 + z3) * FIX_0_541196100;
-      int32_t tmp2 = z1 + z3 * (-FIX_1_847759065);
-      int32_t tmp3 = z1 + z2 * FIX_0_765366865;
+      W32 *w = ws + c;
+      auto D = [&](int r) { return W32((int32_t)in[8 * r] * (int32_t)q[8 * r]); };   // |int16 x uint16| < 2^31
+      W32 z2 = D(2), z3 = D(6);
+      W32 z1 = (z2 + z3) * W32(FIX_0_541196100);
+      W32 tmp2 = z1 + z3 * W32(-FIX_1_847759065);
+      W32 tmp3 = z1 + z2 * W32(FIX_0_765366865);
       z2 = D(0); z3 = D(4);
-      int32_t tmp0 = (z2 + z3) * (1 << CONST_BITS);
-      int32_t tmp1 = (z2 - z3) * (1 << CONST_BITS);
-      const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+      W32 tmp0 = (z2 + z3) * W32(1 << CONST_BITS);
+      W32 tmp1 = (z2 - z3) * W32(1 << CONST_BITS);
+      const W32 tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
       tmp0 = D(7); tmp1 = D(5); tmp2 = D(3); tmp3 = D(1);
       z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-      int32_t z4 = tmp1 + tmp3;
-      const int32_t z5 = (z3 + z4) * FIX_1_175875602;
-      tmp0 *= FIX_0_298631336; tmp1 *= FIX_2_053119869; tmp2 *= FIX_3_072711026; tmp3 *= FIX_1_501321110;
-      z1 *= -FIX_0_899976223; z2 *= -FIX_2_562915447; z3 *= -FIX_1_961570560; z4 *= -FIX_0_390180644;
-      z3 += z5; z4 += z5;
-      tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+      W32 z4 = tmp1 + tmp3;
+      const W32 z5 = (z3 + z4) * W32(FIX_1_175875602);
+      tmp0 = tmp0 * W32(FIX_0_298631336); tmp1 = tmp1 * W32(FIX_2_053119869); tmp2 = tmp2 * W32(FIX_3_072711026); tmp3 = tmp3 * W32(FIX_1_501321110);
+      z1 = z1 * W32(-FIX_0_899976223); z2 = z2 * W32(-FIX_2_562915447); z3 = z3 * W32(-FIX_1_961570560); z4 = z4 * W32(-FIX_0_390180644);
+      z3 = z3 + z5; z4 = z4 + z5;
+      tmp0 = tmp0 + z1 + z3; tmp1 = tmp1 + z2 + z4; tmp2 = tmp2 + z2 + z3; tmp3 = tmp3 + z1 + z4;
       w[8 * 0] = descale(tmp10 + tmp3, CONST_BITS - PASS1_BITS);
       w[8 * 7] = descale(tmp10 - tmp3, CONST_BITS - PASS1_BITS);
       w[8 * 1] = descale(tmp11 + tmp2, CONST_BITS - PASS1_BITS);
@@ -145,27 +158,27 @@ void idct_islow(const int16_t *coef, const uint16_t *quant, uint8_t *out, int ou
       w[8 * 4] = descale(tmp13 - tmp0, CONST_BITS - PASS1_BITS);
    }
    for (int r = 0; r < 8; r++) {
-      const int32_t *w = ws + 8 * r;
+      const W32 *w = ws + 8 * r;
       uint8_t *o = out + (size_t)r * out_stride;
-      int32_t z2 = w[2], z3 = w[6];
-      int32_t z1 = (z2 + z3) * FIX_0_541196100;
-      int32_t tmp2 = z1 + z3 * (-FIX_1_847759065);
-      int32_t tmp3 = z1 + z2 * FIX_0_765366865;
-      int32_t tmp0 = (w[0] + w[4]) * (1 << CONST_BITS);
-      int32_t tmp1 = (w[0] - w[4]) * (1 << CONST_BITS);
-      const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+      W32 z2 = w[2], z3 = w[6];
+      W32 z1 = (z2 + z3) * W32(FIX_0_541196100);
+      W32 tmp2 = z1 + z3 * W32(-FIX_1_847759065);
+      W32 tmp3 = z1 + z2 * W32(FIX_0_765366865);
+      W32 tmp0 = (w[0] + w[4]) * W32(1 << CONST_BITS);
+      W32 tmp1 = (w[0] - w[4]) * W32(1 << CONST_BITS);
+      const W32 tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
       tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
       z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-      int32_t z4 = tmp1 + tmp3;
-      const int32_t z5 = (z3 + z4) * FIX_1_175875602;
-      tmp0 *= FIX_0_298631336; tmp1 *= FIX_2_053119869; tmp2 *= FIX_3_072711026; tmp3 *= FIX_1_501321110;
-      z1 *= -FIX_0_899976223; z2 *= -FIX_2_562915447; z3 *= -FIX_1_961570560; z4 *= -FIX_0_390180644;
-      z3 += z5; z4 += z5;
-      tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+      W32 z4 = tmp1 + tmp3;
+      const W32 z5 = (z3 + z4) * W32(FIX_1_175875602);
+      tmp0 = tmp0 * W32(FIX_0_298631336); tmp1 = tmp1 * W32(FIX_2_053119869); tmp2 = tmp2 * W32(FIX_3_072711026); tmp3 = tmp3 * W32(FIX_1_501321110);
+      z1 = z1 * W32(-FIX_0_899976223); z2 = z2 * W32(-FIX_2_562915447); z3 = z3 * W32(-FIX_1_961570560); z4 = z4 * W32(-FIX_0_390180644);
+      z3 = z3 + z5; z4 = z4 + z5;
+      tmp0 = tmp0 + z1 + z3; tmp1 = tmp1 + z2 + z4; tmp2 = tmp2 + z2 + z3; tmp3 = tmp3 + z1 + z4;
       constexpr int SH = CONST_BITS + PASS1_BITS + 3;
       // range_limit[(x) & RANGE_MASK] of libjpeg == clamp(x + 128, 0, 255) for every value the IDCT of legal data produces;
       // values outside the 10-bit mask window wrap there, the same masking is applied here
-      auto lim = [](int32_t v) { v &= 1023; if (v >= 512) v -= 1024; return clamp8(v + 128); };
+      auto lim = [](W32 x) { int32_t v = x.s(); v &= 1023; if (v >= 512) v -= 1024; return clamp8(v + 128); };
       o[0] = lim(descale(tmp10 + tmp3, SH)); o[7] = lim(descale(tmp10 - tmp3, SH));
       o[1] = lim(descale(tmp11 + tmp2, SH)); o[6] = lim(descale(tmp11 - tmp2, SH));
       o[2] = lim(descale(tmp12 + tmp1, SH)); o[5] = lim(descale(tmp12 - tmp1, SH));
@@ -318,6 +331,9 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
                int nv = 0;
                for (int i = 0; i < 16; i++) nv += seg[o + 1 + i];
                if (th > 3 || tc > 1 || nv > 256 || o + 17 + nv > sl) return HESAFF_ERR_IO;
+               if (tc == 0)   // a DC symbol is a bit count (libjpeg: JERR_BAD_HUFF_TABLE above 15)
+                  for (int i = 0; i < nv; i++)
+                     if (seg[o + 17 + i] > 15) return HESAFF_ERR_IO;
                (tc ? hac : hdc)[th].build(&seg[o + 1], &seg[o + 17], nv);
                o += 17 + nv;
             }
@@ -395,7 +411,7 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
                         memset(blk, 0, sizeof blk);
                         const int t = decode_huff(br, hdc[c->td]);
                         const int diff = t ? extend(br.get(t), t) : 0;
-                        c->pred += diff;
+                        c->pred = (int)((unsigned)c->pred + (unsigned)diff);   // a damaged stream may run the predictor past 32 bits: wrap
                         blk[0] = (int16_t)c->pred;
                         for (int k = 1; k < 64;) {
                            const int rs = decode_huff(br, hac[c->ta]);

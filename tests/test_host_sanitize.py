@@ -1,0 +1,94 @@
+"""AddressSanitizer + UBSan run of the host side of the C ABI (image readers, text writer) on damaged inputs.
+
+CPU only.  The readers replace cv::imread (hesaff.cpp:137) and the writer exportKeypoints (hesaff.cpp:107-130); the
+reference trusts its input, a drop-in that serves batches must refuse a damaged file without reading or writing memory
+it does not own.  GPU AddressSanitizer is not available on the pool, so this is the sanitizer coverage the product gets."""
+import os
+import random
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+SRC = [os.path.join(ROOT, "hesaff_amd", "csrc", "hostio.cpp"), os.path.join(ROOT, "hesaff_amd", "csrc", "jpeg_decode.cpp"),
+       os.path.join(ROOT, "tests", "native", "hostio_sanitize.cpp")]
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    out = str(tmp_path_factory.mktemp("san") / "hostio_sanitize")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
+           "-o", out] + SRC + ["-lz", "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    return out
+
+
+def _run(driver, args):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:allocator_may_return_null=1", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([driver] + args, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, "sanitizer or driver failure (rc %d)\n%s\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-6000:])
+    return r.stdout
+
+
+def _mutants(data, rng, n):
+    out = []
+    for _ in range(n):
+        b = bytearray(data)
+        kind = rng.randrange(4)
+        if kind == 0 and len(b) > 8:                       # truncated
+            b = b[: rng.randrange(1, len(b))]
+        elif kind == 1:                                    # a few flipped bytes, header region favoured
+            for _ in range(rng.randrange(1, 6)):
+                pos = rng.randrange(min(len(b), 600)) if rng.random() < 0.7 else rng.randrange(len(b))
+                b[pos] = rng.randrange(256)
+        elif kind == 2:                                    # a 16/32-bit field blown up (sizes, lengths, counts)
+            pos = rng.randrange(max(1, min(len(b), 400) - 4))
+            b[pos:pos + 4] = bytes([0xFF, 0xFF, 0xFF, rng.randrange(256)])
+        else:                                              # a slice removed or duplicated
+            i = rng.randrange(len(b)); j = min(len(b), i + rng.randrange(1, 64))
+            b = b[:i] + (b[i:j] * 2 if rng.random() < 0.5 else b"") + b[j:]
+        out.append(bytes(b))
+    return out
+
+
+def test_readers_refuse_damaged_files_without_memory_errors(driver, tmp_path):
+    import numpy as np
+    from test_host_side import _png_bytes
+    rng = random.Random(20260202)
+    nrng = np.random.default_rng(5)
+    seeds = [f for f in sorted(os.listdir(GOLDEN)) if f.rsplit(".", 1)[-1] in ("pgm", "ppm", "jpg")]
+    assert any(f.endswith(".jpg") for f in seeds) and any(f.endswith(".pgm") for f in seeds)
+    blobs = [(f, open(os.path.join(GOLDEN, f), "rb").read()) for f in seeds]
+    # PNG seeds of every colour type the reader accepts (grey, RGB, palette, alpha, 16 bit, packed grey)
+    pal = nrng.integers(0, 256, (16, 3), dtype=np.uint8)
+    blobs += [("g8.png", _png_bytes(nrng.integers(0, 256, (23, 31, 1), dtype=np.uint8), 0)),
+              ("rgb.png", _png_bytes(nrng.integers(0, 256, (19, 17, 3), dtype=np.uint8), 2)),
+              ("rgba.png", _png_bytes(nrng.integers(0, 256, (9, 13, 4), dtype=np.uint8), 6)),
+              ("g16.png", _png_bytes(nrng.integers(0, 65536, (11, 7, 1), dtype=np.uint16), 0, depth=16)),
+              ("g2.png", _png_bytes(nrng.integers(0, 4, (10, 21, 1), dtype=np.uint8), 0, depth=2, filters=(0, 2))),
+              ("pal4.png", _png_bytes(nrng.integers(0, 16, (12, 15, 1), dtype=np.uint8), 3, depth=4, palette=pal, filters=(0,)))]
+    paths = []
+    for f, data in blobs:
+        p0 = str(tmp_path / ("intact_" + f)); open(p0, "wb").write(data); paths.append(p0)   # the intact file too
+        for k, m in enumerate(_mutants(data, rng, 150)):
+            p = str(tmp_path / ("%s.%03d" % (f, k)))
+            open(p, "wb").write(m)
+            paths.append(p)
+    # plus files that are not images at all
+    for k, blob in enumerate([b"", b"P5", b"P5\n99999999 99999999\n255\n", b"\x89PNG\r\n\x1a\n", b"\xff\xd8\xff", b"\xff\xd8" + b"\xff\xc0" * 40]):
+        p = str(tmp_path / ("junk%d" % k)); open(p, "wb").write(blob); paths.append(p)
+    out = ""
+    for i in range(0, len(paths), 400):
+        out = _run(driver, ["read"] + paths[i:i + 400])
+    assert "read ok=" in out
+
+
+def test_text_writer_on_arbitrary_bit_patterns(driver):
+    for seed, n in [(1, 1), (2, 333), (3, 20000)]:
+        out = _run(driver, ["format", str(seed), str(n)])
+        assert "same=1" in out
