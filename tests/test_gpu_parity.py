@@ -244,6 +244,48 @@ def test_cli_multi_device_shards_and_isolates_bad_files(tmp_path):
     assert r.returncode == 1 and "--devices" in r.stderr
 
 
+def test_same_bytes_under_one_and_two_ranks(tmp_path):
+    """the same 8 images under world 1 and under world 2 (one process per rank, torch.distributed with gloo,
+    both ranks on this box's GPU): every .hesaff.sift byte is equal, and equal to the C++ CLI's.  The driver's real runs
+    put one GPU under each rank and gather the counts with RCCL."""
+    import json
+    import sys
+    names = []
+    for i, (h, w, seed) in enumerate(((120, 160, 21), (120, 160, 22), (131, 77, 23), (200, 140, 24), (96, 96, 25), (120, 160, 26), (77, 131, 27), (160, 120, 28))):
+        img = band_noise_image(h, w, seed, SMALL_BANDS)
+        q = tmp_path / ("r%d.pgm" % i)
+        q.write_bytes(b"P5\n%d %d\n255\n" % (w, h) + img.tobytes())
+        names.append(str(q))
+    lst = tmp_path / "list.txt"
+    lst.write_text("\n".join(names) + "\n")
+    tool = os.path.join(ROOT, "tools", "batch_ranks.py")
+
+    def collect():
+        out = [open(n + ".hesaff.sift", "rb").read() for n in names]
+        for n in names:
+            os.remove(n + ".hesaff.sift")
+        return out
+    r = subprocess.run([sys.executable, tool, str(lst)], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    one = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    b1 = collect()
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", tool, str(lst), "--one-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    two = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    b2 = collect()
+    assert one["world"] == 1 and two["world"] == 2 and two["per_rank_images"] == [4, 4]
+    assert (one["images"], one["hessian_keypoints"], one["descriptors"]) == (two["images"], two["hessian_keypoints"], two["descriptors"])
+    assert one["images"] == 8 and one["descriptors"] > 300
+    assert b1 == b2 and all(len(b) > 100 for b in b1)
+    exe = os.path.join(ROOT, "hesaff_amd", "bin", "hesaff")
+    r = subprocess.run([exe, "--batch", str(lst)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert collect() == b1
+
+
 def test_two_contexts_on_two_threads_shard_a_batch(ctx):
     """Image-level sharding inside one process: two contexts driven by two host threads, contiguous blocks
     from shard_range, results identical to one context over the whole list."""

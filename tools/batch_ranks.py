@@ -1,0 +1,67 @@
+"""One process per GPU over a list of images: the `torchrun` form of `hesaff --batch <list> --devices ...`.
+
+    python tools/batch_ranks.py list.txt                                   # one process, device 0
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/batch_ranks.py list.txt
+
+Rank r takes the contiguous block shard_range(n, r, world) of the list (the rule of hesaff_shard_range and of the
+multi-device CLI), detects it on device LOCAL_RANK (--one-device: every rank on device 0, for a box with one GPU) and
+writes <image>.hesaff.sift next to every image (hesaff.cpp:170-176).  No feature data crosses ranks; the only collective
+is the all-gather of [Hessian keypoints, descriptors, images] (RCCL; BENCH_DIST_BACKEND=gloo moves it to CPU tensors).
+Rank 0 prints one JSON line with the totals."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hesaff_amd  # noqa: E402
+from hesaff_amd.shard import gather_counts, shard_range  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("list")
+    ap.add_argument("--one-device", action="store_true")
+    ap.add_argument("--chunk", type=int, default=32, help="images per hesaff_detect_batch call")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(0 if args.one_device else local)
+        dist.init_process_group(backend=backend)
+    names = [ln.strip() for ln in open(args.list) if ln.strip() and not ln.startswith("#")]
+    lo, hi = shard_range(len(names), rank, world)
+    ctx = hesaff_amd.HesaffContext(device=0 if args.one_device else local)
+    mr = ctx.params.mrSize
+    nh = nd = 0
+    for i in range(lo, hi, args.chunk):
+        part = names[i:min(hi, i + args.chunk)]
+        # images of different sizes go through separate calls (a batch call takes equally sized images)
+        imgs = [hesaff_amd.read_image(p) for p in part]
+        groups = {}
+        for k, im in enumerate(imgs):
+            groups.setdefault(im.shape[:2], []).append(k)
+        for idx in groups.values():
+            res = ctx.detect_batch_raw([imgs[k] for k in idx])
+            ctx.write_sift_batch_raw([part[k] + ".hesaff.sift" for k in idx], res, mr, 0)
+            nh += sum(r.count_hessian for r in res); nd += sum(r.count_desc for r in res)
+    device = None
+    if world > 1 and backend == "nccl":
+        import torch
+        device = torch.device("cuda", 0 if args.one_device else local)
+    tot = gather_counts([nh, nd, hi - lo], device=device)
+    if rank == 0:
+        print(json.dumps({"world": world, "images": int(tot[:, 2].sum()), "hessian_keypoints": int(tot[:, 0].sum()),
+                          "descriptors": int(tot[:, 1].sum()), "per_rank_images": [int(x) for x in tot[:, 2]]}))
+    ctx.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
