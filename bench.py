@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (BASELINE.json: 2048 UHD images over 8 GPUs)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--density", choices=("dense", "natural"), default="dense",
+                    help="synthetic image family: dense = the headline workload (about 14 k descriptors per Mpx), natural = about 2.5 k per Mpx (photograph-like)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-inclusive and text-export legs")
     ap.add_argument("--host-chunk", type=int, default=32, help="images per pipelined chunk of the host path (hesaff_params.max_batch)")
@@ -143,7 +145,8 @@ def main():
 
     B, H, W = args.batch, args.height, args.width
     # weak scaling: every rank owns B distinct images (global image index = rank*B + i)
-    imgs = band_noise_batch_torch(B, H, W, seed=1234 + rank * B, device=dev)
+    from hesaff_amd.synth import BANDS, BANDS_NATURAL
+    imgs = band_noise_batch_torch(B, H, W, seed=1234 + rank * B, device=dev, bands=BANDS_NATURAL if args.density == "natural" else BANDS)
     torch.cuda.synchronize()
 
     p = hesaff_amd.default_params()
@@ -262,7 +265,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "batch of %d x %dx%d 8-bit grey images per GPU per step, band-noise synthetic, default params" % (B, W, H),
+            "config": {"workload": "batch of %d x %dx%d 8-bit grey images per GPU per step, band-noise synthetic%s, default params"
+                                   % (B, W, H, " (natural density)" if args.density == "natural" else ""),
                        "images_per_gpu_per_step": B, "width": W, "height": H, "sharding": "image-level, %d rank(s)" % world,
                        "descriptors_per_image": tot_desc / max(tot_imgs, 1),
                        "value_is": "device-resident: inputs in HBM before the timed region, records left in HBM (hesaff_detect_batch_device)"},

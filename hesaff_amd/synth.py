@@ -7,6 +7,9 @@ every scale (about 12-15 k Hessian keypoints per Mpx).
 import numpy as np
 
 BANDS = ((1.5, 40.0), (3.0, 40.0), (6.0, 50.0), (12.0, 60.0), (24.0, 60.0))
+# the same family one octave coarser and with a weak finest band: about 2.5 k descriptors per Mpx, the density of
+# ordinary photographs (bench.py --density natural); BANDS is about five times denser
+BANDS_NATURAL = ((3.0, 25.0), (6.0, 40.0), (12.0, 60.0), (24.0, 60.0), (48.0, 50.0))
 
 
 def band_noise_image(height, width, seed=1234, bands=BANDS):
