@@ -482,6 +482,65 @@ __device__ __forceinline__ void hs_resample_reduced_batched(const float *__restr
    }
 }
 
+// The same resample with the rows of T' staged through LDS.  Output row jj reads the plane rows y0(jj) - r .. y0(jj) + 1 + r
+// and y0 grows by `scale` (1.5 .. 12.5) per output row while a window of rows is K + 1 = 9 * scale long: every row of T'
+// is wanted by about ten output rows.  Read straight from the HBM slot (L2) that is (K + 1) dependent 8-byte loads per
+// output, 21 round trips per wavefront and keypoint - 46 % of k_patch_mid<128>, 29 % of <512> in the ablation.  Here as
+// many consecutive output rows as fit are taken per round: their rows of T' come in with one coalesced sweep, and the
+// column pass reads LDS.  Same sums, same order.  T: window row 0 of the padded plane; chunk_rows >= K + 2.
+__device__ __forceinline__ void hs_resample_chunked(const float *__restrict__ T, int P, float scale, const float *__restrict__ taps, int r,
+                                                    float *__restrict__ s_chunk, int chunk_rows, float *s_patch)
+{
+   const int tid = threadIdx.x;
+   const float c0 = (float)(P >> 1);
+   auto y0_of = [&](int jj) {   // first of the two window rows output row jj interpolates between (as in hs_resample_reduced_batched)
+      const float wy = c0 + (float)(jj - (HS_PATCH >> 1)) * scale;
+      return min(max((int)floorf(wy), 0), P - 2);
+   };
+   for (int jj0 = 0; jj0 < HS_PATCH;) {
+      const int ylo = y0_of(jj0) - r;
+      int jj1 = jj0;
+      while (jj1 + 1 < HS_PATCH && y0_of(jj1 + 1) + r + 2 - ylo <= chunk_rows) jj1++;
+      const int nrows = y0_of(jj1) + r + 2 - ylo;
+      {
+         const v2f *src = reinterpret_cast<const v2f *>(T + ylo * HS_NEED);   // ylo >= -r: the plane has r rows above window row 0
+         v2f *dst = reinterpret_cast<v2f *>(s_chunk);
+         const int n2 = nrows * (HS_NEED / 2);
+#pragma unroll 4
+         for (int i = tid; i < n2; i += 256) dst[i] = src[i];
+      }
+      __syncthreads();
+      for (int idx = jj0 * HS_PATCH + tid; idx < (jj1 + 1) * HS_PATCH; idx += 256) {
+         const int jj = hs_div_small(idx, 1.0f / (float)HS_PATCH), ii = idx - jj * HS_PATCH;
+         const int j = jj - (HS_PATCH >> 1), i = ii - (HS_PATCH >> 1);
+         const float rx = c0 + (float)j * 0.0f, ry = c0 + (float)j * scale;
+         float wx = rx + (float)i * scale, wy = ry + (float)i * 0.0f;
+         const float fx = floorf(wx), fy = floorf(wy);
+         wx -= fx; wy -= fy;
+         const int y0 = min(max((int)fy, 0), P - 2);
+         const float *tc = s_chunk + (y0 - ylo) * HS_NEED + 2 * ii;
+         auto ld = [&](int dy) { return *reinterpret_cast<const v2f *>(tc + dy * HS_NEED); };
+         const v2f q0 = ld(0), q1 = ld(1);
+         const float kc = taps[r];
+         v2f da = kc * q0, db = kc * q1;   // chains of window rows y0 and y0 + 1
+         v2f pj = q1, mj = q0;             // rows y0 + j and y0 + 1 - j at j = 1
+#pragma unroll 4
+         for (int jt = 1; jt <= r; jt++) {
+            const v2f pn = ld(jt + 1), mn = ld(-jt);
+            const float kj = taps[r + jt];
+            const v2f sa = pj + mn, sb = pn + mj;
+            da += kj * sa;
+            db += kj * sb;
+            pj = pn;
+            mj = mn;
+         }
+         s_patch[idx] = (1.0f - wy) * ((1.0f - wx) * da.x + wx * da.y) + (wy) * ((1.0f - wx) * db.x + wx * db.y);
+      }
+      __syncthreads();
+      jj0 = jj1 + 1;
+   }
+}
+
 // Gathers of NB x 64 consecutive window pixels (columns xb + lane + 64 it) of NR rows of one window, all issued before
 // the first use, then stored into the rows' LDS lines (row i at srow + i * sstride, r border samples to the left).
 // rc[i]: the row term of the tap coordinate; ctab: the window's column table in LDS, or nullptr (computed per tap).
@@ -708,8 +767,12 @@ template <int PMAX> struct MidGeom {
    static constexpr int SROW = BIG ? HS_BIG_SROW : HS_MID_SROW;
    static constexpr int NTAP = BIG ? HS_BIG_TAPS : 32;
    static constexpr int RPAD = BIG ? HS_BIG_RPAD : HS_MID_RPAD;
-   // s_patch | taps | C table (float2 x (PMAX + 2)) | 4 waves x 3 rows
-   static constexpr int FLOATS = HS_PATCH_ARR + NTAP + 2 * (PMAX + 2) + 12 * SROW;
+   // rows of T' the column pass stages per round (the LDS lines of the window rows are free by then and are reused)
+   static constexpr int CHUNK_MIN = BIG ? 0 : 64;
+   static constexpr int SROWS = 12 * SROW > CHUNK_MIN * HS_NEED ? 12 * SROW : CHUNK_MIN * HS_NEED;
+   static constexpr int CHUNK_ROWS = SROWS / HS_NEED;
+   // s_patch | taps | C table (float2 x (PMAX + 2)) | 4 waves x 3 rows, later the T' chunk
+   static constexpr int FLOATS = HS_PATCH_ARR + NTAP + 2 * (PMAX + 2) + SROWS;
 };
 
 template <int PMAX>
@@ -767,7 +830,10 @@ __global__ __launch_bounds__(256, HS_MID_WAVES) void k_patch_mid(HessList hl, Pa
                                Tp + (size_t)(yy + (K >> 1)) * HS_NEED, K >> 1);
       }
       __syncthreads();   // workgroup-scope release/acquire: the T' rows of all four waves are visible
-      hs_resample_reduced_batched<true>(Tp + (K >> 1) * HS_NEED, P, scale, s_taps, K >> 1, s_patch);
+      if (K + 2 <= GM::CHUNK_ROWS)
+         hs_resample_chunked(Tp + (K >> 1) * HS_NEED, P, scale, s_taps, K >> 1, s_srow, GM::CHUNK_ROWS, s_patch);
+      else   // the widest windows of bin 3 (K > 91): a single output row's window of rows does not fit
+         hs_resample_reduced_batched<true>(Tp + (K >> 1) * HS_NEED, P, scale, s_taps, K >> 1, s_patch);
       __syncthreads();
       for (int i = tid; i < HS_PATCH_PIX; i += 256) io.patches[(size_t)(h - io.h_base) * HS_PATCH_PIX + i] = s_patch[i];
       __syncthreads();
