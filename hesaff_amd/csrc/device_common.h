@@ -71,6 +71,19 @@ __device__ __forceinline__ float hs_bilinear(const float *__restrict__ im, int p
    return in ? v : 0.0f;
 }
 
+// The tap of a window that lies inside the plane (all four corners tested: hs_window_outside): no bounds test, no selects,
+// a 32-bit element offset.  Same arithmetic as the inside case of hs_bilinear.
+__device__ __forceinline__ float hs_tap_inside_ptr(const float *__restrict__ im, int pitch, float wx, float wy)
+{
+   const float fx = floorf(wx), fy = floorf(wy);
+   wx -= fx;
+   wy -= fy;
+   const uint32_t off = (uint32_t)(int)fy * (uint32_t)pitch + (uint32_t)(int)fx;
+   const float *p = im + off;
+   const float p00 = p[0], p01 = p[1], p10 = p[pitch], p11 = p[pitch + 1];
+   return (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + (wy) * ((1.0f - wx) * p10 + wx * p11);
+}
+
 // The same tap through a buffer resource: one image plane (< 4 GB) described by four scalar
 // registers, per-lane 32-bit byte offsets, the second row reached through the scalar offset
 // operand - no 64-bit per-lane pointer arithmetic.  The plane base must be wave-uniform.

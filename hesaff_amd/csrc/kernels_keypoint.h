@@ -8,6 +8,7 @@
 // thread per histogram cell walking its pixels in raster order.  No shuffle trees, no
 // float atomics (both would change the rounding and flip descriptor bytes).
 #pragma once
+#include <type_traits>
 #include "device_common.h"
 #include "kernels_pyramid.h"
 
@@ -57,6 +58,28 @@ struct AffineOut {
 // block = 64 threads (one wavefront), LDS 4 x 3 x 364 floats + mask (19 KB).
 // ---------------------------------------------------------------------------------------
 #define HS_AFF_G 4
+// interpolate()'s return flag ("some tap fell outside the image", helpers.cpp:209-244) for the P x P window of
+// normalizeAffine's smoothing branch (affine.cpp:126), without visiting the P^2 taps.  The tap coordinate
+//    w(j, i) = fl(fl(ofs + fl(j * a_row)) + fl(i * a_col))        j, i in [-half, half]
+// is monotone in i for fixed j and in j for fixed i (a float product or sum with one operand fixed is monotone under
+// round-to-nearest), so over the grid it takes its extremes at the four corners; a tap is inside iff
+// 0 <= floor(w) < limit, i.e. 0 <= w < limit for the integer limits cols - 1 / rows - 1.  Hence "some tap outside" <=>
+// "some corner outside".  Non-finite values: an infinite product at an inner index is also infinite at the corner of the
+// same sign, and a NaN operand makes every coordinate NaN, so a corner fails whenever any tap would.
+__device__ inline bool hs_window_outside(int imRows, int imCols, float ofsx, float ofsy, float a11, float a12, float a21, float a22, int half)
+{
+   const float width = (float)(imCols - 1), height = (float)(imRows - 1);
+   bool outside = false;
+#pragma unroll
+   for (int q = 0; q < 4; q++) {
+      const int j = (q & 1) ? half : -half, i = (q & 2) ? half : -half;
+      const float rx = ofsx + (float)j * a12, ry = ofsy + (float)j * a22;
+      const float fx = floorf(rx + (float)i * a11), fy = floorf(ry + (float)i * a21);
+      outside = outside || !(fx >= 0.0f && fy >= 0.0f && fx < width && fy < height);
+   }
+   return outside;
+}
+
 #define HS_AFF_NT 23    // ceil(361 / 16)
 #ifndef HS_AFF_BATCHES
 #define HS_AFF_BATCHES 2
@@ -105,9 +128,21 @@ __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, con
    load_kp();
    HS_WAVE_LDS_SYNC();
    while (__ballot(active) != 0ull) {
+      bool win_in = true;
       if (active) {
          const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
-         // interpolate(), helpers.cpp:209-244 (return value ignored at affine.cpp:47): 23 taps per lane in two batches
+         // interpolate(), helpers.cpp:209-244 (return value ignored at affine.cpp:47): 23 taps per lane in two batches.
+         // The tap coordinates are monotone in i and in j (hs_window_outside): when the four corners of the 19 x 19 grid
+         // are inside the level, every tap is, and the taps need no bounds test, no selects and only 32-bit offsets;
+         // a window that touches the border (a few per cent) keeps the tested tap, which zeroes what lies outside.
+         win_in = !hs_window_outside(height + 1, width + 1, lx, ly, a11, a12, a21, a22, HS_SMM >> 1);
+      }
+      // one decision per wavefront (a branch per group would split the batches of gathers): the untested taps when the
+      // windows of all its active keypoints are inside, the tested ones for everybody otherwise
+      const bool all_in = __ballot(active && !win_in) == 0ull;
+      auto sample = [&](auto inside_c) {
+         constexpr bool INSIDE = decltype(inside_c)::value;
+         const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
 #pragma unroll
          for (int half = 0; half < HS_AFF_BATCHES; half++) {
             constexpr int NB = (HS_AFF_NT + HS_AFF_BATCHES - 1) / HS_AFF_BATCHES;
@@ -121,8 +156,12 @@ __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, con
                const float ry = ly + (float)j * a22;
                const float wx = rx + (float)i * a11;
                const float wy = ry + (float)i * a21;
-               bool outside = false;
-               sv[t] = hs_bilinear(blur, pitch, width, height, wx, wy, outside);
+               if (INSIDE) {
+                  sv[t] = hs_tap_inside_ptr(blur, pitch, wx, wy);
+               } else {
+                  bool outside = false;
+                  sv[t] = hs_bilinear(blur, pitch, width, height, wx, wy, outside);
+               }
             }
 #pragma unroll
             for (int t = 0; t < NB; t++) HS_KEEP(sv[t]);
@@ -132,6 +171,10 @@ __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, con
                if (idx < HS_SMM_PIX) s_img[idx] = sv[t];
             }
          }
+      };
+      if (active) {
+         if (all_in) sample(std::true_type{});
+         else sample(std::false_type{});
       }
       HS_WAVE_LDS_SYNC();
       if (active) {
@@ -398,28 +441,6 @@ __device__ __forceinline__ int hs_window_p0(float s, float mrSize)
 // only, so it is known right after detection and the host can size / group the patch stage without waiting for the
 // affine iteration.  rows[b] += P for every Hessian keypoint whose window falls into the last bin.
 __global__ __launch_bounds__(256) void k_image_large_rows(HessList hl, const uint32_t *__restrict__ n_ptr, float mrSize, uint32_t *__restrict__ rows);
-
-// interpolate()'s return flag ("some tap fell outside the image", helpers.cpp:209-244) for the P x P window of
-// normalizeAffine's smoothing branch (affine.cpp:126), without visiting the P^2 taps.  The tap coordinate
-//    w(j, i) = fl(fl(ofs + fl(j * a_row)) + fl(i * a_col))        j, i in [-half, half]
-// is monotone in i for fixed j and in j for fixed i (a float product or sum with one operand fixed is monotone under
-// round-to-nearest), so over the grid it takes its extremes at the four corners; a tap is inside iff
-// 0 <= floor(w) < limit, i.e. 0 <= w < limit for the integer limits cols - 1 / rows - 1.  Hence "some tap outside" <=>
-// "some corner outside".  Non-finite values: an infinite product at an inner index is also infinite at the corner of the
-// same sign, and a NaN operand makes every coordinate NaN, so a corner fails whenever any tap would.
-__device__ inline bool hs_window_outside(int imRows, int imCols, float ofsx, float ofsy, float a11, float a12, float a21, float a22, int half)
-{
-   const float width = (float)(imCols - 1), height = (float)(imRows - 1);
-   bool outside = false;
-#pragma unroll
-   for (int q = 0; q < 4; q++) {
-      const int j = (q & 1) ? half : -half, i = (q & 2) ? half : -half;
-      const float rx = ofsx + (float)j * a12, ry = ofsy + (float)j * a22;
-      const float fx = floorf(rx + (float)i * a11), fy = floorf(ry + (float)i * a21);
-      outside = outside || !(fx >= 0.0f && fy >= 0.0f && fx < width && fy < height);
-   }
-   return outside;
-}
 
 template <bool RECTIFY>
 __device__ __forceinline__ void hs_prepare_patch_body(const HessList &hl, uint32_t h_lo, uint32_t n, const AffineOut &aff, int imRows, int imCols,

@@ -10,8 +10,8 @@
 //                   gradient, hm_atan2f_sel -> (mask*grad, o) pairs of the 40x40 weighted pixels.
 //  k_sift_hist      FOUR keypoints per wavefront, lane = (keypoint, spatial cell): the cell's 8
 //                   orientation bins live in LDS ([bin][lane], conflict-free) and the lane walks
-//                   its 16x16 support in raster order (siftdesc.cpp:51-81), operands streamed
-//                   from HBM/L2 one 128-byte cell row at a time.
+//                   its 16x16 support in raster order (siftdesc.cpp:51-81); the wave fetches each step's
+//                   rows coalesced and hands them out through LDS.
 //  k_sift_quantize  normalize / clip / renormalize / quantise (siftdesc.cpp:83-113): the two
 //                   128-term sequential sums again run one thread per keypoint.
 //
@@ -214,8 +214,8 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
 // in raster order, which is the order the reference adds a bin's terms in.  Per pixel: one
 // product chain wr*(wc*val), two read-modify-writes at bins bo0 and bo0+1 (dynamic index, hence
 // LDS and not registers).  Where the reference adds nothing (val <= 0) this adds +0.0f.
-// The (mask*grad, o) rows are read straight from global memory, 8 x 16 bytes per cell row and
-// lane, the next row in flight while the current one is consumed.
+// The (mask*grad, o) rows of a step are fetched by the whole wave as consecutive 16-byte items and handed
+// out through LDS (see "Row staging" below), the next step's rows in flight while the current ones are consumed.
 // grid-stride over groups of 4 keypoints, block 64.
 #ifndef HS_HIST_WAVES
 #define HS_HIST_WAVES 0   // tuning: wavefronts per SIMD to hold the register allocation to (0: the compiler's choice)
@@ -243,22 +243,50 @@ __global__ __launch_bounds__(64, HS_HIST_WAVES) void k_sift_hist(SiftIO io, KpTa
    for (int j = 0; j < 16; j++) cwc[j] = s_cw[cb_c * 16 + j];
    const uint32_t n = io.h_hi - io.h_lo;
    float *acc = s_acc + tid;
+   // Row staging.  At step i the 64 lanes need, of each of the wave's four keypoints, the rows 8 cb_r + i (cb_r = 0..3):
+   // 16 rows x 40 pixels x 8 bytes = 5 KB.  Read lane by lane (8 x 16 bytes each, rows 320 bytes and keypoints 12.8 KB
+   // apart) every load instruction touches ~32 cache lines (texture addresser 78 % busy).  Instead the wave fetches the
+   // 16 rows as 320 consecutive 16-byte items (5 per lane, 3 rows per instruction), parks them in LDS and every lane
+   // takes its 8 items from there; the next step's items are in flight meanwhile (20 registers instead of 32).
+   __shared__ __attribute__((aligned(16))) float4 s_rows[16 * (HS_VO_DIM / 2)];
+   int st_off[5];      // float4 offset of staged item e = tid + 64 u inside the group's gradient pairs (without the step term)
+#pragma unroll
+   for (int u = 0; u < 5; u++) {
+      const int e = tid + 64 * u, row16 = e / (HS_VO_DIM / 2), f = e - row16 * (HS_VO_DIM / 2);
+      st_off[u] = (row16 >> 2) * (HS_VO_PITCH / 2) + 8 * (row16 & 3) * (HS_VO_DIM / 2) + f;
+   }
+   const float4 *my_rows = s_rows + (4 * kq + cb_r) * (HS_VO_DIM / 2) + 4 * cb_c;
    for (uint32_t g = blockIdx.x; 4 * g < n; g += gridDim.x) {
       const uint32_t k = 4 * g + kq;
       const bool valid = k < n && io.alive[io.h_lo + min(k, n - 1)];
 #pragma unroll
       for (int b = 0; b < 8; b++) acc[64 * b] = 0.0f;
-      if (valid) {
-         // float4 index of the cell's first pixel pair: rows are HS_VO_DIM float2 = 20 float4
-         const float4 *g4 = reinterpret_cast<const float4 *>(vo + (size_t)k * HS_VO_PITCH) + (8 * cb_r) * (HS_VO_DIM / 2) + 4 * cb_c;
-         float4 cur[8], nxt[8];
+      // the group's pairs; a group that runs past the list re-reads its last keypoint (values unused)
+      const float4 *g4 = reinterpret_cast<const float4 *>(vo + (size_t)(4 * g) * HS_VO_PITCH);
+      const int kmax = (int)min(3u, n - 1 - 4 * g);   // last keypoint of the group that exists
+      int st_src[5];
 #pragma unroll
-         for (int m = 0; m < 8; m++) cur[m] = g4[m];
+      for (int u = 0; u < 5; u++) {
+         const int kq_e = (tid + 64 * u) / (4 * (HS_VO_DIM / 2));
+         st_src[u] = st_off[u] - (kq_e > kmax ? (kq_e - kmax) * (HS_VO_PITCH / 2) : 0);
+      }
+      // five named registers, not an array: carried around the loop an array ends up in scratch memory
+      float4 st0 = g4[st_src[0]], st1 = g4[st_src[1]], st2 = g4[st_src[2]], st3 = g4[st_src[3]], st4 = g4[st_src[4]];
 #pragma unroll 1
-         for (int i = 0; i < 16; i++) {
-            const float4 *gn = g4 + min(i + 1, 15) * (HS_VO_DIM / 2);
+      for (int i = 0; i < 16; i++) {
+         HS_WAVE_LDS_SYNC();   // every lane has taken step i - 1's items
+         s_rows[tid] = st0; s_rows[tid + 64] = st1; s_rows[tid + 128] = st2; s_rows[tid + 192] = st3; s_rows[tid + 256] = st4;
+         HS_WAVE_LDS_SYNC();
+         // step i + 1's items are requested now and parked at the top of the next round (unconditionally: the last round
+         // re-reads its own rows)
+         {
+            const float4 *gi = g4 + min(i + 1, 15) * (HS_VO_DIM / 2);
+            st0 = gi[st_src[0]]; st1 = gi[st_src[1]]; st2 = gi[st_src[2]]; st3 = gi[st_src[3]]; st4 = gi[st_src[4]];
+         }
+         if (valid) {
+            float4 cur[8];
 #pragma unroll
-            for (int m = 0; m < 8; m++) nxt[m] = gn[m];
+            for (int m = 0; m < 8; m++) cur[m] = my_rows[m];
             const float wr = s_cw[cb_r * 16 + i];
 #pragma unroll
             for (int j = 0; j < 16; j++) {
@@ -277,8 +305,6 @@ __global__ __launch_bounds__(64, HS_HIST_WAVES) void k_sift_hist(SiftIO io, KpTa
                acc[64 * bo0] = a0 + t0;
                acc[64 * bo1] = a1 + t1;
             }
-#pragma unroll
-            for (int m = 0; m < 8; m++) cur[m] = nxt[m];
          }
       }
       if (k < n) {
