@@ -8,3 +8,8 @@ timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_tests.log 2>&1
 bash scripts/gpu_profile_round.sh ${TAG}_prof > gpurun_out/${TAG}_prof.log 2>&1; tail -20 gpurun_out/${TAG}_prof.log | cut -c1-400
 bash scripts/gpu_pmc2.sh ${TAG} 8 > gpurun_out/${TAG}_pmc.md 2>&1; cat gpurun_out/${TAG}_pmc.md
 python scripts/hbm_probe.py > gpurun_out/${TAG}_hbm_probe.txt 2>&1; tail -5 gpurun_out/${TAG}_hbm_probe.txt
+bash scripts/gpu_pmc_lds.sh ${TAG} 8 > gpurun_out/${TAG}_pmc_lds.md 2>&1; cat gpurun_out/${TAG}_pmc_lds.md
+bash scripts/gpu_pmc_mem.sh ${TAG} 8 > gpurun_out/${TAG}_pmc_mem.md 2>&1; cat gpurun_out/${TAG}_pmc_mem.md
+bash scripts/gpu_kernels.sh ${TAG} 32 > gpurun_out/${TAG}_kernels_serial.txt 2>&1; head -16 gpurun_out/${TAG}_kernels_serial.txt
+timeout 900 python tools/fast_mode_report.py --batch 32 > gpurun_out/${TAG}_fast_mode.log 2>&1; tail -1 gpurun_out/${TAG}_fast_mode.log | cut -c1-600
+timeout 600 python bench.py --density natural --no-cpu-baseline > gpurun_out/${TAG}_bench_natural.json 2> /dev/null; cut -c1-200 gpurun_out/${TAG}_bench_natural.json
