@@ -58,7 +58,7 @@ def _mutants(data, rng, n):
 
 def test_readers_refuse_damaged_files_without_memory_errors(driver, tmp_path):
     import numpy as np
-    from test_host_side import _png_bytes
+    from tests.test_host_side import _png_bytes
     rng = random.Random(20260202)
     nrng = np.random.default_rng(5)
     seeds = [f for f in sorted(os.listdir(GOLDEN)) if f.rsplit(".", 1)[-1] in ("pgm", "ppm", "jpg")]
