@@ -113,6 +113,7 @@ def load_library():
     L.hesaff_stage_normalize_affine.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _i32p, _f32p]
     L.hesaff_stage_sift.argtypes = [vp, C.c_int, _f32p, _u8p]
     L.hesaff_stage_math.argtypes = [vp, C.c_int, _f32p, _f32p, _f32p, _f32p]
+    L.hesaff_stage_math_sift.argtypes = [vp, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
     L.hesaff_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.hesaff_table_gauss_mask.argtypes = [C.c_int, _f32p]
     L.hesaff_table_circ_gauss_mask.argtypes = [C.c_int, _f32p]
@@ -129,7 +130,7 @@ ABI_SYMBOLS = [
     "hesaff_write_sift", "hesaff_format_sift", "hesaff_free", "hesaff_read_pnm", "hesaff_stage_gaussian_blur",
     "hesaff_stage_hessian_response", "hesaff_stage_half_image", "hesaff_stage_pyramid", "hesaff_stage_hessian_keypoints",
     "hesaff_stage_find_affine_shape", "hesaff_stage_rectify", "hesaff_stage_normalize_affine", "hesaff_stage_sift",
-    "hesaff_stage_math", "hesaff_table_gauss_mask", "hesaff_table_circ_gauss_mask", "hesaff_table_sift_bins",
+    "hesaff_stage_math", "hesaff_stage_math_sift", "hesaff_table_gauss_mask", "hesaff_table_circ_gauss_mask", "hesaff_table_sift_bins",
     "hesaff_table_gauss_kernel", "hesaff_format_sift_mt", "hesaff_write_sift_batch", "hesaff_test_fmt_g",
     "hesaff_read_png", "hesaff_read_image", "hesaff_device_count", "hesaff_shard_range", "hesaff_read_jpeg",
     "hesaff_host_threads",
@@ -412,3 +413,10 @@ class HesaffContext:
         at = np.zeros_like(a); pw = np.zeros_like(a)
         self._check(self.L.hesaff_stage_math(self.h, a.size, a.reshape(-1), b.reshape(-1), at.reshape(-1), pw.reshape(-1)))
         return at, pw
+
+    def math_sift(self, gy, gx):
+        """-> ori_general, ori_nd, grad_general, grad_nd (hesaff_stage_math_sift)."""
+        gy = np.ascontiguousarray(gy, np.float32).reshape(-1); gx = np.ascontiguousarray(gx, np.float32).reshape(-1)
+        outs = [np.zeros_like(gy) for _ in range(4)]
+        self._check(self.L.hesaff_stage_math_sift(self.h, gy.size, gy, gx, *outs))
+        return outs

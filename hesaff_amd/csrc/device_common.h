@@ -51,6 +51,50 @@ struct DConsts {
       __builtin_amdgcn_wave_barrier();                      \
    } while (0)
 
+// Streaming accesses: data written once and consumed by a later kernel (or read exactly once) is stored / loaded
+// non-temporally so that it does not displace what this kernel and its neighbours re-read from L2 / the memory-side cache
+// (measured: k_sift_grad 21.6 -> 19.9 ms from its 12.8 KB of gradient pairs per keypoint alone).  Each site has a switch
+// (HS_NT_*) for A/B runs of the tuning build.
+typedef float hs_nt2 __attribute__((ext_vector_type(2)));
+typedef float hs_nt4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void hs_store_nt(float *p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void hs_store_nt2(float *p, float a, float b) { hs_nt2 v; v.x = a; v.y = b; __builtin_nontemporal_store(v, reinterpret_cast<hs_nt2 *>(p)); }
+__device__ __forceinline__ void hs_store_nt4(float *p, float a, float b, float c, float d)
+{
+   hs_nt4 v; v.x = a; v.y = b; v.z = c; v.w = d;
+   __builtin_nontemporal_store(v, reinterpret_cast<hs_nt4 *>(p));
+}
+__device__ __forceinline__ float hs_load_nt(const float *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ float4 hs_load_nt4(const float4 *p)
+{
+   const hs_nt4 v = __builtin_nontemporal_load(reinterpret_cast<const hs_nt4 *>(p));
+   return make_float4(v.x, v.y, v.z, v.w);
+}
+#ifndef HS_NT_VO
+#define HS_NT_VO 1        // k_sift_grad's gradient pairs: stores (21.3 -> 19.9 ms; k_sift_hist 14.1 -> 13.3)
+#endif
+#ifndef HS_NT_VO_LD
+#define HS_NT_VO_LD 0     // ... and k_sift_hist's loads of them (measured: 13.7 -> 17.1 ms, not used)
+#endif
+#ifndef HS_NT_PATCH
+#define HS_NT_PATCH 1     // patch kernels' 41 x 41 outputs (the kernels themselves unchanged, k_sift_grad 20.1 -> 18.7 ms)
+#endif
+#ifndef HS_NT_PYR
+#define HS_NT_PYR 1       // pyramid planes (k_blur_hess_march<9 / 13 / 15>: -16 / -9 / -2 %)
+#endif
+#ifndef HS_NT_PYR_R
+#define HS_NT_PYR_R HS_NT_PYR   // ... the response planes separately (read back by k_extrema_march right after the octave's blurs)
+#endif
+#ifndef HS_NT_GRAY
+#define HS_NT_GRAY 1      // the float grey plane written by the initial blur (pyramid stage 18.4-19.6 -> 17.8-18.2 ms at B = 128)
+#endif
+#ifndef HS_NT_EXT
+#define HS_NT_EXT 0       // k_extrema_march's reads of the five response planes
+#endif
+#ifndef HS_NT_MEANVAR
+#define HS_NT_MEANVAR 0   // k_sift_meanvar's patch reads (1: second pass: no change; 2: both passes: 9.8 -> 11.8 ms)
+#endif
+
 // ---- helpers.cpp:227-240 : one bilinear tap; `outside` is OR-ed like `ret` ----
 // (int)floor(w) of the reference is cvttss2si (INT_MIN on NaN/overflow -> "outside");
 // comparing the floored float gives the same classification without the cast.

@@ -179,6 +179,7 @@ HM_HD float hm_atan2f_sel(float y, float x)
    return hm_u2f(hm_f2u(r) ^ ((uint32_t)hy & 0x80000000u));
 }
 
+
 // ---- atan2f a third time, table-driven: the per-interval constants of hm_atan2f_sel come from one 8-float row
 //      (HM_ATAN_TAB, staged in LDS by the device caller) instead of a tree of selects:
 //         num = c1*q + c0,   den = d1*q + d0,   z = hi - ((xr*(s1+s2) - lo) - xr),   xr = num/den
@@ -206,21 +207,60 @@ __host__ __device__ __attribute__((noinline)) inline float hm_atan2f_rare(float 
 inline float hm_atan2f_rare(float y, float x) { return hm_atan2f(y, x); }
 #endif
 
-HM_HD float hm_atan2f_tab(float y, float x, const float *tab)
+// IEEE division and square root for operands that need no range handling.  The compiler's correctly rounded f32
+// division is  v_div_scale x 2, v_rcp, five fma / mul steps, v_div_fmas, v_div_fixup: the scale and fix-up instructions
+// only act on denormal / huge operands and quotients and on zero, infinite or NaN inputs.  With both operands and the
+// quotient in the normal range (or a zero numerator) the remaining steps ARE the division: same intermediate values,
+// same result.  Likewise sqrtf = v_sqrt_f32 (1 ulp) + the choice between the result and its two neighbours by the
+// sign of two fma residuals, framed by a 2^32 scaling for arguments below 2^-96 and a class test for 0 / inf.
+// hm_div_normal with a zero divisor returns NaN, not +-inf (callers replace that lane's result anyway).
+HM_HD float hm_div_normal(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+   const float r0 = __builtin_amdgcn_rcpf(b);
+   const float e0 = __builtin_fmaf(-b, r0, 1.0f);
+   const float r1 = __builtin_fmaf(e0, r0, r0);
+   const float q0 = a * r1;
+   const float e1 = __builtin_fmaf(-b, q0, a);
+   const float q1 = __builtin_fmaf(e1, r1, q0);
+   const float e2 = __builtin_fmaf(-b, q1, a);
+   return __builtin_fmaf(e2, r1, q1);
+#else
+   return a / b;
+#endif
+}
+HM_HD float hm_sqrt_normal(float x)   // x == 0 or normal, finite
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+   float s = __builtin_amdgcn_sqrtf(x);
+   const float sd = hm_u2f(hm_f2u(s) - 1u), su = hm_u2f(hm_f2u(s) + 1u);
+   const float vp = __builtin_fmaf(-sd, s, x), vs = __builtin_fmaf(-su, s, x);
+   s = (vp <= 0.0f) ? sd : s;
+   s = (vs > 0.0f) ? su : s;
+   return s;
+#else
+   return __builtin_sqrtf(x);
+#endif
+}
+
+// ND = true: y and x are zero or normal numbers (never denormal): the two divisions need no range handling.  k_sift_grad's
+// operands are differences of pixel values that are multiples of 2^-17 in [0, 255].
+template <bool ND>
+HM_HD float hm_atan2f_tab_t(float y, float x, const float *tab)
 {
    const float pi_o_2 = hm_u2f(0x3fc90fdbu), pi = hm_u2f(0x40490fdbu), pi_lo = hm_u2f(0xb3bbbd2eu);
    const int32_t hx = (int32_t)hm_f2u(x), hy = (int32_t)hm_f2u(y);
    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
    const int32_t k = (iy - ix) >> 23;
    if ((ix >= 0x7f800000) | (iy >= 0x7f800000) | ((iy != 0) & (ix != 0) & ((k > 60) | (k < -60)))) return hm_atan2f_rare(y, x);
-   const float q = hm_fabsf(y / x);   // NaN for 0/0, +inf for y/0: both replaced below
+   const float q = hm_fabsf(ND ? hm_div_normal(y, x) : y / x);   // NaN for 0/0, +inf (ND: NaN) for y/0: both replaced below
    const int32_t iq = (int32_t)hm_f2u(q);
    const int id = (int)(iq >= 0x3ee00000) + (int)(iq >= 0x3f300000) + (int)(iq >= 0x3f980000) + (int)(iq >= 0x401c0000);
    const float *row = tab + 8 * id;
    const float num = row[0] * q + row[2];
    const float den = row[1] * q + row[3];
    const float hi = row[4], lo = row[5];
-   const float xr = num / den;
+   const float xr = ND ? hm_div_normal(num, den) : num / den;
    const float z = xr * xr;
    const float w = z * z;
    const float aT0 = hm_u2f(0x3eaaaaabu), aT1 = hm_u2f(0xbe4ccccdu), aT2 = hm_u2f(0x3e124925u),
@@ -236,6 +276,8 @@ HM_HD float hm_atan2f_tab(float y, float x, const float *tab)
    r = (ix == 0) ? ((iy == 0) ? ((hx < 0) ? pi : 0.0f) : pi_o_2) : r;
    return hm_u2f(hm_f2u(r) ^ ((uint32_t)hy & 0x80000000u));
 }
+HM_HD float hm_atan2f_tab(float y, float x, const float *tab) { return hm_atan2f_tab_t<false>(y, x, tab); }
+HM_HD float hm_atan2f_tab_nd(float y, float x, const float *tab) { return hm_atan2f_tab_t<true>(y, x, tab); }
 
 // ---- powf(2.0f, y) for |y| < 126 (no overflow/underflow handling needed on this path:
 //      callers pass y = b/3 with |b| <= 1.5, or 1/numberOfScales) ----

@@ -109,7 +109,7 @@ __device__ __forceinline__ void hs_resample_full_tab(const float *S, int pitch, 
       const float *p = S + (in ? yi * pitch + xi : 0);
       const float p00 = p[0], p01 = p[1], p10 = p[pitch], p11 = p[pitch + 1];
       const float v = (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + (wy) * ((1.0f - wx) * p10 + wx * p11);
-      out[idx] = in ? v : 0.0f;
+      if (HS_NT_PATCH) hs_store_nt(out + idx, in ? v : 0.0f); else out[idx] = in ? v : 0.0f;
    }
 }
 
@@ -835,7 +835,10 @@ __global__ __launch_bounds__(256, HS_MID_WAVES) void k_patch_mid(HessList hl, Pa
       else   // the widest windows of bin 3 (K > 91): a single output row's window of rows does not fit
          hs_resample_reduced_batched<true>(Tp + (K >> 1) * HS_NEED, P, scale, s_taps, K >> 1, s_patch);
       __syncthreads();
-      for (int i = tid; i < HS_PATCH_PIX; i += 256) io.patches[(size_t)(h - io.h_base) * HS_PATCH_PIX + i] = s_patch[i];
+      for (int i = tid; i < HS_PATCH_PIX; i += 256) {
+         float *po = io.patches + (size_t)(h - io.h_base) * HS_PATCH_PIX + i;
+         if (HS_NT_PATCH) hs_store_nt(po, s_patch[i]); else *po = s_patch[i];
+      }
       __syncthreads();
    }
 }
@@ -915,7 +918,10 @@ __global__ __launch_bounds__(256) void k_patch_large_finish(PatchWork pw, PatchI
       const float *taps = tb.patch_taps + tb.patch_tap_off[(P0 - 1) >> 1];
       hs_resample_reduced_batched<false>(io.trows + (size_t)pre[it] * HS_NEED, P, scale, taps, K >> 1, s_patch);
       __syncthreads();
-      for (int i = threadIdx.x; i < HS_PATCH_PIX; i += 256) io.patches[(size_t)(h - io.h_base) * HS_PATCH_PIX + i] = s_patch[i];
+      for (int i = threadIdx.x; i < HS_PATCH_PIX; i += 256) {
+         float *po = io.patches + (size_t)(h - io.h_base) * HS_PATCH_PIX + i;
+         if (HS_NT_PATCH) hs_store_nt(po, s_patch[i]); else *po = s_patch[i];
+      }
       __syncthreads();
    }
 }

@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256, (K == 15 ? HS_MARCH15_WAVES : 0)) void k_blur_
 #pragma unroll
             for (int m = 0; m < 5; m++) {
                const int f = lane + 64 * m;
-               if (f >= 12 && f < 12 + BM_STRIP && xs - 12 + f < cols) go[f] = dst5[m];
+               if (f >= 12 && f < 12 + BM_STRIP && xs - 12 + f < cols) { if (HS_NT_GRAY) hs_store_nt(go + f, dst5[m]); else go[f] = dst5[m]; }
             }
          }
          return;
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256, (K == 15 ? HS_MARCH15_WAVES : 0)) void k_blur_
             if (row_in && store_lane) {
                if (WRITE_L) {
                   float *o = outL.img(b) + (long long)yl * outL.pitch + xl;
-                  if (full4) *reinterpret_cast<float4 *>(o) = make_float4(la.x, la.y, lb.x, lb.y);
+                  if (full4) { if (HS_NT_PYR) hs_store_nt4(o, la.x, la.y, lb.x, lb.y); else *reinterpret_cast<float4 *>(o) = make_float4(la.x, la.y, lb.x, lb.y); }
                   else {
                      const float v[4] = {la.x, la.y, lb.x, lb.y};
                      for (int c = 0; c < 4; c++)
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(256, (K == 15 ? HS_MARCH15_WAVES : 0)) void k_blur_
                if (WRITE_HALF) {
                   if ((yl & 1) == 0 && (yl >> 1) < outHalf.rows) {
                      float *o = outHalf.img(b) + (long long)(yl >> 1) * outHalf.pitch + (xl >> 1);
-                     if ((xl >> 1) + 1 < outHalf.cols) *reinterpret_cast<float2 *>(o) = make_float2(la.x, lb.x);
+                     if ((xl >> 1) + 1 < outHalf.cols) { if (HS_NT_PYR) hs_store_nt2(o, la.x, lb.x); else *reinterpret_cast<float2 *>(o) = make_float2(la.x, lb.x); }
                      else if ((xl >> 1) < outHalf.cols) o[0] = la.x;
                   }
                }
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256, (K == 15 ? HS_MARCH15_WAVES : 0)) void k_blur_
                   const float r0 = (yin && cin0) ? ra.x : 0.0f, r1 = (yin && cin1) ? ra.y : 0.0f;
                   const float r2 = (yin && cin2) ? rbv.x : 0.0f, r3 = (yin && cin3) ? rbv.y : 0.0f;
                   float *o = outR.img(b) + (long long)yh * outR.pitch + xl;
-                  if (full4) *reinterpret_cast<float4 *>(o) = make_float4(r0, r1, r2, r3);
+                  if (full4) { if (HS_NT_PYR_R) hs_store_nt4(o, r0, r1, r2, r3); else *reinterpret_cast<float4 *>(o) = make_float4(r0, r1, r2, r3); }
                   else {
                      const float v[4] = {r0, r1, r2, r3};
                      for (int c = 0; c < 4; c++)
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(256, (K == 15 ? HS_MARCH15_WAVES : 0)) void k_blur_
                const float r0 = (yin && cin0) ? ra.x : 0.0f, r1 = (yin && cin1) ? ra.y : 0.0f;
                const float r2 = (yin && cin2) ? rbv.x : 0.0f, r3 = (yin && cin3) ? rbv.y : 0.0f;
                float *o = outR0.img(b) + (long long)yr * outR0.pitch + xl;
-               if (full4) *reinterpret_cast<float4 *>(o) = make_float4(r0, r1, r2, r3);
+               if (full4) { if (HS_NT_PYR_R) hs_store_nt4(o, r0, r1, r2, r3); else *reinterpret_cast<float4 *>(o) = make_float4(r0, r1, r2, r3); }
                else {
                   const float v[4] = {r0, r1, r2, r3};
                   for (int c = 0; c < 4; c++)
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(64) void k_extrema_march(FivePlanes fp, float posTh
    for (int k = 0; k < 2; k++) {
       const long long off = (long long)min(ya - 1 + k, rows - 1) * pitch;
 #pragma unroll
-      for (int p = 0; p < 5; p++) ring[p][k] = *reinterpret_cast<const float4 *>(base[p] + off);
+      for (int p = 0; p < 5; p++) ring[p][k] = HS_NT_EXT ? hs_load_nt4(reinterpret_cast<const float4 *>(base[p] + off)) : *reinterpret_cast<const float4 *>(base[p] + off);
    }
    for (int k0 = 0; k0 < nsteps; k0 += EXM_RS) {
 #pragma unroll
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(64) void k_extrema_march(FivePlanes fp, float posTh
             // two rows ahead, into the slot whose row (k - 3) is no longer needed
             const long long off = (long long)min(ya - 1 + k + 2, rows - 1) * pitch;
 #pragma unroll
-            for (int p = 0; p < 5; p++) ring[p][(u + 2) % EXM_RS] = *reinterpret_cast<const float4 *>(base[p] + off);
+            for (int p = 0; p < 5; p++) ring[p][(u + 2) % EXM_RS] = HS_NT_EXT ? hs_load_nt4(reinterpret_cast<const float4 *>(base[p] + off)) : *reinterpret_cast<const float4 *>(base[p] + off);
          }
          const uint32_t n_lagged = s_n;   // count before the previous step's candidates are all in
          const int y = ya - 2 + k;        // row under test: slots (u-2, u-1, u) = rows y-1, y, y+1

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(64) void k_sift_meanvar(SiftIO io, KpTables tb)
 #pragma unroll 8
          for (int k = 0; k < SM_TILE; k++) {
             const uint32_t kp = min(k0 + k, n - 1);
-            s_tile[k * SM_STRIDE + lane] = io.patches[(size_t)kp * HS_PATCH_PIX + pix];
+            const float *pp = io.patches + (size_t)kp * HS_PATCH_PIX + pix;
+            s_tile[k * SM_STRIDE + lane] = (HS_NT_MEANVAR == 2 || (HS_NT_MEANVAR == 1 && pass == 1)) ? hs_load_nt(pp) : *pp;
          }
          __syncthreads();
          const float *row = s_tile + lane * SM_STRIDE;
@@ -88,6 +89,9 @@ __global__ __launch_bounds__(64) void k_sift_meanvar(SiftIO io, KpTables tb)
 // LDS table (hm_atan2f_tab: no select trees, no divergence).  The next keypoint's pixels are requested before
 // the current one is evaluated.
 // grid: min(n, 256 * 8) blocks of 256 threads.
+#ifndef HS_SGRAD_TILE
+#define HS_SGRAD_TILE 1
+#endif
 #ifndef HS_SGRAD_WAVES
 #define HS_SGRAD_WAVES 0   // tuning: wavefronts per SIMD to hold the register allocation to (0: the compiler's choice)
 #endif
@@ -95,8 +99,18 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
 {
    __shared__ float s_p[HS_PATCH_PIX];
    __shared__ float s_at[HM_ATAN_TAB_FLOATS];
+#if HS_SGRAD_TILE
+   // The keypoint's 40 x 40 pairs are collected here and leave as whole 16-byte items of consecutive addresses (zeros for
+   // the pixels outside the circular mask, which no thread ever writes): 100 full cache lines per keypoint instead of
+   // 8-byte pieces that start and end in the middle of lines.  The kernel is bound by this write stream (without the
+   // stores it runs in half the time).
+   __shared__ __attribute__((aligned(16))) float2 s_vo[HS_VO_PITCH];
+#endif
    const int tid = threadIdx.x;
    const uint32_t n = io.h_hi - io.h_lo;
+#if HS_SGRAD_TILE
+   for (int i = tid; i < HS_VO_PITCH; i += 256) s_vo[i] = make_float2(0.0f, 0.0f);
+#endif
    {
       const float at_init[HM_ATAN_TAB_FLOATS] = HM_ATAN_TAB_INIT;
       if (tid < HM_ATAN_TAB_FLOATS) s_at[tid] = at_init[tid];
@@ -157,8 +171,9 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
       }
 #endif
       // normalise this keypoint's pixels into LDS (helpers.cpp:269-280: ALL pixels, not only the masked ones)
+      const bool cur_norm = !((double)var < 0.0001);   // helpers.cpp:270
       if (cur_alive) {
-         const bool norm = !((double)var < 0.0001);
+         const bool norm = cur_norm;
          const float fac = 50.0f / var;
 #pragma unroll
          for (int q = 0; q < HS_PATCH_PIX_IT; q++) {
@@ -184,27 +199,82 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
       __syncthreads();
       if (cur_alive) {
          float2 *out = vo + (size_t)k * HS_VO_PITCH;
+         // ND (block-uniform): the patch was photometrically normalised.  Its pixels are then 128 + fac * (v - mean) clamped
+         // to [0, 255]: multiples of 2^-17, so gx and gy are zero or at least 2^-17 in magnitude (never denormal) and
+         // gx^2 + gy^2 is zero or at least 2^-34: the square root and the two divisions of atan2f need no range handling
+         // (hmath.h: hm_sqrt_normal, hm_atan2f_tab_nd).  A flat patch (variance below 1e-4, helpers.cpp:270) keeps its
+         // raw pixels and the general forms.
+         auto pixels = [&](auto nd_c) {
+            constexpr bool ND = decltype(nd_c)::value;
 #pragma unroll
-         for (int q = 0; q < HS_SIFT_MSK_IT; q++) {
-            if (omq[q].x >= 0) {
-               const char *sp = reinterpret_cast<const char *>(s_p);
-               const float gx = *reinterpret_cast<const float *>(sp + nbq[q].y) - *reinterpret_cast<const float *>(sp + nbq[q].x);
-               const float gy = *reinterpret_cast<const float *>(sp + nbq[q].w) - *reinterpret_cast<const float *>(sp + nbq[q].z);
-               const float grad = sqrtf(gx * gx + gy * gy);
+            for (int q = 0; q < HS_SIFT_MSK_IT; q++) {
+               if (omq[q].x >= 0) {
+                  const char *sp = reinterpret_cast<const char *>(s_p);
+                  const float gx = *reinterpret_cast<const float *>(sp + nbq[q].y) - *reinterpret_cast<const float *>(sp + nbq[q].x);
+                  const float gy = *reinterpret_cast<const float *>(sp + nbq[q].w) - *reinterpret_cast<const float *>(sp + nbq[q].z);
 #if HS_FAST
-               const float o = hm_fast_orient_coord(hm_fast_atan2f(gy, gx));
+                  const float grad = sqrtf(gx * gx + gy * gy);
+                  const float o = hm_fast_orient_coord(hm_fast_atan2f(gy, gx));
 #else
-               const float ori = hm_atan2f_tab(gy, gx, s_at);
-               const float o = hm_sift_orient_coord(ori);
+                  const float grad = ND ? hm_sqrt_normal(gx * gx + gy * gy) : sqrtf(gx * gx + gy * gy);
+                  const float ori = ND ? hm_atan2f_tab_nd(gy, gx, s_at) : hm_atan2f_tab(gy, gx, s_at);
+                  const float o = hm_sift_orient_coord(ori);
 #endif
-               out[omq[q].x] = make_float2(__int_as_float(omq[q].y) * grad, o);
+#if HS_SGRAD_TILE
+                  s_vo[omq[q].x] = make_float2(__int_as_float(omq[q].y) * grad, o);
+#elif HS_NT_VO
+                  hs_store_nt2(reinterpret_cast<float *>(out + omq[q].x), __int_as_float(omq[q].y) * grad, o);
+#else
+                  out[omq[q].x] = make_float2(__int_as_float(omq[q].y) * grad, o);
+#endif
+               }
+               // the loop is unrolled only so that the per-pixel constants are registers; do not let the scheduler
+               // interleave the iterations (five atan2 bodies in flight cost ~60 VGPRs)
+               __builtin_amdgcn_sched_barrier(0);
             }
-            // the loop is unrolled only so that the per-pixel constants are registers; do not let the scheduler
-            // interleave the iterations (five atan2 bodies in flight cost ~60 VGPRs)
-            __builtin_amdgcn_sched_barrier(0);
+         };
+#if HS_FAST
+         pixels(std::false_type{});
+#else
+         if (cur_norm) pixels(std::true_type{});
+         else pixels(std::false_type{});
+#endif
+      }
+#if HS_SGRAD_TILE
+      __syncthreads();
+      if (cur_alive) {
+         float4 *o4 = reinterpret_cast<float4 *>(vo + (size_t)k * HS_VO_PITCH);
+         const float4 *t4 = reinterpret_cast<const float4 *>(s_vo);
+#pragma unroll
+         for (int i = 0; i < (HS_VO_PITCH / 2 + 255) / 256; i++) {
+            const int e = tid + 256 * i;
+            if (e < HS_VO_PITCH / 2) {
+               const float4 v = t4[e];
+               hs_store_nt4(reinterpret_cast<float *>(o4 + e), v.x, v.y, v.z, v.w);
+            }
          }
       }
+#endif
       __syncthreads();
+   }
+}
+
+// device check (stage API): the per-pixel forms of k_sift_grad, general and range-free, on caller-supplied operands
+__global__ void k_math_sift(int n, const float *__restrict__ gy, const float *__restrict__ gx, float *__restrict__ ori_g,
+                            float *__restrict__ ori_nd, float *__restrict__ grad_g, float *__restrict__ grad_nd)
+{
+   __shared__ float s_at[HM_ATAN_TAB_FLOATS];
+   {
+      const float at_init[HM_ATAN_TAB_FLOATS] = HM_ATAN_TAB_INIT;
+      if (threadIdx.x < HM_ATAN_TAB_FLOATS) s_at[threadIdx.x] = at_init[threadIdx.x];
+   }
+   __syncthreads();
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const float y = gy[i], x = gx[i];
+      ori_g[i] = hm_atan2f(y, x);
+      ori_nd[i] = hm_atan2f_tab_nd(y, x, s_at);
+      grad_g[i] = sqrtf(x * x + y * y);
+      grad_nd[i] = hm_sqrt_normal(x * x + y * y);
    }
 }
 
@@ -271,7 +341,13 @@ __global__ __launch_bounds__(64, HS_HIST_WAVES) void k_sift_hist(SiftIO io, KpTa
          st_src[u] = st_off[u] - (kq_e > kmax ? (kq_e - kmax) * (HS_VO_PITCH / 2) : 0);
       }
       // five named registers, not an array: carried around the loop an array ends up in scratch memory
-      float4 st0 = g4[st_src[0]], st1 = g4[st_src[1]], st2 = g4[st_src[2]], st3 = g4[st_src[3]], st4 = g4[st_src[4]];
+#if HS_NT_VO_LD
+#define HS_VO_LD(p) hs_load_nt4(p)
+#else
+#define HS_VO_LD(p) (*(p))
+#endif
+      float4 st0 = HS_VO_LD(g4 + st_src[0]), st1 = HS_VO_LD(g4 + st_src[1]), st2 = HS_VO_LD(g4 + st_src[2]), st3 = HS_VO_LD(g4 + st_src[3]),
+             st4 = HS_VO_LD(g4 + st_src[4]);
 #pragma unroll 1
       for (int i = 0; i < 16; i++) {
          HS_WAVE_LDS_SYNC();   // every lane has taken step i - 1's items
@@ -281,7 +357,8 @@ __global__ __launch_bounds__(64, HS_HIST_WAVES) void k_sift_hist(SiftIO io, KpTa
          // re-reads its own rows)
          {
             const float4 *gi = g4 + min(i + 1, 15) * (HS_VO_DIM / 2);
-            st0 = gi[st_src[0]]; st1 = gi[st_src[1]]; st2 = gi[st_src[2]]; st3 = gi[st_src[3]]; st4 = gi[st_src[4]];
+            st0 = HS_VO_LD(gi + st_src[0]); st1 = HS_VO_LD(gi + st_src[1]); st2 = HS_VO_LD(gi + st_src[2]); st3 = HS_VO_LD(gi + st_src[3]);
+            st4 = HS_VO_LD(gi + st_src[4]);
          }
          if (valid) {
             float4 cur[8];

@@ -194,6 +194,11 @@ int hesaff_stage_normalize_affine(hesaff_ctx *ctx, const float *img, int rows, i
 int hesaff_stage_sift(hesaff_ctx *ctx, int n, const float *patches, uint8_t *desc);
 /* device evaluation of the pinned libm restatements (hmath.h) for testing */
 int hesaff_stage_math(hesaff_ctx *ctx, int n, const float *a, const float *b, float *atan2_out, float *pow2_out);
+/* the per-pixel forms of the descriptor gradient (helpers.cpp:269-280, siftdesc.cpp:123-137): orientation atan2f(gy, gx) and
+ * magnitude sqrt(gx^2 + gy^2), each in the general form and in the form without range handling that the kernel uses on
+ * photometrically normalised patches (operands zero or normal); for testing that the two agree bit for bit */
+int hesaff_stage_math_sift(hesaff_ctx *ctx, int n, const float *gy, const float *gx, float *ori_general, float *ori_nd,
+                           float *grad_general, float *grad_nd);
 
 /* Host-side tables the kernels use (for known-answer tests): computeGaussMask
  * helpers.cpp:104, computeCircularGaussMask helpers.cpp:131, precomputeBinsAndWeights

@@ -45,6 +45,35 @@ def test_device_math_matches_libm(ctx, oracle):
     assert_bit_equal(pw, refp, "powf(2,.)")
 
 
+def test_range_free_gradient_forms_equal_the_general_ones(ctx):
+    """k_sift_grad evaluates sqrt and atan2f without the range handling of the compiler's division / square root when
+    the patch was photometrically normalised: pixels are then multiples of 2^-17 in [0, 255] and their differences zero
+    or normal.  On that domain the short forms must return the general forms' bits (the general atan2f is pinned to libm
+    in test_device_math_matches_libm)."""
+    rng = np.random.default_rng(11)
+    n = 1 << 24
+    q = np.float32(2.0 ** -17)
+
+    def pix(m):   # pixel values as the kernel produces them: multiples of 2^-17 in [0, 255], many clamped or nearly equal
+        kind = rng.integers(0, 4, m)
+        v = rng.integers(0, 255 * 2 ** 17 + 1, m).astype(np.float64) * 2.0 ** -17
+        v = np.where(kind == 0, np.round(v), v)                       # integers
+        v = np.where(kind == 1, np.minimum(v, 2.0 ** -17 * rng.integers(0, 64, m)), v)   # near the lower clamp
+        return v.astype(np.float32)
+    a, b, c2, d = pix(n), pix(n), pix(n), pix(n)
+    near = rng.random(n) < 0.3
+    b = np.where(near, a + q * rng.integers(-3, 4, n).astype(np.float32), b)     # gradients of a few quanta
+    b = np.clip(b, 0, 255).astype(np.float32)
+    gx = (b - a).astype(np.float32); gy = (d - c2).astype(np.float32)
+    gx[:4096] = 0; gy[2048:6144] = 0                                              # zero operands, both zero
+    gx[6144:8192] = q; gy[8192:10240] = np.float32(255.0)                         # extreme quotients
+    nz = np.concatenate([gx[gx != 0], gy[gy != 0]])
+    assert np.all(np.abs(nz) >= q)                                                # the domain claimed in the kernel
+    og, on, gg, gn = ctx.math_sift(gy, gx)
+    assert_bit_equal(on, og, "atan2f without range handling")
+    assert_bit_equal(gn, gg, "sqrt without range handling")
+
+
 @pytest.mark.parametrize("shape", [(61, 83), (128, 200), (7, 9), (33, 600)])
 @pytest.mark.parametrize("sigma", [0.62, 0.7, 0.9, 1.2262737, 1.5198685, 2.4525473, 4.3])
 def test_gaussian_blur(ctx, oracle, shape, sigma):
