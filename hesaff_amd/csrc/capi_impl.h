@@ -621,6 +621,26 @@ int hesaff_stage_math(hesaff_ctx *c, int n, const float *a, const float *b, floa
    HS_API_END(c)
 }
 
+int hesaff_stage_math_sift(hesaff_ctx *c, int n, const float *gy, const float *gx, float *ori_general, float *ori_nd, float *grad_general,
+                           float *grad_nd)
+{
+   if (!c || !gy || !gx || !ori_general || !ori_nd || !grad_general || !grad_nd || n < 0) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   bind_device(c);
+   if (n == 0) return HESAFF_OK;
+   c->b_stage.ensure((size_t)n * 24);
+   float *d = c->b_stage.as<float>();
+   HIP_TRY(hipMemcpyAsync(d, gy, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(hipMemcpyAsync(d + n, gx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+   hipLaunchKernelGGL(k_math_sift, dim3(std::min(4096, (n + 255) / 256)), dim3(256), 0, c->stream, n, (const float *)d, (const float *)(d + n),
+                      d + 2 * (size_t)n, d + 3 * (size_t)n, d + 4 * (size_t)n, d + 5 * (size_t)n);
+   float *outs[4] = {ori_general, ori_nd, grad_general, grad_nd};
+   for (int q = 0; q < 4; q++) HIP_TRY(hipMemcpyAsync(outs[q], d + (2 + q) * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipStreamSynchronize(c->stream));
+   HIP_TRY(hipGetLastError());
+   HS_API_END(c)
+}
+
 // ---------------------------------- host tables ----------------------------------
 
 int hesaff_table_gauss_mask(int size, float *mask)

@@ -91,6 +91,9 @@ __device__ __forceinline__ float4 hs_load_nt4(const float4 *p)
 #ifndef HS_NT_EXT
 #define HS_NT_EXT 0       // k_extrema_march's reads of the five response planes
 #endif
+#ifndef HS_NT_SGRAD_LD
+#define HS_NT_SGRAD_LD 0  // k_sift_grad's reads of the patch (its last reader)
+#endif
 #ifndef HS_NT_MEANVAR
 #define HS_NT_MEANVAR 0   // k_sift_meanvar's patch reads (1: second pass: no change; 2: both passes: 9.8 -> 11.8 ms)
 #endif

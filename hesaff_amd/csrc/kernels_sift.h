@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
    {
       const float *gp = io.patches + (size_t)k * HS_PATCH_PIX;
 #pragma unroll
-      for (int q = 0; q < HS_PATCH_PIX_IT; q++) pv[q] = gp[min(tid + 256 * q, HS_PATCH_PIX - 1)];
+      for (int q = 0; q < HS_PATCH_PIX_IT; q++) pv[q] = HS_NT_SGRAD_LD ? hs_load_nt(gp + min(tid + 256 * q, HS_PATCH_PIX - 1)) : gp[min(tid + 256 * q, HS_PATCH_PIX - 1)];
    }
    for (; k < n; k += gridDim.x) {
       const bool cur_alive = alive != 0;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
 #endif
          const float *gp = io.patches + (size_t)kn * HS_PATCH_PIX;
 #pragma unroll
-         for (int q = 0; q < HS_PATCH_PIX_IT; q++) pv[q] = gp[min(tid + 256 * q, HS_PATCH_PIX - 1)];
+         for (int q = 0; q < HS_PATCH_PIX_IT; q++) pv[q] = HS_NT_SGRAD_LD ? hs_load_nt(gp + min(tid + 256 * q, HS_PATCH_PIX - 1)) : gp[min(tid + 256 * q, HS_PATCH_PIX - 1)];
       }
       __syncthreads();
       if (cur_alive) {
