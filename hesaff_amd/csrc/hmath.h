@@ -11,8 +11,9 @@
 //   hm_atan2f  : fdlibm e_atan2f.c / s_atanf.c (Sun Microsystems 1993), float-only ops.
 //   hm_pow2f   : powf(2.0f, y) of glibc >= 2.28 (Szabolcs Nagy, ARM optimized-routines
 //                exp2f table method, EXP2F_TABLE_BITS = 5), non-FMA evaluation.
-// tests/test_hmath.py checks both against this image's libm on tens of millions of
-// inputs (host build), and tests/test_gpu_hmath.py checks device == host.
+// tests/test_host_side.py (test_hmath_restatements_equal_glibc) checks both against this image's libm on a host
+// build; tests/test_gpu_parity.py checks device == libm (test_device_math_matches_libm) and the kernel's range-free
+// forms == the general ones (test_range_free_gradient_forms_equal_the_general_ones).
 #pragma once
 #include <stdint.h>
 
