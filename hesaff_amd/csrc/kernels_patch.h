@@ -753,6 +753,9 @@ __device__ __forceinline__ void hs_row_stream3(const HsPlaneBuf &img, float x, f
 #define HS_BIG_TAPS 128   // K <= 113 for P <= 512
 #define HS_MID_RPAD 14    // K / 2 for P <= 128
 #define HS_BIG_RPAD 57    // K / 2 for P <= 512
+#ifndef HS_CHUNK_MIN_ROWS
+#define HS_CHUNK_MIN_ROWS 4   // measured 1 / 4 / 7 / 13: 15.4 / 15.0 / 15.5 / 16.4 ms (bin 3, 32 UHD images)
+#endif
 #ifndef HS_MID_NIT3_BIG
 #define HS_MID_NIT3_BIG 2
 #endif
@@ -830,9 +833,11 @@ __global__ __launch_bounds__(256, HS_MID_WAVES) void k_patch_mid(HessList hl, Pa
                                Tp + (size_t)(yy + (K >> 1)) * HS_NEED, K >> 1);
       }
       __syncthreads();   // workgroup-scope release/acquire: the T' rows of all four waves are visible
-      if (K + 2 <= GM::CHUNK_ROWS)
+      // staged column pass when a round holds at least HS_CHUNK_MIN_ROWS output rows (a round of one or two rows leaves
+      // most of the block's threads idle: 41 outputs per row); otherwise straight from the slot
+      if ((float)(K + 1) + (float)(HS_CHUNK_MIN_ROWS - 1) * scale <= (float)GM::CHUNK_ROWS)
          hs_resample_chunked(Tp + (K >> 1) * HS_NEED, P, scale, s_taps, K >> 1, s_srow, GM::CHUNK_ROWS, s_patch);
-      else   // the widest windows of bin 3 (K > 91): a single output row's window of rows does not fit
+      else
          hs_resample_reduced_batched<true>(Tp + (K >> 1) * HS_NEED, P, scale, s_taps, K >> 1, s_patch);
       __syncthreads();
       for (int i = tid; i < HS_PATCH_PIX; i += 256) {

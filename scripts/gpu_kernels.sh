@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/ks_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export HESAFF_AMD_LIB=$LIB HESAFF_OVERLAP=0
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --batch $BATCH --no-cpu-baseline --no-host-path > $OUT/bench.json 2> $OUT/log.txt
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --batch $BATCH --no-cpu-baseline --no-host-path $BENCH_EXTRA > $OUT/bench.json 2> $OUT/log.txt
 cd $GRAFT_REPO_ROOT
 python3 - $OUT $BATCH <<'PY'
 import csv, sys, glob, json
