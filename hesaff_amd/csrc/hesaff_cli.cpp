@@ -1,6 +1,6 @@
 // hesaff_cli.cpp -- `hesaff <image>` : same command line, stdout line and output file as
 // the reference's main() (hesaff.cpp:133-180); the work runs on the MI355X through
-// libhesaff_amd.so.  Input: binary PGM/PPM (P5/P6), PNG or baseline JPEG.
+// libhesaff_amd.so.  Input: binary PGM/PPM (P5/P6), PNG or JPEG.
 //
 // Extensions (the reference has no flags; it would try to open a file called "--batch"):
 //   hesaff --batch <list file> [--devices <spec>]
@@ -96,7 +96,7 @@ int run_batch_mode(const char *list_path, const char *devices_spec)
    for (int i = 0; i < n_all; i++) {
       if (imgs[i].ok) good.push_back(i);
       else {
-         fprintf(stderr, "hesaff: cannot read '%s' (binary PGM/PPM with maxval 255, PNG or baseline JPEG expected): skipped\n", names[i].c_str());
+         fprintf(stderr, "hesaff: cannot read '%s' (binary PGM/PPM with maxval 255, PNG or JPEG expected): skipped\n", names[i].c_str());
          rc = 1;
       }
    }
@@ -187,7 +187,7 @@ int main(int argc, char **argv)
       uint8_t *data = nullptr;
       int w = 0, h = 0, ch = 0;
       if (hesaff_read_image(argv[1], &data, &w, &h, &ch) != HESAFF_OK) {
-         fprintf(stderr, "hesaff: cannot read '%s' (binary PGM/PPM with maxval 255, PNG or baseline JPEG expected)\n", argv[1]);
+         fprintf(stderr, "hesaff: cannot read '%s' (binary PGM/PPM with maxval 255, PNG or JPEG expected)\n", argv[1]);
          return 1;
       }
       try {

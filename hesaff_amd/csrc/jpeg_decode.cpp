@@ -12,8 +12,10 @@
 //   * YCbCr -> RGB                  -> jdcolor.c fixed-point tables (SCALEBITS 16), JFIF convention;
 //   * range limiting to 0..255 after the IDCT (+128 level shift) and after the colour conversion.
 // tests/test_host_side.py compares every pixel with the libjpeg-turbo decoder bundled with Pillow on 4:4:4,
-// 4:2:2, 4:2:0, 4:4:0, 4:1:1, grey, odd sizes, restart intervals and several qualities.
-// Not decoded (HESAFF_ERR_IO): progressive / lossless / arithmetic-coded / 12-bit / CMYK files.
+// 4:2:2, 4:2:0, 4:4:0, 4:1:1, grey, odd sizes, restart intervals, several qualities, sequential and progressive.
+// Progressive files (SOF2: spectral selection + successive approximation, jdphuff.c) are collected scan by scan into
+// coefficient arrays and transformed once at the end; a COMPLETE file gets no inter-block smoothing in libjpeg, so the
+// pixels are again identical.  Not decoded (HESAFF_ERR_IO): lossless / arithmetic-coded / 12-bit / CMYK files.
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -192,6 +194,7 @@ struct Comp {
    int bw = 0, bh = 0;            // blocks allocated (multiple of the sampling factors: full MCUs)
    int pred = 0;
    std::vector<uint8_t> plane;    // bw*8 x bh*8 samples
+   std::vector<int16_t> coef;     // progressive: bw x bh blocks of 64 coefficients (natural order), filled scan by scan
 };
 
 inline uint16_t be16(const uint8_t *p) { return (uint16_t)((p[0] << 8) | p[1]); }
@@ -292,7 +295,7 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
    Huff hdc[4], hac[4];
    std::vector<Comp> comps;
    int W = 0, H = 0, hmax = 1, vmax = 1, restart = 0;
-   bool have_sof = false, adobe = false, done = false;
+   bool have_sof = false, adobe = false, done = false, progressive = false;
    int adobe_transform = 0;
    size_t pos = 2;
    while (!done) {
@@ -339,8 +342,9 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
             }
             break;
          }
-         case 0xC0: case 0xC1: {   // SOF0 baseline / SOF1 extended sequential (Huffman)
+         case 0xC0: case 0xC1: case 0xC2: {   // SOF0 baseline / SOF1 extended sequential / SOF2 progressive (all Huffman)
             if (have_sof || sl < 6) return HESAFF_ERR_IO;
+            progressive = m == 0xC2;
             if (seg[0] != 8) return HESAFF_ERR_IO;          // sample precision
             H = be16(&seg[1]); W = be16(&seg[3]);
             const int nc = seg[5];
@@ -357,14 +361,17 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
                c.w = (W * c.h + hmax - 1) / hmax; c.hgt = (H * c.v + vmax - 1) / vmax;
                c.bw = mcux * c.h; c.bh = mcuy * c.v;
                // a file cannot hold more coefficient blocks than bytes: refuse absurd headers before allocating
-               if ((unsigned long long)c.bw * c.bh > (unsigned long long)n * 64ull + 4096ull) return HESAFF_ERR_IO;
+               // (a progressive file can describe long runs of empty blocks in a few bits: there only the size is bounded)
+               if (!progressive && (unsigned long long)c.bw * c.bh > (unsigned long long)n * 64ull + 4096ull) return HESAFF_ERR_IO;
+               if (progressive && (unsigned long long)c.bw * c.bh > (1ull << 22)) return HESAFF_ERR_IO;   // 2^28 coefficients
                c.plane.assign((size_t)c.bw * 8 * c.bh * 8, 0);
+               if (progressive) c.coef.assign((size_t)c.bw * c.bh * 64, 0);
             }
             have_sof = true;
             break;
          }
-         case 0xC2: case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
-            return HESAFF_ERR_IO;   // progressive, lossless, differential, arithmetic: not decoded
+         case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
+            return HESAFF_ERR_IO;   // lossless, differential, arithmetic: not decoded
          case 0xDD: if (sl < 2) return HESAFF_ERR_IO; restart = be16(seg); break;
          case 0xEE:   // APP14 "Adobe": colour transform flag
             if (sl >= 12 && memcmp(seg, "Adobe", 5) == 0) { adobe = true; adobe_transform = seg[11]; }
@@ -379,12 +386,110 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
                for (Comp &q : comps) if (q.id == seg[1 + 2 * i]) c = &q;
                if (!c) return HESAFF_ERR_IO;
                c->td = seg[2 + 2 * i] >> 4; c->ta = seg[2 + 2 * i] & 15;
-               if (c->td > 3 || c->ta > 3 || !hdc[c->td].defined || !hac[c->ta].defined || !qt_def[c->tq]) return HESAFF_ERR_IO;
+               if (c->td > 3 || c->ta > 3 || !qt_def[c->tq]) return HESAFF_ERR_IO;
+               if (!progressive && (!hdc[c->td].defined || !hac[c->ta].defined)) return HESAFF_ERR_IO;
                c->pred = 0;
                sc.push_back(c);
             }
             BitReader br;
             br.p = &f[pos + len]; br.end = f.data() + n;
+            if (progressive) {
+               // jdphuff.c: one scan = one band of coefficients (Ss..Se) at one precision step (Ah -> Al)
+               const int Ss = seg[1 + 2 * ns], Se = seg[2 + 2 * ns], Ah = seg[3 + 2 * ns] >> 4, Al = seg[3 + 2 * ns] & 15;
+               if (Ss > Se || Se > 63 || Al > 13 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || (Ah != 0 && Ah != Al + 1)) return HESAFF_ERR_IO;
+               for (Comp *c : sc)
+                  if (Ss == 0 ? !hdc[c->td].defined && Ah == 0 : !hac[c->ta].defined) return HESAFF_ERR_IO;
+               int mx, my;
+               const bool inter = ns > 1;
+               if (inter) { mx = (W + 8 * hmax - 1) / (8 * hmax); my = (H + 8 * vmax - 1) / (8 * vmax); }
+               else { mx = (sc[0]->w + 7) / 8; my = (sc[0]->hgt + 7) / 8; }
+               int to_go = restart;
+               unsigned eobrun = 0;
+               const int p1 = 1 << Al, m1 = -(1 << Al);
+               for (int mcu = 0; mcu < mx * my; mcu++) {
+                  if (restart && to_go == 0) {
+                     br.reset();
+                     const uint8_t *q = br.p;
+                     while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
+                     if (q + 1 < br.end) br.p = q + 2;
+                     for (Comp *c : sc) c->pred = 0;
+                     eobrun = 0;
+                     to_go = restart;
+                  }
+                  const int mr = mcu / mx, mc = mcu % mx;
+                  for (Comp *c : sc) {
+                     const int nbh = inter ? c->h : 1, nbv = inter ? c->v : 1;
+                     for (int by = 0; by < nbv; by++)
+                        for (int bx = 0; bx < nbh; bx++) {
+                           const int bxx = mc * nbh + bx, byy = mr * nbv + by;
+                           int16_t dummy[64];
+                           int16_t *blk = (bxx < c->bw && byy < c->bh) ? &c->coef[((size_t)byy * c->bw + bxx) * 64] : dummy;
+                           if (blk == dummy) memset(dummy, 0, sizeof dummy);
+                           if (Ss == 0) {
+                              if (Ah == 0) {   // DC, first pass: the difference coding of the sequential mode, value scaled by 2^Al
+                                 const int t = decode_huff(br, hdc[c->td]);
+                                 const int diff = t ? extend(br.get(t), t) : 0;
+                                 c->pred = (int)((unsigned)c->pred + (unsigned)diff);
+                                 blk[0] = (int16_t)((unsigned)c->pred << Al);
+                              } else if (br.get(1)) blk[0] = (int16_t)(blk[0] | p1);   // DC refinement: one more bit
+                           } else if (Ah == 0) {   // AC, first pass (decode_mcu_AC_first)
+                              if (eobrun > 0) { eobrun--; continue; }
+                              for (int k = Ss; k <= Se; k++) {
+                                 const int rs = decode_huff(br, hac[c->ta]);
+                                 const int r = rs >> 4, sz = rs & 15;
+                                 if (sz) {
+                                    k += r;
+                                    if (k > 63) break;
+                                    blk[kZigZag[k]] = (int16_t)((unsigned)extend(br.get(sz), sz) << Al);
+                                 } else if (r == 15) k += 15;   // ZRL: sixteen zeros
+                                 else {                          // EOBr: this band ends here for 2^r + extra blocks
+                                    eobrun = 1u << r;
+                                    if (r) eobrun += (unsigned)br.get(r);
+                                    eobrun--;
+                                    break;
+                                 }
+                              }
+                           } else {   // AC refinement (decode_mcu_AC_refine): one more bit for every coefficient already non-zero,
+                                      // newly non-zero coefficients (+-2^Al) placed after runs of still-zero ones
+                              int k = Ss;
+                              if (eobrun == 0) {
+                                 for (; k <= Se; k++) {
+                                    const int rs = decode_huff(br, hac[c->ta]);
+                                    int r = rs >> 4;
+                                    const int sz = rs & 15;
+                                    int val = 0;
+                                    if (sz) val = br.get(1) ? p1 : m1;   // size is 1 in a legal stream
+                                    else if (r != 15) {
+                                       eobrun = 1u << r;
+                                       if (r) eobrun += (unsigned)br.get(r);
+                                       break;   // the rest of the block is handled as part of the run
+                                    }
+                                    // advance over already non-zero coefficients (refining each) and r still-zero ones
+                                    for (; k <= Se; k++) {
+                                       int16_t *cp = blk + kZigZag[k];
+                                       if (*cp != 0) {
+                                          if (br.get(1) && (*cp & p1) == 0) *cp = (int16_t)(*cp + (*cp >= 0 ? p1 : m1));
+                                       } else if (--r < 0) break;
+                                    }
+                                    if (val && k <= 63) blk[kZigZag[k]] = (int16_t)val;
+                                 }
+                              }
+                              if (eobrun > 0) {
+                                 for (; k <= Se; k++) {
+                                    int16_t *cp = blk + kZigZag[k];
+                                    if (*cp != 0 && br.get(1) && (*cp & p1) == 0) *cp = (int16_t)(*cp + (*cp >= 0 ? p1 : m1));
+                                 }
+                                 eobrun--;
+                              }
+                           }
+                        }
+                  }
+                  if (restart) to_go--;
+               }
+               pos = (size_t)(br.p - f.data());
+               if (pos > n) pos = n;
+               continue;
+            }
             // MCU geometry: interleaved scan = MCUs of h x v blocks per component; a single-component scan runs over that
             // component's own blocks, ceil(size / 8) per row and column (A.2.3)
             int mx, my;
@@ -443,6 +548,13 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
       pos += (size_t)len;
    }
    if (!have_sof) return HESAFF_ERR_IO;
+   if (progressive)   // all scans are in: one IDCT per block (a complete file gets no inter-block smoothing in libjpeg either)
+      for (Comp &c : comps) {
+         if (!qt_def[c.tq]) return HESAFF_ERR_IO;
+         for (int byy = 0; byy < c.bh; byy++)
+            for (int bxx = 0; bxx < c.bw; bxx++)
+               idct_islow(&c.coef[((size_t)byy * c.bw + bxx) * 64], qt[c.tq], &c.plane[((size_t)byy * 8) * ((size_t)c.bw * 8) + (size_t)bxx * 8], c.bw * 8);
+      }
    const int nc = (int)comps.size();
    uint8_t *out = (uint8_t *)malloc((size_t)W * H * (nc == 1 ? 1 : 3));
    if (!out) return HESAFF_ERR_NOMEM;

@@ -149,10 +149,10 @@ int hesaff_read_pnm(const char *path, uint8_t **data, int *width, int *height, i
  * channel, alpha dropped, 16-bit samples reduced to the high byte, palette / 1-2-4-bit grey expanded;
  * channels = 1 for grey files, 3 (R,G,B order) otherwise.  Interlaced files: HESAFF_ERR_IO. */
 int hesaff_read_png(const char *path, uint8_t **data, int *width, int *height, int *channels);
-/* baseline (sequential Huffman, 8-bit, grey or YCbCr) JPEG: the integer algorithms of libjpeg at cv::imread's settings
- * (JDCT_ISLOW inverse DCT, "fancy" chroma up-sampling, JFIF colour conversion), pixel for pixel the bytes libjpeg /
- * libjpeg-turbo return; channels = 1 for grey files, 3 (R,G,B order) otherwise.  Progressive, arithmetic-coded,
- * 12-bit and CMYK files: HESAFF_ERR_IO. */
+/* Huffman-coded 8-bit JPEG, sequential or progressive, grey or YCbCr: the integer algorithms of libjpeg at
+ * cv::imread's settings (JDCT_ISLOW inverse DCT, "fancy" chroma up-sampling, JFIF colour conversion), pixel for pixel
+ * the bytes libjpeg / libjpeg-turbo return for a complete file; channels = 1 for grey files, 3 (R,G,B order)
+ * otherwise.  Arithmetic-coded, lossless, 12-bit and CMYK files: HESAFF_ERR_IO. */
 int hesaff_read_jpeg(const char *path, uint8_t **data, int *width, int *height, int *channels);
 /* PGM/PPM, PNG or JPEG by magic number */
 int hesaff_read_image(const char *path, uint8_t **data, int *width, int *height, int *channels);

@@ -274,7 +274,7 @@ def test_read_png_matches_imread_semantics(tmp_path):
 # ------------------------------------------------------------------------------------------
 # JPEG: hesaff_read_jpeg restates libjpeg's integer algorithms at cv::imread's settings
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["jpeg_gray_q90", "jpeg_420_q85", "jpeg_422_q70_rst"])
+@pytest.mark.parametrize("name", ["jpeg_gray_q90", "jpeg_420_q85", "jpeg_422_q70_rst", "jpeg_prog_420_q80", "jpeg_prog_gray_q60"])
 def test_read_jpeg_golden_pixels(name):
     """Committed JPEG files and the pixels libjpeg-turbo (Pillow 12.2) decoded them to when the fixtures were made."""
     import hesaff_amd
@@ -285,7 +285,8 @@ def test_read_jpeg_golden_pixels(name):
 
 def test_read_jpeg_equals_libjpeg_on_many_encodings(tmp_path):
     """Every pixel equals libjpeg-turbo's (through Pillow, when installed): JDCT_ISLOW, fancy up-sampling, JFIF colour
-    conversion -- 4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1, grey; odd sizes down to 1x1; restart intervals; optimised tables."""
+    conversion -- 4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1, grey; odd sizes down to 1x1; restart intervals; optimised tables;
+    sequential and progressive (spectral selection + successive approximation, libjpeg's default scan script)."""
     Image = pytest.importorskip("PIL.Image")
     import io
     import hesaff_amd
@@ -301,7 +302,8 @@ def test_read_jpeg_equals_libjpeg_on_many_encodings(tmp_path):
     p = str(tmp_path / "t.jpg")
     for (h, w) in [(64, 64), (61, 83), (7, 9), (1, 1), (17, 3), (120, 211), (33, 2)]:
         for sub in [0, 1, 2, "4:4:0", "4:1:1", "gray"]:
-            for q, extra in [(30, {}), (75, {"restart_marker_blocks": 3}), (95, {"optimize": True}), (100, {})]:
+            for q, extra in [(30, {}), (75, {"restart_marker_blocks": 3}), (95, {"optimize": True}), (100, {}),
+                             (30, {"progressive": True}), (85, {"progressive": True, "restart_marker_blocks": 2}), (100, {"progressive": True})]:
                 im = Image.fromarray(synth(h, w, sub != "gray"))
                 kw = dict(quality=q, **extra)
                 if sub != "gray":
@@ -316,11 +318,7 @@ def test_read_jpeg_equals_libjpeg_on_many_encodings(tmp_path):
                 got = hesaff_amd.read_image(p)
                 assert got.shape == ref.shape and np.array_equal(got, ref), (h, w, sub, q, extra)
                 n += 1
-    assert n > 100
-    # progressive files are refused, not mis-decoded
-    Image.fromarray(synth(40, 40, True)).save(p, "JPEG", progressive=True)
-    with pytest.raises(hesaff_amd.HesaffError):
-        hesaff_amd.read_image(p)
+    assert n > 200
     # truncated / corrupt files: an error or an image, never a crash
     raw = open(os.path.join(GOLD, "jpeg_420_q85.jpg"), "rb").read()
     for cut in (2, 20, 200, len(raw) // 2, len(raw) - 3):
