@@ -109,7 +109,7 @@ def main():
                     help="synthetic image family: dense = the headline workload (about 14 k descriptors per Mpx), natural = about 2.5 k per Mpx (photograph-like)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-inclusive and text-export legs")
-    ap.add_argument("--host-chunk", type=int, default=32, help="images per pipelined chunk of the host path (hesaff_params.max_batch)")
+    ap.add_argument("--host-chunk", type=int, default=64, help="images per pipelined chunk of the host path (hesaff_params.max_batch)")
     ap.add_argument("--export-images", type=int, default=32, help="images of the batch written as .hesaff.sift text (RAM disk)")
     ap.add_argument("--cpu-images", type=int, default=2, help="images of the batch timed on the CPU oracle, 1 thread (about 14 s each)")
     ap.add_argument("--cpu-workers", type=int, default=-1,

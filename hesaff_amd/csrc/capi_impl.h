@@ -74,7 +74,7 @@ int hesaff_default_params(hesaff_params *p)
    p->mrSize = 3.0f * sqrtf(3.0f);
    p->maxBinValue = 0.2f;
    p->upscaleInputImage = 0;
-   p->max_batch = 16;
+   p->max_batch = 64;
    p->max_kpts_per_mpx = 40000;
    p->fast = 0;
    return HESAFF_OK;

@@ -43,7 +43,7 @@ typedef struct hesaff_params {
    float maxBinValue;          /* 0.2   siftdesc.h:29                 */
    int upscaleInputImage;      /* 0     pyramid.h:34 (1: first octave on the 2x up-sampled image, helpers.cpp:297-329) */
    /* capacity knobs (no reference counterpart) */
-   int max_batch;              /* images processed together on the device (default 16) */
+   int max_batch;              /* images processed together on the device (default 64; hesaff_detect_batch pipelines chunks of this size) */
    int max_kpts_per_mpx;       /* candidate/keypoint capacity per megapixel (default 40000) */
    /* 0 (default): parity mode, results bit-identical to the reference's arithmetic.
     * 1: fast mode: contracted multiply-adds, reassociated sums and approximate
