@@ -81,6 +81,9 @@ __device__ inline bool hs_window_outside(int imRows, int imCols, float ofsx, flo
 }
 
 #define HS_AFF_NT 23    // ceil(361 / 16)
+#ifndef HS_AFF_XCD
+#define HS_AFF_XCD 1
+#endif
 #ifndef HS_AFF_BATCHES
 #define HS_AFF_BATCHES 2
 #endif
@@ -98,10 +101,23 @@ __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, con
    const int lane = threadIdx.x, grp = lane >> 4, li = lane & 15;
    for (int i = lane; i < HS_SMM_PIX; i += 64) s_mask[i] = mask_g[i];
    float *s_img = s_arr[grp][0], *s_pa = s_arr[grp][0], *s_pb = s_arr[grp][1], *s_pc = s_arr[grp][2];   // the a terms replace the image
-   const uint32_t hstep = gridDim.x * HS_AFF_G;
+   // XCD-aware order: block b runs on XCD b % 8 (observed dispatch order, a speed assumption only).  The keypoints are
+   // ordered by image, octave, level and raster position, so neighbours in the list sample the same cache lines of the
+   // same plane: each XCD takes one contiguous eighth of the list, its blocks stride inside that eighth, and those lines
+   // are fetched into ONE private L2 instead of eight.  (Grids that are not a multiple of 8 blocks keep the plain stride.)
+   uint32_t hstep = gridDim.x * HS_AFF_G, h_end = n;
    uint32_t h = first + blockIdx.x * HS_AFF_G + grp;
+   if (HS_AFF_XCD && (gridDim.x & 7u) == 0u && n > first) {
+      const uint32_t n_items = (n - first + HS_AFF_G - 1) / HS_AFF_G;   // groups of HS_AFF_G keypoints
+      const uint32_t xcd = blockIdx.x & 7u, rank = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+      const uint32_t it_lo = (uint32_t)(((unsigned long long)n_items * xcd) >> 3), it_hi = (uint32_t)(((unsigned long long)n_items * (xcd + 1)) >> 3);
+      hstep = per_xcd * HS_AFF_G;
+      h_end = min(first + it_hi * HS_AFF_G, n);
+      h = first + (it_lo + rank) * HS_AFF_G + grp;
+   }
+#define HS_AFF_END h_end
    if (k.maxIterations <= 0) {   // no iteration: U = identity, not converged
-      for (; h < n; h += hstep)
+      for (; h < HS_AFF_END; h += hstep)
          if (li == 0) {
             out.converged[h] = 0; out.iters[h] = 0;
             out.U[4 * h + 0] = 1.0f; out.U[4 * h + 1] = 0.0f; out.U[4 * h + 2] = 0.0f; out.U[4 * h + 3] = 1.0f;
@@ -113,7 +129,7 @@ __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, con
    int pitch = 0, width = 0, height = 0, l = 0;
    float lx = 0, ly = 0, ratio = 0, u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f;
    float eigen_ratio_act = 0.0f, eigen_ratio_bef = 0.0f;   // used by lane li == 0
-   bool active = h < n;
+   bool active = h < HS_AFF_END;
    auto load_kp = [&]() {
       if (active) {
          const AffKp q = fetch(h);
@@ -248,7 +264,7 @@ __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, con
                out.U[4 * h + 0] = u11; out.U[4 * h + 1] = u12; out.U[4 * h + 2] = u21; out.U[4 * h + 3] = u22;
             }
             h += hstep;
-            active = h < n;
+            active = h < HS_AFF_END;
             load_kp();
          } else {
             l++;
