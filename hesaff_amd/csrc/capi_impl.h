@@ -114,9 +114,10 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       }
       HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
       HIP_TRY(hipStreamCreateWithFlags(&c->sift_stream, hipStreamNonBlocking));
+      HIP_TRY(hipStreamCreateWithFlags(&c->sift_stream2, hipStreamNonBlocking));
       HIP_TRY(hipStreamCreateWithFlags(&c->aff_stream, hipStreamNonBlocking));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_detect_done, hipEventDisableTiming));
-      for (int i = 0; i < 2; i++) {
+      for (int i = 0; i < HS_NSLOT; i++) {
          HIP_TRY(hipEventCreateWithFlags(&c->ev_extract_done[i], hipEventDisableTiming));
          HIP_TRY(hipEventCreateWithFlags(&c->ev_sift_done[i], hipEventDisableTiming));
       }
@@ -133,6 +134,7 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       if (const char *wv = getenv("HESAFF_BANDS")) c->force_bands = std::max(0, atoi(wv));
       c->debug = getenv("HESAFF_DEBUG") != nullptr;
       if (const char *sg = getenv("HESAFF_SGRAD_GRID")) c->sgrad_grid = (uint32_t)std::max(0, atoi(sg));
+      if (const char *s2 = getenv("HESAFF_SIFT2")) c->sift2 = atoi(s2) != 0;
 #endif
    } catch (const HsError &e) {
       hesaff_destroy(c);
@@ -163,10 +165,11 @@ void hesaff_destroy(hesaff_ctx *c)
    }
    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
    if (c->sift_stream) { (void)hipStreamSynchronize(c->sift_stream); (void)hipStreamDestroy(c->sift_stream); }
+   if (c->sift_stream2) { (void)hipStreamSynchronize(c->sift_stream2); (void)hipStreamDestroy(c->sift_stream2); }
    if (c->aff_stream) { (void)hipStreamSynchronize(c->aff_stream); (void)hipStreamDestroy(c->aff_stream); }
    if (c->ev_detect_done) (void)hipEventDestroy(c->ev_detect_done);
    for (hipEvent_t e : c->ev_aff) (void)hipEventDestroy(e);
-   for (int i = 0; i < 2; i++) {
+   for (int i = 0; i < HS_NSLOT; i++) {
       if (c->ev_extract_done[i]) (void)hipEventDestroy(c->ev_extract_done[i]);
       if (c->ev_sift_done[i]) (void)hipEventDestroy(c->ev_sift_done[i]);
       c->b_patches2[i].release(); c->b_siftvec2[i].release(); c->b_meanvar2[i].release(); c->b_siftvo2[i].release();

@@ -124,6 +124,7 @@ struct OctGeom {
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 #define HS_NSIDE 4   // side streams of the patch stage (one per window-size bin 0..3)
+#define HS_NSLOT 3   // patch / descriptor buffer slots of the group pipeline
 struct hesaff_ctx {
    hesaff_params par;
    int device = 0;
@@ -190,12 +191,13 @@ struct hesaff_ctx {
    hesaff_timings tm;
    int profiling = 0;
    hipStream_t side_streams[HS_NSIDE] = {nullptr, nullptr, nullptr, nullptr};
-   hipStream_t sift_stream = nullptr;
+   hipStream_t sift_stream = nullptr, sift_stream2 = nullptr;   // descriptor kernels of even / odd groups (sift2: HESAFF_SIFT2)
+   bool sift2 = true;
    hipStream_t aff_stream = nullptr;      // affine shape of image group g+1 runs beside the patch extraction of group g
    hipEvent_t ev_detect_done = nullptr;
    std::vector<hipEvent_t> ev_aff;        // one per image group, grown on demand
-   hipEvent_t ev_extract_done[2] = {nullptr, nullptr}, ev_sift_done[2] = {nullptr, nullptr};
-   DevBuf b_patches2[2], b_siftvec2[2], b_meanvar2[2], b_siftvo2[2];
+   hipEvent_t ev_extract_done[HS_NSLOT] = {}, ev_sift_done[HS_NSLOT] = {};
+   DevBuf b_patches2[HS_NSLOT], b_siftvec2[HS_NSLOT], b_meanvar2[HS_NSLOT], b_siftvo2[HS_NSLOT];
    hipEvent_t ev_fork = nullptr, ev_join[HS_NSIDE] = {nullptr, nullptr, nullptr, nullptr};
    bool fast = false;              // hesaff_params.fast: per-keypoint stages on the kernels of kernels_fast.hip (not bit-exact)
    // schedule knobs: fixed in the product build, environment-driven only under -DHESAFF_TUNING
@@ -866,7 +868,7 @@ void launch_sift(hesaff_ctx *c, hipStream_t ss, const SiftIO &so, uint32_t n, fl
 // per-group patch / descriptor buffers (two slots): sized once per batch for the largest group
 void ensure_group_buffers(hesaff_ctx *c, uint32_t n)
 {
-   for (int slot = 0; slot < 2; slot++) {
+   for (int slot = 0; slot < HS_NSLOT; slot++) {
       c->b_patches2[slot].ensure((size_t)n * HS_PATCH_PIX * 4);
       c->b_siftvec2[slot].ensure((size_t)n * 128 * 4);
       c->b_meanvar2[slot].ensure((size_t)n * 2 * 4);
@@ -931,10 +933,11 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
          c->ev_aff.push_back(e);
       }
       if (max_n) ensure_group_buffers(c, max_n);
-      // Three-deep software pipeline over image groups, one stream per stage:
+      // Software pipeline over image groups, one stream per stage:
       //   affine shape of group g+1 (aff_stream)  |  patch extraction of group g (main + side
-      //   streams, latency-bound)  |  descriptor kernels of group g-1 (sift_stream).
-      // Two patch/descriptor buffer slots alternate.
+      //   streams, latency-bound)  |  descriptor kernels of groups g-1 and g-2 (sift_stream, sift_stream2: the
+      //   HBM-bound mean / variance pass of one group beside the gradient and histogram kernels of the other).
+      // Three patch/descriptor buffer slots rotate.
       hipStream_t as = c->no_overlap ? st : c->aff_stream;
       if (as != st) HIP_TRY(hipStreamWaitEvent(as, c->ev_detect_done, 0));
       auto launch_affine = [&](size_t gi) {
@@ -946,12 +949,12 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
          if (as != st) HIP_TRY(hipEventRecord(c->ev_aff[gi], as));
       };
       if (!groups.empty()) launch_affine(0);
-      bool slot_used[2] = {false, false};
+      bool slot_used[HS_NSLOT] = {};
       for (size_t gi = 0; gi < groups.size(); gi++) {
          const uint32_t h_lo = groups[gi].lo, h_hi = groups[gi].hi, n = h_hi - h_lo;
          if (gi + 1 < groups.size()) launch_affine(gi + 1);
          if (as != st) HIP_TRY(hipStreamWaitEvent(st, c->ev_aff[gi], 0));
-         const int slot = (int)(gi & 1);
+         const int slot = (int)(gi % HS_NSLOT);
          if (slot_used[slot]) HIP_TRY(hipStreamWaitEvent(st, c->ev_sift_done[slot], 0));   // the slot's previous descriptors are finished
          t = tm.begin(T_PATCH);
          HIP_TRY(hipMemsetAsync(cnt + 8, 0, 24 * 4, st));   // bin counts [8..13) and work counters [24..29)
@@ -961,7 +964,7 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
          run_patch_stage(c, s, c->gray, c->b_patches2[slot].as<float>(), h_lo, groups[gi].large_rows);
          tm.end(t);
          HIP_TRY(hipEventRecord(c->ev_extract_done[slot], st));
-         hipStream_t ss = c->no_overlap ? st : c->sift_stream;
+         hipStream_t ss = c->no_overlap ? st : ((c->sift2 && (gi & 1)) ? c->sift_stream2 : c->sift_stream);
          if (ss != st) HIP_TRY(hipStreamWaitEvent(ss, c->ev_extract_done[slot], 0));
          SiftIO so;
          so.patches = c->b_patches2[slot].as<float>(); so.alive = s.pw.alive; so.meanvar = c->b_meanvar2[slot].as<float>();
@@ -972,7 +975,7 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
          HIP_TRY(hipEventRecord(c->ev_sift_done[slot], ss));
          slot_used[slot] = true;
       }
-      for (int sl = 0; sl < 2; sl++)
+      for (int sl = 0; sl < HS_NSLOT; sl++)
          if (slot_used[sl]) HIP_TRY(hipStreamWaitEvent(st, c->ev_sift_done[sl], 0));
    }
    t = tm.begin(T_PACK);
