@@ -124,7 +124,9 @@ struct OctGeom {
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 #define HS_NSIDE 4   // side streams of the patch stage (one per window-size bin 0..3)
+#ifndef HS_NSLOT
 #define HS_NSLOT 3   // patch / descriptor buffer slots of the group pipeline
+#endif
 struct hesaff_ctx {
    hesaff_params par;
    int device = 0;
