@@ -4,9 +4,10 @@
 // descriptor runs in kernels_sift.h):
 //   k_patch_extract_small<0|1>  P <= 41 | 64 : window S and row-pass plane T in LDS, stored with
 //                                      replicated borders; tap count as template parameter
-//   k_patch_mid<128|512>        P <= 128 | 512 : row-streamed; only the 82 blurred columns / rows
-//                                      the 41x41 resample reads are evaluated, T' (P x 82, padded)
-//                                      in a per-block HBM slot
+//   k_patch_mid<128|512>        P <= 128 | 512 : row-streamed, three window rows per wavefront at a time; only the
+//                                      82 blurred columns / rows the 41x41 resample reads are evaluated, T'
+//                                      (P x 82, padded) in a per-block HBM slot, its rows staged through LDS
+//                                      for the column pass
 //   k_patch_large_rows + k_patch_large_finish  P > 512 : one wavefront per chunk of window ROWS
 //                                      writes T' rows to HBM (all rows of all huge keypoints run
 //                                      in parallel), then one block per keypoint finishes.
@@ -23,7 +24,10 @@
 //   * tap coordinates come from two small tables per window, R[row] = (ofsx + j*a12, ofsy + j*a22) and
 //     C[col] = (i*a11, i*a21): (wx, wy) = R + C is the reference's rx + i*a11, ry + i*a21 in one packed add;
 //   * both blur passes work on PAIRS of adjacent outputs with packed FP32 (v_pk_mul_f32 / v_pk_add_f32:
-//     two IEEE products / sums per instruction, same rounding as the scalar forms, no FMA).
+//     two IEEE products / sums per instruction, same rounding as the scalar forms, no FMA); bin 1 register-blocks
+//     4 columns / 4 rows per lane instead (fewer LDS bytes per output);
+//   * the gathers of a window are issued in batches whose size is fixed per window (no tap evaluated twice, no
+//     branch inside a batch); finished patches are stored non-temporally (their readers are later kernels).
 #pragma once
 #include <type_traits>
 #include "kernels_keypoint.h"
