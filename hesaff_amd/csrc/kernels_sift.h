@@ -1,5 +1,5 @@
 // kernels_sift.h -- SIFT descriptor (siftdesc.cpp:115-140, helpers.cpp:246-281) over patches
-// held in HBM, as three kernels whose parallel axis matches the structure of the reference's
+// held in HBM, as four kernels whose parallel axis matches the structure of the reference's
 // arithmetic instead of fighting it:
 //
 //  k_sift_meanvar   the photometric mean / variance are long SEQUENTIAL float sums
@@ -7,7 +7,9 @@
 //                   chain, 64 keypoints per wavefront at full lane efficiency; the patch columns
 //                   are transposed through LDS so that global loads stay coalesced.
 //  k_sift_grad      one block per keypoint, one THREAD per pixel: normalise (once, through LDS),
-//                   gradient, hm_atan2f_sel -> (mask*grad, o) pairs of the 40x40 weighted pixels.
+//                   gradient, hm_atan2f_tab -> (mask*grad, o) pairs of the 40x40 weighted pixels, collected in
+//                   an LDS tile and written as whole cache lines (the kernel is bound by this stream as much as
+//                   by its arithmetic).
 //  k_sift_hist      FOUR keypoints per wavefront, lane = (keypoint, spatial cell): the cell's 8
 //                   orientation bins live in LDS ([bin][lane], conflict-free) and the lane walks
 //                   its 16x16 support in raster order (siftdesc.cpp:51-81); the wave fetches each step's
