@@ -134,6 +134,10 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       if (const char *wv = getenv("HESAFF_BANDS")) c->force_bands = std::max(0, atoi(wv));
       c->debug = getenv("HESAFF_DEBUG") != nullptr;
       if (const char *sg = getenv("HESAFF_SGRAD_GRID")) c->sgrad_grid = (uint32_t)std::max(0, atoi(sg));
+      if (const char *gm = getenv("HESAFF_GRID_MULT")) {   // the persistent grids of the LDS-window patch kernels and of k_sift_hist x this
+         const uint32_t m = (uint32_t)std::max(1, atoi(gm));
+         c->g_small0 *= m; c->g_small1 *= m; c->g_shist *= m;
+      }
       if (const char *s2 = getenv("HESAFF_SIFT2")) c->sift2 = atoi(s2) != 0;
 #endif
    } catch (const HsError &e) {
