@@ -124,6 +124,19 @@ struct OctGeom {
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 #define HS_NSIDE 4   // side streams of the patch stage (one per window-size bin 0..3)
+// grids of the grid-stride list kernels (blocks of 256 threads)
+#ifndef HS_GRID_LOC
+#define HS_GRID_LOC 1024
+#endif
+#ifndef HS_GRID_DED
+#define HS_GRID_DED 512
+#endif
+#ifndef HS_GRID_SCAT
+#define HS_GRID_SCAT 1024
+#endif
+#ifndef HS_GRID_PACK
+#define HS_GRID_PACK 2048
+#endif
 #ifndef HS_NSLOT
 #define HS_NSLOT 3   // patch / descriptor buffer slots of the group pipeline
 #endif
@@ -805,8 +818,8 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
          const int band = ((long long)strips * ((g.rows + 63) / 64) * B >= 4096) ? 64 : 32;
          const dim3 grid(strips, (g.rows + band - 1) / band, B);
          hipLaunchKernelGGL(k_extrema_march, grid, dim3(64), 0, st, fp, c->consts.positiveThreshold, c->consts.negativeThreshold, s.cl, band);
-         hipLaunchKernelGGL(k_localize, dim3(1024), dim3(256), 0, st, oc, s.cl, s.rl, c->consts);
-         hipLaunchKernelGGL(k_dedupe, dim3(512), dim3(256), 0, st, oc, s.rl, (const uint32_t *)(cnt + 32 + o),
+         hipLaunchKernelGGL(k_localize, dim3(HS_GRID_LOC), dim3(256), 0, st, oc, s.cl, s.rl, c->consts);
+         hipLaunchKernelGGL(k_dedupe, dim3(HS_GRID_DED), dim3(256), 0, st, oc, s.rl, (const uint32_t *)(cnt + 32 + o),
                             c->b_bitmask.as<unsigned long long>());
       }
       tm.end(t);
@@ -816,7 +829,7 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
    const long long total_words = (long long)B * c->words_per_image;
    LoadPopc lp; lp.p = c->b_bitmask.as<unsigned long long>();
    exclusive_scan(c, lp, total_words, c->b_prefix.as<uint32_t>(), cnt + 3);
-   hipLaunchKernelGGL(k_scatter_ordered, dim3(1024), dim3(256), 0, st, s.rl, (const unsigned long long *)c->b_bitmask.p,
+   hipLaunchKernelGGL(k_scatter_ordered, dim3(HS_GRID_SCAT), dim3(256), 0, st, s.rl, (const unsigned long long *)c->b_bitmask.p,
                       (const uint32_t *)c->b_prefix.p, s.hl);
    hipLaunchKernelGGL(k_image_counts, dim3((B + 1 + 63) / 64), dim3(64), 0, st, (const uint32_t *)c->b_prefix.p,
                       c->words_per_image, B, (const uint32_t *)(cnt + 3), c->b_starts.as<int32_t>());
@@ -996,7 +1009,7 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
    LoadFlagI32 lf; lf.p = s.pw.alive;
    hipLaunchKernelGGL(k_clear_tail, dim3(1024), dim3(256), 0, st, s.pw.alive, (const uint32_t *)(cnt + 3), c->cap);
    exclusive_scan(c, lf, (long long)c->cap, c->b_rank.as<uint32_t>(), cnt + 4);
-   hipLaunchKernelGGL(k_pack, dim3(2048), dim3(256), 0, st, s.hl, (const uint32_t *)(cnt + 3), s.pw, (const uint32_t *)c->b_rank.p,
+   hipLaunchKernelGGL(k_pack, dim3(HS_GRID_PACK), dim3(256), 0, st, s.hl, (const uint32_t *)(cnt + 3), s.pw, (const uint32_t *)c->b_rank.p,
                       (const uint8_t *)c->b_desc.p, c->b_out.as<KeyRec>());
    hipLaunchKernelGGL(k_desc_starts, dim3((B + 1 + 63) / 64), dim3(64), 0, st, (const int32_t *)c->b_starts.p, B,
                       (const uint32_t *)c->b_rank.p, (const uint32_t *)(cnt + 3), (const uint32_t *)(cnt + 4),
