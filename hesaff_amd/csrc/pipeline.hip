@@ -137,6 +137,9 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 #ifndef HS_GRID_PACK
 #define HS_GRID_PACK 2048
 #endif
+#ifndef HS_OVERSUB
+#define HS_OVERSUB 32u   // oversubscription of the statically strided persistent grids
+#endif
 #ifndef HS_NSLOT
 #define HS_NSLOT 3   // patch / descriptor buffer slots of the group pipeline
 #endif
@@ -218,7 +221,9 @@ struct hesaff_ctx {
    // schedule knobs: fixed in the product build, environment-driven only under -DHESAFF_TUNING
    bool no_overlap = false;        // HESAFF_OVERLAP=0: every kernel alone on the device (per-kernel profiling)
    uint32_t sift_group_kpts = 0;   // HESAFF_GROUP: keypoints per image group; 0 = by batch
-   int aff_blocks_per_cu = 8;      // HESAFF_AFF_BLOCKS: persistent k_affine blocks per CU (19 KB of LDS each, 2 wavefronts per SIMD at 244 VGPRs)
+   int aff_blocks_per_cu = 8;      // HESAFF_AFF_BLOCKS: persistent k_affine blocks per CU (19 KB of LDS each: 8 resident).  Alone on the device
+                                   // 64 / 128 blocks per CU are 4 % faster (20.7 / 20.6 vs 21.6 ms), beside the other stages' kernels they
+                                   // make the step 3.5 % slower (453 vs 438 ms at B = 128): the queued blocks take every slot that frees up
    int side_mask = 15;             // HESAFF_SIDE: bit i = window-size bin i runs on its own side stream
    int force_bands = 0;            // HESAFF_BANDS: force the band count of k_blur_hess_march
    bool debug = false;             // HESAFF_DEBUG=1: launch geometry on stderr
@@ -408,7 +413,7 @@ void set_kernel_attrs(hesaff_ctx *c)
    // resident count start as others finish, and the hardware's block scheduler evens out what a fixed stride cannot
    // (a claim per item on an atomic counter serialises in L2 instead).  Measured per 32 UHD images, x 1 / 8 / 32:
    // k_patch_extract_small<0> 13.8 / 13.3 / 12.9 ms, <1> 6.1 / - / 5.9, k_sift_hist 13.4 / 12.0 / 11.7.
-   c->g_small0 *= 32u; c->g_small1 *= 32u; c->g_shist *= 32u;
+   c->g_small0 *= HS_OVERSUB; c->g_small1 *= HS_OVERSUB; c->g_shist *= HS_OVERSUB;
    if (c->fast) {
       const size_t lds[4] = {small_extract_lds_bytes(0), small_extract_lds_bytes(1), mid_lds_bytes(), big_lds_bytes()};
       hsfast_set_attrs(lds, 0);
