@@ -138,7 +138,7 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 #define HS_GRID_PACK 2048
 #endif
 #ifndef HS_OVERSUB
-#define HS_OVERSUB 32u   // oversubscription of the statically strided persistent grids
+#define HS_OVERSUB 128u   // oversubscription of the statically strided persistent grids (step at B = 128: x 1 / 32 / 128 / 256 / 2048: 443 / 438 / 433 / 434 / 447 ms)
 #endif
 #ifndef HS_NSLOT
 #define HS_NSLOT 3   // patch / descriptor buffer slots of the group pipeline
@@ -409,7 +409,7 @@ void set_kernel_attrs(hesaff_ctx *c)
    // over the resident count so that the tail of a launch is short (measured: one block per keypoint 18.5 ms per 32 UHD
    // images, 6 / 16 / 32 / 64 blocks per CU 15.2 / 13.8 / 13.3 / 13.4)
    c->sgrad_grid = (uint32_t)c->n_cu * 32u;
-   // The statically strided grids are launched 32 x oversubscribed: an item's cost varies several-fold, blocks beyond the
+   // The statically strided grids are launched HS_OVERSUB x oversubscribed: an item's cost varies several-fold, blocks beyond the
    // resident count start as others finish, and the hardware's block scheduler evens out what a fixed stride cannot
    // (a claim per item on an atomic counter serialises in L2 instead).  Measured per 32 UHD images, x 1 / 8 / 32:
    // k_patch_extract_small<0> 13.8 / 13.3 / 12.9 ms, <1> 6.1 / - / 5.9, k_sift_hist 13.4 / 12.0 / 11.7.
