@@ -137,6 +137,12 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 #ifndef HS_GRID_PACK
 #define HS_GRID_PACK 2048
 #endif
+#ifndef HS_MID_CAP
+#define HS_MID_CAP 6   // blocks per CU of the two row-streamed bins (at most; the occupancy query may say fewer)
+#endif
+#ifndef HS_BIG_CAP
+#define HS_BIG_CAP 4
+#endif
 #ifndef HS_OVERSUB
 #define HS_OVERSUB 128u   // oversubscription of the statically strided persistent grids (step at B = 128: x 1 / 32 / 128 / 256 / 2048: 443 / 438 / 433 / 434 / 447 ms)
 #endif
@@ -401,8 +407,8 @@ void set_kernel_attrs(hesaff_ctx *c)
    c->g_small0 = resident_grid(c, k_patch_extract_small<0>, 256, small_extract_lds_bytes(0), 6);
    c->g_small1 = resident_grid(c, k_patch_extract_small<1>, 256, small_extract_lds_bytes(1), 4);
    // the row-streamed bins claim their items dynamically: any grid that fills the device works; one T' slot per block
-   c->g_mid = std::min<uint32_t>(resident_grid(c, k_patch_mid<HS_MID_PMAX>, 256, mid_lds_bytes(), 6), HS_MID_BLOCKS);
-   c->g_big = std::min<uint32_t>(resident_grid(c, k_patch_mid<HS_BIN3_PMAX>, 256, big_lds_bytes(), 4), HS_BIG_BLOCKS);
+   c->g_mid = std::min<uint32_t>(resident_grid(c, k_patch_mid<HS_MID_PMAX>, 256, mid_lds_bytes(), HS_MID_CAP), HS_MID_BLOCKS);
+   c->g_big = std::min<uint32_t>(resident_grid(c, k_patch_mid<HS_BIN3_PMAX>, 256, big_lds_bytes(), HS_BIG_CAP), HS_BIG_BLOCKS);
    c->g_lfin = resident_grid(c, k_patch_large_finish, 256, 0, 4);
    c->g_shist = resident_grid(c, k_sift_hist, 64, 0, 32);
    // k_sift_grad: a block keeps its per-pixel tables and requests the next patch while it works on the current one; well
