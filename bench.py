@@ -97,6 +97,22 @@ def host_cpu_info():
     return info
 
 
+def launch_ranks(n):
+    """Start n ranks of this script under torch.distributed.run on this node and wait for them.  Nothing in this process
+    has initialised the GPU (torch is not even imported yet); the ranks are ordinary child processes."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,12 +130,25 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=2, help="images of the batch timed on the CPU oracle, 1 thread (about 14 s each)")
     ap.add_argument("--cpu-workers", type=int, default=-1,
                     help="worker processes of the multi-core CPU baseline, one image each (-1: one per physical core, at most the batch; 0: skip)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank owns --batch images per step; strong: --global-images images per step in total, "
+                         "split evenly over the ranks (BASELINE.json config 4: 2048 UHD images over 8 GPUs)")
+    ap.add_argument("--global-images", type=int, default=2048, help="images per step of the whole job under --scaling strong")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: this process starts the N ranks itself (one process per GPU under
+    # torch.distributed.run) BEFORE anything here touches torch or the GPU, relays rank 0's JSON line and exits with the
+    # launcher's status.  Under a launcher (WORLD_SIZE set) the world size must be the one asked for.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); refusing to report a line "
+                         "for a different world size" % (args.gpus, world))
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # BENCH_DIST_BACKEND=gloo (testing only): the multi-rank code path on a box with fewer GPUs than
@@ -143,21 +172,49 @@ def main():
     import hesaff_amd
     from hesaff_amd.synth import band_noise_batch_torch
 
-    B, H, W = args.batch, args.height, args.width
-    # weak scaling: every rank owns B distinct images (global image index = rank*B + i)
+    H, W = args.height, args.width
+    from hesaff_amd.shard import shard_range
+    if args.scaling == "strong":
+        # strong scaling: the job's images per step are fixed; rank r owns the contiguous block shard_range gives it
+        # (hesaff_shard_range, the product's own rule) and walks it in library calls of at most --batch images
+        g_lo, g_hi = shard_range(args.global_images, rank, world)
+        per_rank = g_hi - g_lo
+        B = max(1, min(args.batch, per_rank))
+    else:
+        # weak scaling: every rank owns --batch distinct images (global image index = rank * batch + i)
+        per_rank = B = args.batch
+        g_lo = rank * B
     from hesaff_amd.synth import BANDS, BANDS_NATURAL
-    imgs = band_noise_batch_torch(B, H, W, seed=1234 + rank * B, device=dev, bands=BANDS_NATURAL if args.density == "natural" else BANDS)
+    bands = BANDS_NATURAL if args.density == "natural" else BANDS
+    # B distinct images per rank (seeded by global image index); a rank whose share exceeds B cycles through them
+    imgs = band_noise_batch_torch(B, H, W, seed=1234 + g_lo, device=dev, bands=bands)
     torch.cuda.synchronize()
 
     p = hesaff_amd.default_params()
     p.max_batch = B
     ctx = hesaff_amd.HesaffContext(p, device=local_rank)
 
-    def step():
-        return ctx.detect_batch_device(imgs.data_ptr(), B, W, H)
+    bh = {"ms": 0.0, "bytes": 0.0, "launches": 0}
+    stage = {"pyramid_ms": 0.0, "detect_ms": 0.0, "affine_ms": 0.0, "patch_ms": 0.0, "sift_ms": 0.0, "pack_ms": 0.0, "total_ms": 0.0}
+    tot = {"desc": 0, "hess": 0, "imgs": 0, "pyr_bytes": 0.0}
+
+    def step(timed):
+        # one pass of the hot path over this rank's images of a step
+        done = 0
+        while done < per_rank:
+            nb = min(B, per_rank - done)
+            ch, cd, _, total = ctx.detect_batch_device(imgs.data_ptr(), nb, W, H)
+            done += nb
+            if timed:
+                tot["desc"] += int(cd.sum()); tot["hess"] += int(ch.sum()); tot["imgs"] += nb
+                tm = ctx.timings()
+                bh["ms"] += tm.blur_hess_ms; bh["bytes"] += tm.blur_hess_bytes; bh["launches"] += tm.blur_hess_launches
+                tot["pyr_bytes"] += tm.pyramid_bytes
+                for k in stage:
+                    stage[k] += getattr(tm, k)
 
     for _ in range(args.warmup):
-        step()
+        step(False)
     ctx.set_profiling(2)
 
     def barrier():
@@ -165,18 +222,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    bh_ms = 0.0; bh_bytes = 0.0; bh_launches = 0
-    stage = {"pyramid_ms": 0.0, "detect_ms": 0.0, "affine_ms": 0.0, "patch_ms": 0.0, "sift_ms": 0.0, "pack_ms": 0.0, "total_ms": 0.0}
-    n_desc = 0; n_hess = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ch, cd, _, total = step()
-        n_desc += int(cd.sum()); n_hess += int(ch.sum())
-        tm = ctx.timings()
-        bh_ms += tm.blur_hess_ms; bh_bytes += tm.blur_hess_bytes; bh_launches += tm.blur_hess_launches
-        for k in stage:
-            stage[k] += getattr(tm, k)
+        step(True)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -184,8 +233,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     from hesaff_amd.shard import gather_counts
-    counts = gather_counts([n_hess, n_desc, B * args.steps], device=coll_dev if world > 1 else None)
+    n_hess, n_desc = tot["hess"], tot["desc"]
+    bh_ms, bh_bytes, bh_launches = bh["ms"], bh["bytes"], bh["launches"]
+    counts = gather_counts([n_hess, n_desc, tot["imgs"]], device=coll_dev if world > 1 else None)
     tot_hess, tot_desc, tot_imgs = [int(v) for v in counts.sum(axis=0)]
+    per_rank_images = [int(v) for v in counts[:, 2]]
     ctx.close()
 
     # ---- host-inclusive leg: host images -> hesaff_detect_batch -> host records, + text export ----
@@ -250,6 +302,7 @@ def main():
     if rank == 0:
         achieved = (bh_bytes / 1e9) / (bh_ms / 1e3) if bh_ms > 0 else 0.0
         st = {k: v / args.steps for k, v in stage.items()}
+        pyr_bytes_step = tot["pyr_bytes"] / args.steps
         out = {
             "metric": "keypoints/sec (descriptors written), 4K grayscale batch",
             "value": tot_desc / dt,
@@ -261,13 +314,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "batch of %d x %dx%d 8-bit grey images per GPU per step, band-noise synthetic%s, default params"
-                                   % (B, W, H, " (natural density)" if args.density == "natural" else ""),
-                       "images_per_gpu_per_step": B, "width": W, "height": H, "sharding": "image-level, %d rank(s)" % world,
+            "config": {"workload": "batch of %d x %dx%d 8-bit grey images per GPU per step%s, band-noise synthetic%s, default params"
+                                   % (per_rank, W, H, (" (%d distinct, cycled; library calls of %d)" % (B, B)) if per_rank > B else "",
+                                      " (natural density)" if args.density == "natural" else ""),
+                       "images_per_gpu_per_step": per_rank, "images_per_library_call": B, "images_per_step_all_ranks": tot_imgs // max(args.steps, 1),
+                       "per_rank_images_timed": per_rank_images, "width": W, "height": H, "sharding": "image-level, contiguous blocks, %d rank(s), no data-path collective; one all-gather of counts" % world,
                        "descriptors_per_image": tot_desc / max(tot_imgs, 1),
                        "value_is": "device-resident: inputs in HBM before the timed region, records left in HBM (hesaff_detect_batch_device)"},
             "host_path": host_path,
@@ -285,10 +340,10 @@ def main():
                          "traffic": pmc_traffic(B, W, H, bh_launches // max(args.steps, 1)), "launches": bh_launches,
                          "avg_launch_ms": bh_ms / max(bh_launches, 1), "bytes_per_launch_avg": bh_bytes / max(bh_launches, 1),
                          "stage": {"what": "whole pyramid stage incl. grey conversion and initial blur: B_pyr = 5 N0 + 58 sum N_k per image (SURVEY.md 8d)",
-                                   "achieved": (tm.pyramid_bytes / 1e9) / (st["pyramid_ms"] / 1e3) if st["pyramid_ms"] > 0 else 0.0,
-                                   "frac": ((tm.pyramid_bytes / 1e9) / (st["pyramid_ms"] / 1e3)) / HBM_PEAK_GBS if st["pyramid_ms"] > 0 else 0.0}},
+                                   "achieved": (pyr_bytes_step / 1e9) / (st["pyramid_ms"] / 1e3) if st["pyramid_ms"] > 0 else 0.0,
+                                   "frac": ((pyr_bytes_step / 1e9) / (st["pyramid_ms"] / 1e3)) / HBM_PEAK_GBS if st["pyramid_ms"] > 0 else 0.0}},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:   # rank 0 only, also when world > 1 (the other ranks are done)
             from tests import _oracle
             if cpu_sample is None:
                 cpu_sample = list(imgs.cpu().numpy())

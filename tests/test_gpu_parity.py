@@ -703,7 +703,7 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "3",
-           "--width", "640", "--height", "480", "--no-cpu-baseline"]
+           "--width", "640", "--height", "480", "--cpu-images", "1", "--cpu-workers", "0"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -711,6 +711,32 @@ def test_bench_two_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["images_per_gpu_per_step"] == 3 and abs(d["images_per_s"] * d["ms_per_step"] / 1e3 - 6) < 1e-6
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0   # rank 0 keeps the CPU leg when world > 1
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it (the form the driver uses for N = 1): bench.py starts the two
+    ranks itself, before it touches the GPU, and rank 0's line says n_gpus == 2.  Strong scaling: 5 images per step in
+    total, split 3 + 2 by hesaff_shard_range."""
+    import json
+    import sys
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "2",
+           "--width", "640", "--height", "480", "--no-cpu-baseline", "--no-host-path", "--scaling", "strong", "--global-images", "5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert sorted(d["config"]["per_rank_images_timed"]) == [2, 3] and d["config"]["images_per_step_all_ranks"] == 5
+    assert abs(d["images_per_s"] * d["ms_per_step"] / 1e3 - 5) < 1e-6
+    # a launcher that started a different number of ranks than --gpus asks for is an error, not a mislabelled line
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env2, cwd=ROOT, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
 
 
 def _structured_image(kind, h, w, rng):

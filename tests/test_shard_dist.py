@@ -9,6 +9,8 @@ import pytest
 
 from hesaff_amd.shard import shard_range
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_shard_range_partitions():
     for n in [0, 1, 7, 8, 255, 256, 2048]:
@@ -82,3 +84,15 @@ def test_gather_counts_single_process_identity():
     from hesaff_amd.shard import gather_counts
     out = gather_counts([3, 2, 1])
     assert out.shape == (1, 3) and out[0].tolist() == [3, 2, 1]
+
+
+def test_bench_refuses_a_world_size_other_than_gpus():
+    """bench.py --gpus N under a launcher that started another number of ranks must fail loudly (before it needs a GPU)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "--gpus 3" in r.stderr and "2 rank" in r.stderr
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "--gpus 8" in r.stderr
