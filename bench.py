@@ -97,6 +97,49 @@ def host_cpu_info():
     return info
 
 
+def file_path_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device):
+    """hesaff_process_files (what `hesaff --batch` runs: decode threads -> chunks through the device -> writer threads) on
+    n_files binary PGM files of the bench images on a RAM disk, every <name>.hesaff.sift written there too.  One timed run
+    over the whole list, pipeline fill and drain included."""
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="hesaff_e2e_", dir=base)
+    try:
+        # inputs 1 byte per pixel, outputs about 5.3 bytes per pixel at the dense images' 14 k descriptors per Mpx
+        per_image = W * H * 7
+        free = shutil.disk_usage(tmp).free
+        n = int(max(0, min(n_files, (free * 0.6) // per_image)))
+        if n < 2 * chunk:
+            return {"skipped": "RAM disk too small: %d bytes free for %d images" % (free, n_files)}
+        paths = []
+        hdr = b"P5\n%d %d\n255\n" % (W, H)
+        for i in range(n):
+            q = os.path.join(tmp, "img%04d.pgm" % i)
+            with open(q, "wb") as f:
+                f.write(hdr); f.write(host_imgs[i % len(host_imgs)].tobytes())
+            paths.append(q)
+        p = hesaff_amd.default_params()
+        p.max_batch = chunk
+        with hesaff_amd.HesaffContext(p, device=device) as ctx:
+            warm = ctx.process_files(paths[: 2 * chunk])          # buffers, page cache, thread start-up
+            for q in paths[: 2 * chunk]:
+                os.remove(q + ".hesaff.sift")
+            t0 = time.perf_counter()
+            st = ctx.process_files(paths)
+            dt = time.perf_counter() - t0
+            threads = int(ctx.L.hesaff_host_threads())
+        bad = [i for i, s_ in enumerate(st) if s_[0] != 0 or s_[1] != 3] + [i for i, s_ in enumerate(warm) if s_[0] != 0]
+        nbytes = sum(os.path.getsize(q + ".hesaff.sift") for q in paths)
+        rows = sum(s_[3] for s_ in st)
+        return {"images": n, "images_per_s": n / dt, "value": rows / dt, "unit": "keypoints/s", "seconds": dt, "chunk_images": chunk,
+                "failed_files": len(bad), "text_GB_per_s": nbytes / dt / 1e9, "input_GB": n * (W * H + len(hdr)) / 1e9, "output_GB": nbytes / 1e9,
+                "host_threads": threads, "target": tmp.rsplit("/", 1)[0],
+                "what": "hesaff_process_files: %d binary PGM files (%dx%d, the bench images) on a RAM disk -> decode threads -> chunks of %d "
+                        "images through the device (copy in, kernels, copy out overlapped) -> writer threads -> %d .hesaff.sift files on the "
+                        "RAM disk; one timed run, pipeline fill and drain included (hesaff.cpp:133-180 for a list of files)" % (n, W, H, chunk, n)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def launch_ranks(n):
     """Start n ranks of this script under torch.distributed.run on this node and wait for them.  Nothing in this process
     has initialised the GPU (torch is not even imported yet); the ranks are ordinary child processes."""
@@ -130,6 +173,8 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=2, help="images of the batch timed on the CPU oracle, 1 thread (about 14 s each)")
     ap.add_argument("--cpu-workers", type=int, default=-1,
                     help="worker processes of the multi-core CPU baseline, one image each (-1: one per physical core, at most the batch; 0: skip)")
+    ap.add_argument("--e2e-images", type=int, default=192, help="image files of the measured end-to-end file path (0: skip; fewer when the RAM disk is small)")
+    ap.add_argument("--e2e-chunk", type=int, default=32, help="images per device chunk of the end-to-end leg (hesaff_params.max_batch)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: every rank owns --batch images per step; strong: --global-images images per step in total, "
                          "split evenly over the ranks (BASELINE.json config 4: 2048 UHD images over 8 GPUs)")
@@ -243,6 +288,7 @@ def main():
     # ---- host-inclusive leg: host images -> hesaff_detect_batch -> host records, + text export ----
     host_path = None
     text_export = None
+    end_to_end = None
     if not args.no_host_path:
         hp = hesaff_amd.default_params()
         hp.max_batch = max(1, min(args.host_chunk, B))
@@ -288,14 +334,20 @@ def main():
                 det_img_s = host_path["images_per_s"] / max(world, 1)   # per rank
                 text_export = {"images": ne, "rows_per_s": rows / edt, "images_per_s": exp_img_s, "text_GB_per_s": nbytes / edt / 1e9,
                                "bytes_per_image": nbytes / ne, "threads": int(hctx.L.hesaff_host_threads()), "target": tmp.rsplit("/", 1)[0],
-                               # the export of batch i runs on host threads beside the detection of batch i+1: the slower of the two sets the rate
-                               "end_to_end_images_per_s_pipelined": min(exp_img_s, det_img_s),
-                               "end_to_end_images_per_s_sequential": 1.0 / (1.0 / exp_img_s + 1.0 / det_img_s),
-                               "what": "hesaff_write_sift_batch (the reference's text format, hesaff.cpp:107-130) of %d images of the batch" % ne}
+                               # a MODEL from the two legs measured one after the other (the measured pipeline is `end_to_end` below)
+                               "end_to_end_images_per_s_modelled_min_of_legs": min(exp_img_s, det_img_s),
+                               "end_to_end_images_per_s_modelled_sequential": 1.0 / (1.0 / exp_img_s + 1.0 / det_img_s),
+                               "what": "hesaff_write_sift_batch (the reference's text format, hesaff.cpp:107-130) of %d images of the batch, "
+                                       "nothing else running" % ne}
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
         cpu_sample = host_imgs
         hctx.close()
+        # ---- the whole file path, measured: image files -> decode -> device -> .hesaff.sift files (hesaff.cpp:133-180) ----
+        if rank == 0 and args.e2e_images > 0:
+            end_to_end = file_path_leg(hesaff_amd, host_imgs, W, H, args.e2e_images, args.e2e_chunk, local_rank)
+            if end_to_end and host_path:
+                end_to_end["fraction_of_host_path"] = end_to_end["images_per_s"] / (host_path["images_per_s"] / max(world, 1))
     else:
         cpu_sample = None
 
@@ -327,6 +379,7 @@ def main():
                        "value_is": "device-resident: inputs in HBM before the timed region, records left in HBM (hesaff_detect_batch_device)"},
             "host_path": host_path,
             "text_export": text_export,
+            "end_to_end": end_to_end,
             "stage_ms_per_step": {"serial_on_main_stream": {"pyramid_ms": st["pyramid_ms"], "detect_ms": st["detect_ms"], "pack_ms": st["pack_ms"]},
                                   "concurrent_stream_busy_time": {"affine_ms": st["affine_ms"], "patch_ms": st["patch_ms"], "sift_ms": st["sift_ms"]},
                                   "device_total_ms": st["total_ms"],

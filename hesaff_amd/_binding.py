@@ -53,6 +53,16 @@ _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
+ABI_VERSION = 3   # HESAFF_ABI_VERSION of the include/hesaff_amd.h these ctypes structs mirror
+
+
+class FileStatus(C.Structure):
+    """hesaff_file_status"""
+    _fields_ = [("rc", C.c_int32), ("stage", C.c_int32), ("count_hessian", C.c_int32), ("count_desc", C.c_int32)]
+
+
+CHUNK_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_Result))
+
 _lib = None
 
 
@@ -80,12 +90,24 @@ def load_library():
     L = C.CDLL(p)
     vp = C.c_void_p
     L.hesaff_version.restype = C.c_char_p
+    L.hesaff_abi_version.argtypes = []
+    L.hesaff_sizeof_params.argtypes = []; L.hesaff_sizeof_params.restype = C.c_size_t
+    L.hesaff_sizeof_timings.argtypes = []; L.hesaff_sizeof_timings.restype = C.c_size_t
+    if (L.hesaff_abi_version() != ABI_VERSION or L.hesaff_sizeof_params() != C.sizeof(Params)
+            or L.hesaff_sizeof_timings() != C.sizeof(Timings)):
+        raise HesaffError(-2, "%s has ABI version %d (params %d bytes, timings %d bytes); this binding mirrors version %d (%d, %d)"
+                          % (p, L.hesaff_abi_version(), L.hesaff_sizeof_params(), L.hesaff_sizeof_timings(), ABI_VERSION,
+                             C.sizeof(Params), C.sizeof(Timings)))
     L.hesaff_default_params.argtypes = [C.POINTER(Params)]
     L.hesaff_create.argtypes = [C.POINTER(vp), C.POINTER(Params), C.c_int]
     L.hesaff_destroy.argtypes = [vp]; L.hesaff_destroy.restype = None
     L.hesaff_last_error.argtypes = [vp]; L.hesaff_last_error.restype = C.c_char_p
     L.hesaff_detect_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_Result)]
+    L.hesaff_detect_batch_cb.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int), CHUNK_SINK, vp]
+    L.hesaff_process_files.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(FileStatus)]
+    L.hesaff_write_sift_mt.argtypes = [C.c_char_p, vp, C.c_int, C.c_float, C.c_int]
     L.hesaff_detect_batch_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, _i32p, _i32p, C.POINTER(vp), C.POINTER(C.c_int64)]
     L.hesaff_set_profiling.argtypes = [vp, C.c_int]
     L.hesaff_get_timings.argtypes = [vp, C.POINTER(Timings)]
@@ -133,7 +155,8 @@ ABI_SYMBOLS = [
     "hesaff_stage_math", "hesaff_stage_math_sift", "hesaff_table_gauss_mask", "hesaff_table_circ_gauss_mask", "hesaff_table_sift_bins",
     "hesaff_table_gauss_kernel", "hesaff_format_sift_mt", "hesaff_write_sift_batch", "hesaff_test_fmt_g",
     "hesaff_read_png", "hesaff_read_image", "hesaff_device_count", "hesaff_shard_range", "hesaff_read_jpeg",
-    "hesaff_host_threads",
+    "hesaff_host_threads", "hesaff_abi_version", "hesaff_sizeof_params", "hesaff_sizeof_timings", "hesaff_detect_batch_cb",
+    "hesaff_process_files", "hesaff_write_sift_mt",
 ]
 
 
@@ -314,6 +337,43 @@ class HesaffContext:
         res = (_Result * n)()
         self._check(self.L.hesaff_detect_batch(self.h, n, ptrs, ws, hs, st, chs, res))
         return res
+
+    def detect_batch_cb(self, images, sink):
+        """hesaff_detect_batch_cb: sink(image_indices, [(count_hessian, keys copy), ...]) is called once per chunk with
+        records that are valid only during the call (bounded pinned memory); a truthy return value stops the run."""
+        n = len(images)
+        imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        ws = (C.c_int * n)(*[im.shape[1] for im in imgs])
+        hs = (C.c_int * n)(*[im.shape[0] for im in imgs])
+        chs = (C.c_int * n)(*[1 if im.ndim == 2 else 3 for im in imgs])
+        st = (C.c_int * n)(*[im.shape[1] * (1 if im.ndim == 2 else 3) for im in imgs])
+
+        def _sink(_user, m, idx, res):
+            out = []
+            for i in range(m):
+                r = res[i]
+                if r.count_desc > 0:
+                    buf = (C.c_char * (r.count_desc * KEYPOINT_DTYPE.itemsize)).from_address(r.keys)
+                    keys = np.frombuffer(buf, dtype=KEYPOINT_DTYPE).copy()
+                else:
+                    keys = np.zeros(0, KEYPOINT_DTYPE)
+                out.append((r.count_hessian, keys))
+            return 1 if sink([idx[i] for i in range(m)], out) else 0
+        cb = CHUNK_SINK(_sink)
+        self._check(self.L.hesaff_detect_batch_cb(self.h, n, ptrs, ws, hs, st, chs, cb, None))
+
+    def process_files(self, paths, out_paths=None, decode_threads=0, write_threads=0):
+        """hesaff_process_files: image files -> <name>.hesaff.sift through the decode / device / write pipeline.
+        -> list of (rc, stage, count_hessian, count_desc) per file."""
+        n = len(paths)
+        cp = (C.c_char_p * n)(*[os.fsencode(q) for q in paths])
+        op = None
+        if out_paths is not None:
+            op = (C.c_char_p * n)(*[None if q is None else os.fsencode(q) for q in out_paths])
+        st = (FileStatus * n)()
+        self._check(self.L.hesaff_process_files(self.h, n, cp, op, decode_threads, write_threads, st))
+        return [(s.rc, s.stage, s.count_hessian, s.count_desc) for s in st]
 
     def write_sift_batch_raw(self, paths, results, mr_size, threads=0):
         """hesaff_write_sift_batch on hesaff_result records (e.g. a slice of detect_batch_raw's return value)."""

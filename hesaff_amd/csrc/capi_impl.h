@@ -42,11 +42,15 @@ extern "C" {
 const char *hesaff_version(void)
 {
 #ifdef HESAFF_TUNING
-   return "hesaff_amd 0.2 (gfx950, tuning build)";
+   return "hesaff_amd 0.3 (gfx950, tuning build)";
 #else
-   return "hesaff_amd 0.2 (gfx950)";
+   return "hesaff_amd 0.3 (gfx950)";
 #endif
 }
+
+int hesaff_abi_version(void) { return HESAFF_ABI_VERSION; }
+size_t hesaff_sizeof_params(void) { return sizeof(hesaff_params); }
+size_t hesaff_sizeof_timings(void) { return sizeof(hesaff_timings); }
 
 int hesaff_device_count(void)
 {
@@ -116,7 +120,8 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       HIP_TRY(hipStreamCreateWithFlags(&c->sift_stream, hipStreamNonBlocking));
       HIP_TRY(hipStreamCreateWithFlags(&c->sift_stream2, hipStreamNonBlocking));
       HIP_TRY(hipStreamCreateWithFlags(&c->aff_stream, hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&c->ev_detect_done, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&c->ev_detect_done, hipEventDisableTiming | hipEventBlockingSync));
+      HIP_TRY(hipEventCreateWithFlags(&c->ev_batch_done, hipEventDisableTiming | hipEventBlockingSync));
       for (int i = 0; i < HS_NSLOT; i++) {
          HIP_TRY(hipEventCreateWithFlags(&c->ev_extract_done[i], hipEventDisableTiming));
          HIP_TRY(hipEventCreateWithFlags(&c->ev_sift_done[i], hipEventDisableTiming));
@@ -172,6 +177,7 @@ void hesaff_destroy(hesaff_ctx *c)
    if (c->sift_stream2) { (void)hipStreamSynchronize(c->sift_stream2); (void)hipStreamDestroy(c->sift_stream2); }
    if (c->aff_stream) { (void)hipStreamSynchronize(c->aff_stream); (void)hipStreamDestroy(c->aff_stream); }
    if (c->ev_detect_done) (void)hipEventDestroy(c->ev_detect_done);
+   if (c->ev_batch_done) (void)hipEventDestroy(c->ev_batch_done);
    for (hipEvent_t e : c->ev_aff) (void)hipEventDestroy(e);
    for (int i = 0; i < HS_NSLOT; i++) {
       if (c->ev_extract_done[i]) (void)hipEventDestroy(c->ev_extract_done[i]);
@@ -227,121 +233,426 @@ int hesaff_detect_batch_device(hesaff_ctx *c, int n, const void *d_gray, int wid
    HS_API_END(c)
 }
 
-int hesaff_detect_batch(hesaff_ctx *c, int n, const uint8_t *const *images, const int *widths, const int *heights,
-                        const int *strides, const int *channels, hesaff_result *results)
-{
-   if (!c || n < 0 || (n > 0 && (!images || !widths || !heights || !results))) return HESAFF_ERR_ARG;
-   HS_API_BEGIN
-   bind_device(c);
-   if (!c->h2d_stream) {
-      HIP_TRY(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
-      HIP_TRY(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
-      for (int i = 0; i < 2; i++) {
-         HIP_TRY(hipEventCreateWithFlags(&c->ev_h2d[i], hipEventDisableTiming));
-         HIP_TRY(hipEventCreateWithFlags(&c->ev_in_free[i], hipEventDisableTiming));
-         HIP_TRY(hipEventCreateWithFlags(&c->ev_out_ready[i], hipEventDisableTiming));
-         HIP_TRY(hipEventCreateWithFlags(&c->ev_d2h[i], hipEventDisableTiming));
-      }
-   }
-   // chunks: images of equal (width, height, channels), at most max_batch each, in input order
-   struct Chunk { int W, H, ch; std::vector<int> idx; };
-   std::vector<Chunk> chunks;
-   {
-      std::vector<char> done((size_t)n, 0);
-      for (int i = 0; i < n; i++) {
-         if (done[i]) continue;
-         const int W = widths[i], H = heights[i], ch = channels ? channels[i] : 1;
-         if (ch != 1 && ch != 3) throw HsError(HESAFF_ERR_ARG, "channels must be 1 or 3");
-         std::vector<int> grp;
-         for (int j = i; j < n; j++)
-            if (!done[j] && widths[j] == W && heights[j] == H && (channels ? channels[j] : 1) == ch) {
-               if (!images[j] || W < 1 || H < 1) throw HsError(HESAFF_ERR_ARG, "bad image");
-               if (strides && (long long)strides[j] < (long long)W * ch) throw HsError(HESAFF_ERR_ARG, "row stride smaller than width * channels");
-               grp.push_back(j);
-               done[j] = 1;
-            }
-         for (size_t g0 = 0; g0 < grp.size(); g0 += c->par.max_batch) {
-            Chunk k;
-            k.W = W; k.H = H; k.ch = ch;
-            k.idx.assign(grp.begin() + g0, grp.begin() + std::min(grp.size(), g0 + (size_t)c->par.max_batch));
-            chunks.push_back(std::move(k));
-         }
-      }
-   }
-   const int NC = (int)chunks.size();
-   if ((int)c->pin_out.size() < NC) c->pin_out.resize((size_t)NC);
-   std::vector<size_t> key_off((size_t)n, 0);
-   std::vector<int> chunk_of((size_t)n, 0);
+// ------------------------------------------------------------------------------------------------------------------
+// Chunk engine: the host side of every entry point that takes host images (hesaff_detect_batch, hesaff_detect_batch_cb,
+// hesaff_process_files).  A ChunkIO hands over chunks of equally sized images one after the other and receives each
+// chunk's records when they are in host memory:
+//    staging thread :  io.next(chunk k+1) -> pixels into pinned memory -> H2D on its own stream -> io.staged()
+//    caller's thread:  kernels of chunk k (run_batch) ; io.done(chunk k-1) ; D2D + D2H of chunk k on a third stream
+// so the copy in of chunk k+1 and the copy out of chunk k-1 run beside the kernels of chunk k.  Pinned result memory:
+// ring == 0 keeps one block per chunk until the next call (hesaff_detect_batch's contract: every results[i].keys stays
+// valid); ring == N > 0 cycles through N blocks, and the consumer gives a block back with release_block() when it
+// has finished with the chunk (bounded host memory however long the list is).
+// ------------------------------------------------------------------------------------------------------------------
+} // extern "C"
 
-   // stage(k): images of chunk k -> pinned buffer -> device input buffer (k & 1), on the H2D stream.
-   // Runs on a helper thread while the kernels of chunk k-1 are in flight.
-   auto stage = [&](int k) {
+namespace {
+
+struct HostChunk {                // at most max_batch images of one geometry
+   int W = 0, H = 0, ch = 1;
+   std::vector<const uint8_t *> data;
+   std::vector<size_t> stride;    // bytes between rows
+   std::vector<int> index;        // the caller's image numbers
+};
+
+struct ChunkDone {
+   const HostChunk *chunk;
+   const int32_t *count_hessian, *count_desc;   // per image of the chunk
+   const size_t *key_off;                       // first record of each image inside keys
+   const hesaff_keypoint *keys;                 // pinned host memory: valid until the block is released / the next call
+   int block;
+};
+
+struct ChunkIO {
+   virtual bool next(HostChunk &out) = 0;       // staging thread, one call at a time, in order; false: no more chunks
+   virtual void staged(const HostChunk &) {}    // staging thread: the chunk's pixels are in pinned memory, its sources may go
+   virtual void done(const ChunkDone &) = 0;    // caller's thread, in order
+   virtual ~ChunkIO() {}
+};
+
+void release_block(hesaff_ctx *c, int block)
+{
+   {
+      std::lock_guard<std::mutex> lk(c->ring_mu);
+      if (block >= 0 && block < (int)c->ring_busy.size()) c->ring_busy[(size_t)block] = 0;
+   }
+   c->ring_cv.notify_all();
+}
+
+void ensure_copy_streams(hesaff_ctx *c)
+{
+   if (c->h2d_stream) return;
+   HIP_TRY(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+   HIP_TRY(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+   for (int i = 0; i < 2; i++) {
+      HIP_TRY(hipEventCreateWithFlags(&c->ev_h2d[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&c->ev_in_free[i], hipEventDisableTiming | hipEventBlockingSync));
+      HIP_TRY(hipEventCreateWithFlags(&c->ev_out_ready[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&c->ev_d2h[i], hipEventDisableTiming | hipEventBlockingSync));
+   }
+}
+
+void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
+{
+   bind_device(c);
+   ensure_copy_streams(c);
+   struct State {
+      HostChunk q;
+      std::vector<int32_t> nh, nd;
+      std::vector<size_t> off;
+      int total = 0, block = -1, no = 0;
+   };
+   {
+      std::lock_guard<std::mutex> lk(c->ring_mu);
+      c->ring_busy.assign((size_t)std::max(ring, 0), 0);
+   }
+   if (ring > 0 && (int)c->pin_out.size() < ring) c->pin_out.resize((size_t)ring);
+
+   // stage(k): chunk k -> pinned buffer -> device input buffer (k & 1) on the H2D stream; runs while chunk k-1 computes
+   auto stage = [&](int k) -> std::unique_ptr<State> {
       HIP_TRY(hipSetDevice(c->device));
-      const Chunk &q = chunks[k];
+      std::unique_ptr<State> s(new State());
+      if (!io.next(s->q)) return nullptr;
+      const HostChunk &q = s->q;
       const int slot = k & 1;
-      const size_t row_bytes = (size_t)q.W * q.ch, img_bytes = row_bytes * q.H, total = img_bytes * q.idx.size();
-      HIP_TRY(hipEventSynchronize(c->ev_in_free[slot]));   // chunk k-2 no longer reads this input buffer (event unrecorded: returns at once)
+      const size_t row_bytes = (size_t)q.W * q.ch, img_bytes = row_bytes * q.H, total = img_bytes * q.data.size();
+      HIP_TRY(hipEventSynchronize(c->ev_in_free[slot]));   // chunk k-2 no longer reads this input buffer (never recorded: returns at once)
       c->pin_in[slot].ensure(total);
       c->b_in2[slot].ensure(total);
-      for (size_t b = 0; b < q.idx.size(); b++) {
-         const int j = q.idx[b];
-         const size_t stride = strides ? (size_t)strides[j] : row_bytes;
+      for (size_t b = 0; b < q.data.size(); b++) {
+         const size_t stride = q.stride[b];
          uint8_t *dst = (uint8_t *)c->pin_in[slot].p + img_bytes * b;
-         if (stride == row_bytes) memcpy(dst, images[j], img_bytes);
-         else for (int y = 0; y < q.H; y++) memcpy(dst + row_bytes * y, images[j] + stride * y, row_bytes);
+         if (stride == row_bytes) memcpy(dst, q.data[b], img_bytes);
+         else for (int y = 0; y < q.H; y++) memcpy(dst + row_bytes * y, q.data[b] + stride * y, row_bytes);
       }
       HIP_TRY(hipMemcpyAsync(c->b_in2[slot].p, c->pin_in[slot].p, total, hipMemcpyHostToDevice, c->h2d_stream));
       HIP_TRY(hipEventRecord(c->ev_h2d[slot], c->h2d_stream));
+      io.staged(q);
+      return s;
+   };
+   auto deliver = [&](State &s) {
+      if (s.total > 0) HIP_TRY(hipEventSynchronize(c->ev_d2h[s.no & 1]));
+      ChunkDone d;
+      d.chunk = &s.q; d.count_hessian = s.nh.data(); d.count_desc = s.nd.data(); d.key_off = s.off.data();
+      d.keys = (const hesaff_keypoint *)c->pin_out[(size_t)s.block].p; d.block = s.block;
+      io.done(d);
    };
 
-   std::future<void> staged;
-   if (NC > 0) staged = std::async(std::launch::async, stage, 0);
-   struct Pending { int chunk; int total; };
-   std::vector<int> totals((size_t)NC, 0);
+   std::future<std::unique_ptr<State>> staged = std::async(std::launch::async, stage, 0);
+   std::unique_ptr<State> prev;
    try {
-      for (int k = 0; k < NC; k++) {
-         const Chunk &q = chunks[k];
-         const int slot = k & 1, B = (int)q.idx.size();
+      for (int k = 0;; k++) {
+         std::unique_ptr<State> cur = staged.get();           // H2D of chunk k is enqueued
+         if (!cur) break;
+         cur->no = k;
+         staged = std::async(std::launch::async, stage, k + 1);
+         const HostChunk &q = cur->q;
+         const int slot = k & 1, B = (int)q.data.size();
          const size_t row_bytes = (size_t)q.W * q.ch, img_bytes = row_bytes * q.H;
-         staged.get();                                               // H2D of chunk k is enqueued
-         if (k + 1 < NC) staged = std::async(std::launch::async, stage, k + 1);
          HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_h2d[slot], 0));
          plan(c, std::min<int>(c->par.max_batch, B), q.H, q.W);
          run_batch(c, (const uint8_t *)c->b_in2[slot].p, q.ch, (long long)img_bytes, (int)row_bytes, B, q.H, q.W);
          HIP_TRY(hipEventRecord(c->ev_in_free[slot], c->stream));
          const int32_t *hs = c->h_starts.data(), *ds = c->h_starts.data() + (B + 1);
-         const int total = ds[B];
-         totals[k] = total;
+         cur->total = ds[B];
+         cur->nh.resize((size_t)B); cur->nd.resize((size_t)B); cur->off.resize((size_t)B);
          for (int b = 0; b < B; b++) {
-            const int j = q.idx[b];
-            results[j].count_hessian = hs[b + 1] - hs[b];
-            results[j].count_desc = ds[b + 1] - ds[b];
-            key_off[j] = (size_t)ds[b];
-            chunk_of[j] = k;
+            cur->nh[(size_t)b] = hs[b + 1] - hs[b];
+            cur->nd[(size_t)b] = ds[b + 1] - ds[b];
+            cur->off[(size_t)b] = (size_t)ds[b];
          }
-         // results: device copy into the staging slot (frees b_out for the next chunk), then D2H beside the next chunk
-         const size_t bytes = (size_t)total * sizeof(hesaff_keypoint);
-         c->pin_out[k].ensure(std::max<size_t>(bytes, 16));
-         if (total > 0) {
+         // chunk k-1: its copy out was enqueued before the kernels of chunk k and has long finished
+         if (prev) { deliver(*prev); prev.reset(); }
+         // a pinned block for chunk k
+         if (ring > 0) {
+            std::unique_lock<std::mutex> lk(c->ring_mu);
+            int blk = -1;
+            c->ring_cv.wait(lk, [&] {
+               for (int i = 0; i < ring; i++)
+                  if (!c->ring_busy[(size_t)i]) { blk = i; return true; }
+               return false;
+            });
+            c->ring_busy[(size_t)blk] = 1;
+            cur->block = blk;
+         } else {
+            if ((int)c->pin_out.size() <= k) c->pin_out.resize((size_t)k + 1);
+            cur->block = k;
+         }
+         // records: device copy into the staging slot (frees b_out for the next chunk), then D2H beside the next chunk
+         const size_t bytes = (size_t)cur->total * sizeof(hesaff_keypoint);
+         c->pin_out[(size_t)cur->block].ensure(std::max<size_t>(bytes, 16));
+         if (cur->total > 0) {
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_d2h[slot], 0));      // D2H of chunk k-2 has left this staging slot
             c->b_outstage[slot].ensure(bytes);
             HIP_TRY(hipMemcpyAsync(c->b_outstage[slot].p, c->b_out.p, bytes, hipMemcpyDeviceToDevice, c->stream));
             HIP_TRY(hipEventRecord(c->ev_out_ready[slot], c->stream));
             HIP_TRY(hipStreamWaitEvent(c->d2h_stream, c->ev_out_ready[slot], 0));
-            HIP_TRY(hipMemcpyAsync(c->pin_out[k].p, c->b_outstage[slot].p, bytes, hipMemcpyDeviceToHost, c->d2h_stream));
+            HIP_TRY(hipMemcpyAsync(c->pin_out[(size_t)cur->block].p, c->b_outstage[slot].p, bytes, hipMemcpyDeviceToHost, c->d2h_stream));
             HIP_TRY(hipEventRecord(c->ev_d2h[slot], c->d2h_stream));
          }
+         prev = std::move(cur);
       }
+      if (prev) { deliver(*prev); prev.reset(); }
    } catch (...) {
       if (staged.valid()) { try { staged.get(); } catch (...) {} }
       (void)hipStreamSynchronize(c->h2d_stream);
       (void)hipStreamSynchronize(c->d2h_stream);
+      (void)hipStreamSynchronize(c->stream);
       throw;
    }
    HIP_TRY(hipStreamSynchronize(c->d2h_stream));
    HIP_TRY(hipStreamSynchronize(c->stream));
-   for (int i = 0; i < n; i++)
-      results[i].keys = (const hesaff_keypoint *)c->pin_out[chunk_of[i]].p + key_off[i];
+}
+
+// chunks of a caller-supplied image list: images of equal (width, height, channels) grouped in input order
+struct ArrayIO : ChunkIO {
+   std::vector<HostChunk> chunks;
+   size_t pos = 0;
+   hesaff_ctx *c = nullptr;
+   hesaff_result *results = nullptr;             // hesaff_detect_batch: filled in place
+   hesaff_chunk_sink sink = nullptr;             // hesaff_detect_batch_cb
+   void *user = nullptr;
+   int sink_rc = 0;
+   ArrayIO(hesaff_ctx *ctx, int n, const uint8_t *const *images, const int *widths, const int *heights, const int *strides, const int *channels)
+      : c(ctx)
+   {
+      std::vector<char> done((size_t)n, 0);
+      for (int i = 0; i < n; i++) {
+         if (done[(size_t)i]) continue;
+         const int W = widths[i], H = heights[i], ch = channels ? channels[i] : 1;
+         if (ch != 1 && ch != 3) throw HsError(HESAFF_ERR_ARG, "channels must be 1 or 3");
+         std::vector<int> grp;
+         for (int j = i; j < n; j++)
+            if (!done[(size_t)j] && widths[j] == W && heights[j] == H && (channels ? channels[j] : 1) == ch) {
+               if (!images[j] || W < 1 || H < 1) throw HsError(HESAFF_ERR_ARG, "bad image");
+               if (strides && (long long)strides[j] < (long long)W * ch) throw HsError(HESAFF_ERR_ARG, "row stride smaller than width * channels");
+               grp.push_back(j);
+               done[(size_t)j] = 1;
+            }
+         for (size_t g0 = 0; g0 < grp.size(); g0 += (size_t)c->par.max_batch) {
+            HostChunk k;
+            k.W = W; k.H = H; k.ch = ch;
+            for (size_t g = g0; g < std::min(grp.size(), g0 + (size_t)c->par.max_batch); g++) {
+               const int j = grp[g];
+               k.index.push_back(j);
+               k.data.push_back(images[j]);
+               k.stride.push_back(strides ? (size_t)strides[j] : (size_t)W * ch);
+            }
+            chunks.push_back(std::move(k));
+         }
+      }
+   }
+   bool next(HostChunk &out) override
+   {
+      if (pos >= chunks.size() || sink_rc != 0) return false;
+      out = chunks[pos++];
+      return true;
+   }
+   void done(const ChunkDone &d) override
+   {
+      const size_t B = d.chunk->index.size();
+      if (results) {
+         for (size_t b = 0; b < B; b++) {
+            hesaff_result &r = results[d.chunk->index[b]];
+            r.count_hessian = d.count_hessian[b]; r.count_desc = d.count_desc[b]; r.keys = d.keys + d.key_off[b];
+         }
+         return;
+      }
+      std::vector<hesaff_result> tmp(B);
+      for (size_t b = 0; b < B; b++) { tmp[b].count_hessian = d.count_hessian[b]; tmp[b].count_desc = d.count_desc[b]; tmp[b].keys = d.keys + d.key_off[b]; }
+      if (sink_rc == 0) sink_rc = sink(user, (int)B, d.chunk->index.data(), tmp.data());
+      release_block(c, d.block);
+   }
+};
+
+// hesaff_process_files: decoder threads -> chunks -> device -> writer threads
+struct FileIO : ChunkIO {
+   hesaff_ctx *c;
+   int n;
+   const char *const *paths, *const *out_paths;
+   hesaff_file_status *status;
+   float mrSize;
+   struct Img { uint8_t *data = nullptr; int w = 0, h = 0, ch = 0; int state = 0; };   // 0 pending, 1 decoded, 2 unreadable, 3 handed on
+   std::vector<Img> imgs;
+   std::mutex mu;
+   std::condition_variable cv_dec, cv_img, cv_task;
+   int next_decode = 0, consumed = 0, window = 0, pos = 0;
+   bool stop = false;
+   struct Task { int index; const hesaff_keypoint *keys; int n; int chunk; };
+   std::deque<Task> tasks;
+   struct Open { int left; int block; };
+   std::vector<Open> open_chunks;
+   int tasks_in_flight = 0;
+   std::vector<std::thread> decoders, writers;
+
+   FileIO(hesaff_ctx *ctx, int n_, const char *const *p, const char *const *o, hesaff_file_status *st, int dec_threads, int wr_threads)
+      : c(ctx), n(n_), paths(p), out_paths(o), status(st), mrSize(ctx->par.mrSize), imgs((size_t)n_)
+   {
+      window = 2 * c->par.max_batch + dec_threads;
+      try {
+         for (int t = 0; t < dec_threads; t++) decoders.emplace_back([this] { decode_loop(); });
+         for (int t = 0; t < wr_threads; t++) writers.emplace_back([this] { write_loop(); });
+      } catch (...) {
+         shutdown();
+         throw;
+      }
+   }
+   ~FileIO() override { shutdown(); }
+   void shutdown()
+   {
+      { std::lock_guard<std::mutex> lk(mu); stop = true; }
+      cv_dec.notify_all(); cv_img.notify_all(); cv_task.notify_all();
+      for (auto &t : decoders) if (t.joinable()) t.join();
+      for (auto &t : writers) if (t.joinable()) t.join();
+      for (Img &im : imgs) if (im.data) { hesaff_free(im.data); im.data = nullptr; }
+   }
+   void decode_loop()
+   {
+      for (;;) {
+         int i;
+         {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_dec.wait(lk, [&] { return stop || next_decode >= n || next_decode < consumed + window; });
+            if (stop || next_decode >= n) return;
+            i = next_decode++;
+         }
+         Img im;
+         const int rc = paths[i] ? hesaff_read_image(paths[i], &im.data, &im.w, &im.h, &im.ch) : HESAFF_ERR_ARG;
+         {
+            std::lock_guard<std::mutex> lk(mu);
+            if (rc == HESAFF_OK) { im.state = 1; imgs[(size_t)i] = im; }
+            else { imgs[(size_t)i].state = 2; status[i].rc = rc; status[i].stage = HESAFF_FILE_UNREADABLE; }
+         }
+         cv_img.notify_all();
+      }
+   }
+   // the next run of consecutive readable images of one geometry
+   bool next(HostChunk &out) override
+   {
+      std::unique_lock<std::mutex> lk(mu);
+      for (;;) {
+         if (stop || pos >= n) break;
+         cv_img.wait(lk, [&] { return stop || imgs[(size_t)pos].state != 0; });
+         if (stop) break;
+         Img &im = imgs[(size_t)pos];
+         if (im.state == 2) { pos++; consumed = pos; cv_dec.notify_all(); continue; }
+         if (out.data.empty()) { out.W = im.w; out.H = im.h; out.ch = im.ch; }
+         else if (im.w != out.W || im.h != out.H || im.ch != out.ch) break;
+         out.data.push_back(im.data);
+         out.stride.push_back((size_t)im.w * im.ch);
+         out.index.push_back(pos);
+         im.state = 3;
+         pos++;
+         if ((int)out.data.size() >= c->par.max_batch) break;
+      }
+      return !out.data.empty();
+   }
+   void staged(const HostChunk &q) override
+   {
+      {
+         std::lock_guard<std::mutex> lk(mu);
+         for (int i : q.index) { hesaff_free(imgs[(size_t)i].data); imgs[(size_t)i].data = nullptr; }
+         consumed = std::max(consumed, q.index.back() + 1);
+      }
+      cv_dec.notify_all();
+   }
+   void done(const ChunkDone &d) override
+   {
+      const size_t B = d.chunk->index.size();
+      {
+         std::lock_guard<std::mutex> lk(mu);
+         const int id = (int)open_chunks.size();
+         open_chunks.push_back({(int)B, d.block});
+         for (size_t b = 0; b < B; b++) {
+            const int i = d.chunk->index[b];
+            status[i].count_hessian = d.count_hessian[b];
+            status[i].count_desc = d.count_desc[b];
+            status[i].stage = HESAFF_FILE_DETECTED;
+            tasks.push_back({i, d.keys + d.key_off[b], d.count_desc[b], id});
+            tasks_in_flight++;
+         }
+      }
+      cv_task.notify_all();
+   }
+   void write_loop()
+   {
+      for (;;) {
+         Task t;
+         {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_task.wait(lk, [&] { return stop || !tasks.empty(); });
+            if (tasks.empty()) return;   // stop
+            t = tasks.front();
+            tasks.pop_front();
+         }
+         std::string name;
+         const char *o = out_paths ? out_paths[t.index] : nullptr;
+         if (!o) { name = std::string(paths[t.index]) + ".hesaff.sift"; o = name.c_str(); }   // hesaff.cpp:170-173
+         const int rc = hesaff_write_sift_mt(o, t.keys, t.n, mrSize, 1);
+         int blk = -1;
+         {
+            std::lock_guard<std::mutex> lk(mu);
+            status[t.index].rc = rc;
+            if (rc == HESAFF_OK) status[t.index].stage = HESAFF_FILE_WRITTEN;
+            if (--open_chunks[(size_t)t.chunk].left == 0) blk = open_chunks[(size_t)t.chunk].block;
+            tasks_in_flight--;
+         }
+         if (blk >= 0) release_block(c, blk);
+         cv_task.notify_all();
+      }
+   }
+   void wait_writers()
+   {
+      std::unique_lock<std::mutex> lk(mu);
+      cv_task.wait(lk, [&] { return tasks_in_flight == 0; });
+   }
+};
+
+} // namespace
+
+extern "C" {
+
+int hesaff_detect_batch(hesaff_ctx *c, int n, const uint8_t *const *images, const int *widths, const int *heights,
+                        const int *strides, const int *channels, hesaff_result *results)
+{
+   if (!c || n < 0 || (n > 0 && (!images || !widths || !heights || !results))) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   ArrayIO io(c, n, images, widths, heights, strides, channels);
+   io.results = results;
+   run_chunks(c, io, 0);
+   HS_API_END(c)
+}
+
+int hesaff_detect_batch_cb(hesaff_ctx *c, int n, const uint8_t *const *images, const int *widths, const int *heights,
+                           const int *strides, const int *channels, hesaff_chunk_sink sink, void *user)
+{
+   if (!c || n < 0 || !sink || (n > 0 && (!images || !widths || !heights))) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   ArrayIO io(c, n, images, widths, heights, strides, channels);
+   io.sink = sink; io.user = user;
+   run_chunks(c, io, 3);
+   if (io.sink_rc != 0) throw HsError(HESAFF_ERR_IO, "the result sink reported an error");
+   HS_API_END(c)
+}
+
+int hesaff_process_files(hesaff_ctx *c, int n, const char *const *paths, const char *const *out_paths, int decode_threads,
+                         int write_threads, hesaff_file_status *status)
+{
+   if (!c || n < 0 || (n > 0 && (!paths || !status))) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   for (int i = 0; i < n; i++) { status[i].rc = HESAFF_ERR_IO; status[i].stage = HESAFF_FILE_PENDING; status[i].count_hessian = 0; status[i].count_desc = 0; }
+   const int host = hesaff_host_threads();
+   const int dt = std::max(1, std::min(decode_threads > 0 ? decode_threads : std::max(2, host / 4), 64));
+   const int wt = std::max(1, std::min(write_threads > 0 ? write_threads : host, 256));
+   FileIO io(c, n, paths, out_paths, status, dt, wt);
+   try {
+      run_chunks(c, io, 3);
+      io.wait_writers();
+   } catch (...) {
+      io.shutdown();
+      throw;
+   }
+   io.shutdown();
    HS_API_END(c)
 }
 

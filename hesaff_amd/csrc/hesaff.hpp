@@ -43,6 +43,9 @@ struct AffineHessianDetector {
    explicit AffineHessianDetector(const HessianAffineParams &par = HessianAffineParams(), int device = 0)
    {
       if (par.patch_size != 41) throw std::invalid_argument("patch_size is fixed at 41 in this build");
+      // the structs carry no size field: refuse a library built from another header before passing one across
+      if (hesaff_abi_version() != HESAFF_ABI_VERSION || hesaff_sizeof_params() != sizeof(hesaff_params) || hesaff_sizeof_timings() != sizeof(hesaff_timings))
+         throw std::runtime_error("libhesaff_amd.so was built from a different include/hesaff_amd.h (ABI version mismatch)");
       hesaff_default_params(&p_);
       p_.threshold = par.threshold;          // hesaff.cpp:155
       p_.maxIterations = par.max_iter;       // hesaff.cpp:158

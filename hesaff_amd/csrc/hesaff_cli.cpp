@@ -25,12 +25,6 @@
 
 namespace {
 
-struct Image {
-   uint8_t *data = nullptr;
-   int w = 0, h = 0, ch = 0;
-   bool ok = false;
-};
-
 // "0-7", "0,2,5", "1", "all" -> device ordinals
 bool parse_devices(const char *spec, std::vector<int> &out)
 {
@@ -44,23 +38,24 @@ bool parse_devices(const char *spec, std::vector<int> &out)
    while (*p) {
       char *e = nullptr;
       const long a = strtol(p, &e, 10);
-      if (e == p || a < 0) return false;
+      if (e == p || a < 0 || a >= ndev) return false;   // checked before anything is expanded ("0-99999999999")
       long b = a;
       p = e;
       if (*p == '-') {
          b = strtol(p + 1, &e, 10);
-         if (e == p + 1 || b < a) return false;
+         if (e == p + 1 || b < a || b >= ndev) return false;
          p = e;
       }
+      if (out.size() + (size_t)(b - a + 1) > 4096) return false;
       for (long d = a; d <= b; d++) out.push_back((int)d);
       if (*p == ',') p++;
       else if (*p) return false;
    }
-   for (int d : out)
-      if (d >= ndev) return false;
    return !out.empty();
 }
 
+// hesaff --batch: the list is cut into contiguous shards, one per device context (hesaff_shard_range); every shard runs
+// through hesaff_process_files - decode threads -> device -> writer threads, bounded memory - on its own host thread.
 int run_batch_mode(const char *list_path, const char *devices_spec)
 {
    std::ifstream lf(list_path);
@@ -75,45 +70,15 @@ int run_batch_mode(const char *list_path, const char *devices_spec)
       fprintf(stderr, "hesaff: bad --devices '%s' (%d device(s) visible)\n", devices_spec ? devices_spec : "0", hesaff_device_count());
       return 1;
    }
-   const int n_all = (int)names.size();
-   std::vector<Image> imgs((size_t)n_all);
-   int rc = 0;
-   // decode on a few host threads (the files are independent); an unreadable file is reported and skipped,
-   // the other images of the list are still processed (exit code 1 at the end)
-   {
-      std::atomic<int> next(0);
-      auto work = [&] {
-         for (int i; (i = next.fetch_add(1)) < n_all;)
-            imgs[i].ok = hesaff_read_image(names[i].c_str(), &imgs[i].data, &imgs[i].w, &imgs[i].h, &imgs[i].ch) == HESAFF_OK;
-      };
-      std::vector<std::thread> th;
-      const int T = std::max(1, std::min<int>(n_all, std::min(hesaff_host_threads(), 16)));
-      for (int t = 1; t < T; t++) th.emplace_back(work);
-      work();
-      for (auto &x : th) x.join();
-   }
-   std::vector<int> good;
-   for (int i = 0; i < n_all; i++) {
-      if (imgs[i].ok) good.push_back(i);
-      else {
-         fprintf(stderr, "hesaff: cannot read '%s' (binary PGM/PPM with maxval 255, PNG or JPEG expected): skipped\n", names[i].c_str());
-         rc = 1;
-      }
-   }
-   const int n = (int)good.size();
+   const int n = (int)names.size();
    const int world = (int)devices.size();
-   std::vector<hesaff_result> res((size_t)n);
-   std::vector<long long> nh((size_t)world, 0), nd((size_t)world, 0);
+   std::vector<const char *> paths((size_t)n);
+   for (int i = 0; i < n; i++) paths[(size_t)i] = names[(size_t)i].c_str();
+   std::vector<hesaff_file_status> status((size_t)n);
+   for (auto &st : status) { st.rc = HESAFF_ERR_IO; st.stage = HESAFF_FILE_PENDING; st.count_hessian = 0; st.count_desc = 0; }
    std::vector<std::string> errs((size_t)world);
-   std::mutex out_mutex;
-   float mrSize = 0;
-   {
-      hesaff_params par;
-      hesaff_default_params(&par);
-      mrSize = par.mrSize;
-   }
+   int rc = 0;
    const auto t1 = std::chrono::steady_clock::now();
-   // one context per device, each driven by its own host thread over its contiguous shard of the images
    auto device_worker = [&](int rank) {
       int lo = 0, hi = 0;
       hesaff_shard_range(n, rank, world, &lo, &hi);
@@ -123,35 +88,10 @@ int run_batch_mode(const char *list_path, const char *devices_spec)
       hesaff_default_params(&par);
       par.max_batch = std::max(1, std::min(m, 64));
       hesaff_ctx *ctx = nullptr;
-      if (hesaff_create(&ctx, &par, devices[rank]) != HESAFF_OK) { errs[rank] = hesaff_last_error(nullptr); return; }
-      std::vector<const uint8_t *> data((size_t)m);
-      std::vector<int> w((size_t)m), h((size_t)m), ch((size_t)m), stride((size_t)m);
-      for (int k = 0; k < m; k++) {
-         const Image &im = imgs[good[lo + k]];
-         data[k] = im.data; w[k] = im.w; h[k] = im.h; ch[k] = im.ch; stride[k] = im.w * im.ch;
-      }
-      if (hesaff_detect_batch(ctx, m, data.data(), w.data(), h.data(), stride.data(), ch.data(), res.data() + lo) != HESAFF_OK) {
-         errs[rank] = hesaff_last_error(ctx);
-         hesaff_destroy(ctx);
-         return;
-      }
-      std::vector<std::string> outs((size_t)m);
-      std::vector<const char *> outp((size_t)m);
-      for (int k = 0; k < m; k++) {
-         nh[rank] += res[lo + k].count_hessian;
-         nd[rank] += res[lo + k].count_desc;
-         outs[k] = names[good[lo + k]] + ".hesaff.sift";
-         outp[k] = outs[k].c_str();
-      }
-      // the result records live in the context's pinned memory: write this shard's files before the context goes away
-      const int T = std::max(1, hesaff_host_threads() / world);
-      if (hesaff_write_sift_batch(m, outp.data(), res.data() + lo, mrSize, T) != HESAFF_OK) errs[rank] = "cannot write the output files";
-      {
-         std::lock_guard<std::mutex> g(out_mutex);
-         for (int k = 0; k < m; k++)
-            std::cout << names[good[lo + k]] << ": Detected " << res[lo + k].count_hessian << " keypoints and " << res[lo + k].count_desc
-                      << " affine shapes" << std::endl;
-      }
+      if (hesaff_create(&ctx, &par, devices[(size_t)rank]) != HESAFF_OK) { errs[(size_t)rank] = hesaff_last_error(nullptr); return; }
+      const int host = hesaff_host_threads();
+      const int wt = std::max(1, host / world), dt = std::max(1, std::min(16, host / (2 * world)));
+      if (hesaff_process_files(ctx, m, paths.data() + lo, nullptr, dt, wt, status.data() + lo) != HESAFF_OK) errs[(size_t)rank] = hesaff_last_error(ctx);
       hesaff_destroy(ctx);
    };
    {
@@ -162,14 +102,24 @@ int run_batch_mode(const char *list_path, const char *devices_spec)
    }
    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
    long long tot_h = 0, tot_d = 0;
-   for (int r = 0; r < world; r++) {
-      tot_h += nh[r]; tot_d += nd[r];
-      if (!errs[r].empty()) { fprintf(stderr, "hesaff: device %d: %s\n", devices[r], errs[r].c_str()); rc = 1; }
+   int n_ok = 0;
+   for (int r = 0; r < world; r++)
+      if (!errs[(size_t)r].empty()) { fprintf(stderr, "hesaff: device %d: %s\n", devices[(size_t)r], errs[(size_t)r].c_str()); rc = 1; }
+   for (int i = 0; i < n; i++) {
+      const hesaff_file_status &st = status[(size_t)i];
+      if (st.rc == HESAFF_OK) {
+         std::cout << names[(size_t)i] << ": Detected " << st.count_hessian << " keypoints and " << st.count_desc << " affine shapes" << std::endl;
+         tot_h += st.count_hessian; tot_d += st.count_desc; n_ok++;
+      } else {
+         rc = 1;
+         if (st.stage == HESAFF_FILE_DETECTED) fprintf(stderr, "hesaff: cannot write '%s.hesaff.sift'\n", names[(size_t)i].c_str());
+         else if (st.stage == HESAFF_FILE_UNREADABLE)
+            fprintf(stderr, "hesaff: cannot read '%s' (binary PGM/PPM with maxval 255, PNG or JPEG expected): skipped\n", names[(size_t)i].c_str());
+      }
    }
-   std::cout << "Detected " << tot_h << " keypoints and " << tot_d << " affine shapes in " << n << " images in " << dt << " sec.";
+   std::cout << "Detected " << tot_h << " keypoints and " << tot_d << " affine shapes in " << n_ok << " images in " << dt << " sec.";
    if (world > 1) std::cout << " (" << world << " device contexts)";
    std::cout << std::endl;
-   for (Image &im : imgs) hesaff_free(im.data);
    return rc;
 }
 
@@ -177,6 +127,10 @@ int run_batch_mode(const char *list_path, const char *devices_spec)
 
 int main(int argc, char **argv)
 {
+   if (hesaff_abi_version() != HESAFF_ABI_VERSION || hesaff_sizeof_params() != sizeof(hesaff_params)) {
+      fprintf(stderr, "hesaff: libhesaff_amd.so has ABI version %d, this program was built for %d\n", hesaff_abi_version(), HESAFF_ABI_VERSION);
+      return 1;
+   }
    if (argc > 2 && strcmp(argv[1], "--batch") == 0) {
       const char *devices = nullptr;
       if (argc > 4 && strcmp(argv[3], "--devices") == 0) devices = argv[4];

@@ -16,7 +16,10 @@
 #include <utility>
 #include <vector>
 
+#include <cerrno>
+#include <fcntl.h>
 #include <sched.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include "../../include/hesaff_amd.h"
@@ -216,13 +219,25 @@ inline int fmt_g(char *dst, float vf)
    return (int)(p - dst);
 }
 
-inline char *fmt_u8(char *p, unsigned v)
-{
-   if (v >= 100) { *p++ = (char)('0' + v / 100); v %= 100; *p++ = (char)('0' + v / 10); *p++ = (char)('0' + v % 10); }
-   else if (v >= 10) { *p++ = (char)('0' + v / 10); *p++ = (char)('0' + v % 10); }
-   else *p++ = (char)('0' + v);
-   return p;
-}
+// " 0" .. " 255": the separator and the digits of one descriptor byte as one 4-byte store + its length (a row is 128 of
+// them: a table walk instead of 128 divisions and three-way branches)
+struct U8Table {
+   uint32_t w[256];
+   uint8_t len[256];
+   U8Table()
+   {
+      for (unsigned v = 0; v < 256; v++) {
+         char t[4] = {' ', 0, 0, 0};
+         int n = 1;
+         if (v >= 100) { t[n++] = (char)('0' + v / 100); t[n++] = (char)('0' + v / 10 % 10); t[n++] = (char)('0' + v % 10); }
+         else if (v >= 10) { t[n++] = (char)('0' + v / 10); t[n++] = (char)('0' + v % 10); }
+         else t[n++] = (char)('0' + v);
+         memcpy(&w[v], t, 4);
+         len[v] = (uint8_t)n;
+      }
+   }
+};
+const U8Table kU8;
 
 // Output buffers of tens of MB are recycled: hesaff_free() parks a big block in a small cache and
 // the next formatter call takes it again.  First-touch page faults of fresh memory (tens of
@@ -295,7 +310,11 @@ char *format_rows(const hesaff_keypoint *keys, int i0, int i1, float mrSize, cha
       p += fmt_g(p, ea); *p++ = ' ';
       p += fmt_g(p, eb); *p++ = ' ';
       p += fmt_g(p, ec);
-      for (int j = 0; j < 128; j++) { *p++ = ' '; p = fmt_u8(p, k.desc[j]); }
+      for (int j = 0; j < 128; j++) {   // each store is 4 bytes wide, the next one overwrites what was not a digit
+         const unsigned v = k.desc[j];
+         memcpy(p, &kU8.w[v], 4);
+         p += kU8.len[v];
+      }
       *p++ = '\n';
    }
    return p;
@@ -513,14 +532,49 @@ static int write_file(const char *path, const char *buf, size_t len)
 
 int hesaff_write_sift(const char *path, const hesaff_keypoint *keys, int n, float mrSize)
 {
-   if (!path) return HESAFF_ERR_ARG;
-   char *buf = nullptr;
-   size_t len = 0;
-   const int rc = hesaff_format_sift_mt(keys, n, mrSize, 0, &buf, &len);
-   if (rc != HESAFF_OK) return rc;
-   const int wr = write_file(path, buf, len);
-   big_free(buf);
-   return wr;
+   return hesaff_write_sift_mt(path, keys, n, mrSize, 0);
+}
+
+// threads == 1: the file is formatted and written in blocks of a few thousand rows through one buffer that stays in the
+// cache (a UHD image is 40 MB of text: formatting it whole and then copying it into the page cache moves it through
+// DRAM three times, block by block once).  Other thread counts: rows on `threads` workers into one buffer, one write.
+int hesaff_write_sift_mt(const char *path, const hesaff_keypoint *keys, int n, float mrSize, int threads)
+{
+   if (!path || n < 0 || (n > 0 && !keys)) return HESAFF_ERR_ARG;
+   if (threads != 1) {
+      char *buf = nullptr;
+      size_t len = 0;
+      const int rc = hesaff_format_sift_mt(keys, n, mrSize, threads, &buf, &len);
+      if (rc != HESAFF_OK) return rc;
+      const int wr = write_file(path, buf, len);
+      big_free(buf);
+      return wr;
+   }
+   HOSTIO_TRY
+   const int kBlockRows = 4096;
+   static thread_local std::vector<char> tl_buf;
+   tl_buf.resize(64 + (size_t)kBlockRows * kRowMax);
+   char *buf = tl_buf.data();
+   const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+   if (fd < 0) return HESAFF_ERR_IO;
+   size_t fill = (size_t)snprintf(buf, 64, "%d\n%d\n", 128, n);
+   bool ok = true;
+   for (int i0 = 0; ok && (i0 < n || fill > 0); i0 += kBlockRows) {
+      const int i1 = std::min(n, i0 + kBlockRows);
+      char *e = i0 < i1 ? format_rows(keys, i0, i1, mrSize, buf + fill) : buf + fill;
+      size_t left = (size_t)(e - buf);
+      const char *q = buf;
+      while (left > 0) {
+         const ssize_t w = write(fd, q, left);
+         if (w < 0) { if (errno == EINTR) continue; ok = false; break; }
+         q += w; left -= (size_t)w;
+      }
+      fill = 0;
+      if (i1 >= n) break;
+   }
+   if (close(fd) != 0) ok = false;
+   return ok ? HESAFF_OK : HESAFF_ERR_IO;
+   HOSTIO_CATCH
 }
 
 // One file per image of a batch (exportKeypoints once per image, hesaff.cpp:170-176), images
@@ -533,10 +587,7 @@ int hesaff_write_sift_batch(int n_images, const char *const *paths, const hesaff
    std::atomic<int> err(HESAFF_OK);
    run_tasks(n_images, T, [&](int i) {
       if (!paths[i]) { err = HESAFF_ERR_ARG; return; }
-      char *buf = nullptr;
-      size_t len = 0;
-      int rc = hesaff_format_sift_mt(results[i].keys, results[i].count_desc, mrSize, 1, &buf, &len);
-      if (rc == HESAFF_OK) { rc = write_file(paths[i], buf, len); big_free(buf); }
+      const int rc = hesaff_write_sift_mt(paths[i], results[i].keys, results[i].count_desc, mrSize, 1);
       if (rc != HESAFF_OK) err = rc;
    });
    return err.load();

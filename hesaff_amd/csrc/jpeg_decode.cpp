@@ -1,4 +1,4 @@
-// jpeg_decode.cpp -- baseline (sequential, Huffman, 8-bit) JPEG decoder for hesaff_read_image:
+// jpeg_decode.cpp -- Huffman-coded 8-bit JPEG decoder (sequential SOF0/SOF1 and progressive SOF2) for hesaff_read_image:
 // replaces cv::imread(argv[1]) (hesaff.cpp:137) for the format of the Oxford buildings / graf images.
 //
 // Pixels matter here: the detector's output depends on every decoded byte, and cv::imread decodes
@@ -34,8 +34,13 @@ struct Huff {
    bool defined = false;
    uint8_t look_len[512];    // 9-bit lookahead: code length (0 = longer than 9 bits)
    uint8_t look_val[512];
-   void build(const uint8_t *bits /*[1..16] at index 0..15*/, const uint8_t *v, int nv)
+   // false: the code-length counts do not describe a prefix code (more codes of some length than that length has left;
+   // libjpeg: JERR_BAD_HUFF_TABLE).  Such a table must be refused before the lookahead fill below, whose index
+   // code << (9 - l) would leave the 512 entries.
+   bool build(const uint8_t *bits /*[1..16] at index 0..15*/, const uint8_t *v, int nv)
    {
+      defined = false;
+      if (nv < 0 || nv > 256) return false;
       memcpy(vals, v, (size_t)nv);
       int code = 0, k = 0;
       for (int l = 1; l <= 16; l++) {
@@ -43,9 +48,11 @@ struct Huff {
          mincode[l] = code;
          code += bits[l - 1];
          k += bits[l - 1];
+         if (code > (1 << l)) return false;   // over-subscribed at length l
          maxcode[l] = bits[l - 1] ? code - 1 : -1;
          code <<= 1;
       }
+      if (k != nv) return false;
       maxcode[17] = 0x7fffffff;
       memset(look_len, 0, sizeof look_len);
       code = 0; k = 0;
@@ -57,6 +64,7 @@ struct Huff {
          code <<= 1;
       }
       defined = true;
+      return true;
    }
 };
 
@@ -337,7 +345,7 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
                if (tc == 0)   // a DC symbol is a bit count (libjpeg: JERR_BAD_HUFF_TABLE above 15)
                   for (int i = 0; i < nv; i++)
                      if (seg[o + 17 + i] > 15) return HESAFF_ERR_IO;
-               (tc ? hac : hdc)[th].build(&seg[o + 1], &seg[o + 17], nv);
+               if (!(tc ? hac : hdc)[th].build(&seg[o + 1], &seg[o + 17], nv)) return HESAFF_ERR_IO;
                o += 17 + nv;
             }
             break;
@@ -360,10 +368,11 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
             for (Comp &c : comps) {
                c.w = (W * c.h + hmax - 1) / hmax; c.hgt = (H * c.v + vmax - 1) / vmax;
                c.bw = mcux * c.h; c.bh = mcuy * c.v;
-               // a file cannot hold more coefficient blocks than bytes: refuse absurd headers before allocating
-               // (a progressive file can describe long runs of empty blocks in a few bits: there only the size is bounded)
-               if (!progressive && (unsigned long long)c.bw * c.bh > (unsigned long long)n * 64ull + 4096ull) return HESAFF_ERR_IO;
-               if (progressive && (unsigned long long)c.bw * c.bh > (1ull << 22)) return HESAFF_ERR_IO;   // 2^28 coefficients
+               // Refuse absurd headers before allocating: every block of a component costs at least one bit of entropy-coded
+               // data (sequential: its DC symbol; progressive: its DC symbol in the first DC scan - end-of-band runs shorten
+               // the AC scans only), so a file of n bytes holds at most 8 n blocks per component.  The bound below is eight
+               // times more generous and still keeps a 100-byte file from asking for gigabytes of coefficients and planes.
+               if ((unsigned long long)c.bw * c.bh > (unsigned long long)n * 64ull + 4096ull) return HESAFF_ERR_IO;
                c.plane.assign((size_t)c.bw * 8 * c.bh * 8, 0);
                if (progressive) c.coef.assign((size_t)c.bw * c.bh * 64, 0);
             }

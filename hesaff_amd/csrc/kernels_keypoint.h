@@ -520,10 +520,10 @@ __global__ __launch_bounds__(256) void k_image_large_rows(HessList hl, const uin
    }
 }
 
-__global__ __launch_bounds__(256) void k_prepare_patch(HessList hl, uint32_t h_lo, const uint32_t *__restrict__ n_ptr, AffineOut aff, int imRows,
-                                                       int imCols, DConsts k, KpTables tb, PatchWork pw)
+__global__ __launch_bounds__(256) void k_prepare_patch(HessList hl, uint32_t h_lo, uint32_t h_hi, const uint32_t *__restrict__ n_ptr, AffineOut aff,
+                                                       int imRows, int imCols, DConsts k, KpTables tb, PatchWork pw)
 {
-   hs_prepare_patch_body<true>(hl, h_lo, min(*n_ptr, hl.cap), aff, imRows, imCols, k, tb, pw);
+   hs_prepare_patch_body<true>(hl, h_lo, min(min(*n_ptr, hl.cap), h_hi), aff, imRows, imCols, k, tb, pw);   // keypoints [h_lo, h_hi) of the list
 }
 
 // stage API: the rectified matrices are already in pw.A (normalizeAffine's own arguments)

@@ -19,7 +19,12 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <condition_variable>
+#include <deque>
 #include <future>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include "../../include/hesaff_amd.h"
 #include "host_tables.h"
@@ -200,7 +205,10 @@ struct hesaff_ctx {
       void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
    };
    Pinned pin_in[2];
-   std::vector<Pinned> pin_out;       // one block per chunk of the current call, reused by later calls
+   std::vector<Pinned> pin_out;       // result blocks: one per chunk of the current call (hesaff_detect_batch), or a ring of three
+   std::mutex ring_mu;                // (hesaff_detect_batch_cb, hesaff_process_files: a block returns to the ring when its consumer
+   std::condition_variable ring_cv;   //  is done with it - release_block)
+   std::vector<char> ring_busy;
    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_in_free[2] = {nullptr, nullptr}, ev_out_ready[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
    std::vector<int32_t> h_starts;
@@ -218,7 +226,7 @@ struct hesaff_ctx {
    hipStream_t sift_stream = nullptr, sift_stream2 = nullptr;   // descriptor kernels of even / odd groups (sift2: HESAFF_SIFT2)
    bool sift2 = true;
    hipStream_t aff_stream = nullptr;      // affine shape of image group g+1 runs beside the patch extraction of group g
-   hipEvent_t ev_detect_done = nullptr;
+   hipEvent_t ev_detect_done = nullptr, ev_batch_done = nullptr;   // blocking-sync events: the host sleeps instead of spinning
    std::vector<hipEvent_t> ev_aff;        // one per image group, grown on demand
    hipEvent_t ev_extract_done[HS_NSLOT] = {}, ev_sift_done[HS_NSLOT] = {};
    DevBuf b_patches2[HS_NSLOT], b_siftvec2[HS_NSLOT], b_meanvar2[HS_NSLOT], b_siftvo2[HS_NSLOT];
@@ -942,7 +950,7 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       std::vector<int32_t> hs(3 * (B + 1));
       HIP_TRY(hipMemcpyAsync(hs.data(), c->b_starts.p, (size_t)3 * (B + 1) * 4, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipEventRecord(c->ev_detect_done, st));
-      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(hipEventSynchronize(c->ev_detect_done));   // blocking-sync event: no core spins while the detection stage runs
       if ((uint32_t)hs[B] > c->cap) throw HsError(HESAFF_ERR_CAPACITY, "keypoint capacity exceeded; raise hesaff_params.max_kpts_per_mpx");
       const uint32_t *lrows = (const uint32_t *)hs.data() + 2 * (B + 1);
       // image groups [h_lo, h_hi) of at most group_kpts keypoints: about 16 groups per batch keep the
@@ -994,8 +1002,9 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
          if (slot_used[slot]) HIP_TRY(hipStreamWaitEvent(st, c->ev_sift_done[slot], 0));   // the slot's previous descriptors are finished
          t = tm.begin(T_PATCH);
          HIP_TRY(hipMemsetAsync(cnt + 8, 0, 24 * 4, st));   // bin counts [8..13) and work counters [24..29)
-         HIP_TRY(hipMemcpyAsync(cnt + 5, &groups[gi].hi, 4, hipMemcpyHostToDevice, st));
-         hipLaunchKernelGGL(k_prepare_patch, dim3(1024), dim3(256), 0, st, s.hl, h_lo, (const uint32_t *)(cnt + 5), s.ao, H, W, c->consts,
+         // (the group's end travels as a kernel argument: a 4-byte copy from pageable memory would make the host wait
+         //  here until the stream has drained, once per group)
+         hipLaunchKernelGGL(k_prepare_patch, dim3(1024), dim3(256), 0, st, s.hl, h_lo, h_hi, (const uint32_t *)(cnt + 3), s.ao, H, W, c->consts,
                             c->tables, s.pw);
          run_patch_stage(c, s, c->gray, c->b_patches2[slot].as<float>(), h_lo, groups[gi].large_rows);
          tm.end(t);
@@ -1030,7 +1039,8 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
    c->h_starts.resize(2 * (B + 1) + 8);
    HIP_TRY(hipMemcpyAsync(c->h_starts.data(), c->b_starts.p, (size_t)2 * (B + 1) * 4, hipMemcpyDeviceToHost, st));
    HIP_TRY(hipMemcpyAsync(c->h_starts.data() + 2 * (B + 1), cnt, 8 * 4, hipMemcpyDeviceToHost, st));
-   HIP_TRY(hipStreamSynchronize(st));
+   HIP_TRY(hipEventRecord(c->ev_batch_done, st));
+   HIP_TRY(hipEventSynchronize(c->ev_batch_done));
    HIP_TRY(hipGetLastError());
    if (c->profiling) collect_timings(c, tm, B);
    const int32_t *cn = c->h_starts.data() + 2 * (B + 1);

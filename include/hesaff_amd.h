@@ -26,6 +26,16 @@ extern "C" {
 #define HESAFF_ERR_IO (-4)        /* file I/O                                     */
 #define HESAFF_ERR_NOMEM (-5)
 
+/* Layout version of the structs below (hesaff_params, hesaff_timings, hesaff_result, hesaff_file_status).  Neither struct
+ * carries a size field, so a caller built against another header would pass shifted fields without any error: callers
+ * compare hesaff_abi_version() (and, if they wish, the two sizeof functions) with the header they were compiled against
+ * before the first hesaff_create - hesaff.hpp and the Python binding do.  New fields are appended at the END of a
+ * struct and bump this number.   1: round 1;  2: + upscaleInputImage, fast, pack_ms (inserted mid-struct);  3: this header. */
+#define HESAFF_ABI_VERSION 3
+int hesaff_abi_version(void);
+size_t hesaff_sizeof_params(void);
+size_t hesaff_sizeof_timings(void);
+
 typedef struct hesaff_ctx hesaff_ctx;
 
 /* Parameters = the reference's compile-time structs flattened.
@@ -109,6 +119,35 @@ const char *hesaff_last_error(const hesaff_ctx *ctx);   /* ctx may be NULL: last
 int hesaff_detect_batch(hesaff_ctx *ctx, int n, const uint8_t *const *images, const int *widths,
                         const int *heights, const int *strides, const int *channels, hesaff_result *results);
 
+/* The same call with bounded host memory: results are handed to `sink` chunk by chunk (at most max_batch images at a
+ * time, image_index[i] = position in the caller's arrays) and are valid only until sink returns; the library cycles
+ * through three pinned result blocks however long the list is.  (hesaff_detect_batch keeps every chunk's block until
+ * the next call: about 19 MB per dense UHD image, 39 GB for 2048 of them - use this form or hesaff_process_files for
+ * long lists.)  A non-zero return of sink stops the run: HESAFF_ERR_IO. */
+typedef int (*hesaff_chunk_sink)(void *user, int n_images, const int *image_index, const hesaff_result *results);
+int hesaff_detect_batch_cb(hesaff_ctx *ctx, int n, const uint8_t *const *images, const int *widths, const int *heights,
+                           const int *strides, const int *channels, hesaff_chunk_sink sink, void *user);
+
+/* replaces: main() hesaff.cpp:133-180 for a list of image files - cv::imread (:137), grey conversion (:138-148),
+ * detectPyramidKeypoints (:167), the output name <image>.hesaff.sift (:170-173) and exportKeypoints (:175) - as a
+ * bounded three-stage host pipeline on one device: decode threads -> chunks of max_batch consecutive images of one
+ * size through the device (copy in / kernels / copy out overlapped) -> writer threads.  Host memory stays bounded
+ * (about 2 max_batch decoded images and three result blocks).  out_paths may be NULL (or hold NULLs): the reference's
+ * name.  status[i].rc = HESAFF_OK, or why file i was skipped (unreadable input, unwritable output); one bad file does
+ * not stop the others.  decode_threads / write_threads: 0 = auto (hesaff_host_threads). */
+#define HESAFF_FILE_PENDING 0   /* never reached (the run stopped on a device error before this file) */
+#define HESAFF_FILE_UNREADABLE 1
+#define HESAFF_FILE_DETECTED 2  /* detected and described, but the output file could not be written (rc says why) */
+#define HESAFF_FILE_WRITTEN 3
+typedef struct hesaff_file_status {
+   int32_t rc;                 /* HESAFF_OK only in stage HESAFF_FILE_WRITTEN */
+   int32_t stage;              /* how far this file got: HESAFF_FILE_* */
+   int32_t count_hessian;      /* g_numberOfPoints        hesaff.cpp:38 */
+   int32_t count_desc;         /* g_numberOfAffinePoints  hesaff.cpp:39 */
+} hesaff_file_status;
+int hesaff_process_files(hesaff_ctx *ctx, int n, const char *const *paths, const char *const *out_paths, int decode_threads,
+                         int write_threads, hesaff_file_status *status);
+
 /* Same path with inputs already resident in device memory (bench / pipelines that decode
  * on the GPU): d_gray = n contiguous height x width 8-bit grey planes (device pointer).
  * Results stay on the device; per-image counts are copied to the two host arrays.
@@ -125,6 +164,9 @@ int hesaff_get_timings(const hesaff_ctx *ctx, hesaff_timings *t);
  * hesaff_ellipse: (a,b,c) of one region, closed form of the SVD expression hesaff.cpp:115-123. */
 void hesaff_ellipse(const hesaff_keypoint *k, float mrSize, float *a, float *b, float *c);
 int hesaff_write_sift(const char *path, const hesaff_keypoint *keys, int n, float mrSize);
+/* the same file written by `threads` host threads (0 = auto); threads = 1 formats and writes block by block through a
+ * cache-resident buffer (what the per-image workers of hesaff_write_sift_batch / hesaff_process_files do) */
+int hesaff_write_sift_mt(const char *path, const hesaff_keypoint *keys, int n, float mrSize, int threads);
 /* formats into a malloc'ed buffer (*out, *len); caller frees with hesaff_free */
 int hesaff_format_sift(const hesaff_keypoint *keys, int n, float mrSize, char **out, size_t *len);
 /* the same bytes, rows formatted by `threads` host threads (0 = one per core, at most 64);

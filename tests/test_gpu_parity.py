@@ -739,6 +739,108 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
 
 
+def test_detect_batch_cb_streams_the_same_records(oracle):
+    """hesaff_detect_batch_cb (bounded pinned memory: a ring of three result blocks) hands over, chunk by chunk, exactly
+    the records hesaff_detect_batch returns; more chunks than ring blocks, mixed sizes, an image without keypoints."""
+    import hesaff_amd
+    sizes = [(120, 160), (96, 96), (120, 160), (131, 77), (96, 96), (120, 160), (120, 160), (77, 131), (120, 160), (96, 96), (120, 160)]
+    imgs = [band_noise_image(h, w, 40 + i, SMALL_BANDS) for i, (h, w) in enumerate(sizes)]
+    imgs[3] = np.full((131, 77), 90, np.uint8)     # featureless
+    p = hesaff_amd.default_params(); p.max_batch = 2
+    with hesaff_amd.HesaffContext(p, device=0) as ctx:
+        want = ctx.detect_batch(imgs)
+        got = {}
+        calls = []
+
+        def sink(idx, res):
+            calls.append(list(idx))
+            for i, r in zip(idx, res):
+                assert i not in got
+                got[i] = r
+            return 0
+        ctx.detect_batch_cb(imgs, sink)
+        assert sorted(got) == list(range(len(imgs))) and len(calls) >= 7 and max(len(c) for c in calls) <= 2
+        for i, (nh, keys) in enumerate(want):
+            assert got[i][0] == nh and got[i][1].tobytes() == keys.tobytes(), i
+        assert len(want[3][1]) == 0 and sum(len(k) for _, k in want) > 500
+        # a sink that reports failure stops the run with an error
+        with pytest.raises(hesaff_amd.HesaffError):
+            ctx.detect_batch_cb(imgs, lambda idx, res: 1)
+        # ... and the context is still usable
+        again = ctx.detect_batch(imgs[:3])
+        assert all(a[1].tobytes() == b[1].tobytes() for a, b in zip(again, want[:3]))
+
+
+def test_process_files_pipeline(tmp_path, oracle):
+    """hesaff_process_files (decode threads -> device -> writer threads; what `hesaff --batch` runs): every readable file gets
+    the bytes the oracle writes for its pixels; an unreadable input and an unwritable output are reported per file and do
+    not stop the others; explicit output names are honoured."""
+    import hesaff_amd
+    from tests import _oracle
+    sizes = [(120, 160), (120, 160), (96, 96), (131, 77), (120, 160), (120, 160), (120, 160), (96, 96), (200, 140)]
+    paths, outs, texts = [], [], []
+    for i, (h, w) in enumerate(sizes):
+        img = band_noise_image(h, w, 60 + i, SMALL_BANDS)
+        q = tmp_path / ("f%02d.pgm" % i)
+        q.write_bytes(b"P5\n%d %d\n255\n" % (w, h) + img.tobytes())
+        paths.append(str(q)); outs.append(None)
+        texts.append(_oracle.OracleRun(_oracle.gray_from_u8(img)).export_text())
+    bad_in = tmp_path / "broken.pgm"; bad_in.write_bytes(b"P5\n10 10\n255\nshort")
+    paths.insert(2, str(bad_in)); outs.insert(2, None); texts.insert(2, None)
+    outs[4] = str(tmp_path / "elsewhere.txt")                          # explicit output name
+    outs[6] = str(tmp_path / "no_such_dir" / "x.hesaff.sift")         # cannot be written
+    p = hesaff_amd.default_params(); p.max_batch = 2
+    with hesaff_amd.HesaffContext(p, device=0) as ctx:
+        st = ctx.process_files(paths, outs, decode_threads=3, write_threads=3)
+    OK, IO = 0, -4
+    for i, (rc, stage, nh, nd) in enumerate(st):
+        if i == 2:
+            assert (rc, stage, nh, nd) == (IO, 1, 0, 0)                # HESAFF_FILE_UNREADABLE
+        elif i == 6:
+            assert rc == IO and stage == 2 and nd > 0                  # HESAFF_FILE_DETECTED, not written
+        else:
+            assert rc == OK and stage == 3, (i, rc, stage)
+            name = outs[i] or paths[i] + ".hesaff.sift"
+            assert open(name, "rb").read() == texts[i] and nd == int(texts[i].split(b"\n")[1]), i
+    assert not os.path.exists(paths[4] + ".hesaff.sift")
+    # defaults (threads = 0: auto, names = the reference's) on the readable files only
+    good = [q for i, q in enumerate(paths) if i != 2]
+    with hesaff_amd.HesaffContext(device=0) as ctx:
+        st = ctx.process_files(good)
+    assert all(rc == OK and stage == 3 for rc, stage, _, _ in st)
+    for q, t in zip(good, [t for t in texts if t is not None]):
+        assert open(q + ".hesaff.sift", "rb").read() == t
+
+
+def test_sequence_with_homographies_through_cli_and_repeatability_tool(tmp_path, oracle):
+    """BASELINE.json config 5 on its offline stand-in (the Oxford data are not available): a graf-like sequence - one 800x640
+    colour image and copies under known homographies, stored as 4:2:0 JPEG files next to H1toNp files like the Oxford sets -
+    goes through `hesaff --batch` (in-tree JPEG decoder -> device -> writer threads) and tools/repeatability.py.  Every output
+    file equals what the oracle writes for the decoded pixels, so repeatability and matching score are the restated
+    reference's by construction; the table itself is checked for sanity."""
+    import sys
+    import hesaff_amd
+    from tests import _oracle
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import repeatability as rp
+    angles = (20, 40)
+    res = rp.sequence_through_cli(str(tmp_path / "seq"), 800, 640, angles)
+    paths = [str(tmp_path / "seq" / ("img%d.jpg" % (k + 1))) for k in range(1 + len(angles))]
+    from PIL import Image
+    for q in paths:
+        pix = hesaff_amd.read_image(q)
+        assert pix.shape == (640, 800, 3) and np.array_equal(pix, np.asarray(Image.open(q).convert("RGB")))   # == libjpeg's pixels
+        o = _oracle.OracleRun(_oracle.gray_from_u8(pix))
+        assert open(q + ".hesaff.sift", "rb").read() == o.export_text() and o.n_keys > 2000
+    assert os.path.exists(str(tmp_path / "seq" / "H1to2p"))
+    pairs = res["pairs"]
+    assert [e["viewpoint_deg"] for e in pairs] == list(angles)
+    assert pairs[0]["repeatability"] > 0.6 and pairs[0]["matching_score"] > 0.5, pairs
+    assert pairs[1]["repeatability"] > 0.4 and pairs[0]["repeatability"] > pairs[1]["repeatability"], pairs
+    for e in pairs:
+        assert e["correspondences"] >= e["matches"] > 500 and e["correspondences"] <= min(e["n1"], e["n2"])
+
+
 def _structured_image(kind, h, w, rng):
     yy, xx = np.mgrid[0:h, 0:w]
     if kind == "checker":

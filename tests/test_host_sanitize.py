@@ -56,6 +56,91 @@ def _mutants(data, rng, n):
     return out
 
 
+def _dht_mutants(data, rng, n):
+    """Structure-aware damage of a JPEG's Huffman tables: the 16 code-length counts of a DHT table are redistributed while
+    their sum (the number of symbols) stays what the segment length says, so the table passes every length check and only
+    its prefix-code property breaks (over-subscribed lengths, all codes one bit long, ...).  A plain byte flip changes the
+    sum and is refused before the table is ever built."""
+    out = []
+    segs = []
+    pos = 2
+    while pos + 4 <= len(data) and data[pos] == 0xFF:
+        m = data[pos + 1]
+        if m == 0xD8 or m == 0x01 or 0xD0 <= m <= 0xD7:
+            pos += 2
+            continue
+        ln = (data[pos + 2] << 8) | data[pos + 3]
+        if m == 0xC4:
+            o = pos + 4
+            while o + 17 <= pos + 2 + ln:
+                nv = sum(data[o + 1:o + 17])
+                segs.append((o + 1, nv))
+                o += 17 + nv
+        if m == 0xDA:
+            break
+        pos += 2 + ln
+    for _ in range(n):
+        if not segs:
+            break
+        b = bytearray(data)
+        for at, nv in rng.sample(segs, rng.randrange(1, len(segs) + 1)):
+            counts = [0] * 16
+            kind = rng.randrange(4)
+            if kind == 0:                                   # everything at one short length
+                counts[rng.randrange(0, 4)] = nv
+            elif kind == 1:                                 # random split, short lengths favoured
+                left = nv
+                for l in range(16):
+                    c = min(left, 255, rng.randrange(0, max(1, left // 2) + 1)) if l < 15 else min(left, 255)
+                    counts[l] = c; left -= c
+                counts[15] = min(255, counts[15] + left)
+            elif kind == 2:                                 # move a few codes to a shorter length
+                counts = list(b[at:at + 16])
+                for _ in range(rng.randrange(1, 5)):
+                    src = rng.randrange(16)
+                    if counts[src] == 0:
+                        continue
+                    dst = rng.randrange(0, src + 1)
+                    k = rng.randrange(1, counts[src] + 1)
+                    if counts[dst] + k <= 255:
+                        counts[src] -= k; counts[dst] += k
+            else:                                           # exactly one code too many at some length
+                counts = list(b[at:at + 16])
+                l = rng.randrange(0, 9)
+                room = (1 << (l + 1))
+                take = [i for i in range(16) if i != l and counts[i] > 0]
+                while counts[l] <= room and take and sum(counts) == nv:
+                    i = take[-1]
+                    counts[i] -= 1; counts[l] += 1
+                    if counts[i] == 0:
+                        take.pop()
+                    if counts[l] > 255:
+                        break
+                counts[l] = min(counts[l], 255)
+            if sum(counts) == nv and all(0 <= c <= 255 for c in counts):
+                b[at:at + 16] = bytes(counts)
+        out.append(bytes(b))
+    return out
+
+
+# ADVICE r02 (high): SOI + one DHT whose counts say "200 codes of length 1" + EOI.  The lookahead fill of Huff::build wrote
+# past look_len[512] / look_val[512] (UBSan: index 512 out of bounds); the reader must refuse the table instead.
+OVERSUBSCRIBED_DHT = b"\xff\xd8" + b"\xff\xc4" + bytes([0, 2 + 17 + 200]) + bytes([0x10, 200] + [0] * 15) + bytes(range(200)) + b"\xff\xd9"
+
+
+def test_oversubscribed_huffman_table_is_refused(driver, tmp_path):
+    assert len(OVERSUBSCRIBED_DHT) == 225
+    paths = []
+    for k, blob in enumerate([OVERSUBSCRIBED_DHT,
+                              # three one-bit codes; 129 two-bit codes; a full tree plus one
+                              b"\xff\xd8\xff\xc4" + bytes([0, 2 + 17 + 3]) + bytes([0x10, 3] + [0] * 15) + bytes(3) + b"\xff\xd9",
+                              b"\xff\xd8\xff\xc4" + bytes([0, 2 + 17 + 129]) + bytes([0x11, 0, 129] + [0] * 14) + bytes(129) + b"\xff\xd9",
+                              b"\xff\xd8\xff\xc4" + bytes([0, 2 + 17 + 5]) + bytes([0x01, 1, 1, 3] + [0] * 13) + bytes(5) + b"\xff\xd9"]):
+        p = str(tmp_path / ("dht%d.jpg" % k)); open(p, "wb").write(blob); paths.append(p)
+    out = _run(driver, ["read"] + paths)
+    assert "read ok=0" in out, out
+
+
 def test_readers_refuse_damaged_files_without_memory_errors(driver, tmp_path):
     import numpy as np
     from tests.test_host_side import _png_bytes
@@ -79,6 +164,11 @@ def test_readers_refuse_damaged_files_without_memory_errors(driver, tmp_path):
             p = str(tmp_path / ("%s.%03d" % (f, k)))
             open(p, "wb").write(m)
             paths.append(p)
+        if f.endswith(".jpg"):
+            for k, m in enumerate(_dht_mutants(data, rng, 120)):
+                p = str(tmp_path / ("%s.dht%03d" % (f, k)))
+                open(p, "wb").write(m)
+                paths.append(p)
     # plus files that are not images at all
     for k, blob in enumerate([b"", b"P5", b"P5\n99999999 99999999\n255\n", b"\x89PNG\r\n\x1a\n", b"\xff\xd8\xff", b"\xff\xd8" + b"\xff\xc0" * 40]):
         p = str(tmp_path / ("junk%d" % k)); open(p, "wb").write(blob); paths.append(p)

@@ -99,23 +99,19 @@ def evaluate(reg1, desc1, reg2, desc2, H, size1, size2, max_error=0.4, chunk=200
     n1, n2 = len(r1), len(r2)
     if min(n1, n2) == 0:
         return {"n1": int(n1), "n2": int(n2), "correspondences": 0, "repeatability": 0.0, "matches": 0, "matching_score": 0.0}
-    # candidate pairs: centres closer than the sum of the mean radii (cheap prefilter on a grid of cells)
+    # candidate pairs: centres closer than the sum of the mean radii (blocks of rows of the distance matrix; pairs come out
+    # ordered by (i, j))
     rad1 = np.sqrt(ellipse_area(r1) / np.pi); rad2 = np.sqrt(ellipse_area(r2) / np.pi)
-    cell = max(float(np.percentile(np.r_[rad1, rad2], 90)) * 2.0, 8.0)
-    from collections import defaultdict
-    buckets = defaultdict(list)
-    for j, (x, y) in enumerate(r2[:, :2]):
-        buckets[(int(x // cell), int(y // cell))].append(j)
     pi_, pj_ = [], []
-    for i, (x, y) in enumerate(r1[:, :2]):
-        cx, cy = int(x // cell), int(y // cell)
-        reach = int(np.ceil((rad1[i] + cell) / cell))
-        for gx in range(cx - reach, cx + reach + 1):
-            for gy in range(cy - reach, cy + reach + 1):
-                for j in buckets.get((gx, gy), ()):
-                    if (x - r2[j, 0]) ** 2 + (y - r2[j, 1]) ** 2 < (rad1[i] + rad2[j]) ** 2:
-                        pi_.append(i); pj_.append(j)
-    pi_ = np.asarray(pi_, np.int64); pj_ = np.asarray(pj_, np.int64)
+    for s0 in range(0, n1, 512):
+        x = r1[s0:s0 + 512, 0, None] - r2[None, :, 0]; y = r1[s0:s0 + 512, 1, None] - r2[None, :, 1]
+        ii, jj = np.nonzero(x * x + y * y < (rad1[s0:s0 + 512, None] + rad2[None, :]) ** 2)
+        pi_.append(ii + s0); pj_.append(jj)
+    pi_ = np.concatenate(pi_).astype(np.int64); pj_ = np.concatenate(pj_).astype(np.int64)
+    # overlap error >= 1 - min(area) / max(area): pairs that this bound already rejects are not rasterised
+    ar1 = ellipse_area(r1)[pi_]; ar2 = ellipse_area(r2)[pj_]
+    maybe = np.minimum(ar1, ar2) > (1.0 - max_error) * np.maximum(ar1, ar2)
+    pi_, pj_ = pi_[maybe], pj_[maybe]
     err = np.empty(len(pi_))
     for s in range(0, len(pi_), chunk):
         err[s:s + chunk] = overlap_error(r1[pi_[s:s + chunk]], r2[pj_[s:s + chunk]])
@@ -134,10 +130,13 @@ def evaluate(reg1, desc1, reg2, desc2, H, size1, size2, max_error=0.4, chunk=200
     # neighbour of its partner in descriptor space
     matches = 0
     if ncorr:
-        D2 = d2.astype(np.float32)
-        for a, b in pairs:
-            dist = ((D2 - d1[a].astype(np.float32)) ** 2).sum(axis=1)
-            matches += int(np.argmin(dist) == b)
+        # squared distances are integers below 2^24 (128 x 255^2): exact in float64 products
+        D2 = d2.astype(np.float64); n2sq = (D2 * D2).sum(axis=1)
+        pa = np.asarray([a for a, _ in pairs]); pb = np.asarray([b for _, b in pairs])
+        for s0 in range(0, ncorr, 1024):
+            D1 = d1[pa[s0:s0 + 1024]].astype(np.float64)
+            dist = n2sq[None, :] - 2.0 * (D1 @ D2.T)            # + |d1|^2, constant per row
+            matches += int((np.argmin(dist, axis=1) == pb[s0:s0 + 1024]).sum())
     return {"n1": int(n1), "n2": int(n2), "correspondences": int(ncorr), "repeatability": ncorr / min(n1, n2),
             "matches": int(matches), "matching_score": matches / min(n1, n2), "max_overlap_error": max_error}
 
@@ -190,6 +189,64 @@ def synthetic_sequence(width=800, height=640, angles=(10, 20, 30, 40, 50), seed=
                     "(the Oxford sequences are not available offline)" % (width, height), "pairs": out}
 
 
+def write_sequence_files(out_dir, width=800, height=640, angles=(10, 20, 30, 40, 50), seed=1234, quality=92):
+    """A graf-like sequence on disk, laid out like the Oxford sets: img1.jpg .. imgN.jpg (colour JPEG, 4:2:0, so that the
+    library's own JPEG decoder is on the path exactly as with the real data) and H1to2p .. H1toNp (3x3 text).
+    -> (image paths, homographies)."""
+    from PIL import Image
+    from hesaff_amd.synth import band_noise_image
+    g = band_noise_image(height, width, seed).astype(np.float32)
+    t1 = band_noise_image(height, width, seed + 1).astype(np.float32)
+    t2 = band_noise_image(height, width, seed + 2).astype(np.float32)
+    base = np.stack([g, 0.75 * g + 0.25 * t1, 0.75 * g + 0.25 * t2], axis=2)
+    base = np.clip(np.rint(base), 0, 255).astype(np.uint8)
+    os.makedirs(out_dir, exist_ok=True)
+    paths, Hs = [], []
+    for k, a in enumerate((0,) + tuple(angles)):
+        H = np.eye(3) if k == 0 else viewpoint_homography(width, height, a)
+        img = base if k == 0 else np.stack([warp_image(base[:, :, c], H, (width, height)) for c in range(3)], axis=2)
+        q = os.path.join(out_dir, "img%d.jpg" % (k + 1))
+        Image.fromarray(img, "RGB").save(q, "JPEG", quality=quality, subsampling=2)
+        paths.append(q); Hs.append(H)
+        if k > 0:
+            np.savetxt(os.path.join(out_dir, "H1to%dp" % (k + 1)), H)
+    return paths, Hs
+
+
+def evaluate_sequence_files(paths, Hs, size, angles=None):
+    """Repeatability / matching score of image 1 against every other image from their .hesaff.sift files."""
+    r1, d1 = read_sift(paths[0] + ".hesaff.sift")
+    out = []
+    for k in range(1, len(paths)):
+        r2, d2 = read_sift(paths[k] + ".hesaff.sift")
+        ev = evaluate(r1, d1, r2, d2, Hs[k], size, size)
+        ev["pair"] = "img1 -> img%d" % (k + 1)
+        if angles is not None:
+            ev["viewpoint_deg"] = angles[k - 1]
+        out.append(ev)
+    return out
+
+
+def sequence_through_cli(out_dir, width=800, height=640, angles=(10, 20, 30, 40, 50)):
+    """BASELINE.json config 5 on the synthetic stand-in: the sequence as JPEG files -> `hesaff --batch` (decode threads,
+    device, writer threads) -> the evaluation above."""
+    import subprocess
+    paths, Hs = write_sequence_files(out_dir, width, height, angles)
+    lst = os.path.join(out_dir, "list.txt")
+    with open(lst, "w") as f:
+        f.write("\n".join(paths) + "\n")
+    exe = os.path.join(ROOT, "hesaff_amd", "bin", "hesaff")
+    r = subprocess.run([exe, "--batch", lst], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hesaff --batch failed: " + r.stderr[-2000:])
+    return {"data": "synthetic graf-like sequence: %dx%d colour band-noise image and %d copies warped by a camera rotation about the "
+                    "vertical axis, stored as JPEG (quality 92, 4:2:0) and read back by the library's JPEG decoder; the Oxford "
+                    "sequences are not available offline" % (width, height, len(angles)),
+            "command": "python tools/repeatability.py --synthetic-files DIR   (hesaff --batch list.txt, then the evaluation)",
+            "cli_stdout_tail": r.stdout.strip().splitlines()[-1],
+            "pairs": evaluate_sequence_files(paths, Hs, (width, height), list(angles))}
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("files", nargs="*")
@@ -197,7 +254,11 @@ def main():
     ap.add_argument("--size1", nargs=2, type=int, metavar=("W", "H"))
     ap.add_argument("--size2", nargs=2, type=int, metavar=("W", "H"))
     ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--synthetic-files", metavar="DIR", help="write the synthetic sequence as JPEG files into DIR, run `hesaff --batch` on it, evaluate")
     args = ap.parse_args()
+    if args.synthetic_files:
+        print(json.dumps(sequence_through_cli(args.synthetic_files), indent=1))
+        return
     if args.synthetic:
         print(json.dumps(synthetic_sequence()))
         return
