@@ -97,6 +97,55 @@ def host_cpu_info():
     return info
 
 
+def hbm_probe(torch, dev):
+    """What THIS box's HBM delivers to plain streaming kernels (torch elementwise kernels on 2 GB operands), measured in the
+    same run as the roofline lines: boxes of the pool differ by several per cent, and the guide's 8 TB/s is a pin rate."""
+    n = 1 << 29
+    a = torch.empty(n, device=dev, dtype=torch.float32).normal_()
+    b = torch.empty_like(a)
+    c = torch.empty_like(a)
+    out = {}
+
+    def t(f, nbytes, name, reps=5):
+        f(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f()
+        torch.cuda.synchronize()
+        out[name] = nbytes / ((time.perf_counter() - t0) / reps) / 1e9
+    t(lambda: b.copy_(a), 8.0 * n, "copy_1r1w_GBs")
+    t(lambda: b.fill_(1.0), 4.0 * n, "fill_1w_GBs")
+    t(lambda: torch.add(a, b, out=c), 12.0 * n, "add_2r1w_GBs")
+    del a, b, c
+    torch.cuda.empty_cache()
+    return out
+
+
+def density_leg(hesaff_amd, torch, dev, device, B, H, W, seed, steps):
+    """The same step on photograph-like images (about 2.5 k descriptors per Mpx instead of 14 k): device-resident, like `value`."""
+    from hesaff_amd.synth import BANDS_NATURAL, band_noise_batch_torch
+    imgs = band_noise_batch_torch(B, H, W, seed=seed, device=dev, bands=BANDS_NATURAL)
+    torch.cuda.synchronize()
+    p = hesaff_amd.default_params()
+    p.max_batch = B
+    with hesaff_amd.HesaffContext(p, device=device) as ctx:
+        ctx.detect_batch_device(imgs.data_ptr(), B, W, H)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nd = 0
+        for _ in range(steps):
+            _, cd, _, _ = ctx.detect_batch_device(imgs.data_ptr(), B, W, H)
+            nd += int(cd.sum())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    del imgs
+    torch.cuda.empty_cache()
+    return {"value": nd / dt, "unit": "keypoints/s", "images_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "descriptors_per_image": nd / (B * steps),
+            "what": "the same device-resident step on %d x %dx%d images of the photograph-like family (BANDS_NATURAL: one octave coarser, "
+                    "about 2.5 k descriptors per Mpx); not the headline workload" % (B, W, H)}
+
+
 def file_path_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device):
     """hesaff_process_files (what `hesaff --batch` runs: decode threads -> chunks through the device -> writer threads) on
     n_files binary PGM files of the bench images on a RAM disk, every <name>.hesaff.sift written there too.  One timed run
@@ -173,7 +222,8 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=2, help="images of the batch timed on the CPU oracle, 1 thread (about 14 s each)")
     ap.add_argument("--cpu-workers", type=int, default=-1,
                     help="worker processes of the multi-core CPU baseline, one image each (-1: one per physical core, at most the batch; 0: skip)")
-    ap.add_argument("--e2e-images", type=int, default=192, help="image files of the measured end-to-end file path (0: skip; fewer when the RAM disk is small)")
+    ap.add_argument("--natural-steps", type=int, default=2, help="steps of the extra photograph-like-density leg of the default run (0: skip)")
+    ap.add_argument("--e2e-images", type=int, default=384, help="image files of the measured end-to-end file path (0: skip; fewer when the RAM disk is small)")
     ap.add_argument("--e2e-chunk", type=int, default=32, help="images per device chunk of the end-to-end leg (hesaff_params.max_batch)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: every rank owns --batch images per step; strong: --global-images images per step in total, "
@@ -239,7 +289,7 @@ def main():
     p.max_batch = B
     ctx = hesaff_amd.HesaffContext(p, device=local_rank)
 
-    bh = {"ms": 0.0, "bytes": 0.0, "launches": 0}
+    bh = {"ms": 0.0, "bytes": 0.0, "launches": 0, "ex_ms": 0.0, "ex_bytes": 0.0, "ex_launches": 0}
     stage = {"pyramid_ms": 0.0, "detect_ms": 0.0, "affine_ms": 0.0, "patch_ms": 0.0, "sift_ms": 0.0, "pack_ms": 0.0, "total_ms": 0.0}
     tot = {"desc": 0, "hess": 0, "imgs": 0, "pyr_bytes": 0.0}
 
@@ -254,6 +304,7 @@ def main():
                 tot["desc"] += int(cd.sum()); tot["hess"] += int(ch.sum()); tot["imgs"] += nb
                 tm = ctx.timings()
                 bh["ms"] += tm.blur_hess_ms; bh["bytes"] += tm.blur_hess_bytes; bh["launches"] += tm.blur_hess_launches
+                bh["ex_ms"] += tm.extrema_ms; bh["ex_bytes"] += tm.extrema_bytes; bh["ex_launches"] += tm.extrema_launches
                 tot["pyr_bytes"] += tm.pyramid_bytes
                 for k in stage:
                     stage[k] += getattr(tm, k)
@@ -284,6 +335,10 @@ def main():
     tot_hess, tot_desc, tot_imgs = [int(v) for v in counts.sum(axis=0)]
     per_rank_images = [int(v) for v in counts[:, 2]]
     ctx.close()
+    probe = hbm_probe(torch, dev) if rank == 0 else None
+    natural = None
+    if rank == 0 and args.natural_steps > 0 and args.density == "dense" and not args.no_host_path:
+        natural = density_leg(hesaff_amd, torch, dev, local_rank, B, H, W, 1234 + g_lo, args.natural_steps)
 
     # ---- host-inclusive leg: host images -> hesaff_detect_batch -> host records, + text export ----
     host_path = None
@@ -355,6 +410,7 @@ def main():
         achieved = (bh_bytes / 1e9) / (bh_ms / 1e3) if bh_ms > 0 else 0.0
         st = {k: v / args.steps for k, v in stage.items()}
         pyr_bytes_step = tot["pyr_bytes"] / args.steps
+        ex_achieved = (bh["ex_bytes"] / 1e9) / (bh["ex_ms"] / 1e3) if bh["ex_ms"] > 0 else 0.0
         out = {
             "metric": "keypoints/sec (descriptors written), 4K grayscale batch",
             "value": tot_desc / dt,
@@ -380,6 +436,14 @@ def main():
             "host_path": host_path,
             "text_export": text_export,
             "end_to_end": end_to_end,
+            "natural_density": natural,
+            "hbm_probe": probe,
+            "roofline_detect": {"bound": "hbm", "kernel": "k_extrema_march (the three 3x3x3 extrema scans of an octave in one launch; SURVEY.md 8d: "
+                                                          "B_ext = 20 bytes per pixel and octave, five response planes read once)",
+                                "achieved": ex_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ex_achieved / HBM_PEAK_GBS,
+                                "launches": bh["ex_launches"], "avg_launch_ms": bh["ex_ms"] / max(bh["ex_launches"], 1),
+                                "stage": {"what": "whole detection stage (map clear, extrema, localisation, dedupe, ordering scans) against B_ext",
+                                          "achieved": (bh["ex_bytes"] / args.steps / 1e9) / (st["detect_ms"] / 1e3) if st["detect_ms"] > 0 else 0.0}},
             "stage_ms_per_step": {"serial_on_main_stream": {"pyramid_ms": st["pyramid_ms"], "detect_ms": st["detect_ms"], "pack_ms": st["pack_ms"]},
                                   "concurrent_stream_busy_time": {"affine_ms": st["affine_ms"], "patch_ms": st["patch_ms"], "sift_ms": st["sift_ms"]},
                                   "device_total_ms": st["total_ms"],

@@ -39,6 +39,7 @@ class Timings(C.Structure):
         ("pyramid_ms", C.c_float), ("detect_ms", C.c_float), ("affine_ms", C.c_float), ("patch_ms", C.c_float),
         ("sift_ms", C.c_float), ("pack_ms", C.c_float), ("total_ms", C.c_float), ("blur_hess_ms", C.c_float), ("blur_hess_launches", C.c_int32),
         ("blur_hess_bytes", C.c_double), ("pyramid_bytes", C.c_double),
+        ("extrema_ms", C.c_float), ("extrema_launches", C.c_int32), ("extrema_bytes", C.c_double),
     ]
 
 

@@ -72,8 +72,7 @@ void hsfast_sift(hipStream_t st, const FastArgs &a, uint32_t n, void *vo, uint32
    const hsfast::SiftIO so = take<hsfast::SiftIO>(a.so, a.sz_so);
    const hsfast::KpTables tb = take<hsfast::KpTables>(a.tb, a.sz_tb);
    const uint32_t nb64 = (n + 63) / 64;
-   // no k_sift_meanvar: the fast k_sift_grad reduces mean / variance itself
-   hipLaunchKernelGGL(hsfast::k_sift_grad, dim3(std::min(n, g_grad)), dim3(256), 0, st, so, tb, (float2 *)vo);
-   hipLaunchKernelGGL(hsfast::k_sift_hist, dim3(std::min((n + 3) / 4, g_hist)), dim3(64), 0, st, so, tb, (const float2 *)vo);
-   hipLaunchKernelGGL(hsfast::k_sift_quantize, dim3(nb64), dim3(64), 0, st, so, take<hsfast::DConsts>(a.kc, a.sz_kc));
+   (void)nb64; (void)vo; (void)g_hist;
+   // one kernel from the patch to the 128 bytes: nothing but the descriptor leaves the chip (k_desc_fused, kernels_sift.h)
+   hipLaunchKernelGGL(hsfast::k_desc_fused, dim3(std::min(n, g_grad)), dim3(256), 0, st, so, tb, take<hsfast::DConsts>(a.kc, a.sz_kc));
 }

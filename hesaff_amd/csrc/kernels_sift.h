@@ -261,6 +261,157 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
    }
 }
 
+#if HS_FAST
+// ---------------------------------------------------------------------------------------------------------------------
+// k_desc_fused (fast mode only, NOT bit-exact): the whole descriptor of a keypoint on chip - computeSiftDescriptor
+// siftdesc.cpp:115-140 from the 41x41 patch to the 128 bytes in ONE kernel, one 256-thread block per keypoint (persistent
+// grid).  With the reference's summation orders given up, nothing has to leave the chip between the steps:
+//   photometric mean / variance   two block reductions over the 1245 masked pixels (helpers.cpp:253-268)
+//   normalisation                 in place in LDS (helpers.cpp:269-280)
+//   gradient, orientation         one thread per masked pixel (siftdesc.cpp:123-137), device-library atan2f
+//   samplePatch                   pixel-centric: every pixel adds its (at most) 4 cells x 2 orientation bins straight into a
+//                                 128-word LDS histogram (siftdesc.cpp:51-81).  The adds are INTEGER LDS atomics on
+//                                 fixed-point values (2^-14 units: a cell holds at most 256 x 361 < 2^17): ds_add_u32 runs
+//                                 at the LDS rate, whereas a float LDS add under this build's denormal rules is a
+//                                 compare-and-swap loop (measured in round 2: 11 x slower than read-modify-write).
+//   normalize / clip / quantise   two more block reductions (siftdesc.cpp:83-113)
+// HBM traffic per keypoint: the patch read once (6.7 KB) + 128 bytes out; the parity path moves 53 KB (patch read three times,
+// 12.8 KB of gradient pairs written and read).
+// ---------------------------------------------------------------------------------------------------------------------
+#define HS_FIX_ONE 16384.0f
+__device__ __forceinline__ float hsf_block_sum(float v, float *s_red)   // all 256 threads; s_red: 4 floats nobody else is using
+{
+#pragma unroll
+   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+   __syncthreads();
+   return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+__global__ __launch_bounds__(256) void k_desc_fused(SiftIO io, KpTables tb, DConsts kc)
+{
+   __shared__ float s_p[HS_PATCH_ARR];
+   __shared__ unsigned int s_hist[128];
+   __shared__ float s_red[16];
+   const int tid = threadIdx.x;
+   const uint32_t n = io.h_hi - io.h_lo;
+   const int nm = tb.n_masked;
+   // keypoint-independent constants of this thread's five masked pixels: stencil neighbours, mask value, the four spatial
+   // cells a pixel feeds (element offsets into the histogram, packed) and the products of their row / column weights
+   int4 nbq[HS_SIFT_MSK_IT];
+   float mk[HS_SIFT_MSK_IT], ww[HS_SIFT_MSK_IT][4];
+   int m_i[HS_SIFT_MSK_IT];
+   unsigned int cells[HS_SIFT_MSK_IT];
+   bool wt[HS_SIFT_MSK_IT];
+#pragma unroll
+   for (int q = 0; q < HS_SIFT_MSK_IT; q++) {
+      const int sl = tid + 256 * q;
+      nbq[q] = tb.sgrad_nb[sl];
+      const int2 om = tb.sgrad_om[sl];
+      mk[q] = __int_as_float(om.y);
+      m_i[q] = tb.mask_idx[min(sl, nm - 1)];
+      wt[q] = om.x >= 0;
+      const int r = wt[q] ? om.x / HS_VO_DIM : 0, c = wt[q] ? om.x - r * HS_VO_DIM : 0;
+      const int b0r = tb.bin0[r], b1r = tb.bin1[r], b0c = tb.bin0[c], b1c = tb.bin1[c];   // already x 8
+      const float w0r = tb.w0[r], w1r = tb.w1[r], w0c = tb.w0[c], w1c = tb.w1[c];
+      cells[q] = (unsigned)(4 * b0r + b0c) | ((unsigned)(4 * b0r + b1c) << 8) | ((unsigned)(4 * b1r + b0c) << 16) | ((unsigned)(4 * b1r + b1c) << 24);
+      ww[q][0] = w0r * w0c; ww[q][1] = w0r * w1c; ww[q][2] = w1r * w0c; ww[q][3] = w1r * w1c;
+   }
+   uint32_t k = blockIdx.x;
+   if (k >= n) return;
+   float pv[HS_PATCH_PIX_IT];
+   int alive = io.alive[io.h_lo + k];
+   {
+      const float *gp = io.patches + (size_t)k * HS_PATCH_PIX;
+#pragma unroll
+      for (int q = 0; q < HS_PATCH_PIX_IT; q++) pv[q] = gp[min(tid + 256 * q, HS_PATCH_PIX - 1)];
+   }
+   for (; k < n; k += gridDim.x) {
+      const bool cur_alive = alive != 0;
+      const uint32_t kn = k + gridDim.x;
+      if (cur_alive) {
+#pragma unroll
+         for (int q = 0; q < HS_PATCH_PIX_IT; q++) { const int i = tid + 256 * q; if (i < HS_PATCH_PIX) s_p[i] = pv[q]; }
+         if (tid < 128) s_hist[tid] = 0u;
+      }
+      // the next keypoint's patch is requested before this one is evaluated
+      if (kn < n) {
+         alive = io.alive[io.h_lo + kn];
+         const float *gp = io.patches + (size_t)kn * HS_PATCH_PIX;
+#pragma unroll
+         for (int q = 0; q < HS_PATCH_PIX_IT; q++) pv[q] = gp[min(tid + 256 * q, HS_PATCH_PIX - 1)];
+      }
+      if (!cur_alive) continue;   // block-uniform
+      __syncthreads();
+      // photometric mean / variance over the masked pixels (helpers.cpp:253-268), tree sums
+      float ps = 0.0f;
+#pragma unroll
+      for (int q = 0; q < HS_SIFT_MSK_IT; q++) if (tid + 256 * q < nm) ps += s_p[m_i[q]];
+      const float mean = hsf_block_sum(ps, s_red) / (float)nm;
+      float pq = 0.0f;
+#pragma unroll
+      for (int q = 0; q < HS_SIFT_MSK_IT; q++) if (tid + 256 * q < nm) { const float dd = mean - s_p[m_i[q]]; pq += dd * dd; }
+      const float var = sqrtf(hsf_block_sum(pq, s_red + 4) / (float)nm);
+      // every read of the raw patch happened before the barrier inside the second sum: normalise in place (helpers.cpp:269-280)
+      if (!(var < 0.0001f)) {
+         const float fac = 50.0f / var;
+#pragma unroll
+         for (int q = 0; q < HS_PATCH_PIX_IT; q++) {
+            const int i = tid + 256 * q;
+            if (i < HS_PATCH_PIX) {
+               float v = 128.0f + fac * (s_p[i] - mean);
+               v = v > 255.0f ? 255.0f : v;
+               s_p[i] = v < 0.0f ? 0.0f : v;
+            }
+         }
+      }
+      __syncthreads();
+      // gradient + samplePatch, one masked pixel at a time
+#pragma unroll
+      for (int q = 0; q < HS_SIFT_MSK_IT; q++) {
+         if (wt[q]) {
+            const char *sp = reinterpret_cast<const char *>(s_p);
+            const float gx = *reinterpret_cast<const float *>(sp + nbq[q].y) - *reinterpret_cast<const float *>(sp + nbq[q].x);
+            const float gy = *reinterpret_cast<const float *>(sp + nbq[q].w) - *reinterpret_cast<const float *>(sp + nbq[q].z);
+            const float val = mk[q] * sqrtf(gx * gx + gy * gy);
+            if (val > 0.0f) {
+               const float o = hm_fast_orient_coord(hm_fast_atan2f(gy, gx));
+               const int io0 = (int)o;
+               const float wo1 = o - (float)io0, wo0 = 1.0f - wo1;
+               const int b0 = io0 & 7, b1 = (io0 + 1) & 7;
+               const float v0 = val * wo0 * HS_FIX_ONE, v1 = val * wo1 * HS_FIX_ONE;
+#pragma unroll
+               for (int j = 0; j < 4; j++) {
+                  const float w = ww[q][j];
+                  if (w > 0.0f) {
+                     const unsigned cell = (cells[q] >> (8 * j)) & 255u;
+                     atomicAdd(&s_hist[cell + b0], (unsigned int)(w * v0 + 0.5f));
+                     atomicAdd(&s_hist[cell + b1], (unsigned int)(w * v1 + 0.5f));
+                  }
+               }
+            }
+         }
+      }
+      __syncthreads();
+      // normalize, clip, normalize, quantise (siftdesc.cpp:83-113)
+      float x = tid < 128 ? (float)s_hist[tid] * (1.0f / HS_FIX_ONE) : 0.0f;
+      const float len = sqrtf(hsf_block_sum(x * x, s_red + 8));
+      x *= 1.0f / len;
+      const bool clip = x > kc.maxBinValue;
+      if (clip) x = kc.maxBinValue;
+      // "changed" is block-wide: renormalise when any element was clipped
+      const float len2sq = hsf_block_sum(x * x, s_red + 12);
+      const bool any_clip = __syncthreads_or(clip ? 1 : 0) != 0;
+      if (any_clip) x *= 1.0f / sqrtf(len2sq);
+      if (tid < 128) {
+         const float qf = 512.0f * x;
+         const int bq = (qf == qf) ? (int)qf : 0;
+         io.desc[(size_t)(io.h_lo + k) * 128 + tid] = (uint8_t)min(bq, 255);
+      }
+   }
+}
+#endif
+
 // device check (stage API): the per-pixel forms of k_sift_grad, general and range-free, on caller-supplied operands
 __global__ void k_math_sift(int n, const float *__restrict__ gy, const float *__restrict__ gx, float *__restrict__ ori_g,
                             float *__restrict__ ori_nd, float *__restrict__ grad_g, float *__restrict__ grad_nd)

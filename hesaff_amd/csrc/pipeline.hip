@@ -562,7 +562,7 @@ struct StageTimer {
    void end(int id) { if (id >= 0) (void)hipEventRecord(pairs[id].b, streams[id]); }
 };
 
-enum { T_PYR = 0, T_DET = 1, T_AFF = 2, T_PATCH = 3, T_SIFT = 4, T_TOTAL = 5, T_PACK = 6, T_BLURHESS = 100 };
+enum { T_PYR = 0, T_DET = 1, T_AFF = 2, T_PATCH = 3, T_SIFT = 4, T_TOTAL = 5, T_PACK = 6, T_BLURHESS = 100, T_EXTREMA = 101 };
 
 // Band height of k_blur_hess_march: 16 bands per octave is the measured optimum for 16 x 4K at every octave
 // (sweeps in profiles/r01_notes.md); small batches get proportionally more bands to keep ~1000 blocks in flight.
@@ -836,7 +836,9 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
          const int strips = (g.cols + EXM_STRIP - 1) / EXM_STRIP;
          const int band = ((long long)strips * ((g.rows + 63) / 64) * B >= 4096) ? 64 : 32;
          const dim3 grid(strips, (g.rows + band - 1) / band, B);
+         const int te = tm.begin(T_EXTREMA, 20.0 * (double)B * g.rows * g.cols);
          hipLaunchKernelGGL(k_extrema_march, grid, dim3(64), 0, st, fp, c->consts.positiveThreshold, c->consts.negativeThreshold, s.cl, band);
+         tm.end(te);
          hipLaunchKernelGGL(k_localize, dim3(HS_GRID_LOC), dim3(256), 0, st, oc, s.cl, s.rl, c->consts);
          hipLaunchKernelGGL(k_dedupe, dim3(HS_GRID_DED), dim3(256), 0, st, oc, s.rl, (const uint32_t *)(cnt + 32 + o),
                             c->b_bitmask.as<unsigned long long>());
@@ -886,6 +888,7 @@ void collect_timings(hesaff_ctx *c, StageTimer &tm, int B)
          case T_BLURHESS:
             if (p.bytes > 0) { t.blur_hess_ms += ms; t.blur_hess_launches++; t.blur_hess_bytes += p.bytes; }
             break;
+         case T_EXTREMA: t.extrema_ms += ms; t.extrema_launches++; t.extrema_bytes += p.bytes; break;
       }
    }
    double sumN = 0;

@@ -98,6 +98,10 @@ typedef struct hesaff_timings {
    int32_t blur_hess_launches;
    double blur_hess_bytes;     /* algorithmic bytes of those launches (12 N each, + 8 N with the fused R0, + 2 N with the fused decimation) */
    double pyramid_bytes;       /* algorithmic bytes B_pyr = 5 N0 + 58 sum N_k, whole batch   */
+   /* appended in ABI version 3 (profiling level 2) */
+   float extrema_ms;           /* sum of the k_extrema_march launches (3x3x3 extrema of the three scans of an octave) */
+   int32_t extrema_launches;
+   double extrema_bytes;       /* algorithmic bytes of those launches: 20 N per octave (five response planes read once), SURVEY.md 8d B_ext */
 } hesaff_timings;
 
 int hesaff_default_params(hesaff_params *p);
