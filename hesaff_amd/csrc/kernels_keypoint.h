@@ -277,8 +277,9 @@ __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, con
 #if HS_FAST
 // Fast-mode form of the iteration (kernels_fast.hip only; NOT bit-exact): the three 361-term sums of the second-moment
 // matrix are accumulated per lane (23 terms each) and combined with a shuffle tree over the 16 lanes of a group, which
-// removes the product arrays from LDS and both serial stretches of the parity form; invSqrt runs in float on every lane
-// (no broadcast), multiply-adds are contracted.
+// removes the product arrays from LDS (7 KB instead of 19 KB per wavefront) and both serial stretches of the parity
+// form; invSqrt runs in float on every lane (no broadcast), multiply-adds are contracted.  The tap phase is the parity
+// kernel's: untested taps when the window's four corners are inside (hs_window_outside), the XCD-aware keypoint order.
 template <class Fetch>
 __device__ __forceinline__ void hs_affine_groups_fast(uint32_t first, uint32_t n, const float *__restrict__ mask_g, const DConsts &k, AffineOut out,
                                                       Fetch fetch)
@@ -288,13 +289,21 @@ __device__ __forceinline__ void hs_affine_groups_fast(uint32_t first, uint32_t n
    const int lane = threadIdx.x, grp = lane >> 4, li = lane & 15;
    for (int i = lane; i < HS_SMM_PIX; i += 64) s_mask[i] = mask_g[i];
    float *img = s_img[grp];
-   const uint32_t hstep = gridDim.x * HS_AFF_G;
+   uint32_t hstep = gridDim.x * HS_AFF_G, h_end = n;
    uint32_t h = first + blockIdx.x * HS_AFF_G + grp;
+   if (HS_AFF_XCD && (gridDim.x & 7u) == 0u && n > first) {
+      const uint32_t n_items = (n - first + HS_AFF_G - 1) / HS_AFF_G;
+      const uint32_t xcd = blockIdx.x & 7u, rank = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+      const uint32_t it_lo = (uint32_t)(((unsigned long long)n_items * xcd) >> 3), it_hi = (uint32_t)(((unsigned long long)n_items * (xcd + 1)) >> 3);
+      hstep = per_xcd * HS_AFF_G;
+      h_end = min(first + it_hi * HS_AFF_G, n);
+      h = first + (it_lo + rank) * HS_AFF_G + grp;
+   }
    const float *blur = nullptr;
    int pitch = 0, width = 0, height = 0, l = 0;
    float lx = 0, ly = 0, ratio = 0, u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f;
    float eigen_ratio_act = 0.0f, eigen_ratio_bef = 0.0f;
-   bool active = h < n;
+   bool active = h < h_end;
    auto load_kp = [&]() {
       if (active) {
          const AffKp q = fetch(h);
@@ -309,7 +318,11 @@ __device__ __forceinline__ void hs_affine_groups_fast(uint32_t first, uint32_t n
    load_kp();
    HS_WAVE_LDS_SYNC();
    while (__ballot(active) != 0ull) {
-      if (active) {
+      bool win_in = true;
+      if (active) win_in = !hs_window_outside(height + 1, width + 1, lx, ly, u11 * ratio, u12 * ratio, u21 * ratio, u22 * ratio, HS_SMM >> 1);
+      const bool all_in = __ballot(active && !win_in) == 0ull;
+      auto sample = [&](auto inside_c) {
+         constexpr bool INSIDE = decltype(inside_c)::value;
          const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
 #pragma unroll
          for (int half = 0; half < 2; half++) {
@@ -320,8 +333,9 @@ __device__ __forceinline__ void hs_affine_groups_fast(uint32_t first, uint32_t n
                const int idx = min(li + 16 * (half * NB + t), HS_SMM_PIX - 1);
                const int jj = idx / HS_SMM, ii = idx - jj * HS_SMM;
                const int j = jj - (HS_SMM >> 1), i = ii - (HS_SMM >> 1);
-               bool outside = false;
-               sv[t] = hs_bilinear(blur, pitch, width, height, lx + (float)j * a12 + (float)i * a11, ly + (float)j * a22 + (float)i * a21, outside);
+               const float wx = lx + (float)j * a12 + (float)i * a11, wy = ly + (float)j * a22 + (float)i * a21;
+               if (INSIDE) sv[t] = hs_tap_inside_ptr(blur, pitch, wx, wy);
+               else { bool outside = false; sv[t] = hs_bilinear(blur, pitch, width, height, wx, wy, outside); }
             }
 #pragma unroll
             for (int t = 0; t < NB; t++) HS_KEEP(sv[t]);
@@ -331,6 +345,10 @@ __device__ __forceinline__ void hs_affine_groups_fast(uint32_t first, uint32_t n
                if (idx < HS_SMM_PIX) img[idx] = sv[t];
             }
          }
+      };
+      if (active) {
+         if (all_in) sample(std::true_type{});
+         else sample(std::false_type{});
       }
       HS_WAVE_LDS_SYNC();
       if (active) {
@@ -378,7 +396,7 @@ __device__ __forceinline__ void hs_affine_groups_fast(uint32_t first, uint32_t n
                out.U[4 * h + 0] = u11; out.U[4 * h + 1] = u12; out.U[4 * h + 2] = u21; out.U[4 * h + 3] = u22;
             }
             h += hstep;
-            active = h < n;
+            active = h < h_end;
             load_kp();
          } else {
             l++;

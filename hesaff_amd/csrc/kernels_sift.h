@@ -303,13 +303,18 @@ __global__ __launch_bounds__(256) void k_desc_fused(SiftIO io, KpTables tb, DCon
    int m_i[HS_SIFT_MSK_IT];
    unsigned int cells[HS_SIFT_MSK_IT];
    bool wt[HS_SIFT_MSK_IT];
+   // The 1280 table slots are dealt out through the permutation s -> 19 s mod 1280 (19 is coprime to 1280): the 64 lanes of a
+   // wavefront then work on pixels 19 apart in the raster list of the mask - spread over the whole patch, i.e. over all 16
+   // cells - instead of 64 neighbours that would all add to the same two or four cells and serialise in the LDS atomics.
+   bool inm[HS_SIFT_MSK_IT];
 #pragma unroll
    for (int q = 0; q < HS_SIFT_MSK_IT; q++) {
-      const int sl = tid + 256 * q;
+      const int sl = ((tid + 256 * q) * 19) % 1280;
       nbq[q] = tb.sgrad_nb[sl];
       const int2 om = tb.sgrad_om[sl];
       mk[q] = __int_as_float(om.y);
       m_i[q] = tb.mask_idx[min(sl, nm - 1)];
+      inm[q] = sl < nm;
       wt[q] = om.x >= 0;
       const int r = wt[q] ? om.x / HS_VO_DIM : 0, c = wt[q] ? om.x - r * HS_VO_DIM : 0;
       const int b0r = tb.bin0[r], b1r = tb.bin1[r], b0c = tb.bin0[c], b1c = tb.bin1[c];   // already x 8
@@ -346,11 +351,11 @@ __global__ __launch_bounds__(256) void k_desc_fused(SiftIO io, KpTables tb, DCon
       // photometric mean / variance over the masked pixels (helpers.cpp:253-268), tree sums
       float ps = 0.0f;
 #pragma unroll
-      for (int q = 0; q < HS_SIFT_MSK_IT; q++) if (tid + 256 * q < nm) ps += s_p[m_i[q]];
+      for (int q = 0; q < HS_SIFT_MSK_IT; q++) if (inm[q]) ps += s_p[m_i[q]];
       const float mean = hsf_block_sum(ps, s_red) / (float)nm;
       float pq = 0.0f;
 #pragma unroll
-      for (int q = 0; q < HS_SIFT_MSK_IT; q++) if (tid + 256 * q < nm) { const float dd = mean - s_p[m_i[q]]; pq += dd * dd; }
+      for (int q = 0; q < HS_SIFT_MSK_IT; q++) if (inm[q]) { const float dd = mean - s_p[m_i[q]]; pq += dd * dd; }
       const float var = sqrtf(hsf_block_sum(pq, s_red + 4) / (float)nm);
       // every read of the raw patch happened before the barrier inside the second sum: normalise in place (helpers.cpp:269-280)
       if (!(var < 0.0001f)) {
