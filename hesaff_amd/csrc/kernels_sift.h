@@ -279,6 +279,20 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
 // 12.8 KB of gradient pairs written and read).
 // ---------------------------------------------------------------------------------------------------------------------
 #define HS_FIX_ONE 16384.0f
+// orientation coordinate o = 8 (atan2(gy, gx) + 2 pi) / (2 pi) in [4, 12] without the math library: octant folding + an odd
+// minimax polynomial of degree 9 on [0, 1] (|error| < 1e-5 rad, three orders of magnitude below what moves a quantised bin)
+__device__ __forceinline__ float hsf_orient_coord(float gy, float gx)
+{
+   const float ax = fabsf(gx), ay = fabsf(gy);
+   const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+   const float t = mn * __builtin_amdgcn_rcpf(mx);   // caller guarantees mx > 0
+   const float s2 = t * t;
+   float p = ((((0.0208351f * s2 - 0.0851330f) * s2 + 0.1801410f) * s2 - 0.3302995f) * s2 + 0.9998660f) * t;   // atan(t), t in [0, 1]
+   p = ay > ax ? 1.57079633f - p : p;
+   p = gx < 0.0f ? 3.14159265f - p : p;
+   p = gy < 0.0f ? -p : p;
+   return p * 1.27323954f + 8.0f;   // 8 / (2 pi) = 4 / pi
+}
 __device__ __forceinline__ float hsf_block_sum(float v, float *s_red)   // all 256 threads; s_red: 4 floats nobody else is using
 {
 #pragma unroll
@@ -380,11 +394,13 @@ __global__ __launch_bounds__(256) void k_desc_fused(SiftIO io, KpTables tb, DCon
             const float gy = *reinterpret_cast<const float *>(sp + nbq[q].w) - *reinterpret_cast<const float *>(sp + nbq[q].z);
             const float val = mk[q] * sqrtf(gx * gx + gy * gy);
             if (val > 0.0f) {
-               const float o = hm_fast_orient_coord(hm_fast_atan2f(gy, gx));
+               const float o = hsf_orient_coord(gy, gx);
                const int io0 = (int)o;
                const float wo1 = o - (float)io0, wo0 = 1.0f - wo1;
                const int b0 = io0 & 7, b1 = (io0 + 1) & 7;
                const float v0 = val * wo0 * HS_FIX_ONE, v1 = val * wo1 * HS_FIX_ONE;
+               // the test per cell pays: the LDS atomics, not the VALU, set this kernel's pace (measured: unconditional adds of
+               // zero for the clamped cells of border pixels, 25 % more atomics, cost +15 % time)
 #pragma unroll
                for (int j = 0; j < 4; j++) {
                   const float w = ww[q][j];
