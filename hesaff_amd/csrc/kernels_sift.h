@@ -268,19 +268,19 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
 // grid).  With the reference's summation orders given up, nothing has to leave the chip between the steps:
 //   photometric mean / variance   two block reductions over the 1245 masked pixels (helpers.cpp:253-268)
 //   normalisation                 in place in LDS (helpers.cpp:269-280)
-//   gradient, orientation         one thread per masked pixel (siftdesc.cpp:123-137), device-library atan2f
-//   samplePatch                   pixel-centric: every pixel adds its (at most) 4 cells x 2 orientation bins straight into a
-//                                 128-word LDS histogram (siftdesc.cpp:51-81).  The adds are INTEGER LDS atomics on
-//                                 fixed-point values (2^-14 units: a cell holds at most 256 x 361 < 2^17): ds_add_u32 runs
-//                                 at the LDS rate, whereas a float LDS add under this build's denormal rules is a
-//                                 compare-and-swap loop (measured in round 2: 11 x slower than read-modify-write).
+//   gradient, orientation         one thread per masked pixel (siftdesc.cpp:123-137), polynomial atan2 -> (mask*grad, o) in LDS
+//   samplePatch                   thread = (cell, row of the cell's 16 x 16 support): 16 pixels each into 8 thread-private LDS words
+//                                 (plain read-add-write, no atomics), then thread = (cell, bin) adds the 16 partial sums
+//                                 (siftdesc.cpp:51-81).  A first version added every pixel's 8 contributions with integer LDS
+//                                 atomics on fixed-point values: ds_add_u32 ran at about 3 lane-operations per clock and CU and
+//                                 took 60 % of the kernel (29 ms per 32 UHD images; unconditional adds for clamped cells, +25 %
+//                                 atomics, cost +15 % time).
 //   normalize / clip / quantise   two more block reductions (siftdesc.cpp:83-113)
 // HBM traffic per keypoint: the patch read once (6.7 KB) + 128 bytes out; the parity path moves 53 KB (patch read three times,
 // 12.8 KB of gradient pairs written and read).
 // ---------------------------------------------------------------------------------------------------------------------
-#define HS_FIX_ONE 16384.0f
 // orientation coordinate o = 8 (atan2(gy, gx) + 2 pi) / (2 pi) in [4, 12] without the math library: octant folding + an odd
-// minimax polynomial of degree 9 on [0, 1] (|error| < 1e-5 rad, three orders of magnitude below what moves a quantised bin)
+// minimax polynomial of degree 9 on [0, 1] (|error| < 1.2e-5 rad, orders of magnitude below what moves a quantised bin)
 __device__ __forceinline__ float hsf_orient_coord(float gy, float gx)
 {
    const float ax = fabsf(gx), ay = fabsf(gy);
@@ -293,6 +293,7 @@ __device__ __forceinline__ float hsf_orient_coord(float gy, float gx)
    p = gy < 0.0f ? -p : p;
    return p * 1.27323954f + 8.0f;   // 8 / (2 pi) = 4 / pi
 }
+
 __device__ __forceinline__ float hsf_block_sum(float v, float *s_red)   // all 256 threads; s_red: 4 floats nobody else is using
 {
 #pragma unroll
@@ -302,40 +303,45 @@ __device__ __forceinline__ float hsf_block_sum(float v, float *s_red)   // all 2
    return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
+#define HSF_BIN_STRIDE 257   // words between a thread's consecutive private bins: odd, so that the 64 lanes of a wave spread over the banks
+
 __global__ __launch_bounds__(256) void k_desc_fused(SiftIO io, KpTables tb, DConsts kc)
 {
    __shared__ float s_p[HS_PATCH_ARR];
-   __shared__ unsigned int s_hist[128];
+   __shared__ __attribute__((aligned(16))) float2 s_vo[HS_VO_PITCH];
+   __shared__ float s_bins[8 * HSF_BIN_STRIDE];
+   __shared__ float s_cw[64];
    __shared__ float s_red[16];
    const int tid = threadIdx.x;
    const uint32_t n = io.h_hi - io.h_lo;
    const int nm = tb.n_masked;
-   // keypoint-independent constants of this thread's five masked pixels: stencil neighbours, mask value, the four spatial
-   // cells a pixel feeds (element offsets into the histogram, packed) and the products of their row / column weights
+   // phase A constants: this thread's five masked pixels (stencil neighbours, output slot, mask value)
    int4 nbq[HS_SIFT_MSK_IT];
-   float mk[HS_SIFT_MSK_IT], ww[HS_SIFT_MSK_IT][4];
+   int2 omq[HS_SIFT_MSK_IT];
    int m_i[HS_SIFT_MSK_IT];
-   unsigned int cells[HS_SIFT_MSK_IT];
-   bool wt[HS_SIFT_MSK_IT];
-   // The 1280 table slots are dealt out through the permutation s -> 19 s mod 1280 (19 is coprime to 1280): the 64 lanes of a
-   // wavefront then work on pixels 19 apart in the raster list of the mask - spread over the whole patch, i.e. over all 16
-   // cells - instead of 64 neighbours that would all add to the same two or four cells and serialise in the LDS atomics.
-   bool inm[HS_SIFT_MSK_IT];
 #pragma unroll
    for (int q = 0; q < HS_SIFT_MSK_IT; q++) {
-      const int sl = ((tid + 256 * q) * 19) % 1280;
-      nbq[q] = tb.sgrad_nb[sl];
-      const int2 om = tb.sgrad_om[sl];
-      mk[q] = __int_as_float(om.y);
-      m_i[q] = tb.mask_idx[min(sl, nm - 1)];
-      inm[q] = sl < nm;
-      wt[q] = om.x >= 0;
-      const int r = wt[q] ? om.x / HS_VO_DIM : 0, c = wt[q] ? om.x - r * HS_VO_DIM : 0;
-      const int b0r = tb.bin0[r], b1r = tb.bin1[r], b0c = tb.bin0[c], b1c = tb.bin1[c];   // already x 8
-      const float w0r = tb.w0[r], w1r = tb.w1[r], w0c = tb.w0[c], w1c = tb.w1[c];
-      cells[q] = (unsigned)(4 * b0r + b0c) | ((unsigned)(4 * b0r + b1c) << 8) | ((unsigned)(4 * b1r + b0c) << 16) | ((unsigned)(4 * b1r + b1c) << 24);
-      ww[q][0] = w0r * w0c; ww[q][1] = w0r * w1c; ww[q][2] = w1r * w0c; ww[q][3] = w1r * w1c;
+      nbq[q] = tb.sgrad_nb[tid + 256 * q];
+      omq[q] = tb.sgrad_om[tid + 256 * q];
+      m_i[q] = tb.mask_idx[min(tid + 256 * q, nm - 1)];
    }
+   for (int i = tid; i < HS_VO_PITCH; i += 256) s_vo[i] = make_float2(0.0f, 0.0f);   // pixels outside the mask stay (0, 0)
+   {
+      // cell weights as in k_sift_hist: spatial bin b gets w1[r] from rows with bin1 == b, w0[r] from rows with bin0 == b
+      const int b = tid >> 4, i = tid & 15, r = 8 * b + i;
+      float w = 0.0f;
+      if (tid < 64 && r < HS_PATCH) {
+         if (tb.bin0[r] == 8 * b && tb.w0[r] != 0.0f) w = tb.w0[r];
+         else if (tb.bin1[r] == 8 * b) w = tb.w1[r];
+      }
+      if (tid < 64) s_cw[tid] = w;
+   }
+   __syncthreads();
+   // phase B constants: thread = (cell, row i of the cell's 16 x 16 support)
+   const int cell = tid >> 4, ri = tid & 15, cy = cell >> 2, cx = cell & 3;
+   const float wr = s_cw[cy * 16 + ri];
+   const float2 *my_row = s_vo + (8 * cy + ri) * HS_VO_DIM + 8 * cx;
+   float *pb = s_bins + tid;
    uint32_t k = blockIdx.x;
    if (k >= n) return;
    float pv[HS_PATCH_PIX_IT];
@@ -351,7 +357,6 @@ __global__ __launch_bounds__(256) void k_desc_fused(SiftIO io, KpTables tb, DCon
       if (cur_alive) {
 #pragma unroll
          for (int q = 0; q < HS_PATCH_PIX_IT; q++) { const int i = tid + 256 * q; if (i < HS_PATCH_PIX) s_p[i] = pv[q]; }
-         if (tid < 128) s_hist[tid] = 0u;
       }
       // the next keypoint's patch is requested before this one is evaluated
       if (kn < n) {
@@ -365,11 +370,11 @@ __global__ __launch_bounds__(256) void k_desc_fused(SiftIO io, KpTables tb, DCon
       // photometric mean / variance over the masked pixels (helpers.cpp:253-268), tree sums
       float ps = 0.0f;
 #pragma unroll
-      for (int q = 0; q < HS_SIFT_MSK_IT; q++) if (inm[q]) ps += s_p[m_i[q]];
+      for (int q = 0; q < HS_SIFT_MSK_IT; q++) if (tid + 256 * q < nm) ps += s_p[m_i[q]];
       const float mean = hsf_block_sum(ps, s_red) / (float)nm;
       float pq = 0.0f;
 #pragma unroll
-      for (int q = 0; q < HS_SIFT_MSK_IT; q++) if (inm[q]) { const float dd = mean - s_p[m_i[q]]; pq += dd * dd; }
+      for (int q = 0; q < HS_SIFT_MSK_IT; q++) if (tid + 256 * q < nm) { const float dd = mean - s_p[m_i[q]]; pq += dd * dd; }
       const float var = sqrtf(hsf_block_sum(pq, s_red + 4) / (float)nm);
       // every read of the raw patch happened before the barrier inside the second sum: normalise in place (helpers.cpp:269-280)
       if (!(var < 0.0001f)) {
@@ -385,44 +390,53 @@ __global__ __launch_bounds__(256) void k_desc_fused(SiftIO io, KpTables tb, DCon
          }
       }
       __syncthreads();
-      // gradient + samplePatch, one masked pixel at a time
+      // phase A: gradient magnitude and orientation of the masked pixels (siftdesc.cpp:123-137) -> (mask*grad, o)
 #pragma unroll
       for (int q = 0; q < HS_SIFT_MSK_IT; q++) {
-         if (wt[q]) {
+         if (omq[q].x >= 0) {
             const char *sp = reinterpret_cast<const char *>(s_p);
             const float gx = *reinterpret_cast<const float *>(sp + nbq[q].y) - *reinterpret_cast<const float *>(sp + nbq[q].x);
             const float gy = *reinterpret_cast<const float *>(sp + nbq[q].w) - *reinterpret_cast<const float *>(sp + nbq[q].z);
-            const float val = mk[q] * sqrtf(gx * gx + gy * gy);
-            if (val > 0.0f) {
-               const float o = hsf_orient_coord(gy, gx);
-               const int io0 = (int)o;
-               const float wo1 = o - (float)io0, wo0 = 1.0f - wo1;
-               const int b0 = io0 & 7, b1 = (io0 + 1) & 7;
-               const float v0 = val * wo0 * HS_FIX_ONE, v1 = val * wo1 * HS_FIX_ONE;
-               // the test per cell pays: the LDS atomics, not the VALU, set this kernel's pace (measured: unconditional adds of
-               // zero for the clamped cells of border pixels, 25 % more atomics, cost +15 % time)
-#pragma unroll
-               for (int j = 0; j < 4; j++) {
-                  const float w = ww[q][j];
-                  if (w > 0.0f) {
-                     const unsigned cell = (cells[q] >> (8 * j)) & 255u;
-                     atomicAdd(&s_hist[cell + b0], (unsigned int)(w * v0 + 0.5f));
-                     atomicAdd(&s_hist[cell + b1], (unsigned int)(w * v1 + 0.5f));
-                  }
-               }
-            }
+            const float g2 = gx * gx + gy * gy;
+            const float val = __int_as_float(omq[q].y) * sqrtf(g2);
+            s_vo[omq[q].x] = make_float2(val, g2 > 0.0f ? hsf_orient_coord(gy, gx) : 8.0f);
          }
       }
       __syncthreads();
-      // normalize, clip, normalize, quantise (siftdesc.cpp:83-113)
-      float x = tid < 128 ? (float)s_hist[tid] * (1.0f / HS_FIX_ONE) : 0.0f;
+      // phase B: samplePatch (siftdesc.cpp:51-81), thread-private bins
+#pragma unroll
+      for (int b = 0; b < 8; b++) pb[b * HSF_BIN_STRIDE] = 0.0f;
+      {
+         float4 cur[8];
+#pragma unroll
+         for (int m = 0; m < 8; m++) cur[m] = reinterpret_cast<const float4 *>(my_row)[m];
+#pragma unroll
+         for (int j = 0; j < 16; j++) {
+            const float qx = (j & 1) ? cur[j >> 1].z : cur[j >> 1].x;
+            const float qy = (j & 1) ? cur[j >> 1].w : cur[j >> 1].y;
+            const float v = (wr * s_cw[cx * 16 + j]) * qx;
+            const int io0 = (int)qy;
+            const int bo0 = io0 & 7, bo1 = (io0 + 1) & 7;
+            const float t1 = v * (qy - (float)io0), t0 = v - t1;
+            const float a0 = pb[bo0 * HSF_BIN_STRIDE], a1 = pb[bo1 * HSF_BIN_STRIDE];   // bo0 != bo1
+            pb[bo0 * HSF_BIN_STRIDE] = a0 + t0;
+            pb[bo1 * HSF_BIN_STRIDE] = a1 + t1;
+         }
+      }
+      __syncthreads();
+      // thread = (cell, bin): the 16 partial sums of the cell's rows; then normalize, clip, normalize, quantise (siftdesc.cpp:83-113)
+      float x = 0.0f;
+      if (tid < 128) {
+         const float *src = s_bins + (tid & 7) * HSF_BIN_STRIDE + (tid >> 3) * 16;
+#pragma unroll
+         for (int i = 0; i < 16; i++) x += src[i];
+      }
       const float len = sqrtf(hsf_block_sum(x * x, s_red + 8));
       x *= 1.0f / len;
       const bool clip = x > kc.maxBinValue;
       if (clip) x = kc.maxBinValue;
-      // "changed" is block-wide: renormalise when any element was clipped
       const float len2sq = hsf_block_sum(x * x, s_red + 12);
-      const bool any_clip = __syncthreads_or(clip ? 1 : 0) != 0;
+      const bool any_clip = __syncthreads_or(clip ? 1 : 0) != 0;   // "changed": renormalise when any element was clipped
       if (any_clip) x *= 1.0f / sqrtf(len2sq);
       if (tid < 128) {
          const float qf = 512.0f * x;
