@@ -146,7 +146,7 @@ def density_leg(hesaff_amd, torch, dev, device, B, H, W, seed, steps):
                     "about 2.5 k descriptors per Mpx); not the headline workload" % (B, W, H)}
 
 
-def file_path_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device):
+def file_path_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, fmt=1):
     """hesaff_process_files (what `hesaff --batch` runs: decode threads -> chunks through the device -> writer threads) on
     n_files binary PGM files of the bench images on a RAM disk, every <name>.hesaff.sift written there too.  One timed run
     over the whole list, pipeline fill and drain included."""
@@ -168,23 +168,26 @@ def file_path_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device):
             paths.append(q)
         p = hesaff_amd.default_params()
         p.max_batch = chunk
+        ext = ".hesaff.sift" if fmt == 1 else ".hesaff.bin"
         with hesaff_amd.HesaffContext(p, device=device) as ctx:
+            ctx.set_output_format(fmt)
             warm = ctx.process_files(paths[: 2 * chunk])          # buffers, page cache, thread start-up
             for q in paths[: 2 * chunk]:
-                os.remove(q + ".hesaff.sift")
+                os.remove(q + ext)
             t0 = time.perf_counter()
             st = ctx.process_files(paths)
             dt = time.perf_counter() - t0
             threads = int(ctx.L.hesaff_host_threads())
         bad = [i for i, s_ in enumerate(st) if s_[0] != 0 or s_[1] != 3] + [i for i, s_ in enumerate(warm) if s_[0] != 0]
-        nbytes = sum(os.path.getsize(q + ".hesaff.sift") for q in paths)
+        nbytes = sum(os.path.getsize(q + ext) for q in paths)
         rows = sum(s_[3] for s_ in st)
         return {"images": n, "images_per_s": n / dt, "value": rows / dt, "unit": "keypoints/s", "seconds": dt, "chunk_images": chunk,
-                "failed_files": len(bad), "text_GB_per_s": nbytes / dt / 1e9, "input_GB": n * (W * H + len(hdr)) / 1e9, "output_GB": nbytes / 1e9,
+                "output": "text (.hesaff.sift, the reference's format)" if fmt == 1 else "binary sidecar (.hesaff.bin, 148 bytes per row)",
+                "failed_files": len(bad), "output_GB_per_s": nbytes / dt / 1e9, "input_GB": n * (W * H + len(hdr)) / 1e9, "output_GB": nbytes / 1e9,
                 "host_threads": threads, "target": tmp.rsplit("/", 1)[0],
                 "what": "hesaff_process_files: %d binary PGM files (%dx%d, the bench images) on a RAM disk -> decode threads -> chunks of %d "
-                        "images through the device (copy in, kernels, copy out overlapped) -> writer threads -> %d .hesaff.sift files on the "
-                        "RAM disk; one timed run, pipeline fill and drain included (hesaff.cpp:133-180 for a list of files)" % (n, W, H, chunk, n)}
+                        "images through the device (copy in, kernels, copy out overlapped) -> writer threads -> %d %s files on the "
+                        "RAM disk; one timed run, pipeline fill and drain included (hesaff.cpp:133-180 for a list of files)" % (n, W, H, chunk, n, ext)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -401,8 +404,12 @@ def main():
         # ---- the whole file path, measured: image files -> decode -> device -> .hesaff.sift files (hesaff.cpp:133-180) ----
         if rank == 0 and args.e2e_images > 0:
             end_to_end = file_path_leg(hesaff_amd, host_imgs, W, H, args.e2e_images, args.e2e_chunk, local_rank)
-            if end_to_end and host_path:
+            if end_to_end and host_path and "images_per_s" in end_to_end:
                 end_to_end["fraction_of_host_path"] = end_to_end["images_per_s"] / (host_path["images_per_s"] / max(world, 1))
+                eb = file_path_leg(hesaff_amd, host_imgs, W, H, args.e2e_images, args.e2e_chunk, local_rank, fmt=2)
+                if "images_per_s" in eb:
+                    eb["fraction_of_host_path"] = eb["images_per_s"] / (host_path["images_per_s"] / max(world, 1))
+                end_to_end["binary_sidecar"] = eb
     else:
         cpu_sample = None
 

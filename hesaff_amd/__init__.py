@@ -14,6 +14,9 @@ from ._binding import (  # noqa: F401
     format_sift_mt,
     write_sift,
     write_sift_batch,
+    write_bin,
+    read_bin,
+    BIN_ROW_DTYPE,
     read_image,
     read_pnm,
     ellipse,

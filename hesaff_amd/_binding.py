@@ -109,6 +109,8 @@ def load_library():
                                          C.POINTER(C.c_int), C.POINTER(C.c_int), CHUNK_SINK, vp]
     L.hesaff_process_files.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(FileStatus)]
     L.hesaff_write_sift_mt.argtypes = [C.c_char_p, vp, C.c_int, C.c_float, C.c_int]
+    L.hesaff_write_bin.argtypes = [C.c_char_p, vp, C.c_int, C.c_float]
+    L.hesaff_set_output_format.argtypes = [vp, C.c_int]
     L.hesaff_detect_batch_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, _i32p, _i32p, C.POINTER(vp), C.POINTER(C.c_int64)]
     L.hesaff_set_profiling.argtypes = [vp, C.c_int]
     L.hesaff_get_timings.argtypes = [vp, C.POINTER(Timings)]
@@ -157,7 +159,7 @@ ABI_SYMBOLS = [
     "hesaff_table_gauss_kernel", "hesaff_format_sift_mt", "hesaff_write_sift_batch", "hesaff_test_fmt_g",
     "hesaff_read_png", "hesaff_read_image", "hesaff_device_count", "hesaff_shard_range", "hesaff_read_jpeg",
     "hesaff_host_threads", "hesaff_abi_version", "hesaff_sizeof_params", "hesaff_sizeof_timings", "hesaff_detect_batch_cb",
-    "hesaff_process_files", "hesaff_write_sift_mt",
+    "hesaff_process_files", "hesaff_write_sift_mt", "hesaff_write_bin", "hesaff_set_output_format",
 ]
 
 
@@ -254,6 +256,31 @@ def write_sift(path, keys, mr_size):
     rc = load_library().hesaff_write_sift(os.fsencode(path), keys.ctypes.data, len(keys), mr_size)
     if rc != 0:
         raise HesaffError(rc, "hesaff_write_sift(%s)" % path)
+
+
+BIN_ROW_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("a", "<f4"), ("b", "<f4"), ("c", "<f4"), ("desc", "u1", (128,))])
+
+
+def write_bin(path, keys, mr_size):
+    keys = np.ascontiguousarray(keys, dtype=KEYPOINT_DTYPE)
+    rc = load_library().hesaff_write_bin(os.fsencode(path), keys.ctypes.data, len(keys), mr_size)
+    if rc != 0:
+        raise HesaffError(rc, "hesaff_write_bin(%s)" % path)
+
+
+def read_bin(path):
+    """.hesaff.bin (hesaff_write_bin) -> structured array of BIN_ROW_DTYPE."""
+    with open(path, "rb") as f:
+        head = f.read(16)
+        if len(head) != 16 or head[:8] != b"HESAFFB1":
+            raise HesaffError(-4, "%s is not a .hesaff.bin file" % path)
+        dim, n = np.frombuffer(head[8:], "<u4")
+        if dim != 128:
+            raise HesaffError(-4, "descriptor dimension %d" % dim)
+        rows = np.frombuffer(f.read(), dtype=BIN_ROW_DTYPE)
+    if len(rows) != n:
+        raise HesaffError(-4, "%s is truncated" % path)
+    return rows
 
 
 def read_image(path):
@@ -363,6 +390,10 @@ class HesaffContext:
             return 1 if sink([idx[i] for i in range(m)], out) else 0
         cb = CHUNK_SINK(_sink)
         self._check(self.L.hesaff_detect_batch_cb(self.h, n, ptrs, ws, hs, st, chs, cb, None))
+
+    def set_output_format(self, fmt):
+        """1 = text (.hesaff.sift, default), 2 = binary sidecar (.hesaff.bin), 3 = both."""
+        self._check(self.L.hesaff_set_output_format(self.h, fmt))
 
     def process_files(self, paths, out_paths=None, decode_threads=0, write_threads=0):
         """hesaff_process_files: image files -> <name>.hesaff.sift through the decode / device / write pipeline.

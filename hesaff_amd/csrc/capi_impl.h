@@ -472,6 +472,7 @@ struct FileIO : ChunkIO {
    const char *const *paths, *const *out_paths;
    hesaff_file_status *status;
    float mrSize;
+   int fmt;
    struct Img { uint8_t *data = nullptr; int w = 0, h = 0, ch = 0; int state = 0; };   // 0 pending, 1 decoded, 2 unreadable, 3 handed on
    std::vector<Img> imgs;
    std::mutex mu;
@@ -486,7 +487,7 @@ struct FileIO : ChunkIO {
    std::vector<std::thread> decoders, writers;
 
    FileIO(hesaff_ctx *ctx, int n_, const char *const *p, const char *const *o, hesaff_file_status *st, int dec_threads, int wr_threads)
-      : c(ctx), n(n_), paths(p), out_paths(o), status(st), mrSize(ctx->par.mrSize), imgs((size_t)n_)
+      : c(ctx), n(n_), paths(p), out_paths(o), status(st), mrSize(ctx->par.mrSize), fmt(ctx->out_format), imgs((size_t)n_)
    {
       window = 2 * c->par.max_batch + dec_threads;
       try {
@@ -585,10 +586,16 @@ struct FileIO : ChunkIO {
             t = tasks.front();
             tasks.pop_front();
          }
-         std::string name;
          const char *o = out_paths ? out_paths[t.index] : nullptr;
-         if (!o) { name = std::string(paths[t.index]) + ".hesaff.sift"; o = name.c_str(); }   // hesaff.cpp:170-173
-         const int rc = hesaff_write_sift_mt(o, t.keys, t.n, mrSize, 1);
+         int rc = HESAFF_OK;
+         if (fmt & HESAFF_OUT_TEXT) {
+            const std::string name = o ? std::string(o) : std::string(paths[t.index]) + ".hesaff.sift";   // hesaff.cpp:170-173
+            rc = hesaff_write_sift_mt(name.c_str(), t.keys, t.n, mrSize, 1);
+         }
+         if ((fmt & HESAFF_OUT_BIN) && rc == HESAFF_OK) {
+            const std::string name = o ? (std::string(o) + ((fmt & HESAFF_OUT_TEXT) ? ".bin" : "")) : std::string(paths[t.index]) + ".hesaff.bin";
+            rc = hesaff_write_bin(name.c_str(), t.keys, t.n, mrSize);
+         }
          int blk = -1;
          {
             std::lock_guard<std::mutex> lk(mu);
@@ -633,6 +640,13 @@ int hesaff_detect_batch_cb(hesaff_ctx *c, int n, const uint8_t *const *images, c
    run_chunks(c, io, 3);
    if (io.sink_rc != 0) throw HsError(HESAFF_ERR_IO, "the result sink reported an error");
    HS_API_END(c)
+}
+
+int hesaff_set_output_format(hesaff_ctx *c, int format)
+{
+   if (!c || (format & ~(HESAFF_OUT_TEXT | HESAFF_OUT_BIN)) != 0 || format == 0) return HESAFF_ERR_ARG;
+   c->out_format = format;
+   return HESAFF_OK;
 }
 
 int hesaff_process_files(hesaff_ctx *c, int n, const char *const *paths, const char *const *out_paths, int decode_threads,

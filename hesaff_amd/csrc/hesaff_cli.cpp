@@ -8,6 +8,8 @@
 //       --devices 0-7 | 0,2,5 | all   shards the list over several GPUs of the node: one context per device, each on
 //       its own host thread, contiguous blocks of images (hesaff_shard_range), no data exchanged between devices;
 //       the per-device counts are summed on the host.  A device may be named more than once.
+//       --output text | bin | both    what every image gets: <image>.hesaff.sift (default), the binary sidecar
+//       <image>.hesaff.bin (the same rows unprinted, include/hesaff_amd.h: hesaff_write_bin), or both.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -56,7 +58,7 @@ bool parse_devices(const char *spec, std::vector<int> &out)
 
 // hesaff --batch: the list is cut into contiguous shards, one per device context (hesaff_shard_range); every shard runs
 // through hesaff_process_files - decode threads -> device -> writer threads, bounded memory - on its own host thread.
-int run_batch_mode(const char *list_path, const char *devices_spec)
+int run_batch_mode(const char *list_path, const char *devices_spec, int out_format)
 {
    std::ifstream lf(list_path);
    if (!lf) { fprintf(stderr, "hesaff: cannot read list '%s'\n", list_path); return 1; }
@@ -89,6 +91,7 @@ int run_batch_mode(const char *list_path, const char *devices_spec)
       par.max_batch = std::max(1, std::min(m, 64));
       hesaff_ctx *ctx = nullptr;
       if (hesaff_create(&ctx, &par, devices[(size_t)rank]) != HESAFF_OK) { errs[(size_t)rank] = hesaff_last_error(nullptr); return; }
+      hesaff_set_output_format(ctx, out_format);
       const int host = hesaff_host_threads();
       const int wt = std::max(1, host / world), dt = std::max(1, std::min(16, host / (2 * world)));
       if (hesaff_process_files(ctx, m, paths.data() + lo, nullptr, dt, wt, status.data() + lo) != HESAFF_OK) errs[(size_t)rank] = hesaff_last_error(ctx);
@@ -112,7 +115,7 @@ int run_batch_mode(const char *list_path, const char *devices_spec)
          tot_h += st.count_hessian; tot_d += st.count_desc; n_ok++;
       } else {
          rc = 1;
-         if (st.stage == HESAFF_FILE_DETECTED) fprintf(stderr, "hesaff: cannot write '%s.hesaff.sift'\n", names[(size_t)i].c_str());
+         if (st.stage == HESAFF_FILE_DETECTED) fprintf(stderr, "hesaff: cannot write the output of '%s'\n", names[(size_t)i].c_str());
          else if (st.stage == HESAFF_FILE_UNREADABLE)
             fprintf(stderr, "hesaff: cannot read '%s' (binary PGM/PPM with maxval 255, PNG or JPEG expected): skipped\n", names[(size_t)i].c_str());
       }
@@ -133,9 +136,20 @@ int main(int argc, char **argv)
    }
    if (argc > 2 && strcmp(argv[1], "--batch") == 0) {
       const char *devices = nullptr;
-      if (argc > 4 && strcmp(argv[3], "--devices") == 0) devices = argv[4];
-      else if (argc > 3) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all]\n"); return 1; }
-      return run_batch_mode(argv[2], devices);
+      int out_format = HESAFF_OUT_TEXT;
+      bool bad = false;
+      for (int i = 3; i < argc && !bad; i += 2) {
+         if (i + 1 >= argc) bad = true;
+         else if (strcmp(argv[i], "--devices") == 0) devices = argv[i + 1];
+         else if (strcmp(argv[i], "--output") == 0) {
+            if (strcmp(argv[i + 1], "text") == 0) out_format = HESAFF_OUT_TEXT;
+            else if (strcmp(argv[i + 1], "bin") == 0) out_format = HESAFF_OUT_BIN;
+            else if (strcmp(argv[i + 1], "both") == 0) out_format = HESAFF_OUT_TEXT | HESAFF_OUT_BIN;
+            else bad = true;
+         } else bad = true;
+      }
+      if (bad) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all] [--output text|bin|both]\n"); return 1; }
+      return run_batch_mode(argv[2], devices, out_format);
    }
    if (argc > 1) {
       uint8_t *data = nullptr;

@@ -577,6 +577,47 @@ int hesaff_write_sift_mt(const char *path, const hesaff_keypoint *keys, int n, f
    HOSTIO_CATCH
 }
 
+// Binary sidecar of the text file: the same five floats and 128 bytes per row, not printed.  Little-endian:
+//   char magic[8] = "HESAFFB1"; uint32 dim = 128; uint32 count; count x { float x, y, a, b, c; uint8 desc[128] }  (148 bytes each)
+int hesaff_write_bin(const char *path, const hesaff_keypoint *keys, int n, float mrSize)
+{
+   if (!path || n < 0 || (n > 0 && !keys)) return HESAFF_ERR_ARG;
+   HOSTIO_TRY
+   const size_t kRec = 5 * 4 + 128, kBlock = 8192;
+   static thread_local std::vector<char> tl_bin;
+   tl_bin.resize(16 + kBlock * kRec);
+   char *buf = tl_bin.data();
+   const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+   if (fd < 0) return HESAFF_ERR_IO;
+   memcpy(buf, "HESAFFB1", 8);
+   const uint32_t dim = 128, cnt = (uint32_t)n;
+   memcpy(buf + 8, &dim, 4); memcpy(buf + 12, &cnt, 4);
+   size_t fill = 16;
+   bool ok = true;
+   for (int i0 = 0; ok; i0 += (int)kBlock) {
+      const int i1 = std::min(n, i0 + (int)kBlock);
+      char *p = buf + fill;
+      for (int i = i0; i < i1; i++) {
+         float v[5] = {keys[i].x, keys[i].y, 0, 0, 0};
+         hesaff_ellipse(&keys[i], mrSize, &v[2], &v[3], &v[4]);
+         memcpy(p, v, 20); memcpy(p + 20, keys[i].desc, 128);
+         p += kRec;
+      }
+      size_t left = (size_t)(p - buf);
+      const char *q = buf;
+      while (left > 0) {
+         const ssize_t w = write(fd, q, left);
+         if (w < 0) { if (errno == EINTR) continue; ok = false; break; }
+         q += w; left -= (size_t)w;
+      }
+      fill = 0;
+      if (i1 >= n) break;
+   }
+   if (close(fd) != 0) ok = false;
+   return ok ? HESAFF_OK : HESAFF_ERR_IO;
+   HOSTIO_CATCH
+}
+
 // One file per image of a batch (exportKeypoints once per image, hesaff.cpp:170-176), images
 // taken by `threads` workers from a shared counter; every worker formats its image on its own.
 int hesaff_write_sift_batch(int n_images, const char *const *paths, const hesaff_result *results, float mrSize, int threads)

@@ -222,6 +222,7 @@ struct hesaff_ctx {
 
    hesaff_timings tm;
    int profiling = 0;
+   int out_format = HESAFF_OUT_TEXT;   // hesaff_set_output_format
    hipStream_t side_streams[HS_NSIDE] = {nullptr, nullptr, nullptr, nullptr};
    hipStream_t sift_stream = nullptr, sift_stream2 = nullptr;   // descriptor kernels of even / odd groups (sift2: HESAFF_SIFT2)
    bool sift2 = true;

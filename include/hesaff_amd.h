@@ -151,6 +151,12 @@ typedef struct hesaff_file_status {
 } hesaff_file_status;
 int hesaff_process_files(hesaff_ctx *ctx, int n, const char *const *paths, const char *const *out_paths, int decode_threads,
                          int write_threads, hesaff_file_status *status);
+/* What hesaff_process_files writes for every image: HESAFF_OUT_TEXT (default) = <image>.hesaff.sift in the reference's text
+ * format; HESAFF_OUT_BIN = <image>.hesaff.bin (hesaff_write_bin); HESAFF_OUT_TEXT | HESAFF_OUT_BIN = both.  With out_paths
+ * given, the binary file is out_paths[i] + ".bin" when both are written, out_paths[i] itself when only the binary one is. */
+#define HESAFF_OUT_TEXT 1
+#define HESAFF_OUT_BIN 2
+int hesaff_set_output_format(hesaff_ctx *ctx, int format);
 
 /* Same path with inputs already resident in device memory (bench / pipelines that decode
  * on the GPU): d_gray = n contiguous height x width 8-bit grey planes (device pointer).
@@ -171,6 +177,10 @@ int hesaff_write_sift(const char *path, const hesaff_keypoint *keys, int n, floa
 /* the same file written by `threads` host threads (0 = auto); threads = 1 formats and writes block by block through a
  * cache-resident buffer (what the per-image workers of hesaff_write_sift_batch / hesaff_process_files do) */
 int hesaff_write_sift_mt(const char *path, const hesaff_keypoint *keys, int n, float mrSize, int threads);
+/* Binary sidecar of the same rows (no counterpart in the reference): the five floats unprinted and the
+ * 128 descriptor bytes, 148 bytes per row instead of about 355 bytes of text.  Little-endian:
+ *   char magic[8] = "HESAFFB1"; uint32 dim = 128; uint32 count; count x { float x, y, a, b, c; uint8 desc[128] } */
+int hesaff_write_bin(const char *path, const hesaff_keypoint *keys, int n, float mrSize);
 /* formats into a malloc'ed buffer (*out, *len); caller frees with hesaff_free */
 int hesaff_format_sift(const hesaff_keypoint *keys, int n, float mrSize, char **out, size_t *len);
 /* the same bytes, rows formatted by `threads` host threads (0 = one per core, at most 64);

@@ -803,13 +803,21 @@ def test_process_files_pipeline(tmp_path, oracle):
             name = outs[i] or paths[i] + ".hesaff.sift"
             assert open(name, "rb").read() == texts[i] and nd == int(texts[i].split(b"\n")[1]), i
     assert not os.path.exists(paths[4] + ".hesaff.sift")
-    # defaults (threads = 0: auto, names = the reference's) on the readable files only
+    # defaults (threads = 0: auto, names = the reference's) on the readable files only; text + binary sidecar
     good = [q for i, q in enumerate(paths) if i != 2]
     with hesaff_amd.HesaffContext(device=0) as ctx:
+        ctx.set_output_format(3)
         st = ctx.process_files(good)
+        mr = ctx.params.mrSize
     assert all(rc == OK and stage == 3 for rc, stage, _, _ in st)
     for q, t in zip(good, [t for t in texts if t is not None]):
         assert open(q + ".hesaff.sift", "rb").read() == t
+        rows = hesaff_amd.read_bin(q + ".hesaff.bin")
+        lines = t.split(b"\n")
+        assert len(rows) == int(lines[1])
+        for i in range(0, len(rows), 37):          # the text is the %g print of the sidecar's floats
+            tok = lines[2 + i].split()
+            assert tok[:5] == [b"%g" % float(rows[k][i]) for k in ("x", "y", "a", "b", "c")] and [int(v) for v in tok[5:]] == rows["desc"][i].tolist()
 
 
 def test_sequence_with_homographies_through_cli_and_repeatability_tool(tmp_path, oracle):

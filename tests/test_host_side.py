@@ -327,3 +327,34 @@ def test_read_jpeg_equals_libjpeg_on_many_encodings(tmp_path):
             hesaff_amd.read_image(p)
         except hesaff_amd.HesaffError:
             pass
+
+
+def test_binary_sidecar_holds_the_rows_of_the_text_file(tmp_path):
+    """hesaff_write_bin (optional sidecar): the same rows as the text export - x, y, the ellipse (a, b, c)
+    and the 128 bytes - unprinted; the text file is the 6-significant-digit print of exactly these floats."""
+    import hesaff_amd
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 9000):
+        keys = np.zeros(n, hesaff_amd.KEYPOINT_DTYPE)
+        keys["x"] = rng.uniform(0, 3840, n); keys["y"] = rng.uniform(0, 2160, n); keys["s"] = rng.uniform(1, 40, n)
+        keys["a11"] = rng.uniform(0.5, 2, n); keys["a21"] = rng.uniform(-1, 1, n); keys["a22"] = 1.0 / np.maximum(keys["a11"], 1e-3)
+        keys["desc"] = rng.integers(0, 256, (n, 128), dtype=np.uint8)
+        mr = hesaff_amd.default_params().mrSize
+        q = str(tmp_path / ("k%d.hesaff.bin" % n))
+        hesaff_amd.write_bin(q, keys, mr)
+        assert os.path.getsize(q) == 16 + 148 * n
+        rows = hesaff_amd.read_bin(q)
+        assert len(rows) == n and np.array_equal(rows["desc"], keys["desc"])
+        assert np.array_equal(rows["x"], keys["x"]) and np.array_equal(rows["y"], keys["y"])
+        e = hesaff_amd.ellipse(keys, mr)
+        assert np.array_equal(np.stack([rows["a"], rows["b"], rows["c"]], 1), e.astype(np.float32).reshape(n, 3))
+        # the text file prints these floats with %g
+        text = hesaff_amd.format_sift(keys, mr).split(b"\n")
+        assert int(text[1]) == n
+        for i in (0, n // 2, n - 1) if n else ():
+            tok = text[2 + i].split()
+            want = [b"%g" % float(v) for v in (rows["x"][i], rows["y"][i], rows["a"][i], rows["b"][i], rows["c"][i])]
+            assert tok[:5] == want and [int(t) for t in tok[5:]] == rows["desc"][i].tolist()
+    with pytest.raises(hesaff_amd.HesaffError):
+        (tmp_path / "junk.bin").write_bytes(b"not a sidecar")
+        hesaff_amd.read_bin(str(tmp_path / "junk.bin"))

@@ -24,7 +24,14 @@ sys.path.insert(0, ROOT)
 
 
 def read_sift(path):
-    """-> (regions [n,5] float64: u v a b c, descriptors [n,128] uint8)."""
+    """.hesaff.sift (text) or .hesaff.bin (binary sidecar) -> (regions [n,5] float64: u v a b c, descriptors [n,128] uint8)."""
+    with open(path, "rb") as f:
+        magic = f.read(8)
+    if magic == b"HESAFFB1":
+        import hesaff_amd
+        rows = hesaff_amd.read_bin(path)
+        reg = np.stack([rows[k].astype(np.float64) for k in ("x", "y", "a", "b", "c")], 1) if len(rows) else np.zeros((0, 5))
+        return reg, np.ascontiguousarray(rows["desc"])
     with open(path, "rb") as f:
         dim = int(f.readline()); n = int(f.readline())
         data = np.loadtxt(f, dtype=np.float64, ndmin=2) if n > 0 else np.zeros((0, 5 + dim))
