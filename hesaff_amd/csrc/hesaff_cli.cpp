@@ -8,6 +8,9 @@
 //       --devices 0-7 | 0,2,5 | all   shards the list over several GPUs of the node: one context per device, each on
 //       its own host thread, contiguous blocks of images (hesaff_shard_range), no data exchanged between devices;
 //       the per-device counts are summed on the host.  A device may be named more than once.
+//       --schedule static | dynamic   static (default): one contiguous shard per device context.  dynamic: the list is cut into
+//       blocks of 256 images and every device context takes the next block when it has finished its own - for lists whose
+//       keypoint density varies strongly along the list; the output files are the same either way.
 //       --output text | bin | both    what every image gets: <image>.hesaff.sift (default), the binary sidecar
 //       <image>.hesaff.bin (the same rows unprinted, include/hesaff_amd.h: hesaff_write_bin), or both.
 #include <chrono>
@@ -58,7 +61,7 @@ bool parse_devices(const char *spec, std::vector<int> &out)
 
 // hesaff --batch: the list is cut into contiguous shards, one per device context (hesaff_shard_range); every shard runs
 // through hesaff_process_files - decode threads -> device -> writer threads, bounded memory - on its own host thread.
-int run_batch_mode(const char *list_path, const char *devices_spec, int out_format)
+int run_batch_mode(const char *list_path, const char *devices_spec, int out_format, bool dynamic)
 {
    std::ifstream lf(list_path);
    if (!lf) { fprintf(stderr, "hesaff: cannot read list '%s'\n", list_path); return 1; }
@@ -81,20 +84,29 @@ int run_batch_mode(const char *list_path, const char *devices_spec, int out_form
    std::vector<std::string> errs((size_t)world);
    int rc = 0;
    const auto t1 = std::chrono::steady_clock::now();
+   const int kBlock = 256;
+   std::atomic<int> next_block(0);
    auto device_worker = [&](int rank) {
       int lo = 0, hi = 0;
       hesaff_shard_range(n, rank, world, &lo, &hi);
-      if (hi <= lo) return;
-      const int m = hi - lo;
+      if (!dynamic && hi <= lo) return;
       hesaff_params par;
       hesaff_default_params(&par);
-      par.max_batch = std::max(1, std::min(m, 64));
+      par.max_batch = std::max(1, std::min(dynamic ? n : hi - lo, 64));
       hesaff_ctx *ctx = nullptr;
       if (hesaff_create(&ctx, &par, devices[(size_t)rank]) != HESAFF_OK) { errs[(size_t)rank] = hesaff_last_error(nullptr); return; }
       hesaff_set_output_format(ctx, out_format);
       const int host = hesaff_host_threads();
       const int wt = std::max(1, host / world), dt = std::max(1, std::min(16, host / (2 * world)));
-      if (hesaff_process_files(ctx, m, paths.data() + lo, nullptr, dt, wt, status.data() + lo) != HESAFF_OK) errs[(size_t)rank] = hesaff_last_error(ctx);
+      for (;;) {
+         if (dynamic) {   // the next block of the list nobody has taken yet
+            lo = next_block.fetch_add(1) * kBlock;
+            hi = std::min(n, lo + kBlock);
+         }
+         if (hi <= lo) break;
+         if (hesaff_process_files(ctx, hi - lo, paths.data() + lo, nullptr, dt, wt, status.data() + lo) != HESAFF_OK) { errs[(size_t)rank] = hesaff_last_error(ctx); break; }
+         if (!dynamic) break;
+      }
       hesaff_destroy(ctx);
    };
    {
@@ -137,19 +149,22 @@ int main(int argc, char **argv)
    if (argc > 2 && strcmp(argv[1], "--batch") == 0) {
       const char *devices = nullptr;
       int out_format = HESAFF_OUT_TEXT;
-      bool bad = false;
+      bool bad = false, dynamic = false;
       for (int i = 3; i < argc && !bad; i += 2) {
          if (i + 1 >= argc) bad = true;
          else if (strcmp(argv[i], "--devices") == 0) devices = argv[i + 1];
-         else if (strcmp(argv[i], "--output") == 0) {
+         else if (strcmp(argv[i], "--schedule") == 0) {
+            if (strcmp(argv[i + 1], "dynamic") == 0) dynamic = true;
+            else if (strcmp(argv[i + 1], "static") != 0) bad = true;
+         } else if (strcmp(argv[i], "--output") == 0) {
             if (strcmp(argv[i + 1], "text") == 0) out_format = HESAFF_OUT_TEXT;
             else if (strcmp(argv[i + 1], "bin") == 0) out_format = HESAFF_OUT_BIN;
             else if (strcmp(argv[i + 1], "both") == 0) out_format = HESAFF_OUT_TEXT | HESAFF_OUT_BIN;
             else bad = true;
          } else bad = true;
       }
-      if (bad) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all] [--output text|bin|both]\n"); return 1; }
-      return run_batch_mode(argv[2], devices, out_format);
+      if (bad) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all] [--output text|bin|both] [--schedule static|dynamic]\n"); return 1; }
+      return run_batch_mode(argv[2], devices, out_format, dynamic);
    }
    if (argc > 1) {
       uint8_t *data = nullptr;

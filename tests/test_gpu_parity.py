@@ -254,11 +254,11 @@ def test_cli_multi_device_shards_and_isolates_bad_files(tmp_path):
     lst = tmp_path / "list.txt"
     lst.write_text("\n".join(names[:3] + [str(bad)] + names[3:]) + "\n")
 
-    def run(devs):
+    def run(devs, extra=()):
         for n in names:
             if os.path.exists(n + ".hesaff.sift"):
                 os.remove(n + ".hesaff.sift")
-        r = subprocess.run([exe, "--batch", str(lst), "--devices", devs], capture_output=True, text=True)
+        r = subprocess.run([exe, "--batch", str(lst), "--devices", devs] + list(extra), capture_output=True, text=True)
         assert r.returncode == 1, (r.stdout, r.stderr)               # the broken file
         assert "broken.pgm" in r.stderr and "skipped" in r.stderr
         m = re.search(r"Detected (\d+) keypoints and (\d+) affine shapes in 7 images", r.stdout)
@@ -269,8 +269,15 @@ def test_cli_multi_device_shards_and_isolates_bad_files(tmp_path):
     three, tot3 = run("0,0,0")
     assert tot1 == tot2 == tot3 and tot1[1] > 300
     assert one == two == three and all(len(b) > 100 for b in one)
+    # dynamic schedule (device contexts pull blocks of the list) and the binary sidecar next to the text: the same text files
+    dyn, totd = run("0,0", ("--schedule", "dynamic", "--output", "both"))
+    assert dyn == one and totd == tot1 and all(os.path.getsize(n + ".hesaff.bin") == 16 + 148 * int(b.split(b"\n")[1]) for n, b in zip(names, one))
     r = subprocess.run([exe, "--batch", str(lst), "--devices", "0-99"], capture_output=True, text=True)
     assert r.returncode == 1 and "--devices" in r.stderr
+    r = subprocess.run([exe, "--batch", str(lst), "--devices", "0-99999999999"], capture_output=True, text=True)   # no expansion before the check
+    assert r.returncode == 1 and "--devices" in r.stderr
+    r = subprocess.run([exe, "--batch", str(lst), "--output", "xml"], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage" in r.stderr
 
 
 def test_same_bytes_under_one_and_two_ranks(tmp_path):
