@@ -254,7 +254,10 @@ def main():
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     if backend == "gloo":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    if world > 1:
+    # under a launcher the process group is always initialised - also for one rank, so that `torchrun --nproc-per-node 1
+    # bench.py` exercises the RCCL barrier / all-reduce / all-gather on a one-GPU box; plain `python bench.py` has no group
+    grouped = world > 1 or "WORLD_SIZE" in os.environ
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
@@ -317,7 +320,7 @@ def main():
     ctx.set_profiling(2)
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -327,14 +330,14 @@ def main():
         step(True)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     from hesaff_amd.shard import gather_counts
     n_hess, n_desc = tot["hess"], tot["desc"]
     bh_ms, bh_bytes, bh_launches = bh["ms"], bh["bytes"], bh["launches"]
-    counts = gather_counts([n_hess, n_desc, tot["imgs"]], device=coll_dev if world > 1 else None)
+    counts = gather_counts([n_hess, n_desc, tot["imgs"]], device=coll_dev if grouped else None)
     tot_hess, tot_desc, tot_imgs = [int(v) for v in counts.sum(axis=0)]
     per_rank_images = [int(v) for v in counts[:, 2]]
     ctx.close()
@@ -365,11 +368,11 @@ def main():
             hdesc += sum(r.count_desc for r in res)
         barrier()
         hdt = time.perf_counter() - t1
-        if world > 1:
+        if grouped:
             t = torch.tensor([hdt], device=coll_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             hdt = float(t.item())
-        hc = gather_counts([hdesc, B * hsteps], device=coll_dev if world > 1 else None).sum(axis=0)
+        hc = gather_counts([hdesc, B * hsteps], device=coll_dev if grouped else None).sum(axis=0)
         host_path = {"value": float(hc[0]) / hdt, "unit": "keypoints/s", "images_per_s": float(hc[1]) / hdt, "steps": hsteps,
                      "ms_per_step": hdt / hsteps * 1e3, "chunk_images": int(hp.max_batch),
                      "what": "hesaff_detect_batch: pageable host images -> pinned staging -> H2D -> kernels -> D2H -> pinned host records; "
@@ -425,6 +428,7 @@ def main():
             "images_per_s": tot_imgs / dt,
             "hessian_keypoints_per_s": tot_hess / dt,
             "n_gpus": world,
+            "collective_backend": (backend if backend != "nccl" else "nccl (RCCL)") if grouped else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -507,7 +511,7 @@ def main():
                                                            % (nw, B, nw, ("%g" % quota) if quota else "unlimited", mdt, max(r[1] for r in res)),
                                                  "cpu": cpu}
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -721,6 +721,22 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0   # rank 0 keeps the CPU leg when world > 1
 
 
+def test_bench_one_rank_through_rccl():
+    """bench.py under torchrun with ONE rank and the real backend: process group on RCCL, barrier, max all-reduce of the time and
+    the count all-gather all run on the GPU (two ranks cannot share a device under RCCL, hence the gloo knob in the other tests)."""
+    import json
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("BENCH_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--batch", "2",
+           "--width", "640", "--height", "480", "--no-cpu-baseline", "--no-host-path"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["collective_backend"] == "nccl (RCCL)" and d["value"] > 0 and d["config"]["per_rank_images_timed"] == [2]
+
+
 def test_bench_gpus_flag_starts_the_ranks_itself():
     """`python bench.py --gpus 2` with no launcher around it (the form the driver uses for N = 1): bench.py starts the two
     ranks itself, before it touches the GPU, and rank 0's line says n_gpus == 2.  Strong scaling: 5 images per step in
