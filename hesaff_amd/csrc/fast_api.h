@@ -18,3 +18,6 @@ void hsfast_patch_bins(hipStream_t s0, hipStream_t s1, hipStream_t s2, hipStream
 void hsfast_patch_large(hipStream_t st, const FastArgs &a, uint32_t *row_prefix, uint32_t gblocks, size_t lds, int srow_stride, int tap_stride, uint32_t g_finish);
 void hsfast_sift(hipStream_t st, const FastArgs &a, uint32_t n, void *vo, uint32_t g_grad, uint32_t g_hist);
 void hsfast_set_attrs(const size_t lds[4], size_t lds_large);
+// fast level 2: windows of bins first_bin.. sampled from the scale-space level with the matching blur (k_patch_pyramid)
+void hsfast_patch_pyramid(hipStream_t st, const FastArgs &a, int n_octaves, float pd0, int first_bin, uint32_t grid);
+void hsfast_patch_bin0(hipStream_t st, const FastArgs &a, uint32_t grid, size_t lds);

@@ -76,3 +76,15 @@ void hsfast_sift(hipStream_t st, const FastArgs &a, uint32_t n, void *vo, uint32
    // one kernel from the patch to the 128 bytes: nothing but the descriptor leaves the chip (k_desc_fused, kernels_sift.h)
    hipLaunchKernelGGL(hsfast::k_desc_fused, dim3(std::min(n, g_grad)), dim3(256), 0, st, so, tb, take<hsfast::DConsts>(a.kc, a.sz_kc));
 }
+
+void hsfast_patch_bin0(hipStream_t st, const FastArgs &a, uint32_t grid, size_t lds)
+{
+   hipLaunchKernelGGL(hsfast::k_patch_extract_small<0>, dim3(grid), dim3(256), lds, st, take<hsfast::HessList>(a.hl, a.sz_hl), take<hsfast::PatchWork>(a.pw, a.sz_pw),
+                      take<hsfast::PatchIO>(a.io, a.sz_io), take<hsfast::KpTables>(a.tb, a.sz_tb));
+}
+
+void hsfast_patch_pyramid(hipStream_t st, const FastArgs &a, int n_octaves, float pd0, int first_bin, uint32_t grid)
+{
+   hipLaunchKernelGGL(hsfast::k_patch_pyramid, dim3(grid), dim3(256), 0, st, take<hsfast::HessList>(a.hl, a.sz_hl), take<hsfast::PatchWork>(a.pw, a.sz_pw),
+                      take<hsfast::PatchIO>(a.io, a.sz_io), take<hsfast::PlaneTab>(a.pt, a.sz_pt), n_octaves, pd0, first_bin);
+}

@@ -953,3 +953,63 @@ __global__ __launch_bounds__(256) void k_large_prefix(PatchWork pw, uint32_t *__
    }
    if (threadIdx.x == 0) pre[n] = carry;
 }
+
+
+#if HS_FAST
+// ---------------------------------------------------------------------------------------------------------------------
+// k_patch_pyramid (fast level 2 only; a DIFFERENT ALGORITHM from the reference's for these windows):
+// normalizeAffine (affine.cpp:102-144) warps a P x P window of the ORIGINAL image at unit spacing, blurs it with
+// sigma = 1.5 * P0 / 41 and takes every (P0 / 41)-th sample.  For P > 41 that is P^2 bilinear taps and a K = 0.22 P tap
+// separable blur per keypoint - bins 2-4 (15 % of the keypoints) cost 60 % of the patch stage.  The scale space already
+// holds the image blurred with sigma = 1.6 * 2^(octave + level / 3): this kernel takes the 41 x 41 samples straight
+// from the stored level whose blur is closest (in log scale) to 1.5 * P0 / 41, at the affine-warped positions: 1681 taps,
+// no blur.  What it ignores: the reference's blur is isotropic in the NORMALISED frame (anisotropic in the image for an
+// elongated region), the level's blur is isotropic in the image; and the blur matches only to +-12 %.
+// One 256-thread block per keypoint, grid-stride over the lists of bins first_bin .. HS_NBINS-1.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_patch_pyramid(HessList hl, PatchWork pw, PatchIO io, PlaneTab pt, int n_octaves, float pd0, int first_bin)
+{
+   const int tid = threadIdx.x;
+   uint32_t base = 0;
+   for (int bin = first_bin; bin < HS_NBINS; bin++) {
+      const uint32_t cnt = min(pw.bin_count[bin], pw.cap);
+      // blocks continue round-robin across the bins' lists
+      for (uint32_t wi = (blockIdx.x + gridDim.x - base % gridDim.x) % gridDim.x; wi < cnt; wi += gridDim.x) {
+         const uint32_t h = pw.bin_items[(size_t)bin * pw.cap + wi];
+         const int b = hl.meta[h] >> 8;
+         const float x = hl.x[h], y = hl.y[h];
+         const float a11 = pw.A[4 * h], a12 = pw.A[4 * h + 1], a21 = pw.A[4 * h + 2], a22 = pw.A[4 * h + 3];
+         const float scale = (float)pw.P0[h] / (float)HS_PATCH;
+         // level with sigma closest to 1.5 * scale: sigma(o, l) = 1.6 * 2^(o + l / 3) in pixels of the original image
+         const float t = 3.0f * log2f(fmaxf(1.5f * scale / 1.6f, 1.0f));        // octave * 3 + level, fractional
+         int ol = (int)(t + 0.5f);
+         ol = min(ol, 3 * n_octaves - 1);
+         const int o = ol / 3, l = ol - 3 * o;
+         const DPlane &P = pt.L[o][l];
+         const float *img = P.img(b);
+         const float pd = pd0 * (float)(1 << o), inv = 1.0f / pd;
+         const float xmax = (float)(P.cols - 1) - 0.001f, ymax = (float)(P.rows - 1) - 0.001f;
+         float *out = io.patches + (size_t)(h - io.h_base) * HS_PATCH_PIX;
+         const float b11 = a11 * scale * inv, b12 = a12 * scale * inv, b21 = a21 * scale * inv, b22 = a22 * scale * inv;
+         const float ox = x * inv, oy = y * inv;
+#pragma unroll
+         for (int q = 0; q < HS_PATCH_PIX_IT; q++) {
+            const int idx = tid + 256 * q;
+            if (idx < HS_PATCH_PIX) {
+               const int jj = idx / HS_PATCH, ii = idx - jj * HS_PATCH;
+               const float i = (float)(ii - (HS_PATCH >> 1)), j = (float)(jj - (HS_PATCH >> 1));
+               // helpers.cpp:209-244 argument order: a12 / a22 multiply the row index j, a11 / a21 the column index i
+               float wx = ox + j * b12 + i * b11, wy = oy + j * b22 + i * b21;
+               wx = fminf(fmaxf(wx, 0.0f), xmax); wy = fminf(fmaxf(wy, 0.0f), ymax);
+               const float fx = floorf(wx), fy = floorf(wy);
+               wx -= fx; wy -= fy;
+               const float *p = img + (long long)(int)fy * P.pitch + (int)fx;
+               const float p00 = p[0], p01 = p[1], p10 = p[P.pitch], p11 = p[P.pitch + 1];
+               out[idx] = (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + wy * ((1.0f - wx) * p10 + wx * p11);
+            }
+         }
+      }
+      base += cnt;
+   }
+}
+#endif

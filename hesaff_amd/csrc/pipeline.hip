@@ -233,6 +233,7 @@ struct hesaff_ctx {
    DevBuf b_patches2[HS_NSLOT], b_siftvec2[HS_NSLOT], b_meanvar2[HS_NSLOT], b_siftvo2[HS_NSLOT];
    hipEvent_t ev_fork = nullptr, ev_join[HS_NSIDE] = {nullptr, nullptr, nullptr, nullptr};
    bool fast = false;              // hesaff_params.fast: per-keypoint stages on the kernels of kernels_fast.hip (not bit-exact)
+   bool fast_pyramid = false;      // hesaff_params.fast == 2: windows beyond bin 0 sampled from the scale-space level with the matching blur
    // schedule knobs: fixed in the product build, environment-driven only under -DHESAFF_TUNING
    bool no_overlap = false;        // HESAFF_OVERLAP=0: every kernel alone on the device (per-kernel profiling)
    uint32_t sift_group_kpts = 0;   // HESAFF_GROUP: keypoints per image group; 0 = by batch
@@ -663,7 +664,8 @@ FastArgs fast_args(const hesaff_ctx *c, const Lists &s, const PatchIO *io, const
 // normalizeAffine for every keypoint k_prepare_patch left alive and binned.  Every launch is a persistent grid of
 // fixed size that reads its work-list length from the device-side bin counters: the host never waits for them.
 // large_rows_bound: upper bound of the large bin's T' rows in this group (from k_image_large_rows).
-void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *patches_out, uint32_t h_base, uint32_t large_rows_bound)
+void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *patches_out, uint32_t h_base, uint32_t large_rows_bound,
+                     const PlaneTab *pt = nullptr)
 {
    hipStream_t st = c->stream;
    PatchIO io;
@@ -671,6 +673,21 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
    io.image = image;
    io.patches = patches_out;
    io.h_base = h_base;
+   if (c->fast && c->fast_pyramid && pt) {
+      // fast level 2: bin 0 (P <= 41) on the LDS-window kernel, every larger window from the pyramid (k_patch_pyramid)
+      hipStream_t s0 = st;
+      const bool forked = c->side_streams[0] && !c->no_overlap;
+      if (forked) {
+         HIP_TRY(hipEventRecord(c->ev_fork, st));
+         HIP_TRY(hipStreamWaitEvent(c->side_streams[0], c->ev_fork, 0));
+         s0 = c->side_streams[0];
+      }
+      hsfast_patch_bin0(s0, fast_args(c, s, &io, nullptr, nullptr), c->g_small0, small_extract_lds_bytes(0));
+      if (forked) HIP_TRY(hipEventRecord(c->ev_join[0], s0));
+      hsfast_patch_pyramid(st, fast_args(c, s, &io, pt, nullptr), (int)c->oct.size(), c->consts.pd0, 1, (uint32_t)c->n_cu * 32u);
+      if (forked) HIP_TRY(hipStreamWaitEvent(st, c->ev_join[0], 0));
+      return;
+   }
    // The bins are independent (disjoint keypoints) and each kernel leaves CU resources idle
    // (LDS- or latency-bound), so they run concurrently on side streams.
    hipStream_t s0 = st, s1 = st, s2 = st, s3 = st;
@@ -1010,7 +1027,7 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
          //  here until the stream has drained, once per group)
          hipLaunchKernelGGL(k_prepare_patch, dim3(1024), dim3(256), 0, st, s.hl, h_lo, h_hi, (const uint32_t *)(cnt + 3), s.ao, H, W, c->consts,
                             c->tables, s.pw);
-         run_patch_stage(c, s, c->gray, c->b_patches2[slot].as<float>(), h_lo, groups[gi].large_rows);
+         run_patch_stage(c, s, c->gray, c->b_patches2[slot].as<float>(), h_lo, groups[gi].large_rows, &pt);
          tm.end(t);
          HIP_TRY(hipEventRecord(c->ev_extract_done[slot], st));
          hipStream_t ss = c->no_overlap ? st : ((c->sift2 && (gi & 1)) ? c->sift_stream2 : c->sift_stream);

@@ -58,7 +58,10 @@ typedef struct hesaff_params {
    /* 0 (default): parity mode, results bit-identical to the reference's arithmetic.
     * 1: fast mode: contracted multiply-adds, reassociated sums and approximate
     *    division / square root / atan2 in the per-keypoint kernels; NOT bit-exact, see DESIGN.md for the
-    *    measured mismatch rate. */
+    *    measured mismatch rate.
+    * 2: fast mode + a different algorithm for the windows larger than the 41 x 41 patch: their samples are taken from the
+    *    scale-space level whose blur matches (1681 taps) instead of warping and blurring a P x P window of the original
+    *    (affine.cpp:114-135); descriptors of those keypoints differ visibly, see DESIGN.md for the measured effect. */
    int fast;
 } hesaff_params;
 

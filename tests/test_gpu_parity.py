@@ -629,6 +629,29 @@ def test_fast_mode_is_close_to_parity_mode(ctx):
         assert c["shape_rel_delta_p50_p99_max"][0] < 1e-4, c
 
 
+def test_fast_level_2_keeps_geometry_and_small_windows(ctx):
+    """hesaff_params.fast = 2 replaces normalizeAffine's warp + blur by samples of the matching scale-space level for every window
+    larger than the 41 x 41 patch - another algorithm for those keypoints, not an approximation of the arithmetic.  What must
+    hold: detection, affine shapes and the set of described keypoints are those of fast = 1, keypoints with small windows keep
+    their fast = 1 descriptor, the others stay correlated with it."""
+    import hesaff_amd
+    imgs = [band_noise_image(480, 640, 77)]
+    with hesaff_amd.HesaffContext(_params(fast=1), device=0) as c1, hesaff_amd.HesaffContext(_params(fast=2), device=0) as c2:
+        (n1, k1), = c1.detect_batch(imgs)
+        (n2, k2), = c2.detect_batch(imgs)
+        mr = c1.params.mrSize
+    assert n1 == n2 and len(k1) == len(k2) > 3000
+    for f in ("x", "y", "s", "a11", "a12", "a21", "a22", "response", "type"):
+        assert np.array_equal(k1[f], k2[f]), f
+    P0 = 2 * np.ceil(k1["s"] * np.float32(mr)).astype(np.int64) + 1
+    small = P0 + 2 <= 41
+    assert small.sum() > 1000 and (~small).sum() > 500
+    assert np.array_equal(k1["desc"][small], k2["desc"][small])
+    a = k1["desc"][~small].astype(np.float64); b = k2["desc"][~small].astype(np.float64)
+    cos = (a * b).sum(1) / np.maximum(np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1), 1e-9)
+    assert np.median(cos) > 0.9, float(np.median(cos))
+
+
 def test_survey_probe_output_md5_on_gpu(ctx):
     """The product's .hesaff.sift of SURVEY App. C's 640x480 probe image has the md5 the survey recorded from the
     COMPILED reference's output file (e004ba88...): 4183 rows, every coordinate, ellipse term and descriptor byte."""

@@ -51,6 +51,9 @@ def compare(par, fast):
     out["rows_with_delta_le_4"] = int((dd.max(axis=1) <= 4).sum())
     nrm = np.linalg.norm(a["desc"].astype(np.float64) - b["desc"].astype(np.float64), axis=1)
     out["desc_l2_distance_p50_p99_max"] = [float(np.percentile(nrm, 50)), float(np.percentile(nrm, 99)), float(nrm.max())]
+    na = np.linalg.norm(a["desc"].astype(np.float64), axis=1); nb = np.linalg.norm(b["desc"].astype(np.float64), axis=1)
+    cos = (a["desc"].astype(np.float64) * b["desc"].astype(np.float64)).sum(axis=1) / np.maximum(na * nb, 1e-9)
+    out["desc_cosine_p01_p10_p50"] = [float(np.percentile(cos, 1)), float(np.percentile(cos, 10)), float(np.percentile(cos, 50))]
     A = np.stack([a["a11"], a["a21"], a["a22"]], 1).astype(np.float64)
     Bm = np.stack([b["a11"], b["a21"], b["a22"]], 1).astype(np.float64)
     rel = np.abs(A - Bm).max(axis=1) / np.maximum(np.abs(A).max(axis=1), 1e-12)
@@ -65,6 +68,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--level", type=int, default=1, help="hesaff_params.fast of the fast run (1, or 2: + pyramid-sampled large windows)")
     a = ap.parse_args()
     import torch
     import hesaff_amd
@@ -75,7 +79,7 @@ def main():
     for mode in (0, 1):
         p = hesaff_amd.default_params()
         p.max_batch = a.batch
-        p.fast = mode
+        p.fast = a.level if mode else 0
         with hesaff_amd.HesaffContext(p, device=0) as ctx:
             ctx.detect_batch_device(imgs.data_ptr(), a.batch, a.width, a.height)
             torch.cuda.synchronize()
@@ -106,6 +110,7 @@ def main():
     m = max(tot.get("matched_within_0.01px", 0), 1)
     report = {
         "workload": "%d x %dx%d band-noise images, default parameters, hesaff_detect_batch_device" % (a.batch, a.width, a.height),
+        "fast_level": a.level,
         "hessian_keypoints_equal": bool(np.array_equal(ch0, ch1)),
         "parity_ms_per_step": t0 * 1e3, "fast_ms_per_step": t1 * 1e3, "speed_up": t0 / t1,
         "descriptors_parity": int(cd0.sum()), "descriptors_fast": int(cd1.sum()),

@@ -234,7 +234,7 @@ def evaluate_sequence_files(paths, Hs, size, angles=None):
     return out
 
 
-def sequence_through_cli(out_dir, width=800, height=640, angles=(10, 20, 30, 40, 50)):
+def sequence_through_cli(out_dir, width=800, height=640, angles=(10, 20, 30, 40, 50), fast=0):
     """BASELINE.json config 5 on the synthetic stand-in: the sequence as JPEG files -> `hesaff --batch` (decode threads,
     device, writer threads) -> the evaluation above."""
     import subprocess
@@ -242,14 +242,29 @@ def sequence_through_cli(out_dir, width=800, height=640, angles=(10, 20, 30, 40,
     lst = os.path.join(out_dir, "list.txt")
     with open(lst, "w") as f:
         f.write("\n".join(paths) + "\n")
-    exe = os.path.join(ROOT, "hesaff_amd", "bin", "hesaff")
-    r = subprocess.run([exe, "--batch", lst], capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hesaff --batch failed: " + r.stderr[-2000:])
+    if fast:
+        # the CLI has no switch for the fast modes: the same file pipeline (hesaff_process_files) through the binding
+        import hesaff_amd
+        p = hesaff_amd.default_params()
+        p.fast = fast
+        with hesaff_amd.HesaffContext(p, device=0) as ctx:
+            st = ctx.process_files(paths)
+        if any(s_[0] != 0 for s_ in st):
+            raise RuntimeError("hesaff_process_files failed: %r" % (st,))
+
+        class R:
+            stdout = "hesaff_process_files, hesaff_params.fast = %d: %d descriptors" % (fast, sum(s_[3] for s_ in st))
+        r = R()
+    else:
+        exe = os.path.join(ROOT, "hesaff_amd", "bin", "hesaff")
+        r = subprocess.run([exe, "--batch", lst], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hesaff --batch failed: " + r.stderr[-2000:])
     return {"data": "synthetic graf-like sequence: %dx%d colour band-noise image and %d copies warped by a camera rotation about the "
                     "vertical axis, stored as JPEG (quality 92, 4:2:0) and read back by the library's JPEG decoder; the Oxford "
                     "sequences are not available offline" % (width, height, len(angles)),
-            "command": "python tools/repeatability.py --synthetic-files DIR   (hesaff --batch list.txt, then the evaluation)",
+            "command": "python tools/repeatability.py --synthetic-files DIR%s   (hesaff --batch list.txt, then the evaluation)" % ((" --fast %d" % fast) if fast else ""),
+            "fast": fast,
             "cli_stdout_tail": r.stdout.strip().splitlines()[-1],
             "pairs": evaluate_sequence_files(paths, Hs, (width, height), list(angles))}
 
@@ -262,9 +277,10 @@ def main():
     ap.add_argument("--size2", nargs=2, type=int, metavar=("W", "H"))
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--synthetic-files", metavar="DIR", help="write the synthetic sequence as JPEG files into DIR, run `hesaff --batch` on it, evaluate")
+    ap.add_argument("--fast", type=int, default=0, help="with --synthetic-files: hesaff_params.fast (0 = parity mode through the CLI)")
     args = ap.parse_args()
     if args.synthetic_files:
-        print(json.dumps(sequence_through_cli(args.synthetic_files), indent=1))
+        print(json.dumps(sequence_through_cli(args.synthetic_files, fast=args.fast), indent=1))
         return
     if args.synthetic:
         print(json.dumps(synthetic_sequence()))
