@@ -248,37 +248,9 @@ int hesaff_detect_batch_device(hesaff_ctx *c, int n, const void *d_gray, int wid
 } // extern "C"
 
 namespace {
+using namespace hesaff_engine;
 
-struct HostChunk {                // at most max_batch images of one geometry
-   int W = 0, H = 0, ch = 1;
-   std::vector<const uint8_t *> data;
-   std::vector<size_t> stride;    // bytes between rows
-   std::vector<int> index;        // the caller's image numbers
-};
-
-struct ChunkDone {
-   const HostChunk *chunk;
-   const int32_t *count_hessian, *count_desc;   // per image of the chunk
-   const size_t *key_off;                       // first record of each image inside keys
-   const hesaff_keypoint *keys;                 // pinned host memory: valid until the block is released / the next call
-   int block;
-};
-
-struct ChunkIO {
-   virtual bool next(HostChunk &out) = 0;       // staging thread, one call at a time, in order; false: no more chunks
-   virtual void staged(const HostChunk &) {}    // staging thread: the chunk's pixels are in pinned memory, its sources may go
-   virtual void done(const ChunkDone &) = 0;    // caller's thread, in order
-   virtual ~ChunkIO() {}
-};
-
-void release_block(hesaff_ctx *c, int block)
-{
-   {
-      std::lock_guard<std::mutex> lk(c->ring_mu);
-      if (block >= 0 && block < (int)c->ring_busy.size()) c->ring_busy[(size_t)block] = 0;
-   }
-   c->ring_cv.notify_all();
-}
+void release_block(hesaff_ctx *c, int block) { c->ring.release(block); }
 
 void ensure_copy_streams(hesaff_ctx *c)
 {
@@ -303,10 +275,7 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
       std::vector<size_t> off;
       int total = 0, block = -1, no = 0;
    };
-   {
-      std::lock_guard<std::mutex> lk(c->ring_mu);
-      c->ring_busy.assign((size_t)std::max(ring, 0), 0);
-   }
+   c->ring.reset(ring);
    if (ring > 0 && (int)c->pin_out.size() < ring) c->pin_out.resize((size_t)ring);
 
    // stage(k): chunk k -> pinned buffer -> device input buffer (k & 1) on the H2D stream; runs while chunk k-1 computes
@@ -366,15 +335,7 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
          if (prev) { deliver(*prev); prev.reset(); }
          // a pinned block for chunk k
          if (ring > 0) {
-            std::unique_lock<std::mutex> lk(c->ring_mu);
-            int blk = -1;
-            c->ring_cv.wait(lk, [&] {
-               for (int i = 0; i < ring; i++)
-                  if (!c->ring_busy[(size_t)i]) { blk = i; return true; }
-               return false;
-            });
-            c->ring_busy[(size_t)blk] = 1;
-            cur->block = blk;
+            cur->block = c->ring.acquire();
          } else {
             if ((int)c->pin_out.size() <= k) c->pin_out.resize((size_t)k + 1);
             cur->block = k;
@@ -466,156 +427,6 @@ struct ArrayIO : ChunkIO {
    }
 };
 
-// hesaff_process_files: decoder threads -> chunks -> device -> writer threads
-struct FileIO : ChunkIO {
-   hesaff_ctx *c;
-   int n;
-   const char *const *paths, *const *out_paths;
-   hesaff_file_status *status;
-   float mrSize;
-   int fmt;
-   struct Img { uint8_t *data = nullptr; int w = 0, h = 0, ch = 0; int state = 0; };   // 0 pending, 1 decoded, 2 unreadable, 3 handed on
-   std::vector<Img> imgs;
-   std::mutex mu;
-   std::condition_variable cv_dec, cv_img, cv_task;
-   int next_decode = 0, consumed = 0, window = 0, pos = 0;
-   bool stop = false;
-   struct Task { int index; const hesaff_keypoint *keys; int n; int chunk; };
-   std::deque<Task> tasks;
-   struct Open { int left; int block; };
-   std::vector<Open> open_chunks;
-   int tasks_in_flight = 0;
-   std::vector<std::thread> decoders, writers;
-
-   FileIO(hesaff_ctx *ctx, int n_, const char *const *p, const char *const *o, hesaff_file_status *st, int dec_threads, int wr_threads)
-      : c(ctx), n(n_), paths(p), out_paths(o), status(st), mrSize(ctx->par.mrSize), fmt(ctx->out_format), imgs((size_t)n_)
-   {
-      window = 2 * c->par.max_batch + dec_threads;
-      try {
-         for (int t = 0; t < dec_threads; t++) decoders.emplace_back([this] { decode_loop(); });
-         for (int t = 0; t < wr_threads; t++) writers.emplace_back([this] { write_loop(); });
-      } catch (...) {
-         shutdown();
-         throw;
-      }
-   }
-   ~FileIO() override { shutdown(); }
-   void shutdown()
-   {
-      { std::lock_guard<std::mutex> lk(mu); stop = true; }
-      cv_dec.notify_all(); cv_img.notify_all(); cv_task.notify_all();
-      for (auto &t : decoders) if (t.joinable()) t.join();
-      for (auto &t : writers) if (t.joinable()) t.join();
-      for (Img &im : imgs) if (im.data) { hesaff_free(im.data); im.data = nullptr; }
-   }
-   void decode_loop()
-   {
-      for (;;) {
-         int i;
-         {
-            std::unique_lock<std::mutex> lk(mu);
-            cv_dec.wait(lk, [&] { return stop || next_decode >= n || next_decode < consumed + window; });
-            if (stop || next_decode >= n) return;
-            i = next_decode++;
-         }
-         Img im;
-         const int rc = paths[i] ? hesaff_read_image(paths[i], &im.data, &im.w, &im.h, &im.ch) : HESAFF_ERR_ARG;
-         {
-            std::lock_guard<std::mutex> lk(mu);
-            if (rc == HESAFF_OK) { im.state = 1; imgs[(size_t)i] = im; }
-            else { imgs[(size_t)i].state = 2; status[i].rc = rc; status[i].stage = HESAFF_FILE_UNREADABLE; }
-         }
-         cv_img.notify_all();
-      }
-   }
-   // the next run of consecutive readable images of one geometry
-   bool next(HostChunk &out) override
-   {
-      std::unique_lock<std::mutex> lk(mu);
-      for (;;) {
-         if (stop || pos >= n) break;
-         cv_img.wait(lk, [&] { return stop || imgs[(size_t)pos].state != 0; });
-         if (stop) break;
-         Img &im = imgs[(size_t)pos];
-         if (im.state == 2) { pos++; consumed = pos; cv_dec.notify_all(); continue; }
-         if (out.data.empty()) { out.W = im.w; out.H = im.h; out.ch = im.ch; }
-         else if (im.w != out.W || im.h != out.H || im.ch != out.ch) break;
-         out.data.push_back(im.data);
-         out.stride.push_back((size_t)im.w * im.ch);
-         out.index.push_back(pos);
-         im.state = 3;
-         pos++;
-         if ((int)out.data.size() >= c->par.max_batch) break;
-      }
-      return !out.data.empty();
-   }
-   void staged(const HostChunk &q) override
-   {
-      {
-         std::lock_guard<std::mutex> lk(mu);
-         for (int i : q.index) { hesaff_free(imgs[(size_t)i].data); imgs[(size_t)i].data = nullptr; }
-         consumed = std::max(consumed, q.index.back() + 1);
-      }
-      cv_dec.notify_all();
-   }
-   void done(const ChunkDone &d) override
-   {
-      const size_t B = d.chunk->index.size();
-      {
-         std::lock_guard<std::mutex> lk(mu);
-         const int id = (int)open_chunks.size();
-         open_chunks.push_back({(int)B, d.block});
-         for (size_t b = 0; b < B; b++) {
-            const int i = d.chunk->index[b];
-            status[i].count_hessian = d.count_hessian[b];
-            status[i].count_desc = d.count_desc[b];
-            status[i].stage = HESAFF_FILE_DETECTED;
-            tasks.push_back({i, d.keys + d.key_off[b], d.count_desc[b], id});
-            tasks_in_flight++;
-         }
-      }
-      cv_task.notify_all();
-   }
-   void write_loop()
-   {
-      for (;;) {
-         Task t;
-         {
-            std::unique_lock<std::mutex> lk(mu);
-            cv_task.wait(lk, [&] { return stop || !tasks.empty(); });
-            if (tasks.empty()) return;   // stop
-            t = tasks.front();
-            tasks.pop_front();
-         }
-         const char *o = out_paths ? out_paths[t.index] : nullptr;
-         int rc = HESAFF_OK;
-         if (fmt & HESAFF_OUT_TEXT) {
-            const std::string name = o ? std::string(o) : std::string(paths[t.index]) + ".hesaff.sift";   // hesaff.cpp:170-173
-            rc = hesaff_write_sift_mt(name.c_str(), t.keys, t.n, mrSize, 1);
-         }
-         if ((fmt & HESAFF_OUT_BIN) && rc == HESAFF_OK) {
-            const std::string name = o ? (std::string(o) + ((fmt & HESAFF_OUT_TEXT) ? ".bin" : "")) : std::string(paths[t.index]) + ".hesaff.bin";
-            rc = hesaff_write_bin(name.c_str(), t.keys, t.n, mrSize);
-         }
-         int blk = -1;
-         {
-            std::lock_guard<std::mutex> lk(mu);
-            status[t.index].rc = rc;
-            if (rc == HESAFF_OK) status[t.index].stage = HESAFF_FILE_WRITTEN;
-            if (--open_chunks[(size_t)t.chunk].left == 0) blk = open_chunks[(size_t)t.chunk].block;
-            tasks_in_flight--;
-         }
-         if (blk >= 0) release_block(c, blk);
-         cv_task.notify_all();
-      }
-   }
-   void wait_writers()
-   {
-      std::unique_lock<std::mutex> lk(mu);
-      cv_task.wait(lk, [&] { return tasks_in_flight == 0; });
-   }
-};
-
 } // namespace
 
 extern "C" {
@@ -659,7 +470,7 @@ int hesaff_process_files(hesaff_ctx *c, int n, const char *const *paths, const c
    const int host = hesaff_host_threads();
    const int dt = std::max(1, std::min(decode_threads > 0 ? decode_threads : std::max(2, host / 4), 64));
    const int wt = std::max(1, std::min(write_threads > 0 ? write_threads : host, 256));
-   FileIO io(c, n, paths, out_paths, status, dt, wt);
+   FileIO io(&c->ring, c->par.max_batch, c->par.mrSize, c->out_format, n, paths, out_paths, status, dt, wt);
    try {
       run_chunks(c, io, 3);
       io.wait_writers();

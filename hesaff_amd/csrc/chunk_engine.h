@@ -1,0 +1,225 @@
+// chunk_engine.h -- the host-only half of the chunk engine (capi_impl.h): the chunk types, the ring of pinned result blocks
+// and FileIO, the decoder / writer thread pools of hesaff_process_files.  Nothing here touches HIP, so that this code - every
+// mutex, condition variable and hand-over between threads of the file pipeline - also runs under ThreadSanitizer and
+// AddressSanitizer on a CPU with a mock device loop (tests/native/engine_sanitize.cpp, tests/test_host_sanitize.py).
+#pragma once
+#include <condition_variable>
+#include <cstdint>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/hesaff_amd.h"
+
+namespace hesaff_engine {
+
+// Pinned result blocks in rotation: a block is busy from the copy out of a chunk until its consumer gives it back.
+struct BlockRing {
+   std::mutex mu;
+   std::condition_variable cv;
+   std::vector<char> busy;
+   void reset(int n)
+   {
+      std::lock_guard<std::mutex> lk(mu);
+      busy.assign((size_t)(n > 0 ? n : 0), 0);
+   }
+   int acquire()   // waits for a free block
+   {
+      std::unique_lock<std::mutex> lk(mu);
+      int blk = -1;
+      cv.wait(lk, [&] {
+         for (size_t i = 0; i < busy.size(); i++)
+            if (!busy[i]) { blk = (int)i; return true; }
+         return false;
+      });
+      busy[(size_t)blk] = 1;
+      return blk;
+   }
+   void release(int block)
+   {
+      {
+         std::lock_guard<std::mutex> lk(mu);
+         if (block >= 0 && block < (int)busy.size()) busy[(size_t)block] = 0;
+      }
+      cv.notify_all();
+   }
+};
+
+struct HostChunk {                // at most max_batch images of one geometry
+   int W = 0, H = 0, ch = 1;
+   std::vector<const uint8_t *> data;
+   std::vector<size_t> stride;    // bytes between rows
+   std::vector<int> index;        // the caller's image numbers
+};
+
+struct ChunkDone {
+   const HostChunk *chunk;
+   const int32_t *count_hessian, *count_desc;   // per image of the chunk
+   const size_t *key_off;                       // first record of each image inside keys
+   const hesaff_keypoint *keys;                 // pinned host memory: valid until the block is released / the next call
+   int block;
+};
+
+struct ChunkIO {
+   virtual bool next(HostChunk &out) = 0;       // staging thread, one call at a time, in order; false: no more chunks
+   virtual void staged(const HostChunk &) {}    // staging thread: the chunk's pixels are in pinned memory, its sources may go
+   virtual void done(const ChunkDone &) = 0;    // caller's thread, in order
+   virtual ~ChunkIO() {}
+};
+
+// hesaff_process_files: decoder threads -> chunks -> device -> writer threads
+struct FileIO : ChunkIO {
+   BlockRing *ring;
+   int max_batch;
+   int n;
+   const char *const *paths, *const *out_paths;
+   hesaff_file_status *status;
+   float mrSize;
+   int fmt;
+   struct Img { uint8_t *data = nullptr; int w = 0, h = 0, ch = 0; int state = 0; };   // 0 pending, 1 decoded, 2 unreadable, 3 handed on
+   std::vector<Img> imgs;
+   std::mutex mu;
+   std::condition_variable cv_dec, cv_img, cv_task;
+   int next_decode = 0, consumed = 0, window = 0, pos = 0;
+   bool stop = false;
+   struct Task { int index; const hesaff_keypoint *keys; int n; int chunk; };
+   std::deque<Task> tasks;
+   struct Open { int left; int block; };
+   std::vector<Open> open_chunks;
+   int tasks_in_flight = 0;
+   std::vector<std::thread> decoders, writers;
+
+   FileIO(BlockRing *ring_, int max_batch_, float mrSize_, int fmt_, int n_, const char *const *p, const char *const *o, hesaff_file_status *st,
+          int dec_threads, int wr_threads)
+      : ring(ring_), max_batch(max_batch_), n(n_), paths(p), out_paths(o), status(st), mrSize(mrSize_), fmt(fmt_), imgs((size_t)n_)
+   {
+      window = 2 * max_batch + dec_threads;
+      try {
+         for (int t = 0; t < dec_threads; t++) decoders.emplace_back([this] { decode_loop(); });
+         for (int t = 0; t < wr_threads; t++) writers.emplace_back([this] { write_loop(); });
+      } catch (...) {
+         shutdown();
+         throw;
+      }
+   }
+   ~FileIO() override { shutdown(); }
+   void shutdown()
+   {
+      { std::lock_guard<std::mutex> lk(mu); stop = true; }
+      cv_dec.notify_all(); cv_img.notify_all(); cv_task.notify_all();
+      for (auto &t : decoders) if (t.joinable()) t.join();
+      for (auto &t : writers) if (t.joinable()) t.join();
+      for (Img &im : imgs) if (im.data) { hesaff_free(im.data); im.data = nullptr; }
+   }
+   void decode_loop()
+   {
+      for (;;) {
+         int i;
+         {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_dec.wait(lk, [&] { return stop || next_decode >= n || next_decode < consumed + window; });
+            if (stop || next_decode >= n) return;
+            i = next_decode++;
+         }
+         Img im;
+         const int rc = paths[i] ? hesaff_read_image(paths[i], &im.data, &im.w, &im.h, &im.ch) : HESAFF_ERR_ARG;
+         {
+            std::lock_guard<std::mutex> lk(mu);
+            if (rc == HESAFF_OK) { im.state = 1; imgs[(size_t)i] = im; }
+            else { imgs[(size_t)i].state = 2; status[i].rc = rc; status[i].stage = HESAFF_FILE_UNREADABLE; }
+         }
+         cv_img.notify_all();
+      }
+   }
+   // the next run of consecutive readable images of one geometry
+   bool next(HostChunk &out) override
+   {
+      std::unique_lock<std::mutex> lk(mu);
+      for (;;) {
+         if (stop || pos >= n) break;
+         cv_img.wait(lk, [&] { return stop || imgs[(size_t)pos].state != 0; });
+         if (stop) break;
+         Img &im = imgs[(size_t)pos];
+         if (im.state == 2) { pos++; consumed = pos; cv_dec.notify_all(); continue; }
+         if (out.data.empty()) { out.W = im.w; out.H = im.h; out.ch = im.ch; }
+         else if (im.w != out.W || im.h != out.H || im.ch != out.ch) break;
+         out.data.push_back(im.data);
+         out.stride.push_back((size_t)im.w * im.ch);
+         out.index.push_back(pos);
+         im.state = 3;
+         pos++;
+         if ((int)out.data.size() >= max_batch) break;
+      }
+      return !out.data.empty();
+   }
+   void staged(const HostChunk &q) override
+   {
+      {
+         std::lock_guard<std::mutex> lk(mu);
+         for (int i : q.index) { hesaff_free(imgs[(size_t)i].data); imgs[(size_t)i].data = nullptr; }
+         consumed = std::max(consumed, q.index.back() + 1);
+      }
+      cv_dec.notify_all();
+   }
+   void done(const ChunkDone &d) override
+   {
+      const size_t B = d.chunk->index.size();
+      {
+         std::lock_guard<std::mutex> lk(mu);
+         const int id = (int)open_chunks.size();
+         open_chunks.push_back({(int)B, d.block});
+         for (size_t b = 0; b < B; b++) {
+            const int i = d.chunk->index[b];
+            status[i].count_hessian = d.count_hessian[b];
+            status[i].count_desc = d.count_desc[b];
+            status[i].stage = HESAFF_FILE_DETECTED;
+            tasks.push_back({i, d.keys + d.key_off[b], d.count_desc[b], id});
+            tasks_in_flight++;
+         }
+      }
+      cv_task.notify_all();
+   }
+   void write_loop()
+   {
+      for (;;) {
+         Task t;
+         {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_task.wait(lk, [&] { return stop || !tasks.empty(); });
+            if (tasks.empty()) return;   // stop
+            t = tasks.front();
+            tasks.pop_front();
+         }
+         const char *o = out_paths ? out_paths[t.index] : nullptr;
+         int rc = HESAFF_OK;
+         if (fmt & HESAFF_OUT_TEXT) {
+            const std::string name = o ? std::string(o) : std::string(paths[t.index]) + ".hesaff.sift";   // hesaff.cpp:170-173
+            rc = hesaff_write_sift_mt(name.c_str(), t.keys, t.n, mrSize, 1);
+         }
+         if ((fmt & HESAFF_OUT_BIN) && rc == HESAFF_OK) {
+            const std::string name = o ? (std::string(o) + ((fmt & HESAFF_OUT_TEXT) ? ".bin" : "")) : std::string(paths[t.index]) + ".hesaff.bin";
+            rc = hesaff_write_bin(name.c_str(), t.keys, t.n, mrSize);
+         }
+         int blk = -1;
+         {
+            std::lock_guard<std::mutex> lk(mu);
+            status[t.index].rc = rc;
+            if (rc == HESAFF_OK) status[t.index].stage = HESAFF_FILE_WRITTEN;
+            if (--open_chunks[(size_t)t.chunk].left == 0) blk = open_chunks[(size_t)t.chunk].block;
+            tasks_in_flight--;
+         }
+         if (blk >= 0) ring->release(blk);
+         cv_task.notify_all();
+      }
+   }
+   void wait_writers()
+   {
+      std::unique_lock<std::mutex> lk(mu);
+      cv_task.wait(lk, [&] { return tasks_in_flight == 0; });
+   }
+};
+
+
+} // namespace hesaff_engine

@@ -33,6 +33,7 @@
 #include "kernels_sift.h"
 #include "kernels_pyramid.h"
 #include "fast_api.h"
+#include "chunk_engine.h"
 
 namespace hesaff {
 OctaveSchedule make_schedule(float initialSigma, bool upscale)
@@ -206,9 +207,7 @@ struct hesaff_ctx {
    };
    Pinned pin_in[2];
    std::vector<Pinned> pin_out;       // result blocks: one per chunk of the current call (hesaff_detect_batch), or a ring of three
-   std::mutex ring_mu;                // (hesaff_detect_batch_cb, hesaff_process_files: a block returns to the ring when its consumer
-   std::condition_variable ring_cv;   //  is done with it - release_block)
-   std::vector<char> ring_busy;
+   hesaff_engine::BlockRing ring;     // (hesaff_detect_batch_cb, hesaff_process_files: a block returns to the ring when its consumer is done with it)
    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_in_free[2] = {nullptr, nullptr}, ev_out_ready[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
    std::vector<int32_t> h_starts;

@@ -182,3 +182,50 @@ def test_text_writer_on_arbitrary_bit_patterns(driver):
     for seed, n in [(1, 1), (2, 333), (3, 20000)]:
         out = _run(driver, ["format", str(seed), str(n)])
         assert "same=1" in out
+
+
+ENGINE_SRC = [os.path.join(ROOT, "hesaff_amd", "csrc", "hostio.cpp"), os.path.join(ROOT, "hesaff_amd", "csrc", "jpeg_decode.cpp"),
+              os.path.join(ROOT, "tests", "native", "engine_sanitize.cpp")]
+
+
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_file_pipeline_threads_under_sanitizers(san, tmp_path):
+    """The host-only half of hesaff_process_files (hesaff_amd/csrc/chunk_engine.h: decoder threads, the bounded look-ahead window,
+    chunk formation, the ring of three result blocks, writer threads, per-file status) under ThreadSanitizer and under
+    AddressSanitizer + UBSan, with the device replaced by a mock loop of the same threading shape (tests/native/
+    engine_sanitize.cpp).  The GPU suite runs the same code for its results; this run is for its races and lifetimes."""
+    import numpy as np
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "engine_sanitize")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=" + san, "-fno-omit-frame-pointer", "-o", exe] + ENGINE_SRC + ["-lz", "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    rng = np.random.default_rng(3)
+    names = []
+    for i in range(45):
+        h, w = [(30, 40), (30, 40), (25, 31), (30, 40), (30, 40)][i % 5]      # runs of equal and unequal sizes
+        q = tmp_path / ("i%02d.pgm" % i)
+        q.write_bytes(b"P5\n%d %d\n255\n" % (w, h) + rng.integers(0, 256, (h, w), dtype=np.uint8).tobytes())
+        names.append(str(q))
+    bad = tmp_path / "bad.pgm"; bad.write_bytes(b"P5\n9 9\n255\nxx")
+    names.insert(7, str(bad)); names.append(str(bad))
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1")
+    for max_batch, dt, wt, fmt in ((1, 1, 1, 1), (4, 3, 3, 3), (64, 8, 2, 2), (3, 2, 8, 1)):
+        for n_ in names:
+            for ext in (".hesaff.sift", ".hesaff.bin"):
+                if os.path.exists(n_ + ext):
+                    os.remove(n_ + ext)
+        r = subprocess.run([exe, str(max_batch), str(dt), str(wt), str(fmt)] + names, capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, (max_batch, dt, wt, fmt, r.stdout[-500:], r.stderr[-4000:])
+        assert "files=47 written=45 unreadable=2 other=0" in r.stdout, r.stdout
+        rows = int(r.stdout.strip().rsplit("rows=", 1)[1])
+        got = 0
+        for n_ in names:
+            if n_ == str(bad):
+                continue
+            if fmt & 1:
+                got += int(open(n_ + ".hesaff.sift", "rb").read().split(b"\n", 2)[1])
+            if fmt & 2:
+                assert (os.path.getsize(n_ + ".hesaff.bin") - 16) % 148 == 0
+        assert (fmt & 1) == 0 or got == rows
