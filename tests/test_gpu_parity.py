@@ -866,6 +866,44 @@ def test_process_files_pipeline(tmp_path, oracle):
             assert tok[:5] == [b"%g" % float(rows[k][i]) for k in ("x", "y", "a", "b", "c")] and [int(v) for v in tok[5:]] == rows["desc"][i].tolist()
 
 
+def test_process_files_mixed_formats_against_the_oracle(tmp_path, oracle):
+    """One list with PGM, colour PPM, PNG, sequential and progressive JPEG files of several sizes through hesaff_process_files:
+    every output equals the oracle's text for the pixels the in-tree readers deliver (pixels == Pillow's, i.e. libjpeg / zlib)."""
+    import hesaff_amd
+    from PIL import Image
+    from tests import _oracle
+    rng = np.random.default_rng(17)
+    paths = []
+    for i, (h, w) in enumerate(((150, 200), (150, 200), (131, 177), (200, 260), (150, 200), (96, 128))):
+        g = band_noise_image(h, w, 300 + i, SMALL_BANDS)
+        rgb = np.stack([g, np.roll(g, 3, 1), np.roll(g, 5, 0)], 2)
+        kind = ("pgm", "ppm", "png", "jpg", "pjpg", "gpng")[i]
+        q = str(tmp_path / ("m%d.%s" % (i, {"pjpg": "jpg", "gpng": "png"}.get(kind, kind))))
+        if kind == "pgm":
+            open(q, "wb").write(b"P5\n%d %d\n255\n" % (w, h) + g.tobytes())
+        elif kind == "ppm":
+            open(q, "wb").write(b"P6\n%d %d\n255\n" % (w, h) + rgb.tobytes())
+        elif kind == "png":
+            Image.fromarray(rgb, "RGB").save(q, "PNG")
+        elif kind == "gpng":
+            Image.fromarray(g, "L").save(q, "PNG")
+        elif kind == "jpg":
+            Image.fromarray(rgb, "RGB").save(q, "JPEG", quality=88, subsampling=1)
+        else:
+            Image.fromarray(rgb, "RGB").save(q, "JPEG", quality=80, subsampling=2, progressive=True)
+        paths.append(q)
+    p = hesaff_amd.default_params(); p.max_batch = 3
+    with hesaff_amd.HesaffContext(p, device=0) as ctx:
+        st = ctx.process_files(paths, decode_threads=2, write_threads=2)
+    for q, (rc, stage, nh, nd) in zip(paths, st):
+        assert rc == 0 and stage == 3, (q, rc, stage)
+        pix = hesaff_amd.read_image(q)
+        ref = np.asarray(Image.open(q).convert("RGB" if pix.ndim == 3 else "L"))
+        assert np.array_equal(pix, ref), q
+        o = _oracle.OracleRun(_oracle.gray_from_u8(pix))
+        assert open(q + ".hesaff.sift", "rb").read() == o.export_text() and nd == o.n_keys and nh == o.n_hessian and nd > 50, q
+
+
 def test_sequence_with_homographies_through_cli_and_repeatability_tool(tmp_path, oracle):
     """BASELINE.json config 5 on its offline stand-in (the Oxford data are not available): a graf-like sequence - one 800x640
     colour image and copies under known homographies, stored as 4:2:0 JPEG files next to H1toNp files like the Oxford sets -
