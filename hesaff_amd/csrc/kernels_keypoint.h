@@ -81,6 +81,14 @@ __device__ inline bool hs_window_outside(int imRows, int imCols, float ofsx, flo
 }
 
 #define HS_AFF_NT 23    // ceil(361 / 16)
+// the parity kernel's own grouping (tuning: -DHS_AFFP_G=2 gives each keypoint 32 lanes: half the LDS per wavefront, twice the
+// wavefronts per CU, but the serial sums and the double-precision tail then serve two keypoints instead of four)
+#ifndef HS_AFFP_G
+#define HS_AFFP_G 4
+#endif
+#define HS_AFFP_L (64 / HS_AFFP_G)
+#define HS_AFFP_SH (HS_AFFP_G == 4 ? 4 : (HS_AFFP_G == 2 ? 5 : 6))
+#define HS_AFFP_NT ((HS_SMM_PIX + HS_AFFP_L - 1) / HS_AFFP_L)
 #ifndef HS_AFF_XCD
 #define HS_AFF_XCD 1
 #endif
@@ -95,25 +103,25 @@ template <class Fetch>
 __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, const float *__restrict__ mask_g, const DConsts &k, AffineOut out,
                                                  Fetch fetch)
 {
-   __shared__ __attribute__((aligned(16))) float s_arr[HS_AFF_G][3][HS_AFF_ARR];   // img, then a terms | b terms | c terms
+   __shared__ __attribute__((aligned(16))) float s_arr[HS_AFFP_G][3][HS_AFF_ARR];   // img, then a terms | b terms | c terms
    __shared__ float s_mask[HS_AFF_ARR];
-   __shared__ float s_bc[HS_AFF_G][8];
-   const int lane = threadIdx.x, grp = lane >> 4, li = lane & 15;
+   __shared__ float s_bc[HS_AFFP_G][8];
+   const int lane = threadIdx.x, grp = lane >> HS_AFFP_SH, li = lane & (HS_AFFP_L - 1);
    for (int i = lane; i < HS_SMM_PIX; i += 64) s_mask[i] = mask_g[i];
    float *s_img = s_arr[grp][0], *s_pa = s_arr[grp][0], *s_pb = s_arr[grp][1], *s_pc = s_arr[grp][2];   // the a terms replace the image
    // XCD-aware order: block b runs on XCD b % 8 (observed dispatch order, a speed assumption only).  The keypoints are
    // ordered by image, octave, level and raster position, so neighbours in the list sample the same cache lines of the
    // same plane: each XCD takes one contiguous eighth of the list, its blocks stride inside that eighth, and those lines
    // are fetched into ONE private L2 instead of eight.  (Grids that are not a multiple of 8 blocks keep the plain stride.)
-   uint32_t hstep = gridDim.x * HS_AFF_G, h_end = n;
-   uint32_t h = first + blockIdx.x * HS_AFF_G + grp;
+   uint32_t hstep = gridDim.x * HS_AFFP_G, h_end = n;
+   uint32_t h = first + blockIdx.x * HS_AFFP_G + grp;
    if (HS_AFF_XCD && (gridDim.x & 7u) == 0u && n > first) {
-      const uint32_t n_items = (n - first + HS_AFF_G - 1) / HS_AFF_G;   // groups of HS_AFF_G keypoints
+      const uint32_t n_items = (n - first + HS_AFFP_G - 1) / HS_AFFP_G;   // groups of HS_AFFP_G keypoints
       const uint32_t xcd = blockIdx.x & 7u, rank = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
       const uint32_t it_lo = (uint32_t)(((unsigned long long)n_items * xcd) >> 3), it_hi = (uint32_t)(((unsigned long long)n_items * (xcd + 1)) >> 3);
-      hstep = per_xcd * HS_AFF_G;
-      h_end = min(first + it_hi * HS_AFF_G, n);
-      h = first + (it_lo + rank) * HS_AFF_G + grp;
+      hstep = per_xcd * HS_AFFP_G;
+      h_end = min(first + it_hi * HS_AFFP_G, n);
+      h = first + (it_lo + rank) * HS_AFFP_G + grp;
    }
 #define HS_AFF_END h_end
    if (k.maxIterations <= 0) {   // no iteration: U = identity, not converged
@@ -161,11 +169,11 @@ __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, con
          const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
 #pragma unroll
          for (int half = 0; half < HS_AFF_BATCHES; half++) {
-            constexpr int NB = (HS_AFF_NT + HS_AFF_BATCHES - 1) / HS_AFF_BATCHES;
+            constexpr int NB = (HS_AFFP_NT + HS_AFF_BATCHES - 1) / HS_AFF_BATCHES;
             float sv[NB];
 #pragma unroll
             for (int t = 0; t < NB; t++) {
-               const int idx = min(li + 16 * (half * NB + t), HS_SMM_PIX - 1);
+               const int idx = min(li + HS_AFFP_L * (half * NB + t), HS_SMM_PIX - 1);
                const int jj = idx / HS_SMM, ii = idx - jj * HS_SMM;
                const int j = jj - (HS_SMM >> 1), i = ii - (HS_SMM >> 1);
                const float rx = lx + (float)j * a12;
@@ -183,7 +191,7 @@ __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, con
             for (int t = 0; t < NB; t++) HS_KEEP(sv[t]);
 #pragma unroll
             for (int t = 0; t < NB; t++) {
-               const int idx = li + 16 * (half * NB + t);
+               const int idx = li + HS_AFFP_L * (half * NB + t);
                if (idx < HS_SMM_PIX) s_img[idx] = sv[t];
             }
          }
@@ -196,10 +204,10 @@ __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, con
       if (active) {
          // computeGradient affine.cpp:14-33 + products affine.cpp:62-68.  The a terms take the place of
          // the sampled image in LDS, so they wait in registers until every lane has read its neighbours.
-         float pa[HS_AFF_NT];
+         float pa[HS_AFFP_NT];
 #pragma unroll
-         for (int t = 0; t < HS_AFF_NT; t++) {
-            const int idx = min(li + 16 * t, HS_SMM_PIX - 1);
+         for (int t = 0; t < HS_AFFP_NT; t++) {
+            const int idx = min(li + HS_AFFP_L * t, HS_SMM_PIX - 1);
             const int r = idx / HS_SMM, c = idx - r * HS_SMM;
             // hs_grad with clamped neighbour indices (one-sided differences at the tile border)
             const float gxx = s_img[idx + (c < HS_SMM - 1 ? 1 : 0)] - s_img[idx - (c > 0 ? 1 : 0)];
@@ -207,15 +215,15 @@ __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, con
             const float v = s_mask[idx];
             const float gxy = gxx * gyy;
             pa[t] = gxx * gxx * v;
-            if (li + 16 * t < HS_SMM_PIX) {
+            if (li + HS_AFFP_L * t < HS_SMM_PIX) {
                s_pb[idx] = gxy * v;
                s_pc[idx] = gyy * gyy * v;
             }
          }
          HS_WAVE_LDS_SYNC();
 #pragma unroll
-         for (int t = 0; t < HS_AFF_NT; t++) {
-            const int idx = li + 16 * t;
+         for (int t = 0; t < HS_AFFP_NT; t++) {
+            const int idx = li + HS_AFFP_L * t;
             if (idx < HS_SMM_PIX) s_pa[idx] = pa[t];
          }
       }

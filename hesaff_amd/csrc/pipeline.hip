@@ -1006,7 +1006,7 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       if (as != st) HIP_TRY(hipStreamWaitEvent(as, c->ev_detect_done, 0));
       auto launch_affine = [&](size_t gi) {
          const int ta = tm.begin(T_AFF, 0, as);
-         const uint32_t agrid = std::min<uint32_t>((groups[gi].hi - groups[gi].lo + 3) / 4, (uint32_t)c->n_cu * c->aff_blocks_per_cu);
+         const uint32_t agrid = std::min<uint32_t>((groups[gi].hi - groups[gi].lo + HS_AFFP_G - 1) / HS_AFFP_G, (uint32_t)c->n_cu * c->aff_blocks_per_cu);
          if (c->fast) hsfast_affine(as, std::min<uint32_t>((groups[gi].hi - groups[gi].lo + 3) / 4, (uint32_t)c->n_cu * 12u), fast_args(c, s, nullptr, &pt, nullptr), groups[gi].lo, groups[gi].hi, (const uint32_t *)(cnt + 3));
          else hipLaunchKernelGGL(k_affine, dim3(agrid), dim3(64), 0, as, pt, s.hl, groups[gi].lo, groups[gi].hi, (const uint32_t *)(cnt + 3), c->tables, c->consts, s.ao);
          tm.end(ta);
