@@ -340,8 +340,3 @@ HM_HD float hm_sift_orient_coord(float ori)
    return (float)q2;
 }
 
-#if HS_FAST && defined(__HIPCC__)
-// fast mode: the device math library's atan2f (about 1 ulp, no interval tables) and the orientation coordinate in float
-__device__ __forceinline__ float hm_fast_atan2f(float y, float x) { return atan2f(y, x); }
-__device__ __forceinline__ float hm_fast_orient_coord(float ori) { return 8.0f * (ori + 6.2831855f) * 0.15915494f; }
-#endif

@@ -124,21 +124,12 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
    int2 omq[HS_SIFT_MSK_IT];
 #pragma unroll
    for (int q = 0; q < HS_SIFT_MSK_IT; q++) { nbq[q] = tb.sgrad_nb[tid + 256 * q]; omq[q] = tb.sgrad_om[tid + 256 * q]; }
-#if HS_FAST
-   int m_i[HS_SIFT_MSK_IT];
-#pragma unroll
-   for (int q = 0; q < HS_SIFT_MSK_IT; q++) m_i[q] = tb.mask_idx[min(tid + 256 * q, nm - 1)];
-#endif
    uint32_t k = blockIdx.x;
    if (k >= n) return;
    // first keypoint's operands
    float pv[HS_PATCH_PIX_IT];
    int alive = io.alive[io.h_lo + k];
-#if HS_FAST
-   float mean = 0.0f, var = 0.0f;
-#else
    float mean = io.meanvar[2 * (size_t)k], var = io.meanvar[2 * (size_t)k + 1];
-#endif
    {
       const float *gp = io.patches + (size_t)k * HS_PATCH_PIX;
 #pragma unroll
@@ -146,32 +137,6 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
    }
    for (; k < n; k += gridDim.x) {
       const bool cur_alive = alive != 0;
-#if HS_FAST
-      // fast mode: photometric mean / variance by a block reduction right here (no k_sift_meanvar pass, the patch is read
-      // once); sums are re-associated, NOT bit-exact
-      {
-         __shared__ float s_red[8];
-#pragma unroll
-         for (int q = 0; q < HS_PATCH_PIX_IT; q++) { const int i = tid + 256 * q; if (i < HS_PATCH_PIX) s_p[i] = pv[q]; }
-         __syncthreads();
-         float ps = 0.0f;
-#pragma unroll
-         for (int q = 0; q < HS_SIFT_MSK_IT; q++) if (tid + 256 * q < nm) ps += s_p[m_i[q]];
-#pragma unroll
-         for (int d = 32; d >= 1; d >>= 1) ps += __shfl_xor(ps, d, 64);
-         if ((tid & 63) == 0) s_red[tid >> 6] = ps;
-         __syncthreads();
-         mean = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (float)nm;
-         float pq = 0.0f;
-#pragma unroll
-         for (int q = 0; q < HS_SIFT_MSK_IT; q++) if (tid + 256 * q < nm) { const float dd = mean - s_p[m_i[q]]; pq += dd * dd; }
-#pragma unroll
-         for (int d = 32; d >= 1; d >>= 1) pq += __shfl_xor(pq, d, 64);
-         if ((tid & 63) == 0) s_red[4 + (tid >> 6)] = pq;
-         __syncthreads();
-         var = sqrtf((s_red[4] + s_red[5] + s_red[6] + s_red[7]) / (float)nm);
-      }
-#endif
       // normalise this keypoint's pixels into LDS (helpers.cpp:269-280: ALL pixels, not only the masked ones)
       const bool cur_norm = !((double)var < 0.0001);   // helpers.cpp:270
       if (cur_alive) {
@@ -191,9 +156,7 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
       const uint32_t kn = k + gridDim.x;
       if (kn < n) {
          alive = io.alive[io.h_lo + kn];
-#if !HS_FAST
          mean = io.meanvar[2 * (size_t)kn]; var = io.meanvar[2 * (size_t)kn + 1];
-#endif
          const float *gp = io.patches + (size_t)kn * HS_PATCH_PIX;
 #pragma unroll
          for (int q = 0; q < HS_PATCH_PIX_IT; q++) pv[q] = HS_NT_SGRAD_LD ? hs_load_nt(gp + min(tid + 256 * q, HS_PATCH_PIX - 1)) : gp[min(tid + 256 * q, HS_PATCH_PIX - 1)];
@@ -214,14 +177,9 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
                   const char *sp = reinterpret_cast<const char *>(s_p);
                   const float gx = *reinterpret_cast<const float *>(sp + nbq[q].y) - *reinterpret_cast<const float *>(sp + nbq[q].x);
                   const float gy = *reinterpret_cast<const float *>(sp + nbq[q].w) - *reinterpret_cast<const float *>(sp + nbq[q].z);
-#if HS_FAST
-                  const float grad = sqrtf(gx * gx + gy * gy);
-                  const float o = hm_fast_orient_coord(hm_fast_atan2f(gy, gx));
-#else
                   const float grad = ND ? hm_sqrt_normal(gx * gx + gy * gy) : sqrtf(gx * gx + gy * gy);
                   const float ori = ND ? hm_atan2f_tab_nd(gy, gx, s_at) : hm_atan2f_tab(gy, gx, s_at);
                   const float o = hm_sift_orient_coord(ori);
-#endif
 #if HS_SGRAD_TILE
                   s_vo[omq[q].x] = make_float2(__int_as_float(omq[q].y) * grad, o);
 #elif HS_NT_VO
@@ -235,12 +193,8 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
                __builtin_amdgcn_sched_barrier(0);
             }
          };
-#if HS_FAST
-         pixels(std::false_type{});
-#else
          if (cur_norm) pixels(std::true_type{});
          else pixels(std::false_type{});
-#endif
       }
 #if HS_SGRAD_TILE
       __syncthreads();

@@ -119,9 +119,12 @@ def main():
         "desc_delta_le_1_pct_of_matched": 100.0 * tot.get("rows_with_delta_le_1", 0) / m,
         "desc_delta_le_4_pct_of_matched": 100.0 * tot.get("rows_with_delta_le_4", 0) / m,
         "totals": tot,
-        "what_differs": "fast mode: contracted multiply-adds and approximate division / sqrt in the affine, patch and descriptor kernels, "
-                        "shuffle-tree sums for the second-moment matrix and the photometric mean / variance, device-library atan2f, "
-                        "float orientation coordinate; pyramid, extrema, localisation, ordering and the window geometry are the parity kernels",
+        "what_differs": "fast = 1: contracted multiply-adds and approximate division / sqrt in the affine, patch and descriptor kernels, "
+                        "shuffle-tree sums for the second-moment matrix, the whole descriptor in one on-chip kernel (block reductions for "
+                        "the photometric mean / variance and the norms, polynomial atan2, float orientation coordinate, histogram terms "
+                        "added per thread and combined); pyramid, extrema, localisation, ordering and the window geometry are the parity "
+                        "kernels.  fast = 2: in addition the windows larger than the 41 x 41 patch are sampled from the scale-space level "
+                        "with the matching blur instead of being warped and blurred (another algorithm for those keypoints)",
     }
     print(json.dumps(report))
     if a.out:
