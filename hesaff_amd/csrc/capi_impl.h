@@ -145,6 +145,7 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
          c->g_small0 *= m; c->g_small1 *= m; c->g_shist *= m;
       }
       if (const char *s2 = getenv("HESAFF_SIFT2")) c->sift2 = atoi(s2) != 0;
+      if (const char *tp = getenv("HESAFF_TAPER")) c->taper_groups = atoi(tp) != 0;
 #endif
    } catch (const HsError &e) {
       hesaff_destroy(c);

@@ -236,6 +236,7 @@ struct hesaff_ctx {
    // schedule knobs: fixed in the product build, environment-driven only under -DHESAFF_TUNING
    bool no_overlap = false;        // HESAFF_OVERLAP=0: every kernel alone on the device (per-kernel profiling)
    uint32_t sift_group_kpts = 0;   // HESAFF_GROUP: keypoints per image group; 0 = by batch
+   bool taper_groups = false;      // HESAFF_TAPER: small groups at both ends of a batch (pipeline fill / drain)
    int aff_blocks_per_cu = 8;      // HESAFF_AFF_BLOCKS: persistent k_affine blocks per CU (19 KB of LDS each: 8 resident).  Alone on the device
                                    // 64 / 128 blocks per CU are 4 % faster (20.7 / 20.6 vs 21.6 ms), beside the other stages' kernels they
                                    // make the step 3.5 % slower (453 vs 438 ms at B = 128): the queued blocks take every slot that frees up
@@ -983,7 +984,14 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       for (int g0 = 0; g0 < B;) {
          int g1 = g0 + 1;
          unsigned long long rows = lrows[g0];
-         while (g1 < B && (uint32_t)(hs[g1 + 1] - hs[g0]) <= group_kpts && rows + lrows[g1] <= c->trows_rows) { rows += lrows[g1]; g1++; }
+         // tapered schedule: the first groups grow (1/8, 1/8, 1/4, 1/2 of the limit) and the last ones shrink the same way, so that
+         // the pipeline's fill (affine shape of the first group alone on the device) and drain (descriptors of the last) are short
+         uint32_t limit = group_kpts;
+         if (c->taper_groups) {
+            const uint32_t done = (uint32_t)hs[g0], left = (uint32_t)hs[B] - done;
+            limit = std::min(group_kpts, std::max(group_kpts / 8u, std::min(done, left / 2u)));
+         }
+         while (g1 < B && (uint32_t)(hs[g1 + 1] - hs[g0]) <= limit && rows + lrows[g1] <= c->trows_rows) { rows += lrows[g1]; g1++; }
          if (rows > 0xffffffffull) throw HsError(HESAFF_ERR_NOMEM, "window rows of one image exceed 32 bits");
          if (hs[g1] > hs[g0]) {
             groups.push_back({(uint32_t)hs[g0], (uint32_t)hs[g1], (uint32_t)rows});
