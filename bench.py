@@ -121,6 +121,24 @@ def hbm_probe(torch, dev):
     return out
 
 
+def fast_leg(hesaff_amd, torch, imgs, device, B, H, W, level, steps):
+    """The same device-resident step with hesaff_params.fast = level (NOT bit-exact)."""
+    p = hesaff_amd.default_params()
+    p.max_batch = B
+    p.fast = level
+    with hesaff_amd.HesaffContext(p, device=device) as ctx:
+        ctx.detect_batch_device(imgs.data_ptr(), B, W, H)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nd = 0
+        for _ in range(steps):
+            _, cd, _, _ = ctx.detect_batch_device(imgs.data_ptr(), B, W, H)
+            nd += int(cd.sum())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"value": nd / dt, "unit": "keypoints/s", "images_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps}
+
+
 def density_leg(hesaff_amd, torch, dev, device, B, H, W, seed, steps):
     """The same step on photograph-like images (about 2.5 k descriptors per Mpx instead of 14 k): device-resident, like `value`."""
     from hesaff_amd.synth import BANDS_NATURAL, band_noise_batch_torch
@@ -225,6 +243,7 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=2, help="images of the batch timed on the CPU oracle, 1 thread (about 14 s each)")
     ap.add_argument("--cpu-workers", type=int, default=-1,
                     help="worker processes of the multi-core CPU baseline, one image each (-1: one per physical core, at most the batch; 0: skip)")
+    ap.add_argument("--fast-steps", type=int, default=2, help="steps of the two fast-mode legs of the default run (0: skip)")
     ap.add_argument("--natural-steps", type=int, default=2, help="steps of the extra photograph-like-density leg of the default run (0: skip)")
     ap.add_argument("--e2e-images", type=int, default=384, help="image files of the measured end-to-end file path (0: skip; fewer when the RAM disk is small)")
     ap.add_argument("--e2e-chunk", type=int, default=32, help="images per device chunk of the end-to-end leg (hesaff_params.max_batch)")
@@ -341,6 +360,13 @@ def main():
     tot_hess, tot_desc, tot_imgs = [int(v) for v in counts.sum(axis=0)]
     per_rank_images = [int(v) for v in counts[:, 2]]
     ctx.close()
+    fast_modes = None
+    if rank == 0 and args.fast_steps > 0 and not args.no_host_path:
+        fast_modes = {"what": "the same device-resident step with hesaff_params.fast = 1 (same algorithm, free summation order, fused on-chip "
+                              "descriptor) and = 2 (+ windows larger than the patch sampled from the scale space); NOT bit-exact, not the headline "
+                              "value; mismatch rates in profiles/r03_fast_mode*.json",
+                      "fast_1": fast_leg(hesaff_amd, torch, imgs, local_rank, B, H, W, 1, args.fast_steps),
+                      "fast_2": fast_leg(hesaff_amd, torch, imgs, local_rank, B, H, W, 2, args.fast_steps)}
     probe = hbm_probe(torch, dev) if rank == 0 else None
     natural = None
     if rank == 0 and args.natural_steps > 0 and args.density == "dense" and not args.no_host_path:
@@ -421,6 +447,9 @@ def main():
         st = {k: v / args.steps for k, v in stage.items()}
         pyr_bytes_step = tot["pyr_bytes"] / args.steps
         ex_achieved = (bh["ex_bytes"] / 1e9) / (bh["ex_ms"] / 1e3) if bh["ex_ms"] > 0 else 0.0
+        if fast_modes:
+            for k in ("fast_1", "fast_2"):
+                fast_modes[k]["speed_up_over_parity_rank0"] = (dt / args.steps * 1e3) / fast_modes[k]["ms_per_step"] if per_rank == B else None
         out = {
             "metric": "keypoints/sec (descriptors written), 4K grayscale batch",
             "value": tot_desc / dt,
@@ -448,6 +477,7 @@ def main():
             "text_export": text_export,
             "end_to_end": end_to_end,
             "natural_density": natural,
+            "fast_modes": fast_modes,
             "hbm_probe": probe,
             "roofline_detect": {"bound": "hbm", "kernel": "k_extrema_march (the three 3x3x3 extrema scans of an octave in one launch; SURVEY.md 8d: "
                                                           "B_ext = 20 bytes per pixel and octave, five response planes read once)",
