@@ -383,7 +383,7 @@ def main():
         host_imgs = list(imgs.cpu().numpy())           # B pageable host images; the library stages them through pinned memory
         del imgs
         torch.cuda.empty_cache()
-        hctx.detect_batch(host_imgs[: 2 * hp.max_batch])   # warm-up: buffers of both pipeline slots
+        hctx.detect_batch_raw(host_imgs)                   # warm-up: device buffers of both pipeline slots and one pinned result block per chunk
         hsteps = max(1, min(args.steps, 2))
         barrier()
         t1 = time.perf_counter()

@@ -290,11 +290,28 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
       HIP_TRY(hipEventSynchronize(c->ev_in_free[slot]));   // chunk k-2 no longer reads this input buffer (never recorded: returns at once)
       c->pin_in[slot].ensure(total);
       c->b_in2[slot].ensure(total);
-      for (size_t b = 0; b < q.data.size(); b++) {
-         const size_t stride = q.stride[b];
-         uint8_t *dst = (uint8_t *)c->pin_in[slot].p + img_bytes * b;
-         if (stride == row_bytes) memcpy(dst, q.data[b], img_bytes);
-         else for (int y = 0; y < q.H; y++) memcpy(dst + row_bytes * y, q.data[b] + stride * y, row_bytes);
+      // pixels into the pinned buffer: a chunk of 64 UHD images is 0.5 GB - on four threads when it is worth it (the first chunk's
+      // copy is the pipeline's fill: nothing runs on the device meanwhile)
+      auto copy_images = [&](size_t b0, size_t b1) {
+         for (size_t b = b0; b < b1; b++) {
+            const size_t stride = q.stride[b];
+            uint8_t *dst = (uint8_t *)c->pin_in[slot].p + img_bytes * b;
+            if (stride == row_bytes) memcpy(dst, q.data[b], img_bytes);
+            else for (int y = 0; y < q.H; y++) memcpy(dst + row_bytes * y, q.data[b] + stride * y, row_bytes);
+         }
+      };
+      const size_t nimg = q.data.size();
+      const size_t nthr = (total >= ((size_t)32 << 20) && nimg >= 4) ? 4 : 1;
+      {
+         std::vector<std::thread> th;
+         size_t t = 1;
+         try {
+            for (; t < nthr; t++) th.emplace_back(copy_images, nimg * t / nthr, nimg * (t + 1) / nthr);
+         } catch (...) {   // a thread that cannot be started: its share (and the rest) is copied right here
+         }
+         copy_images(0, nimg / nthr);
+         if (t < nthr) copy_images(nimg * t / nthr, nimg);
+         for (auto &x : th) x.join();
       }
       HIP_TRY(hipMemcpyAsync(c->b_in2[slot].p, c->pin_in[slot].p, total, hipMemcpyHostToDevice, c->h2d_stream));
       HIP_TRY(hipEventRecord(c->ev_h2d[slot], c->h2d_stream));
