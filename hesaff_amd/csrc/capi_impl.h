@@ -409,16 +409,30 @@ struct ArrayIO : ChunkIO {
                grp.push_back(j);
                done[(size_t)j] = 1;
             }
-         for (size_t g0 = 0; g0 < grp.size(); g0 += (size_t)c->par.max_batch) {
+         // chunk sizes: max_batch, except that a long run starts and ends with smaller chunks (1/4, 1/2 of it): the first chunk's
+         // copy in and the last chunk's copy out are the pipeline's fill and drain - nothing overlaps them
+         const size_t mb = (size_t)c->par.max_batch, N = grp.size();
+         std::vector<size_t> sizes;
+         if (N >= 4 * mb && mb >= 8) {
+            sizes.push_back(mb / 4); sizes.push_back(mb / 2);
+            size_t left = N - mb / 4 - mb / 2 - (mb / 2 + mb / 4);
+            while (left > 0) { const size_t t = std::min(mb, left); sizes.push_back(t); left -= t; }
+            sizes.push_back(mb / 2); sizes.push_back(mb / 4);
+         } else {
+            for (size_t left = N; left > 0;) { const size_t t = std::min(mb, left); sizes.push_back(t); left -= t; }
+         }
+         size_t g0 = 0;
+         for (size_t sz : sizes) {
             HostChunk k;
             k.W = W; k.H = H; k.ch = ch;
-            for (size_t g = g0; g < std::min(grp.size(), g0 + (size_t)c->par.max_batch); g++) {
+            for (size_t g = g0; g < g0 + sz; g++) {
                const int j = grp[g];
                k.index.push_back(j);
                k.data.push_back(images[j]);
                k.stride.push_back(strides ? (size_t)strides[j] : (size_t)W * ch);
             }
             chunks.push_back(std::move(k));
+            g0 += sz;
          }
       }
    }
