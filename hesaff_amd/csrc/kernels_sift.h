@@ -4,8 +4,9 @@
 //
 //  k_sift_meanvar   the photometric mean / variance are long SEQUENTIAL float sums
 //                   (helpers.cpp:253-266, 1245 terms each).  One THREAD per keypoint runs the
-//                   chain, 64 keypoints per wavefront at full lane efficiency; the patch columns
-//                   are transposed through LDS so that global loads stay coalesced.
+//                   chain, 16 keypoints per wavefront (a quarter of the lanes add: the kernel is bound by its
+//                   two reads of every patch, and the smaller working set lets the memory-side cache serve the second);
+//                   the patch columns are transposed through LDS so that global loads stay coalesced.
 //  k_sift_grad      one block per keypoint, one THREAD per pixel: normalise (once, through LDS),
 //                   gradient, hm_atan2f_tab -> (mask*grad, o) pairs of the 40x40 weighted pixels, collected in
 //                   an LDS tile and written as whole cache lines (the kernel is bound by this stream as much as
@@ -34,45 +35,63 @@ struct SiftIO {
 #define HS_VO_PITCH (HS_VO_DIM * HS_VO_DIM)   // float2 per keypoint in the gradient-pair buffer (rows 16-byte aligned)
 #define HS_SIFT_MSK_IT 5   // ceil(1245 / 256): pixels inside the circular mask per thread of a 256-thread block
 #define SM_TILE 64
-#define SM_STRIDE 65   // LDS row stride: lane k walking row k is conflict-free
 
-// grid: ceil(n / 64) blocks of 64 threads
+// grid: ceil(n / SM_KP) blocks of 64 threads.
+// SM_KP = keypoints per wavefront.  64 (every lane owns a keypoint) is the form with the fewest instructions, but a wavefront
+// then re-reads its 64 patches (430 KB) in the second pass long after the first, and the kernel is bound by HBM (VALU 9 % busy).
+// With 16 keypoints per wavefront (lanes 0..15 add; tiles of 16 keypoints x 256 masked pixels, the same 64 loads in flight) the
+// patches that a CU's resident wavefronts hold between their two passes shrink to about 0.75 MB - 190 MB over the device, inside
+// its 256 MB memory-side cache, which then serves most of the second pass.  Measured per 256 UHD images, kernel alone:
+// SM_KP = 64 / 32 / 16 / 8: 111.5 / 100.8 / 89.0 / 254.9 ms (8: the additions become the bottleneck); step 868 / 862 / 854 / 954 ms.
+#ifndef SM_KP
+#define SM_KP 16
+#endif
+#define SM_PX (64 * 64 / SM_KP)      // masked pixels per tile step
+#define SM_ROW (SM_PX + 1)           // LDS row stride: lane k walking row k is conflict-free
 __global__ __launch_bounds__(64) void k_sift_meanvar(SiftIO io, KpTables tb)
 {
-   __shared__ float s_tile[SM_TILE * SM_STRIDE];
+   __shared__ float s_tile[SM_KP * SM_ROW];
    const int lane = threadIdx.x;
    const uint32_t n = io.h_hi - io.h_lo;
-   const uint32_t k0 = blockIdx.x * SM_TILE;           // first keypoint (relative) of this block
+   const uint32_t k0 = blockIdx.x * SM_KP;           // first keypoint (relative) of this block
    const int nm = tb.n_masked;
    const float gsum = (float)nm;
-   const uint32_t kmine = min(k0 + lane, n - 1);
+   const uint32_t kmine = min(k0 + (uint32_t)min(lane, SM_KP - 1), n - 1);
    // pass 0: sum ; pass 1: sum of squared deviations
    float sum = 0.0f, mean = 0.0f;
    for (int pass = 0; pass < 2; pass++) {
       float acc = 0.0f;
-      for (int c0 = 0; c0 < nm; c0 += SM_TILE) {
-         const int cnt = min(SM_TILE, nm - c0);
-         // stage: row k = keypoint k0+k, column l = masked pixel c0+l ; coalesced along l
-         const int pix = (lane < cnt) ? tb.mask_idx[c0 + lane] : 0;
+      for (int c0 = 0; c0 < nm; c0 += SM_PX) {
+         const int cnt = min(SM_PX, nm - c0);
+         // stage: row k = keypoint k0+k, column l = masked pixel c0+l ; coalesced along l (64 lanes x SM_PX / 64 columns each)
+         int pix[SM_PX / 64];
+#pragma unroll
+         for (int u = 0; u < SM_PX / 64; u++) pix[u] = (lane + 64 * u < cnt) ? tb.mask_idx[c0 + lane + 64 * u] : 0;
 #pragma unroll 8
-         for (int k = 0; k < SM_TILE; k++) {
+         for (int k = 0; k < SM_KP; k++) {
             const uint32_t kp = min(k0 + k, n - 1);
-            const float *pp = io.patches + (size_t)kp * HS_PATCH_PIX + pix;
-            s_tile[k * SM_STRIDE + lane] = (HS_NT_MEANVAR == 2 || (HS_NT_MEANVAR == 1 && pass == 1)) ? hs_load_nt(pp) : *pp;
+            const float *pp = io.patches + (size_t)kp * HS_PATCH_PIX;
+#pragma unroll
+            for (int u = 0; u < SM_PX / 64; u++) {
+               const float *q = pp + pix[u];
+               s_tile[k * SM_ROW + lane + 64 * u] = (HS_NT_MEANVAR == 2 || (HS_NT_MEANVAR == 1 && pass == 1)) ? hs_load_nt(q) : *q;
+            }
          }
          __syncthreads();
-         const float *row = s_tile + lane * SM_STRIDE;
-         if (pass == 0) {
-            for (int l = 0; l < cnt; l++) acc += row[l];                                   // helpers.cpp:257
-         } else {
-            for (int l = 0; l < cnt; l++) { const float d = mean - row[l]; acc += d * d; }   // helpers.cpp:266
+         if (lane < SM_KP) {
+            const float *row = s_tile + lane * SM_ROW;
+            if (pass == 0) {
+               for (int l = 0; l < cnt; l++) acc += row[l];                                   // helpers.cpp:257
+            } else {
+               for (int l = 0; l < cnt; l++) { const float d = mean - row[l]; acc += d * d; }   // helpers.cpp:266
+            }
          }
          __syncthreads();
       }
       if (pass == 0) { sum = acc; mean = sum / gsum; }
       else {
          const float var = sqrtf(acc / gsum);   // helpers.cpp:268
-         if (k0 + lane < n) { io.meanvar[2 * (size_t)kmine] = mean; io.meanvar[2 * (size_t)kmine + 1] = var; }
+         if (lane < SM_KP && k0 + lane < n) { io.meanvar[2 * (size_t)kmine] = mean; io.meanvar[2 * (size_t)kmine + 1] = var; }
       }
    }
 }

@@ -924,7 +924,7 @@ void launch_sift(hesaff_ctx *c, hipStream_t ss, const SiftIO &so, uint32_t n, fl
       return;
    }
    const uint32_t nb64 = (n + 63) / 64;
-   hipLaunchKernelGGL(k_sift_meanvar, dim3(nb64), dim3(64), 0, ss, so, c->tables);
+   hipLaunchKernelGGL(k_sift_meanvar, dim3((n + SM_KP - 1) / SM_KP), dim3(64), 0, ss, so, c->tables);
    hipLaunchKernelGGL(k_sift_grad, dim3(c->sgrad_grid ? std::min(n, c->sgrad_grid) : n), dim3(256), 0, ss, so, c->tables, vo);
    hipLaunchKernelGGL(k_sift_hist, dim3(std::min<uint32_t>((n + 3) / 4, c->g_shist)), dim3(64), 0, ss, so, c->tables, (const float2 *)vo);
    hipLaunchKernelGGL(k_sift_quantize, dim3(nb64), dim3(64), 0, ss, so, c->consts);
