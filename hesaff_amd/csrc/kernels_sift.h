@@ -46,7 +46,12 @@ struct SiftIO {
 #ifndef SM_KP
 #define SM_KP 16
 #endif
-#define SM_PX (64 * 64 / SM_KP)      // masked pixels per tile step
+#ifndef SM_PX
+#define SM_PX (64 * 64 / SM_KP)      // masked pixels per tile step (a multiple of 64)
+#endif
+#ifndef SM_UNROLL
+#define SM_UNROLL 8
+#endif
 #define SM_ROW (SM_PX + 1)           // LDS row stride: lane k walking row k is conflict-free
 __global__ __launch_bounds__(64) void k_sift_meanvar(SiftIO io, KpTables tb)
 {
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(64) void k_sift_meanvar(SiftIO io, KpTables tb)
          int pix[SM_PX / 64];
 #pragma unroll
          for (int u = 0; u < SM_PX / 64; u++) pix[u] = (lane + 64 * u < cnt) ? tb.mask_idx[c0 + lane + 64 * u] : 0;
-#pragma unroll 8
+#pragma unroll SM_UNROLL
          for (int k = 0; k < SM_KP; k++) {
             const uint32_t kp = min(k0 + k, n - 1);
             const float *pp = io.patches + (size_t)kp * HS_PATCH_PIX;
