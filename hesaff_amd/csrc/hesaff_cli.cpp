@@ -11,6 +11,8 @@
 //       --schedule static | dynamic   static (default): one contiguous shard per device context.  dynamic: the list is cut into
 //       blocks of 256 images and every device context takes the next block when it has finished its own - for lists whose
 //       keypoint density varies strongly along the list; the output files are the same either way.
+//       --fast 1 | 2                  hesaff_params.fast: the not-bit-exact per-keypoint kernels (1: same algorithm, free summation order;
+//       2: also windows larger than the patch sampled from the scale space); default 0 = parity mode.
 //       --output text | bin | both    what every image gets: <image>.hesaff.sift (default), the binary sidecar
 //       <image>.hesaff.bin (the same rows unprinted, include/hesaff_amd.h: hesaff_write_bin), or both.
 #include <chrono>
@@ -61,7 +63,7 @@ bool parse_devices(const char *spec, std::vector<int> &out)
 
 // hesaff --batch: the list is cut into contiguous shards, one per device context (hesaff_shard_range); every shard runs
 // through hesaff_process_files - decode threads -> device -> writer threads, bounded memory - on its own host thread.
-int run_batch_mode(const char *list_path, const char *devices_spec, int out_format, bool dynamic)
+int run_batch_mode(const char *list_path, const char *devices_spec, int out_format, bool dynamic, int fast)
 {
    std::ifstream lf(list_path);
    if (!lf) { fprintf(stderr, "hesaff: cannot read list '%s'\n", list_path); return 1; }
@@ -93,6 +95,7 @@ int run_batch_mode(const char *list_path, const char *devices_spec, int out_form
       hesaff_params par;
       hesaff_default_params(&par);
       par.max_batch = std::max(1, std::min(dynamic ? n : hi - lo, 64));
+      par.fast = fast;
       hesaff_ctx *ctx = nullptr;
       if (hesaff_create(&ctx, &par, devices[(size_t)rank]) != HESAFF_OK) { errs[(size_t)rank] = hesaff_last_error(nullptr); return; }
       hesaff_set_output_format(ctx, out_format);
@@ -148,12 +151,15 @@ int main(int argc, char **argv)
    }
    if (argc > 2 && strcmp(argv[1], "--batch") == 0) {
       const char *devices = nullptr;
-      int out_format = HESAFF_OUT_TEXT;
+      int out_format = HESAFF_OUT_TEXT, fast = 0;
       bool bad = false, dynamic = false;
       for (int i = 3; i < argc && !bad; i += 2) {
          if (i + 1 >= argc) bad = true;
          else if (strcmp(argv[i], "--devices") == 0) devices = argv[i + 1];
-         else if (strcmp(argv[i], "--schedule") == 0) {
+         else if (strcmp(argv[i], "--fast") == 0) {
+            if (strcmp(argv[i + 1], "0") == 0 || strcmp(argv[i + 1], "1") == 0 || strcmp(argv[i + 1], "2") == 0) fast = atoi(argv[i + 1]);
+            else bad = true;
+         } else if (strcmp(argv[i], "--schedule") == 0) {
             if (strcmp(argv[i + 1], "dynamic") == 0) dynamic = true;
             else if (strcmp(argv[i + 1], "static") != 0) bad = true;
          } else if (strcmp(argv[i], "--output") == 0) {
@@ -163,8 +169,8 @@ int main(int argc, char **argv)
             else bad = true;
          } else bad = true;
       }
-      if (bad) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all] [--output text|bin|both] [--schedule static|dynamic]\n"); return 1; }
-      return run_batch_mode(argv[2], devices, out_format, dynamic);
+      if (bad) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all] [--output text|bin|both] [--schedule static|dynamic] [--fast 0|1|2]\n"); return 1; }
+      return run_batch_mode(argv[2], devices, out_format, dynamic, fast);
    }
    if (argc > 1) {
       uint8_t *data = nullptr;

@@ -278,6 +278,9 @@ def test_cli_multi_device_shards_and_isolates_bad_files(tmp_path):
     assert r.returncode == 1 and "--devices" in r.stderr
     r = subprocess.run([exe, "--batch", str(lst), "--output", "xml"], capture_output=True, text=True)
     assert r.returncode == 1 and "usage" in r.stderr
+    # --fast 2: same keypoints (row counts), other descriptors for the larger windows
+    fast, totf = run("0", ("--fast", "2"))
+    assert totf == tot1 and [b.split(b"\n")[1] for b in fast] == [b.split(b"\n")[1] for b in one] and fast != one
 
 
 def test_same_bytes_under_one_and_two_ranks(tmp_path):

@@ -242,24 +242,10 @@ def sequence_through_cli(out_dir, width=800, height=640, angles=(10, 20, 30, 40,
     lst = os.path.join(out_dir, "list.txt")
     with open(lst, "w") as f:
         f.write("\n".join(paths) + "\n")
-    if fast:
-        # the CLI has no switch for the fast modes: the same file pipeline (hesaff_process_files) through the binding
-        import hesaff_amd
-        p = hesaff_amd.default_params()
-        p.fast = fast
-        with hesaff_amd.HesaffContext(p, device=0) as ctx:
-            st = ctx.process_files(paths)
-        if any(s_[0] != 0 for s_ in st):
-            raise RuntimeError("hesaff_process_files failed: %r" % (st,))
-
-        class R:
-            stdout = "hesaff_process_files, hesaff_params.fast = %d: %d descriptors" % (fast, sum(s_[3] for s_ in st))
-        r = R()
-    else:
-        exe = os.path.join(ROOT, "hesaff_amd", "bin", "hesaff")
-        r = subprocess.run([exe, "--batch", lst], capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("hesaff --batch failed: " + r.stderr[-2000:])
+    exe = os.path.join(ROOT, "hesaff_amd", "bin", "hesaff")
+    r = subprocess.run([exe, "--batch", lst] + (["--fast", str(fast)] if fast else []), capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hesaff --batch failed: " + r.stderr[-2000:])
     return {"data": "synthetic graf-like sequence: %dx%d colour band-noise image and %d copies warped by a camera rotation about the "
                     "vertical axis, stored as JPEG (quality 92, 4:2:0) and read back by the library's JPEG decoder; the Oxford "
                     "sequences are not available offline" % (width, height, len(angles)),
