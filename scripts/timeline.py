@@ -4,10 +4,15 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', ''), r.get('Queue_Id', '')) for r in rows]
 ks.sort()
-# the last step starts at the last k_gray launch
-t0 = max(s for s, e, n, q in ks if n.startswith('k_gray'))
+# the last step starts at its first pyramid launch: the initial blur that also converts the 8-bit source (template flag SRC8 = true,
+# the only k_blur_hess_march instantiation whose last argument is true), or k_gray on the non-default paths
+starts = [s for s, e, n, q in ks if n.startswith('k_gray') or (n.startswith('k_blur_hess_march') and n.rstrip('>').endswith('true') and ', false, false, false, true' in n)]
+t0 = max(starts)
 ks = [k for k in ks if k[0] >= t0]
-t1 = max(e for s, e, n, q in ks)
+# ... and ends with its k_pack launch (what follows in the trace belongs to other legs of the bench)
+ends = [e for s, e, n, q in ks if n.startswith('k_pack')]
+t1 = min(ends) if ends else max(e for s, e, n, q in ks)
+ks = [k for k in ks if k[0] < t1]
 print('step span %.1f ms, %d launches' % ((t1 - t0) / 1e6, len(ks)))
 def fam(n):
     for key, f in (('k_patch_extract_small<0', 'small0'), ('k_patch_extract_small<1', 'small1'), ('k_patch_small<0', 'small0'), ('k_patch_small<1', 'small1'), ('k_patch_mid<128', 'mid128'), ('k_patch_mid<512', 'mid512'),
@@ -15,7 +20,7 @@ def fam(n):
                    ('k_affine', 'affine'), ('k_blur_hess', 'pyr'), ('k_extrema', 'extrema'), ('k_localize', 'extrema'), ('k_prepare', 'prep')):
         if n.startswith(key): return f
     return 'other'
-SL = 5e6
+SL = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 5e6
 nsl = int((t1 - t0) / SL) + 1
 acc = [collections.Counter() for _ in range(nsl)]
 # union busy time
