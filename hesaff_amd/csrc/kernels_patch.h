@@ -143,6 +143,13 @@ __device__ __forceinline__ void hs_resample_full_tab(const float *S, int pitch, 
 #ifndef HS_MID_WAVES
 #define HS_MID_WAVES 0
 #endif
+#ifndef HS_MID_SCALAR
+#define HS_MID_SCALAR 1     // the row pass of the row-streamed windows as scalar sliding-window chains: every sample is read from LDS once (the pair form reads
+                            // it twice) and no register pairs are assembled; k_patch_mid<512> 195.5 -> 178.1, <128> 149.5 -> 144.0 ms per 256 images
+#endif
+#ifndef HS_MID_SCALAR_TAIL
+#define HS_MID_SCALAR_TAIL 0   // the same form in the one- and two-row variants (tail rows of a window, k_patch_large_rows): measured slower (182.8 vs 179.4, 33.9 vs 32.2 ms)
+#endif
 #ifndef HS_SMALL_SCALAR
 #define HS_SMALL_SCALAR 1   // the plain (pair) form of the LDS-window blur with scalar instead of packed operations: -186 register moves, no scratch; bin 0 156.6 -> 153.7 ms per 256 images
 #endif
@@ -649,9 +656,24 @@ __device__ __forceinline__ void hs_row_stream(const HsPlaneBuf &img, float x, fl
       const float *s = srow + x0;   // s[jt] = S[clamp(x0 - r + jt)],  s[jt + 1] = S[clamp(x0 + 1 - r + jt)]
       auto G = [&](int jt) { v2f g; g.x = s[jt]; g.y = s[jt + 1]; return g; };
       // RowFilter order; a window of this path has P0 >= 63, i.e. K = odd(int(9 * P0 / 41 + 1)) >= 15 (never the K <= 5 form)
-      v2f t = taps[0] * G(0);
+      v2f t;
+      if (HS_MID_SCALAR_TAIL) {   // scalar sliding-window chains (see hs_row_stream3)
+         float a0 = s[0], a1 = s[1];
+         const float k0 = taps[0];
+         float t0 = k0 * a0, t1 = k0 * a1;
 #pragma unroll 8
-      for (int jt = 1; jt < K; jt++) t += taps[jt] * G(jt);
+         for (int jt = 1; jt < K; jt++) {
+            const float k = taps[jt];
+            a0 = a1;
+            a1 = s[jt + 1];
+            t0 += k * a0; t1 += k * a1;
+         }
+         t.x = t0; t.y = t1;
+      } else {
+         t = taps[0] * G(0);
+#pragma unroll 8
+         for (int jt = 1; jt < K; jt++) t += taps[jt] * G(jt);
+      }
       v2f *o = reinterpret_cast<v2f *>(out82) + lane;
       *o = t;
       // padded T' plane: the first / last window row is replicated pad_r times above / below (wave-uniform)
@@ -687,12 +709,28 @@ __device__ __forceinline__ void hs_row_stream2(const HsPlaneBuf &img, float x, f
       const float *sA = srowA + x0, *sB = srowB + x0;
       auto GA = [&](int jt) { v2f g; g.x = sA[jt]; g.y = sA[jt + 1]; return g; };
       auto GB = [&](int jt) { v2f g; g.x = sB[jt]; g.y = sB[jt + 1]; return g; };
-      v2f tA = taps[0] * GA(0), tB = taps[0] * GB(0);
+      v2f tA, tB;
+      if (HS_MID_SCALAR_TAIL) {   // scalar sliding-window chains (see hs_row_stream3)
+         float a0 = sA[0], a1 = sA[1], b0 = sB[0], b1 = sB[1];
+         const float k0 = taps[0];
+         float tA0 = k0 * a0, tA1 = k0 * a1, tB0 = k0 * b0, tB1 = k0 * b1;
 #pragma unroll 4
-      for (int jt = 1; jt < K; jt++) {
-         const float k = taps[jt];
-         tA += k * GA(jt);
-         tB += k * GB(jt);
+         for (int jt = 1; jt < K; jt++) {
+            const float k = taps[jt];
+            a0 = a1; b0 = b1;
+            a1 = sA[jt + 1]; b1 = sB[jt + 1];
+            tA0 += k * a0; tA1 += k * a1;
+            tB0 += k * b0; tB1 += k * b1;
+         }
+         tA.x = tA0; tA.y = tA1; tB.x = tB0; tB.y = tB1;
+      } else {
+         tA = taps[0] * GA(0); tB = taps[0] * GB(0);
+#pragma unroll 4
+         for (int jt = 1; jt < K; jt++) {
+            const float k = taps[jt];
+            tA += k * GA(jt);
+            tB += k * GB(jt);
+         }
       }
       v2f *oA = reinterpret_cast<v2f *>(outA) + lane, *oB = reinterpret_cast<v2f *>(outB) + lane;
       *oA = tA;
@@ -743,12 +781,30 @@ __device__ __forceinline__ void hs_row_stream3(const HsPlaneBuf &img, float x, f
       const float *sA = srow + rowA * sstride + xA, *sB = srow + rowB * sstride + xB;
       auto GA = [&](int jt) { v2f g; g.x = sA[jt]; g.y = sA[jt + 1]; return g; };
       auto GB = [&](int jt) { v2f g; g.x = sB[jt]; g.y = sB[jt + 1]; return g; };
-      v2f tA2 = taps[0] * GA(0), tB2 = taps[0] * GB(0);
+      v2f tA2, tB2;
+      if (HS_MID_SCALAR) {
+         // four scalar chains on a sliding window: every sample of the two rows is read once (the pair form reads it twice, as the
+         // second element of tap j and the first of tap j + 1) and no register pairs are assembled
+         float a0 = sA[0], a1 = sA[1], b0 = sB[0], b1 = sB[1];
+         const float k0 = taps[0];
+         float tA0 = k0 * a0, tA1 = k0 * a1, tB0 = k0 * b0, tB1 = k0 * b1;
 #pragma unroll 4
-      for (int jt = 1; jt < K; jt++) {
-         const float k = taps[jt];
-         tA2 += k * GA(jt);
-         tB2 += k * GB(jt);
+         for (int jt = 1; jt < K; jt++) {
+            const float k = taps[jt];
+            a0 = a1; b0 = b1;
+            a1 = sA[jt + 1]; b1 = sB[jt + 1];
+            tA0 += k * a0; tA1 += k * a1;
+            tB0 += k * b0; tB1 += k * b1;
+         }
+         tA2.x = tA0; tA2.y = tA1; tB2.x = tB0; tB2.y = tB1;
+      } else {
+         tA2 = taps[0] * GA(0); tB2 = taps[0] * GB(0);
+#pragma unroll 4
+         for (int jt = 1; jt < K; jt++) {
+            const float k = taps[jt];
+            tA2 += k * GA(jt);
+            tB2 += k * GB(jt);
+         }
       }
       const int yA = rowA ? yy1 : yy0, yB = rowB == 2 ? yy2 : yy1;
       v2f *oA = reinterpret_cast<v2f *>(rowA ? out1 : out0) + colA;
