@@ -245,7 +245,7 @@ def main():
                     help="worker processes of the multi-core CPU baseline, one image each (-1: one per physical core, at most the batch; 0: skip)")
     ap.add_argument("--fast-steps", type=int, default=2, help="steps of the two fast-mode legs of the default run (0: skip)")
     ap.add_argument("--natural-steps", type=int, default=2, help="steps of the extra photograph-like-density leg of the default run (0: skip)")
-    ap.add_argument("--e2e-images", type=int, default=384, help="image files of the measured end-to-end file path (0: skip; fewer when the RAM disk is small)")
+    ap.add_argument("--e2e-images", type=int, default=512, help="image files of the measured end-to-end file path (0: skip; fewer when the RAM disk is small)")
     ap.add_argument("--e2e-chunk", type=int, default=32, help="images per device chunk of the end-to-end leg (hesaff_params.max_batch)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: every rank owns --batch images per step; strong: --global-images images per step in total, "
