@@ -11,8 +11,11 @@ Prints ONE JSON line (rank 0):
                 records left in HBM (hesaff_detect_batch_device) -- the harness contract for `value`;
   host_path     the same batch through hesaff_detect_batch: host images in -> H2D -> kernels -> D2H -> host
                 records out, chunks pipelined (SURVEY.md 8d: "H2D -> D2H inclusive"), in the same run;
-  text_export   hesaff_write_sift_batch (exportKeypoints hesaff.cpp:107-130 for every image) to a RAM disk on a
-                bounded subset, and the end-to-end rate with the export of batch i beside the detection of i+1;
+  end_to_end    hesaff_process_files on EVERY rank at once: PGM files on a RAM disk -> decode threads -> device (rows of the
+                .hesaff.sift files formatted by the GPU) -> writer threads that only write(); each rank with the host-thread
+                budget one device of an 8-GPU node gets (2 + 2 threads); aggregate over the ranks;
+  text_export   the host formatter alone (hesaff_write_sift_batch, the stage API's writer) on a bounded subset;
+  photo_density the same device-resident step on mosaics of real photographs (scikit-learn's sample images);
   roofline      the dominant pyramid kernel (k_blur_hess_march: Gaussian + det-of-Hessian), timed live with HIP
                 events on the library's stream;
   cpu_baseline  the CPU oracle (a port of the reference, 1 thread) on a bounded sample of the same images;
@@ -140,43 +143,62 @@ def fast_leg(hesaff_amd, torch, imgs, device, B, H, W, level, steps):
 
 
 def density_leg(hesaff_amd, torch, dev, device, B, H, W, seed, steps):
-    """The same step on photograph-like images (about 2.5 k descriptors per Mpx instead of 14 k): device-resident, like `value`."""
-    from hesaff_amd.synth import BANDS_NATURAL, band_noise_batch_torch
-    imgs = band_noise_batch_torch(B, H, W, seed=seed, device=dev, bands=BANDS_NATURAL)
+    """The same device-resident step on photographs: B distinct mosaics of scikit-learn's two sample photographs at their native
+    resolution (flips and shifts per image, hesaff_amd/synth.py); the band-noise family one octave coarser stands in when the
+    photographs are not installed.  Per-stage times of the step are reported: on this content the pyramid and detection stages
+    (fixed cost per pixel) weigh three times what they weigh on the dense headline images."""
+    from hesaff_amd.synth import BANDS_NATURAL, band_noise_batch_torch, load_sample_photos, photo_mosaic_batch_torch
+    photos = load_sample_photos()
+    if photos:
+        imgs = photo_mosaic_batch_torch(B, H, W, first_index=seed, device=dev, photos=photos)
+        what = ("%d distinct %dx%d mosaics of scikit-learn's sample photographs (china.jpg, flower.jpg at native resolution, random "
+                "flips per tile, random shift per image; decoded by the in-tree JPEG reader)" % (B, W, H))
+    else:
+        imgs = band_noise_batch_torch(B, H, W, seed=seed, device=dev, bands=BANDS_NATURAL)
+        what = "%d x %dx%d band-noise images one octave coarser than the headline family (sample photographs not installed)" % (B, W, H)
     torch.cuda.synchronize()
     p = hesaff_amd.default_params()
     p.max_batch = B
+    stage = {"pyramid_ms": 0.0, "detect_ms": 0.0, "affine_ms": 0.0, "patch_ms": 0.0, "sift_ms": 0.0, "pack_ms": 0.0, "total_ms": 0.0}
     with hesaff_amd.HesaffContext(p, device=device) as ctx:
         ctx.detect_batch_device(imgs.data_ptr(), B, W, H)
+        ctx.set_profiling(1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        nd = 0
+        nd = nh = 0
         for _ in range(steps):
-            _, cd, _, _ = ctx.detect_batch_device(imgs.data_ptr(), B, W, H)
-            nd += int(cd.sum())
+            ch, cd, _, _ = ctx.detect_batch_device(imgs.data_ptr(), B, W, H)
+            nd += int(cd.sum()); nh += int(ch.sum())
+            tm = ctx.timings()
+            for k in stage:
+                stage[k] += getattr(tm, k) / steps
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     del imgs
     torch.cuda.empty_cache()
     return {"value": nd / dt, "unit": "keypoints/s", "images_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "descriptors_per_image": nd / (B * steps),
-            "what": "the same device-resident step on %d x %dx%d images of the photograph-like family (BANDS_NATURAL: one octave coarser, "
-                    "about 2.5 k descriptors per Mpx); not the headline workload" % (B, W, H)}
+            "descriptors_per_image": nd / (B * steps), "hessian_keypoints_per_image": nh / (B * steps),
+            "descriptors_per_mpx": nd / (B * steps) / (W * H / 1e6), "photographs": bool(photos),
+            "stage_ms_per_step": stage, "serial_head_fraction": (stage["pyramid_ms"] + stage["detect_ms"]) / max(stage["total_ms"], 1e-9),
+            "what": "the same device-resident step on " + what + "; not the headline workload"}
 
 
-def file_path_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, fmt=1):
-    """hesaff_process_files (what `hesaff --batch` runs: decode threads -> chunks through the device -> writer threads) on
-    n_files binary PGM files of the bench images on a RAM disk, every <name>.hesaff.sift written there too.  One timed run
-    over the whole list, pipeline fill and drain included."""
+def file_path_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, fmt=1, decode_threads=2, write_threads=2, world=1, sync=None):
+    """hesaff_process_files (what `hesaff --batch` runs: decode threads -> chunks through the device, rows formatted there ->
+    writer threads that only write) on n_files binary PGM files of the bench images on a RAM disk, every <name>.hesaff.sift
+    written there too.  One timed run over the whole list, pipeline fill and drain included.  Every rank runs this at the same
+    time (`sync` = barrier before the timed run) with the same host-thread budget."""
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     tmp = tempfile.mkdtemp(prefix="hesaff_e2e_", dir=base)
     try:
         # inputs 1 byte per pixel, outputs about 5.3 bytes per pixel at the dense images' 14 k descriptors per Mpx
         per_image = W * H * 7
         free = shutil.disk_usage(tmp).free
-        n = int(max(0, min(n_files, (free * 0.6) // per_image)))
+        n = int(max(0, min(n_files, (free * 0.6 / max(world, 1)) // per_image)))
         if n < 2 * chunk:
-            return {"skipped": "RAM disk too small: %d bytes free for %d images" % (free, n_files)}
+            if sync:
+                sync()
+            return {"skipped": "RAM disk too small: %d bytes free for %d images on %d rank(s)" % (free, n_files, world)}
         paths = []
         hdr = b"P5\n%d %d\n255\n" % (W, H)
         for i in range(n):
@@ -189,11 +211,13 @@ def file_path_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, fmt=1):
         ext = ".hesaff.sift" if fmt == 1 else ".hesaff.bin"
         with hesaff_amd.HesaffContext(p, device=device) as ctx:
             ctx.set_output_format(fmt)
-            warm = ctx.process_files(paths[: 2 * chunk])          # buffers, page cache, thread start-up
-            for q in paths[: 2 * chunk]:
+            warm = ctx.process_files(paths[: 3 * chunk], decode_threads=decode_threads, write_threads=write_threads)   # buffers (all three pinned blocks), page cache, thread start-up
+            for q in paths[: 3 * chunk]:
                 os.remove(q + ext)
+            if sync:
+                sync()
             t0 = time.perf_counter()
-            st = ctx.process_files(paths)
+            st = ctx.process_files(paths, decode_threads=decode_threads, write_threads=write_threads)
             dt = time.perf_counter() - t0
             threads = int(ctx.L.hesaff_host_threads())
         bad = [i for i, s_ in enumerate(st) if s_[0] != 0 or s_[1] != 3] + [i for i, s_ in enumerate(warm) if s_[0] != 0]
@@ -202,10 +226,13 @@ def file_path_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, fmt=1):
         return {"images": n, "images_per_s": n / dt, "value": rows / dt, "unit": "keypoints/s", "seconds": dt, "chunk_images": chunk,
                 "output": "text (.hesaff.sift, the reference's format)" if fmt == 1 else "binary sidecar (.hesaff.bin, 148 bytes per row)",
                 "failed_files": len(bad), "output_GB_per_s": nbytes / dt / 1e9, "input_GB": n * (W * H + len(hdr)) / 1e9, "output_GB": nbytes / 1e9,
-                "host_threads": threads, "target": tmp.rsplit("/", 1)[0],
-                "what": "hesaff_process_files: %d binary PGM files (%dx%d, the bench images) on a RAM disk -> decode threads -> chunks of %d "
-                        "images through the device (copy in, kernels, copy out overlapped) -> writer threads -> %d %s files on the "
-                        "RAM disk; one timed run, pipeline fill and drain included (hesaff.cpp:133-180 for a list of files)" % (n, W, H, chunk, n, ext)}
+                "rows": rows, "output_bytes": nbytes,
+                "decode_threads": decode_threads, "write_threads": write_threads, "host_threads_available": threads, "target": tmp.rsplit("/", 1)[0],
+                "what": "hesaff_process_files: %d binary PGM files (%dx%d, the bench images) on a RAM disk -> %d decode threads -> chunks of %d "
+                        "images through the device (copy in, kernels, rows of the output files formatted on the device, copy out, all overlapped) "
+                        "-> %d writer threads (write() only) -> %d %s files on the RAM disk; one timed run, pipeline fill and drain included "
+                        "(hesaff.cpp:133-180 for a list of files); the thread budget is what one device of an 8-GPU node gets from this "
+                        "host's CPU quota" % (n, W, H, decode_threads, chunk, write_threads, n, ext)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

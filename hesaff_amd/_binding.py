@@ -54,7 +54,7 @@ _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
-ABI_VERSION = 3   # HESAFF_ABI_VERSION of the include/hesaff_amd.h these ctypes structs mirror
+ABI_VERSION = 4   # HESAFF_ABI_VERSION of the include/hesaff_amd.h these ctypes structs mirror
 
 
 class FileStatus(C.Structure):
@@ -139,6 +139,10 @@ def load_library():
     L.hesaff_stage_sift.argtypes = [vp, C.c_int, _f32p, _u8p]
     L.hesaff_stage_math.argtypes = [vp, C.c_int, _f32p, _f32p, _f32p, _f32p]
     L.hesaff_stage_math_sift.argtypes = [vp, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
+    L.hesaff_stage_export.argtypes = [vp, vp, C.c_int, C.c_float, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.hesaff_stage_fmt_g.argtypes = [vp, C.c_int, _f32p, vp, _i32p]
+    L.hesaff_write_sift_rows.argtypes = [C.c_char_p, vp, C.c_size_t, C.c_int]
+    L.hesaff_write_bin_rows.argtypes = [C.c_char_p, vp, C.c_int]
     L.hesaff_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.hesaff_table_gauss_mask.argtypes = [C.c_int, _f32p]
     L.hesaff_table_circ_gauss_mask.argtypes = [C.c_int, _f32p]
@@ -160,6 +164,7 @@ ABI_SYMBOLS = [
     "hesaff_read_png", "hesaff_read_image", "hesaff_device_count", "hesaff_shard_range", "hesaff_read_jpeg",
     "hesaff_host_threads", "hesaff_abi_version", "hesaff_sizeof_params", "hesaff_sizeof_timings", "hesaff_detect_batch_cb",
     "hesaff_process_files", "hesaff_write_sift_mt", "hesaff_write_bin", "hesaff_set_output_format",
+    "hesaff_write_sift_rows", "hesaff_write_bin_rows", "hesaff_stage_export", "hesaff_stage_fmt_g",
 ]
 
 
@@ -499,6 +504,24 @@ class HesaffContext:
         d = np.zeros((len(p), 128), np.uint8)
         self._check(self.L.hesaff_stage_sift(self.h, len(p), p, d))
         return d
+
+    def export(self, keys, mr_size=None, fmt=1):
+        """exportKeypoints on the device (hesaff_stage_export): bytes of the .hesaff.sift file (fmt 1) or of the sidecar (fmt 2)."""
+        keys = np.ascontiguousarray(keys, dtype=KEYPOINT_DTYPE)
+        buf = C.c_void_p(); n = C.c_size_t()
+        mr = self.params.mrSize if mr_size is None else mr_size
+        self._check(self.L.hesaff_stage_export(self.h, keys.ctypes.data, len(keys), C.c_float(mr), fmt, C.byref(buf), C.byref(n)))
+        try:
+            return C.string_at(buf.value, n.value)
+        finally:
+            self.L.hesaff_free(buf)
+
+    def fmt_g(self, v):
+        """The device's "%g" print of float32 values -> list of bytes."""
+        v = np.ascontiguousarray(v, np.float32).reshape(-1)
+        text = np.zeros((len(v), 16), np.uint8); lens = np.zeros(len(v), np.int32)
+        self._check(self.L.hesaff_stage_fmt_g(self.h, len(v), v, text.ctypes.data, lens))
+        return text, lens
 
     def math(self, a, b):
         a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)

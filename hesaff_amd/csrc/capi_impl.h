@@ -167,7 +167,8 @@ void hesaff_destroy(hesaff_ctx *c)
                      &c->t_patch_off, &c->t_patch_k, &c->b_gray, &c->b_up, &c->b_L, &c->b_L3, &c->b_R, &c->b_map, &c->b_bitmask, &c->b_prefix,
                      &c->b_blocksums, &c->b_generic, &c->b_counters, &c->b_cand, &c->b_rec_f, &c->b_rec_i, &c->b_rec_w, &c->b_hess_f, &c->b_hess_i,
                      &c->b_aff, &c->b_pw, &c->b_bins, &c->b_rank, &c->b_desc, &c->b_out, &c->b_starts, &c->b_patches,
-                     &c->b_stage, &c->b_input, &c->t_mask_idx, &c->t_sgrad_nb, &c->t_sgrad_om, &c->b_rowprefix, &c->b_trows, &c->b_trows2, &c->b_trows3};
+                     &c->b_stage, &c->b_input, &c->t_mask_idx, &c->t_sgrad_nb, &c->t_sgrad_om, &c->b_rowprefix, &c->b_trows, &c->b_trows2, &c->b_trows3,
+                     &c->b_ex_len, &c->b_ex_sums, &c->b_ex_off, &c->b_ex_imgoff, &c->b_ex_starts};
    for (DevBuf *b : bufs) b->release();
    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
    for (int i = 0; i < HS_NSIDE; i++) {
@@ -274,8 +275,11 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
       HostChunk q;
       std::vector<int32_t> nh, nd;
       std::vector<size_t> off;
+      std::vector<unsigned long long> toff;   // WANT_TEXT: byte offset of every image's rows
+      size_t text_at = 0, bin_at = 0;         // where the text / sidecar rows start inside the result block
       int total = 0, block = -1, no = 0;
    };
+   const int wants = io.wants();
    c->ring.reset(ring);
    if (ring > 0 && (int)c->pin_out.size() < ring) c->pin_out.resize((size_t)ring);
 
@@ -301,7 +305,7 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
          }
       };
       const size_t nimg = q.data.size();
-      const size_t nthr = (total >= ((size_t)32 << 20) && nimg >= 4) ? 4 : 1;
+      const size_t nthr = (total >= ((size_t)32 << 20) && nimg >= 4) ? (size_t)std::max(1, std::min(4, c->stage_threads)) : 1;
       {
          std::vector<std::thread> th;
          size_t t = 1;
@@ -321,8 +325,11 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
    auto deliver = [&](State &s) {
       if (s.total > 0) HIP_TRY(hipEventSynchronize(c->ev_d2h[s.no & 1]));
       ChunkDone d;
+      const char *blk = (const char *)c->pin_out[(size_t)s.block].p;
       d.chunk = &s.q; d.count_hessian = s.nh.data(); d.count_desc = s.nd.data(); d.key_off = s.off.data();
-      d.keys = (const hesaff_keypoint *)c->pin_out[(size_t)s.block].p; d.block = s.block;
+      d.keys = (wants & WANT_KEYS) ? (const hesaff_keypoint *)blk : nullptr; d.block = s.block;
+      if (wants & WANT_TEXT) { d.text = blk + s.text_at; d.text_off = s.toff.data(); }
+      if (wants & WANT_BIN) d.bin = blk + s.bin_at;
       io.done(d);
    };
 
@@ -338,8 +345,18 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
          const int slot = k & 1, B = (int)q.data.size();
          const size_t row_bytes = (size_t)q.W * q.ch, img_bytes = row_bytes * q.H;
          HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_h2d[slot], 0));
-         plan(c, std::min<int>(c->par.max_batch, B), q.H, q.W);
-         run_batch(c, (const uint8_t *)c->b_in2[slot].p, q.ch, (long long)img_bytes, (int)row_bytes, B, q.H, q.W);
+         try {
+            plan(c, std::min<int>(c->par.max_batch, B), q.H, q.W);
+            run_batch(c, (const uint8_t *)c->b_in2[slot].p, q.ch, (long long)img_bytes, (int)row_bytes, B, q.H, q.W);
+         } catch (const HsError &e) {
+            // this chunk's images cannot be planned (geometry) or exceed the planned keypoint capacity: that is about these
+            // images, not about the device.  Both are thrown with the main stream idle; the other chunks go on when the
+            // consumer can note the failure per image (hesaff_process_files), otherwise the call fails as a whole.
+            if (e.code != HESAFF_ERR_ARG && e.code != HESAFF_ERR_CAPACITY) throw;
+            HIP_TRY(hipEventRecord(c->ev_in_free[slot], c->stream));
+            if (!io.failed(q, e.code)) throw;
+            continue;
+         }
          HIP_TRY(hipEventRecord(c->ev_in_free[slot], c->stream));
          const int32_t *hs = c->h_starts.data(), *ds = c->h_starts.data() + (B + 1);
          cur->total = ds[B];
@@ -349,6 +366,19 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
             cur->nd[(size_t)b] = ds[b + 1] - ds[b];
             cur->off[(size_t)b] = (size_t)ds[b];
          }
+         // layout of the chunk's result block: [records][text rows][sidecar rows], what the consumer wants of them
+         const size_t n_rows = (size_t)cur->total;
+         const KeyRec *d_keys = c->b_out.as<KeyRec>();
+         size_t at = 0;
+         auto place = [&at](size_t bytes) { const size_t o = at; at = (at + bytes + 255) & ~(size_t)255; return o; };
+         const size_t keys_at = (wants & WANT_KEYS) ? place(n_rows * sizeof(hesaff_keypoint)) : 0;
+         unsigned long long text_bytes = 0;
+         if (wants & WANT_TEXT) {   // row lengths and offsets first: the host needs the byte count (a short wait on the main stream)
+            text_bytes = export_text_prepare(c, d_keys, (uint32_t)n_rows, c->b_starts.as<int32_t>() + (B + 1), B, cur->toff);
+            cur->text_at = place((size_t)text_bytes);
+         }
+         if (wants & WANT_BIN) cur->bin_at = place(n_rows * EX_BIN_ROW);
+         const size_t bytes = at;
          // chunk k-1: its copy out was enqueued before the kernels of chunk k and has long finished
          if (prev) { deliver(*prev); prev.reset(); }
          // a pinned block for chunk k
@@ -358,16 +388,19 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
             if ((int)c->pin_out.size() <= k) c->pin_out.resize((size_t)k + 1);
             cur->block = k;
          }
-         // records: device copy into the staging slot (frees b_out for the next chunk), then D2H beside the next chunk
-         const size_t bytes = (size_t)cur->total * sizeof(hesaff_keypoint);
-         c->pin_out[(size_t)cur->block].ensure(std::max<size_t>(bytes, 16));
+         // device copy / formatting into the staging slot (frees b_out for the next chunk), then D2H beside the next chunk
+         if (ring > 0) c->pin_out[(size_t)cur->block].ensure_grow(std::max<size_t>(bytes, 16));
+         else c->pin_out[(size_t)cur->block].ensure(std::max<size_t>(bytes, 16));
          if (cur->total > 0) {
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_d2h[slot], 0));      // D2H of chunk k-2 has left this staging slot
-            c->b_outstage[slot].ensure(bytes);
-            HIP_TRY(hipMemcpyAsync(c->b_outstage[slot].p, c->b_out.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+            if (bytes > c->b_outstage[slot].bytes) c->b_outstage[slot].ensure(bytes + bytes / 4);
+            char *stg = (char *)c->b_outstage[slot].p;
+            if (wants & WANT_KEYS) HIP_TRY(hipMemcpyAsync(stg + keys_at, c->b_out.p, n_rows * sizeof(hesaff_keypoint), hipMemcpyDeviceToDevice, c->stream));
+            if (wants & WANT_TEXT) export_text_write(c, d_keys, (uint32_t)n_rows, stg + cur->text_at);
+            if (wants & WANT_BIN) export_bin_rows(c, d_keys, (uint32_t)n_rows, stg + cur->bin_at);
             HIP_TRY(hipEventRecord(c->ev_out_ready[slot], c->stream));
             HIP_TRY(hipStreamWaitEvent(c->d2h_stream, c->ev_out_ready[slot], 0));
-            HIP_TRY(hipMemcpyAsync(c->pin_out[(size_t)cur->block].p, c->b_outstage[slot].p, bytes, hipMemcpyDeviceToHost, c->d2h_stream));
+            HIP_TRY(hipMemcpyAsync(c->pin_out[(size_t)cur->block].p, stg, bytes, hipMemcpyDeviceToHost, c->d2h_stream));
             HIP_TRY(hipEventRecord(c->ev_d2h[slot], c->d2h_stream));
          }
          prev = std::move(cur);
@@ -392,7 +425,7 @@ struct ArrayIO : ChunkIO {
    hesaff_result *results = nullptr;             // hesaff_detect_batch: filled in place
    hesaff_chunk_sink sink = nullptr;             // hesaff_detect_batch_cb
    void *user = nullptr;
-   int sink_rc = 0;
+   std::atomic<int> sink_rc{0};                 // written by done() on the caller's thread, read by next() on the staging thread
    ArrayIO(hesaff_ctx *ctx, int n, const uint8_t *const *images, const int *widths, const int *heights, const int *strides, const int *channels)
       : c(ctx)
    {
@@ -438,7 +471,7 @@ struct ArrayIO : ChunkIO {
    }
    bool next(HostChunk &out) override
    {
-      if (pos >= chunks.size() || sink_rc != 0) return false;
+      if (pos >= chunks.size() || sink_rc.load() != 0) return false;
       out = chunks[pos++];
       return true;
    }
@@ -454,7 +487,7 @@ struct ArrayIO : ChunkIO {
       }
       std::vector<hesaff_result> tmp(B);
       for (size_t b = 0; b < B; b++) { tmp[b].count_hessian = d.count_hessian[b]; tmp[b].count_desc = d.count_desc[b]; tmp[b].keys = d.keys + d.key_off[b]; }
-      if (sink_rc == 0) sink_rc = sink(user, (int)B, d.chunk->index.data(), tmp.data());
+      if (sink_rc.load() == 0) sink_rc.store(sink(user, (int)B, d.chunk->index.data(), tmp.data()));
       release_block(c, d.block);
    }
 };
@@ -482,7 +515,7 @@ int hesaff_detect_batch_cb(hesaff_ctx *c, int n, const uint8_t *const *images, c
    ArrayIO io(c, n, images, widths, heights, strides, channels);
    io.sink = sink; io.user = user;
    run_chunks(c, io, 3);
-   if (io.sink_rc != 0) throw HsError(HESAFF_ERR_IO, "the result sink reported an error");
+   if (io.sink_rc.load() != 0) throw HsError(HESAFF_ERR_IO, "the result sink reported an error");
    HS_API_END(c)
 }
 
@@ -502,7 +535,9 @@ int hesaff_process_files(hesaff_ctx *c, int n, const char *const *paths, const c
    const int host = hesaff_host_threads();
    const int dt = std::max(1, std::min(decode_threads > 0 ? decode_threads : std::max(2, host / 4), 64));
    const int wt = std::max(1, std::min(write_threads > 0 ? write_threads : host, 256));
-   FileIO io(&c->ring, c->par.max_batch, c->par.mrSize, c->out_format, n, paths, out_paths, status, dt, wt);
+   // the rows are formatted on the device (kernels_export.h): the writer threads only write()
+   FileIO io(&c->ring, c->par.max_batch, c->par.mrSize, c->out_format, n, paths, out_paths, status, dt, wt, true);
+   c->stage_threads = std::max(1, std::min(4, dt));
    try {
       run_chunks(c, io, 3);
       io.wait_writers();
@@ -774,6 +809,79 @@ int hesaff_stage_sift(hesaff_ctx *c, int n, const float *patches, uint8_t *desc)
    so.vec = (float *)(base + off_vec); so.desc = (uint8_t *)(base + off_desc); so.h_lo = 0; so.h_hi = (uint32_t)n;
    launch_sift(c, c->stream, so, (uint32_t)n, (float2 *)(base + off_vo));
    HIP_TRY(hipMemcpyAsync(desc, base + off_desc, N * 128, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipStreamSynchronize(c->stream));
+   HIP_TRY(hipGetLastError());
+   HS_API_END(c)
+}
+
+// exportKeypoints on the device for caller-supplied records: the kernels hesaff_process_files runs per chunk
+int hesaff_stage_export(hesaff_ctx *c, const hesaff_keypoint *keys, int n, float mrSize, int format, char **out, size_t *len)
+{
+   if (!c || n < 0 || (n > 0 && !keys) || !out || !len || (format != HESAFF_OUT_TEXT && format != HESAFF_OUT_BIN)) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   bind_device(c);
+   const float saved = c->par.mrSize;
+   c->par.mrSize = mrSize;
+   char *buf = nullptr;
+   try {
+      const size_t N = (size_t)n;
+      c->b_stage.ensure(std::max<size_t>(N * sizeof(KeyRec), 16));
+      if (n > 0) HIP_TRY(hipMemcpyAsync(c->b_stage.p, keys, N * sizeof(KeyRec), hipMemcpyHostToDevice, c->stream));
+      const KeyRec *d_keys = c->b_stage.as<KeyRec>();
+      char head[64];
+      size_t hl, body;
+      if (format == HESAFF_OUT_TEXT) {
+         const int32_t starts[2] = {0, n};
+         c->b_ex_starts.ensure(16);
+         HIP_TRY(hipMemcpyAsync(c->b_ex_starts.p, starts, sizeof starts, hipMemcpyHostToDevice, c->stream));
+         std::vector<unsigned long long> off;
+         body = (size_t)export_text_prepare(c, d_keys, (uint32_t)n, c->b_ex_starts.as<int32_t>(), 1, off);
+         hl = (size_t)snprintf(head, sizeof head, "%d\n%d\n", 128, n);
+      } else {
+         body = N * EX_BIN_ROW;
+         memcpy(head, "HESAFFB1", 8);
+         const uint32_t dim = 128, cnt = (uint32_t)n;
+         memcpy(head + 8, &dim, 4); memcpy(head + 12, &cnt, 4);
+         hl = 16;
+      }
+      buf = (char *)malloc(hl + body + 1);
+      if (!buf) throw HsError(HESAFF_ERR_NOMEM, "malloc failed");
+      memcpy(buf, head, hl);
+      if (body > 0) {
+         c->b_generic.ensure(body + 16);
+         if (format == HESAFF_OUT_TEXT) export_text_write(c, d_keys, (uint32_t)n, (char *)c->b_generic.p);
+         else export_bin_rows(c, d_keys, (uint32_t)n, (char *)c->b_generic.p);
+         HIP_TRY(hipMemcpyAsync(buf + hl, c->b_generic.p, body, hipMemcpyDeviceToHost, c->stream));
+      }
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(hipGetLastError());
+      *out = buf;
+      *len = hl + body;
+   } catch (...) {
+      c->par.mrSize = saved;
+      free(buf);
+      throw;
+   }
+   c->par.mrSize = saved;
+   HS_API_END(c)
+}
+
+int hesaff_stage_fmt_g(hesaff_ctx *c, int n, const float *v, char *text, int32_t *lens)
+{
+   if (!c || n < 0 || (n > 0 && (!v || !text || !lens))) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   bind_device(c);
+   if (n == 0) return HESAFF_OK;
+   const size_t N = (size_t)n;
+   c->b_stage.ensure(N * (4 + 16 + 4));
+   float *d_v = c->b_stage.as<float>();
+   int32_t *d_len = (int32_t *)(d_v + N);
+   char *d_text = (char *)(d_len + N);
+   HIP_TRY(hipMemcpyAsync(d_v, v, N * 4, hipMemcpyHostToDevice, c->stream));
+   HIP_TRY(hipMemsetAsync(d_text, 0, N * 16, c->stream));
+   hipLaunchKernelGGL(k_fmt_g_test, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, (const float *)d_v, d_text, d_len);
+   HIP_TRY(hipMemcpyAsync(text, d_text, N * 16, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipMemcpyAsync(lens, d_len, N * 4, hipMemcpyDeviceToHost, c->stream));
    HIP_TRY(hipStreamSynchronize(c->stream));
    HIP_TRY(hipGetLastError());
    HS_API_END(c)

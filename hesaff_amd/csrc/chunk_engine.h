@@ -54,18 +54,30 @@ struct HostChunk {                // at most max_batch images of one geometry
    std::vector<int> index;        // the caller's image numbers
 };
 
+// what a consumer wants copied to the host for every chunk
+enum { WANT_KEYS = 1,    // the hesaff_keypoint records (hesaff.cpp:41-48)
+       WANT_TEXT = 2,    // the rows of the .hesaff.sift files, formatted on the device (kernels_export.h; hesaff.cpp:124-128)
+       WANT_BIN = 4 };   // the 148-byte rows of the binary sidecar
+
 struct ChunkDone {
    const HostChunk *chunk;
    const int32_t *count_hessian, *count_desc;   // per image of the chunk
-   const size_t *key_off;                       // first record of each image inside keys
-   const hesaff_keypoint *keys;                 // pinned host memory: valid until the block is released / the next call
+   const size_t *key_off;                       // first record of each image inside keys (= first row inside bin)
+   const hesaff_keypoint *keys;                 // WANT_KEYS; pinned host memory: valid until the block is released / the next call
    int block;
+   const char *text = nullptr;                     // WANT_TEXT: the rows of all images of the chunk back to back (no file headers)
+   const unsigned long long *text_off = nullptr;   //            image b owns text[text_off[b] .. text_off[b + 1])
+   const char *bin = nullptr;                      // WANT_BIN: image b's rows start at bin + key_off[b] * 148
 };
 
 struct ChunkIO {
    virtual bool next(HostChunk &out) = 0;       // staging thread, one call at a time, in order; false: no more chunks
    virtual void staged(const HostChunk &) {}    // staging thread: the chunk's pixels are in pinned memory, its sources may go
    virtual void done(const ChunkDone &) = 0;    // caller's thread, in order
+   virtual int wants() const { return WANT_KEYS; }
+   // caller's thread: the device refused this chunk (rc = HESAFF_ERR_ARG: image geometry, HESAFF_ERR_CAPACITY: more keypoints than
+   // planned for).  true: noted per image, go on with the next chunk; false: the whole call fails with rc
+   virtual bool failed(const HostChunk &, int /*rc*/) { return false; }
    virtual ~ChunkIO() {}
 };
 
@@ -78,13 +90,14 @@ struct FileIO : ChunkIO {
    hesaff_file_status *status;
    float mrSize;
    int fmt;
+   bool device_format;   // rows arrive formatted (ChunkDone::text / bin): the writers only write()
    struct Img { uint8_t *data = nullptr; int w = 0, h = 0, ch = 0; int state = 0; };   // 0 pending, 1 decoded, 2 unreadable, 3 handed on
    std::vector<Img> imgs;
    std::mutex mu;
    std::condition_variable cv_dec, cv_img, cv_task;
    int next_decode = 0, consumed = 0, window = 0, pos = 0;
    bool stop = false;
-   struct Task { int index; const hesaff_keypoint *keys; int n; int chunk; };
+   struct Task { int index; const hesaff_keypoint *keys; int n; int chunk; const char *text; size_t text_len; const char *bin; };
    std::deque<Task> tasks;
    struct Open { int left; int block; };
    std::vector<Open> open_chunks;
@@ -92,8 +105,9 @@ struct FileIO : ChunkIO {
    std::vector<std::thread> decoders, writers;
 
    FileIO(BlockRing *ring_, int max_batch_, float mrSize_, int fmt_, int n_, const char *const *p, const char *const *o, hesaff_file_status *st,
-          int dec_threads, int wr_threads)
-      : ring(ring_), max_batch(max_batch_), n(n_), paths(p), out_paths(o), status(st), mrSize(mrSize_), fmt(fmt_), imgs((size_t)n_)
+          int dec_threads, int wr_threads, bool device_format_ = false)
+      : ring(ring_), max_batch(max_batch_), n(n_), paths(p), out_paths(o), status(st), mrSize(mrSize_), fmt(fmt_), device_format(device_format_),
+        imgs((size_t)n_)
    {
       window = 2 * max_batch + dec_threads;
       try {
@@ -124,11 +138,16 @@ struct FileIO : ChunkIO {
             i = next_decode++;
          }
          Img im;
-         const int rc = paths[i] ? hesaff_read_image(paths[i], &im.data, &im.w, &im.h, &im.ch) : HESAFF_ERR_ARG;
+         int rc = paths[i] ? hesaff_read_image(paths[i], &im.data, &im.w, &im.h, &im.ch) : HESAFF_ERR_ARG;
+         int stage = HESAFF_FILE_UNREADABLE;
+         if (rc == HESAFF_OK && (im.w > 65535 || im.h > 65535)) {   // the device plans 16-bit pixel coordinates (plan(), pipeline.hip)
+            hesaff_free(im.data); im.data = nullptr;
+            rc = HESAFF_ERR_ARG; stage = HESAFF_FILE_REJECTED;
+         }
          {
             std::lock_guard<std::mutex> lk(mu);
             if (rc == HESAFF_OK) { im.state = 1; imgs[(size_t)i] = im; }
-            else { imgs[(size_t)i].state = 2; status[i].rc = rc; status[i].stage = HESAFF_FILE_UNREADABLE; }
+            else { imgs[(size_t)i].state = 2; status[i].rc = rc; status[i].stage = stage; }
          }
          cv_img.notify_all();
       }
@@ -175,11 +194,25 @@ struct FileIO : ChunkIO {
             status[i].count_hessian = d.count_hessian[b];
             status[i].count_desc = d.count_desc[b];
             status[i].stage = HESAFF_FILE_DETECTED;
-            tasks.push_back({i, d.keys + d.key_off[b], d.count_desc[b], id});
+            Task t{i, d.keys ? d.keys + d.key_off[b] : nullptr, d.count_desc[b], id, nullptr, 0, nullptr};
+            if (d.text) { t.text = d.text + d.text_off[b]; t.text_len = (size_t)(d.text_off[b + 1] - d.text_off[b]); }
+            if (d.bin) t.bin = d.bin + d.key_off[b] * (size_t)148;
+            tasks.push_back(t);
             tasks_in_flight++;
          }
       }
       cv_task.notify_all();
+   }
+   int wants() const override
+   {
+      if (!device_format) return WANT_KEYS;
+      return ((fmt & HESAFF_OUT_TEXT) ? WANT_TEXT : 0) | ((fmt & HESAFF_OUT_BIN) ? WANT_BIN : 0);
+   }
+   bool failed(const HostChunk &q, int rc) override
+   {
+      std::lock_guard<std::mutex> lk(mu);
+      for (int i : q.index) { status[i].rc = rc; status[i].stage = HESAFF_FILE_REJECTED; }
+      return true;
    }
    void write_loop()
    {
@@ -196,11 +229,13 @@ struct FileIO : ChunkIO {
          int rc = HESAFF_OK;
          if (fmt & HESAFF_OUT_TEXT) {
             const std::string name = o ? std::string(o) : std::string(paths[t.index]) + ".hesaff.sift";   // hesaff.cpp:170-173
-            rc = hesaff_write_sift_mt(name.c_str(), t.keys, t.n, mrSize, 1);
+            if (device_format) rc = hesaff_write_sift_rows(name.c_str(), t.text, t.text_len, t.n);
+            else rc = hesaff_write_sift_mt(name.c_str(), t.keys, t.n, mrSize, 1);
          }
          if ((fmt & HESAFF_OUT_BIN) && rc == HESAFF_OK) {
             const std::string name = o ? (std::string(o) + ((fmt & HESAFF_OUT_TEXT) ? ".bin" : "")) : std::string(paths[t.index]) + ".hesaff.bin";
-            rc = hesaff_write_bin(name.c_str(), t.keys, t.n, mrSize);
+            if (device_format) rc = hesaff_write_bin_rows(name.c_str(), t.bin, t.n);
+            else rc = hesaff_write_bin(name.c_str(), t.keys, t.n, mrSize);
          }
          int blk = -1;
          {

@@ -23,6 +23,7 @@
 #include <zlib.h>
 
 #include "../../include/hesaff_amd.h"
+#include "export_fmt.h"
 
 namespace {
 
@@ -152,71 +153,13 @@ int read_png_bytes(const std::vector<uint8_t> &f, uint8_t **data, int *width, in
 // the format exportKeypoints uses (hesaff.cpp:125).  snprintf is the definition ...
 inline int fmt_g_libc(char *dst, float v) { return snprintf(dst, 32, "%g", (double)v); }
 
-// ... and this is the fast path that produces the same bytes with exact integer arithmetic:
-// v = mant * 2^e (e < 0 in the range handled here), so the six significant digits are
-// round-half-even((mant * 10^(5-X)) >> -e) with X = floor(log10 v); the product fits 128 bits
-// for 1e-22 <= |v| < 1e6.  Everything else (larger, smaller, inf, nan) goes to libc.
-// tests/test_host_side.py compares both on millions of floats.
-typedef unsigned __int128 u128;
-struct Pow10Table {
-   u128 p[28];
-   Pow10Table() { p[0] = 1; for (int i = 1; i < 28; i++) p[i] = p[i - 1] * 10u; }
-};
-const Pow10Table kP10;
-
+// ... and export_fmt.h (shared with the GPU formatter, kernels_export.h) produces the same bytes with exact integer
+// arithmetic over the whole binary32 range.  tests/test_host_side.py compares both on millions of floats.
 inline int fmt_g(char *dst, float vf)
 {
-   uint32_t bits;
-   memcpy(&bits, &vf, 4);
-   const uint32_t ex = (bits >> 23) & 255u, fr = bits & 0x7fffffu;
-   char *p = dst;
-   if (ex == 0 && fr == 0) {
-      if (bits >> 31) *p++ = '-';
-      *p++ = '0';
-      return (int)(p - dst);
-   }
-   if (ex == 255 || ex == 0) return fmt_g_libc(dst, vf);   // inf, nan, denormal
-   const uint32_t mant = fr | 0x800000u;
-   const int e = (int)ex - 150;   // |v| = mant * 2^e, 2^23 <= mant < 2^24
-   if (e >= 0) return fmt_g_libc(dst, vf);   // |v| >= 2^23 > 1e6
-   const int sh = -e;
-   int X = (int)std::floor((23 + e) * 0.30102999566398120);   // floor(log10 |v|) or one less
-   u128 q = 0, rem = 0, half = 0;
-   for (int tries = 0;; tries++) {
-      if (X > 5 || X < -22 || tries > 2 || sh > 126) return fmt_g_libc(dst, vf);
-      const u128 N = (u128)mant * kP10.p[5 - X];   // < 2^24 * 10^27 < 2^114
-      q = N >> sh;
-      if (q >= 1000000u) { X++; continue; }
-      if (q < 100000u) { X--; continue; }
-      rem = N & ((((u128)1) << sh) - 1);
-      half = ((u128)1) << (sh - 1);
-      break;
-   }
-   unsigned d = (unsigned)q;
-   if (rem > half || (rem == half && (d & 1u))) d++;
-   if (d == 1000000u) { d = 100000u; X++; }
-   if (bits >> 31) *p++ = '-';
-   char dig[6];
-   for (int i = 5; i >= 0; i--) { dig[i] = (char)('0' + d % 10); d /= 10; }
-   int nd = 6;
-   while (nd > 1 && dig[nd - 1] == '0') nd--;   // %g strips trailing zeros
-   if (X < -4 || X >= 6) {
-      *p++ = dig[0];
-      if (nd > 1) { *p++ = '.'; for (int i = 1; i < nd; i++) *p++ = dig[i]; }
-      *p++ = 'e';
-      int ax = X;
-      if (ax < 0) { *p++ = '-'; ax = -ax; } else *p++ = '+';
-      *p++ = (char)('0' + ax / 10);
-      *p++ = (char)('0' + ax % 10);
-   } else if (X >= 0) {
-      for (int i = 0; i <= X; i++) *p++ = dig[i];   // nd may be <= X: the stripped zeros belong to the integer part
-      if (nd > X + 1) { *p++ = '.'; for (int i = X + 1; i < nd; i++) *p++ = dig[i]; }
-   } else {
-      *p++ = '0'; *p++ = '.';
-      for (int i = 0; i < -X - 1; i++) *p++ = '0';
-      for (int i = 0; i < nd; i++) *p++ = dig[i];
-   }
-   return (int)(p - dst);
+   HxPtr out{dst};
+   hx_fmt_g(out, vf);
+   return (int)(out.p - dst);
 }
 
 // " 0" .. " 255": the separator and the digits of one descriptor byte as one 4-byte store + its length (a row is 128 of
@@ -420,38 +363,10 @@ int hesaff_read_image(const char *path, uint8_t **data, int *width, int *height,
    return HESAFF_ERR_IO;
 }
 
-// hesaff.cpp:115-123, statement by statement:
-//    float sc = mrSize * k.s;  SVD svd(A, FULL_UV);  d[i] = 1.0f/(d[i]*d[i]*sc*sc);
-//    A = svd.u * Mat::diag(svd.w) * svd.u.t();   ->  a = A(0,0), b = A(0,1), c = A(1,1)
-// cv::SVD (OpenCV's float Jacobi solver) is replaced by the closed-form symmetric
-// eigen-decomposition of A A^T evaluated in double; u and w are then stored as float like the
-// members of cv::SVD, d is the reference's float expression and the two matrix products
-// accumulate in double like cv::gemm does for CV_32F.  (a,b,c) carry the 1e-4 tolerance of
-// north_star; on SURVEY.md App. C's 640x480 input this form reproduces the md5 of the compiled
-// reference's output file.
+// hesaff.cpp:115-123 in closed form: export_fmt.h (one definition for the host writer and the GPU formatter)
 void hesaff_ellipse(const hesaff_keypoint *k, float mrSize, float *a, float *b, float *c)
 {
-   const float sc = mrSize * k->s;
-   const double a11 = k->a11, a12 = k->a12, a21 = k->a21, a22 = k->a22;
-   const double m00 = a11 * a11 + a12 * a12, m01 = a11 * a21 + a12 * a22, m11 = a21 * a21 + a22 * a22;
-   const double tr = m00 + m11, df = m00 - m11;
-   const double disc = std::sqrt(df * df + 4.0 * m01 * m01);
-   const double l1 = (tr + disc) / 2.0, l2 = (tr - disc) / 2.0;
-   // unit eigenvector of the larger eigenvalue: (l1 - m11, m01) or (m01, l1 - m00), the longer one
-   double vx = l1 - m11, vy = m01;
-   const double ux = m01, uy = l1 - m00;
-   if (ux * ux + uy * uy > vx * vx + vy * vy) { vx = ux; vy = uy; }
-   const double n = std::sqrt(vx * vx + vy * vy);
-   float cu = 1.0f, su = 0.0f;
-   if (n > 0) { cu = (float)(vx / n); su = (float)(vy / n); }
-   float w0 = (float)std::sqrt(l1), w1 = (float)std::sqrt(l2);
-   w0 = 1.0f / (w0 * w0 * sc * sc);
-   w1 = 1.0f / (w1 * w1 * sc * sc);
-   const float p00 = (float)((double)cu * w0), p01 = (float)(-(double)su * w1);
-   const float p10 = (float)((double)su * w0), p11 = (float)((double)cu * w1);
-   *a = (float)((double)p00 * cu + (double)p01 * -su);
-   *b = (float)((double)p00 * su + (double)p01 * cu);
-   *c = (float)((double)p10 * su + (double)p11 * cu);
+   hx_ellipse(k->s, k->a11, k->a12, k->a21, k->a22, mrSize, a, b, c);
 }
 
 int hesaff_format_sift(const hesaff_keypoint *keys, int n, float mrSize, char **out, size_t *len)
@@ -616,6 +531,46 @@ int hesaff_write_bin(const char *path, const hesaff_keypoint *keys, int n, float
    if (close(fd) != 0) ok = false;
    return ok ? HESAFF_OK : HESAFF_ERR_IO;
    HOSTIO_CATCH
+}
+
+// a whole buffer to an open descriptor
+static bool write_all(int fd, const char *q, size_t left)
+{
+   while (left > 0) {
+      const ssize_t w = write(fd, q, left < ((size_t)1 << 30) ? left : ((size_t)1 << 30));
+      if (w < 0) { if (errno == EINTR) continue; return false; }
+      q += w; left -= (size_t)w;
+   }
+   return true;
+}
+
+// The file of hesaff.cpp:109-128 from rows that are already text (formatted on the device, kernels_export.h): the two header
+// lines, then the rows as they are.
+int hesaff_write_sift_rows(const char *path, const char *rows, size_t len, int n)
+{
+   if (!path || n < 0 || (len > 0 && !rows)) return HESAFF_ERR_ARG;
+   const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+   if (fd < 0) return HESAFF_ERR_IO;
+   char head[64];
+   const int hl = snprintf(head, sizeof head, "%d\n%d\n", 128, n);
+   bool ok = write_all(fd, head, (size_t)hl) && write_all(fd, rows, len);
+   if (close(fd) != 0) ok = false;
+   return ok ? HESAFF_OK : HESAFF_ERR_IO;
+}
+
+// hesaff_write_bin's file from rows that are already packed (148 bytes each)
+int hesaff_write_bin_rows(const char *path, const char *rows, int n)
+{
+   if (!path || n < 0 || (n > 0 && !rows)) return HESAFF_ERR_ARG;
+   const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+   if (fd < 0) return HESAFF_ERR_IO;
+   char head[16];
+   memcpy(head, "HESAFFB1", 8);
+   const uint32_t dim = 128, cnt = (uint32_t)n;
+   memcpy(head + 8, &dim, 4); memcpy(head + 12, &cnt, 4);
+   bool ok = write_all(fd, head, 16) && write_all(fd, rows, (size_t)n * 148);
+   if (close(fd) != 0) ok = false;
+   return ok ? HESAFF_OK : HESAFF_ERR_IO;
 }
 
 // One file per image of a batch (exportKeypoints once per image, hesaff.cpp:170-176), images

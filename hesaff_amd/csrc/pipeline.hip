@@ -13,6 +13,7 @@
 // schedule, let alone its results, because of an environment variable.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -32,6 +33,7 @@
 #include "kernels_patch.h"
 #include "kernels_sift.h"
 #include "kernels_pyramid.h"
+#include "kernels_export.h"
 #include "fast_api.h"
 #include "chunk_engine.h"
 
@@ -203,6 +205,13 @@ struct hesaff_ctx {
          if (e != hipSuccess) { p = nullptr; throw HsError(HESAFF_ERR_NOMEM, std::string("hipHostMalloc failed: ") + hipGetErrorString(e)); }
          bytes = need;
       }
+      // a block that is asked for a little more every other chunk (result blocks: the chunks' keypoint counts differ) grows with
+      // head-room, so that hipHostFree + hipHostMalloc (hundreds of MB, device-synchronising) stop after the first chunks
+      void ensure_grow(size_t need)
+      {
+         if (need <= bytes) return;
+         ensure((need + need / 4 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1));
+      }
       void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
    };
    Pinned pin_in[2];
@@ -212,6 +221,7 @@ struct hesaff_ctx {
    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_in_free[2] = {nullptr, nullptr}, ev_out_ready[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
    std::vector<int32_t> h_starts;
    DevBuf t_mask_idx, t_sgrad_nb, t_sgrad_om, b_rowprefix, b_trows, b_trows2, b_trows3;
+   DevBuf b_ex_len, b_ex_sums, b_ex_off, b_ex_imgoff, b_ex_starts;   // device export (kernels_export.h): row lengths, sums / offsets per 64 rows, offsets per image
    size_t rows_lds_set = 0;            // dynamic LDS opt-in of k_patch_large_rows on THIS device
    // persistent grids of the LDS-window kernels: exactly as many blocks as the device holds at once (CUs x resident
    // blocks per CU), so that every block takes the same share of a bin's list; queried per device at hesaff_create
@@ -222,6 +232,7 @@ struct hesaff_ctx {
    hesaff_timings tm;
    int profiling = 0;
    int out_format = HESAFF_OUT_TEXT;   // hesaff_set_output_format
+   int stage_threads = 4;              // host threads that copy a chunk's pixels into pinned memory (hesaff_process_files: within its thread budget)
    hipStream_t side_streams[HS_NSIDE] = {nullptr, nullptr, nullptr, nullptr};
    hipStream_t sift_stream = nullptr, sift_stream2 = nullptr;   // descriptor kernels of even / odd groups (sift2: HESAFF_SIFT2)
    bool sift2 = true;
@@ -1075,6 +1086,44 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
    if (cn[2] != 0 || (uint32_t)cn[1] > c->cap)
       throw HsError(HESAFF_ERR_CAPACITY, "keypoint capacity exceeded; raise hesaff_params.max_kpts_per_mpx");
    if (cn[6] != 0) throw HsError(HESAFF_ERR_NOMEM, "large-window row buffer exceeded (internal bound violated)");
+}
+
+// ---- exportKeypoints on the device (kernels_export.h) ----
+// Lengths of the n rows of `keys`, their 64-row offsets, and the byte offset of every image's first row (d_starts: B + 1 row
+// starts on the device).  The host waits for the stream here: it needs the byte counts to size the copy out.
+unsigned long long export_text_prepare(hesaff_ctx *c, const KeyRec *keys, uint32_t n, const int32_t *d_starts, int B,
+                                       std::vector<unsigned long long> &img_off)
+{
+   img_off.assign((size_t)B + 1, 0ull);
+   if (n == 0) return 0ull;
+   hipStream_t st = c->stream;
+   const uint32_t nblk = (n + EX_ROWS - 1) / EX_ROWS;
+   c->b_ex_len.ensure(((size_t)n + 64) * 2);
+   c->b_ex_sums.ensure((size_t)nblk * 4);
+   c->b_ex_off.ensure(((size_t)nblk + 1) * 8);
+   c->b_ex_imgoff.ensure(((size_t)B + 1) * 8);
+   hipLaunchKernelGGL(k_text_len, dim3((n + 255) / 256), dim3(256), 0, st, keys, n, c->par.mrSize, c->b_ex_len.as<uint16_t>(), c->b_ex_sums.as<uint32_t>());
+   hipLaunchKernelGGL(k_text_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)c->b_ex_sums.p, nblk, c->b_ex_off.as<unsigned long long>());
+   hipLaunchKernelGGL(k_text_imgoff, dim3((B + 1 + 63) / 64), dim3(64), 0, st, d_starts, B, (const uint16_t *)c->b_ex_len.p,
+                      (const unsigned long long *)c->b_ex_off.p, c->b_ex_imgoff.as<unsigned long long>());
+   HIP_TRY(hipMemcpyAsync(img_off.data(), c->b_ex_imgoff.p, ((size_t)B + 1) * 8, hipMemcpyDeviceToHost, st));
+   HIP_TRY(hipStreamSynchronize(st));
+   HIP_TRY(hipGetLastError());
+   return img_off[(size_t)B];
+}
+
+// ... and the rows themselves into d_text (export_text_prepare's byte count), on the main stream
+void export_text_write(hesaff_ctx *c, const KeyRec *keys, uint32_t n, char *d_text)
+{
+   if (n == 0) return;
+   hipLaunchKernelGGL(k_text_write, dim3((n + EX_ROWS - 1) / EX_ROWS), dim3(EX_ROWS), 0, c->stream, keys, n, c->par.mrSize, (const uint16_t *)c->b_ex_len.p,
+                      (const unsigned long long *)c->b_ex_off.p, d_text);
+}
+
+void export_bin_rows(hesaff_ctx *c, const KeyRec *keys, uint32_t n, char *d_bin)
+{
+   if (n == 0) return;
+   hipLaunchKernelGGL(k_bin_rows, dim3(std::min<uint32_t>((n + 7) / 8, 4096u)), dim3(256), 0, c->stream, keys, n, c->par.mrSize, (uint32_t *)d_bin);
 }
 
 } // namespace

@@ -30,8 +30,9 @@ extern "C" {
  * carries a size field, so a caller built against another header would pass shifted fields without any error: callers
  * compare hesaff_abi_version() (and, if they wish, the two sizeof functions) with the header they were compiled against
  * before the first hesaff_create - hesaff.hpp and the Python binding do.  New fields are appended at the END of a
- * struct and bump this number.   1: round 1;  2: + upscaleInputImage, fast, pack_ms (inserted mid-struct);  3: this header. */
-#define HESAFF_ABI_VERSION 3
+ * struct and bump this number.   1: round 1;  2: + upscaleInputImage, fast, pack_ms (inserted mid-struct);  3: + extrema_*;
+ * 4: this header (hesaff_params.fast = 1 withdrawn, HESAFF_FILE_REJECTED, rows formatted on the device). */
+#define HESAFF_ABI_VERSION 4
 int hesaff_abi_version(void);
 size_t hesaff_sizeof_params(void);
 size_t hesaff_sizeof_timings(void);
@@ -146,6 +147,9 @@ int hesaff_detect_batch_cb(hesaff_ctx *ctx, int n, const uint8_t *const *images,
 #define HESAFF_FILE_UNREADABLE 1
 #define HESAFF_FILE_DETECTED 2  /* detected and described, but the output file could not be written (rc says why) */
 #define HESAFF_FILE_WRITTEN 3
+#define HESAFF_FILE_REJECTED 4  /* decoded, but the device refused it: a side above 65535 pixels or a window the kernels cannot hold
+                                   (rc = HESAFF_ERR_ARG), more keypoints than max_kpts_per_mpx plans for (HESAFF_ERR_CAPACITY); the other
+                                   files of the list are not affected */
 typedef struct hesaff_file_status {
    int32_t rc;                 /* HESAFF_OK only in stage HESAFF_FILE_WRITTEN */
    int32_t stage;              /* how far this file got: HESAFF_FILE_* */
@@ -184,6 +188,11 @@ int hesaff_write_sift_mt(const char *path, const hesaff_keypoint *keys, int n, f
  * 128 descriptor bytes, 148 bytes per row instead of about 355 bytes of text.  Little-endian:
  *   char magic[8] = "HESAFFB1"; uint32 dim = 128; uint32 count; count x { float x, y, a, b, c; uint8 desc[128] } */
 int hesaff_write_bin(const char *path, const hesaff_keypoint *keys, int n, float mrSize);
+/* The same two files from rows that are already formatted / packed - hesaff_process_files formats them on the device
+ * (kernels_export.h) so that its writer threads only write: `rows` = len bytes of "x y a b c d1 .. d128\n" lines (n of them) or
+ * n rows of 148 bytes; the header lines (hesaff.cpp:109-110) / the 16-byte sidecar header are added here. */
+int hesaff_write_sift_rows(const char *path, const char *rows, size_t len, int n);
+int hesaff_write_bin_rows(const char *path, const char *rows, int n);
 /* formats into a malloc'ed buffer (*out, *len); caller frees with hesaff_free */
 int hesaff_format_sift(const hesaff_keypoint *keys, int n, float mrSize, char **out, size_t *len);
 /* the same bytes, rows formatted by `threads` host threads (0 = one per core, at most 64);
@@ -251,6 +260,13 @@ int hesaff_stage_normalize_affine(hesaff_ctx *ctx, const float *img, int rows, i
 /* SIFTDescriptor::computeSiftDescriptor siftdesc.cpp:115-140 for n 41x41 patches;
  * desc[n][128] = the values of `vec` cast as at hesaff.cpp:91. */
 int hesaff_stage_sift(hesaff_ctx *ctx, int n, const float *patches, uint8_t *desc);
+/* exportKeypoints hesaff.cpp:107-130 on the device for n records in host memory (what hesaff_process_files runs per chunk):
+ * format = HESAFF_OUT_TEXT: the bytes of the .hesaff.sift file, == hesaff_format_sift; HESAFF_OUT_BIN: the bytes of the sidecar,
+ * == hesaff_write_bin's file.  *out is malloc'ed (hesaff_free). */
+int hesaff_stage_export(hesaff_ctx *ctx, const hesaff_keypoint *keys, int n, float mrSize, int format, char **out, size_t *len);
+/* the device's "%g" print of n floats: 16 bytes per value in text (unused bytes 0) and its length in lens; for testing that
+ * it equals the host's over the whole binary32 range */
+int hesaff_stage_fmt_g(hesaff_ctx *ctx, int n, const float *v, char *text, int32_t *lens);
 /* device evaluation of the pinned libm restatements (hmath.h) for testing */
 int hesaff_stage_math(hesaff_ctx *ctx, int n, const float *a, const float *b, float *atan2_out, float *pow2_out);
 /* the per-pixel forms of the descriptor gradient (helpers.cpp:269-280, siftdesc.cpp:123-137): orientation atan2f(gy, gx) and

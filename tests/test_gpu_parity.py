@@ -983,3 +983,138 @@ def test_fuzz_ragged_sizes_and_structured_content(ctx, oracle):
                 assert_bit_equal(keys[name], g[:, j], "%s of image %d (%s %s)" % (name, i, kinds[i % 5], img.shape))
         total += len(keys)
     assert total > 3000
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# exportKeypoints on the device (kernels_export.h; hesaff.cpp:107-130): the writer threads of hesaff_process_files only write()
+# ---------------------------------------------------------------------------------------------------------------
+def _fmt_g_inputs():
+    rng = np.random.default_rng(77)
+    every_exponent = (np.arange(0, 256, dtype=np.uint32)[:, None] << 23 | rng.integers(0, 1 << 23, (256, 64), dtype=np.uint32)).reshape(-1)
+    parts = [
+        rng.integers(0, 2**32, 1_000_000, dtype=np.uint64).astype(np.uint32).view(np.float32),            # any bit pattern
+        every_exponent.view(np.float32), (every_exponent | 0x80000000).view(np.float32),                    # every binade, both signs
+        (np.arange(0, 256, dtype=np.uint32) << 23).view(np.float32),                                        # every power of two, 0, inf
+        ((np.arange(1, 256, dtype=np.uint32) << 23) - 1).view(np.float32),                                  # ... and the value below it
+        rng.integers(0, 1 << 23, 50_000, dtype=np.uint32).view(np.float32),                                 # denormals
+        (10.0 ** np.arange(-45, 39, dtype=np.float64)).astype(np.float32),                                  # decimal powers
+        np.nextafter((10.0 ** np.arange(-44, 39, dtype=np.float64)).astype(np.float32), np.float32(0)),     # ... and the value below
+        rng.uniform(0, 4096, 500_000).astype(np.float32),                                                   # coordinates
+        (10.0 ** rng.uniform(-8, 2, 500_000) * rng.choice([-1.0, 1.0], 500_000)).astype(np.float32),        # ellipse terms
+        np.array([0.0, -0.0, 999999.5, 999999.4, 999999.96, 9.9999995e-5, 123456.5, 1234565.0, 8388608.0, 8388607.5, 16777216.0, 1e22,
+                  1e-22, 9.5e-23, 1e23, np.inf, -np.inf, np.nan, -np.nan, 3.4028235e38, 1.17549435e-38, 1e-45], np.float32),
+        (np.arange(0, 500_000, dtype=np.float32) + 0.5) / np.float32(8.0),                                  # exact binary ties
+        (np.arange(1, 300_001, dtype=np.float64) * 1e-6 + 0.5e-6).astype(np.float32),                      # decimal near-ties
+    ]
+    return np.ascontiguousarray(np.concatenate(parts), np.float32)
+
+
+def test_device_float_print_equals_printf_g(ctx):
+    """The device's "%g" (export_fmt.h compiled for gfx950: 128-bit fast path, 256-bit division everywhere else) prints every
+    float like snprintf("%g") on the host does - the format of operator<<(ostream&, float), hesaff.cpp:125."""
+    import hesaff_amd
+    v = _fmt_g_inputs()
+    assert hesaff_amd.load_library().hesaff_test_fmt_g(v, len(v)) == 0          # host build of the same header == libc
+    text, lens = ctx.fmt_g(v)
+    want = np.char.mod("%g", v.astype(np.float64))
+    neg_nan = np.isnan(v) & (v.view(np.uint32) >> 31 == 1)                        # numpy prints "nan" for both signs, glibc "-nan"
+    want[neg_nan] = "-nan"
+    got = text.view("S16").reshape(-1)
+    assert lens.min() >= 1 and lens.max() <= 12
+    bad = np.flatnonzero(got != want.astype("S16"))
+    assert len(bad) == 0, [(float(v[i]), got[i], want[i]) for i in bad[:10]]
+    assert np.array_equal(lens, np.char.str_len(want))
+
+
+def test_device_export_equals_host_writer_and_oracle(ctx, oracle):
+    """hesaff_stage_export (the kernels hesaff_process_files formats every chunk with) gives, byte for byte, the file the host
+    writer gives and the oracle's exportKeypoints text: golden images, SURVEY App. C's probe (its md5), a 3840x2160 image; the
+    sidecar rows equal hesaff_write_bin's."""
+    import hashlib
+    import json
+    import hesaff_amd
+    mr = ctx.params.mrSize
+    for name in ["band_131x77", "band_96x96", "band_160x120", "tiny_20x15"]:
+        img = hesaff_amd.read_pnm(os.path.join(GOLD, name + ".pgm"))
+        (_, keys), = ctx.detect_batch([img])
+        want = open(os.path.join(GOLD, name + ".hesaff.sift"), "rb").read()
+        assert ctx.export(keys) == want == oracle.OracleRun(oracle.gray_from_u8(img)).export_text(), name
+    man = json.load(open(os.path.join(GOLD, "manifest.json")))["probe_vga"]
+    (_, keys), = ctx.detect_batch([hesaff_amd.read_pnm(os.path.join(GOLD, "probe_vga.pgm"))])
+    assert hashlib.md5(ctx.export(keys)).hexdigest() == man["sift_md5"]
+    img = band_noise_image(2160, 3840, 1234)
+    (_, keys), = ctx.detect_batch([img])
+    text = ctx.export(keys)
+    assert text == hesaff_amd.format_sift(keys, mr) and len(keys) > 100000 and len(text) > 30_000_000
+    assert text == oracle.OracleRun(oracle.gray_from_u8(img)).export_text()
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        q = os.path.join(d, "x.bin")
+        hesaff_amd.write_bin(q, keys, mr)
+        assert ctx.export(keys, fmt=2) == open(q, "rb").read()
+        # the writer half: header + rows as they are
+        L = hesaff_amd.load_library()
+        body = text[text.index(b"\n", 4) + 1:]
+        assert L.hesaff_write_sift_rows(os.fsencode(q), body, len(body), len(keys)) == 0 and open(q, "rb").read() == text
+
+
+def test_device_export_of_arbitrary_records(ctx):
+    """Records no image produces - non-finite and denormal coordinates, degenerate shapes, every descriptor byte value, row
+    counts around the 64-row blocks of the write kernel - still print like the host writer prints them."""
+    import hesaff_amd
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 63, 64, 65, 127, 4097, 70001):
+        keys = np.zeros(n, hesaff_amd.KEYPOINT_DTYPE)
+        for f in ("x", "y", "s", "a11", "a12", "a21", "a22"):
+            keys[f] = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+        half = n // 2
+        keys["x"][:half] = rng.uniform(0, 4000, half); keys["y"][:half] = rng.uniform(0, 2200, half); keys["s"][:half] = rng.uniform(0.5, 90, half)
+        keys["a11"][:half] = rng.uniform(0.3, 3, half); keys["a12"][:half] = 0; keys["a21"][:half] = rng.uniform(-2, 2, half)
+        keys["a22"][:half] = 1.0 / keys["a11"][:half]
+        keys["desc"] = rng.integers(0, 256, (n, 128), dtype=np.uint8)
+        if n > 300:
+            keys["desc"][:256] = np.arange(256, dtype=np.uint8)[:, None]
+            keys["desc"][256] = 255; keys["desc"][257] = 0
+        for mr in (5.196152, 1.0):
+            assert ctx.export(keys, mr) == hesaff_amd.format_sift(keys, mr), (n, mr)
+        bin_rows = ctx.export(keys, 5.196152, fmt=2)
+        assert len(bin_rows) == 16 + 148 * n and bin_rows[:8] == b"HESAFFB1"
+        rows = np.frombuffer(bin_rows[16:], dtype=hesaff_amd.BIN_ROW_DTYPE)
+        assert np.array_equal(rows["desc"], keys["desc"]) and np.array_equal(rows["x"].view(np.uint32), keys["x"].view(np.uint32))
+        if n:
+            e = hesaff_amd.ellipse(keys[: min(n, 500)], 5.196152)
+            assert np.array_equal(np.stack([rows[k][: len(e)] for k in "abc"], 1).view(np.uint32), e.view(np.uint32))
+
+
+def test_process_files_isolates_images_the_device_refuses(tmp_path, oracle):
+    """one image the device cannot take - a side above 65535 pixels, or more keypoints than max_kpts_per_mpx plans
+    for - is reported per file (HESAFF_FILE_REJECTED) and the rest of the list is written."""
+    import hesaff_amd
+    from tests import _oracle
+    paths = []
+    imgs = [band_noise_image(120, 160, 500 + i, SMALL_BANDS) for i in range(5)]
+    for i, img in enumerate(imgs):
+        q = tmp_path / ("g%d.pgm" % i)
+        q.write_bytes(b"P5\n160 120\n255\n" + img.tobytes())
+        paths.append(str(q))
+    wide = tmp_path / "wide.pgm"
+    wide.write_bytes(b"P5\n70000 8\n255\n" + bytes(70000 * 8))
+    paths.insert(2, str(wide))
+    p = hesaff_amd.default_params(); p.max_batch = 2
+    with hesaff_amd.HesaffContext(p, device=0) as ctx:
+        st = ctx.process_files(paths, decode_threads=2, write_threads=2)
+    for i, (rc, stage, nh, nd) in enumerate(st):
+        if i == 2:
+            assert (rc, stage) == (-2, 4)                     # HESAFF_ERR_ARG, HESAFF_FILE_REJECTED
+        else:
+            assert (rc, stage) == (0, 3), (i, rc, stage)
+            img = imgs[i if i < 2 else i - 1]
+            assert open(paths[i] + ".hesaff.sift", "rb").read() == _oracle.OracleRun(_oracle.gray_from_u8(img)).export_text()
+    # capacity: 1000 keypoints per Mpx planned (4096 at least), a 640x480 dense image has more than 4096 candidates
+    dense = tmp_path / "dense.pgm"
+    dense.write_bytes(b"P5\n640 480\n255\n" + band_noise_image(480, 640, 9).tobytes())
+    paths2 = [paths[0], str(dense), paths[1], paths[3]]
+    p = hesaff_amd.default_params(); p.max_batch = 1; p.max_kpts_per_mpx = 1000
+    with hesaff_amd.HesaffContext(p, device=0) as ctx:
+        st = ctx.process_files(paths2, decode_threads=1, write_threads=1)
+    assert [(rc, stage) for rc, stage, _, _ in st] == [(0, 3), (-3, 4), (0, 3), (0, 3)]
