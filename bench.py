@@ -242,6 +242,11 @@ def launch_ranks(n):
     has initialised the GPU (torch is not even imported yet); the ranks are ordinary child processes."""
     import socket
     import subprocess
+    if os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl":
+        import torch   # device_count() does not initialise the GPU (the ranks are started as children afterwards)
+        have = torch.cuda.device_count()
+        if n > have:
+            raise SystemExit("bench.py: --gpus %d but this node has %d visible GPU(s): one rank per GPU over RCCL needs %d" % (n, have, n))
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -261,17 +266,20 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (BASELINE.json: 2048 UHD images over 8 GPUs)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--density", choices=("dense", "natural"), default="dense",
-                    help="synthetic image family: dense = the headline workload (about 14 k descriptors per Mpx), natural = about 2.5 k per Mpx (photograph-like)")
+    ap.add_argument("--density", choices=("dense", "natural", "photo"), default="dense",
+                    help="image family: dense = the headline workload (band noise, about 14 k descriptors per Mpx); natural = the same family one octave "
+                         "coarser (2.5 k per Mpx); photo = mosaics of scikit-learn's sample photographs (about 3.5 k per Mpx)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-inclusive and text-export legs")
     ap.add_argument("--host-chunk", type=int, default=64, help="images per pipelined chunk of the host path (hesaff_params.max_batch)")
     ap.add_argument("--export-images", type=int, default=32, help="images of the batch written as .hesaff.sift text (RAM disk)")
-    ap.add_argument("--cpu-images", type=int, default=2, help="images of the batch timed on the CPU oracle, 1 thread (about 14 s each)")
+    ap.add_argument("--cpu-images", type=int, default=4, help="images of the batch timed on the CPU oracle, 1 thread (about 14 s each)")
     ap.add_argument("--cpu-workers", type=int, default=-1,
                     help="worker processes of the multi-core CPU baseline, one image each (-1: one per physical core, at most the batch; 0: skip)")
-    ap.add_argument("--fast-steps", type=int, default=2, help="steps of the two fast-mode legs of the default run (0: skip)")
-    ap.add_argument("--natural-steps", type=int, default=2, help="steps of the extra photograph-like-density leg of the default run (0: skip)")
+    ap.add_argument("--fast-steps", type=int, default=2, help="steps of the fast-mode leg (hesaff_params.fast = 2) of the default run (0: skip)")
+    ap.add_argument("--photo-steps", type=int, default=2, help="steps of the extra leg on photographs of the default run (0: skip)")
+    ap.add_argument("--e2e-decode-threads", type=int, default=2, help="decoder threads of the end-to-end leg, per rank")
+    ap.add_argument("--e2e-write-threads", type=int, default=2, help="writer threads of the end-to-end leg, per rank (2 + 2 = one device's share of 16 CPUs over 8 GPUs)")
     ap.add_argument("--e2e-images", type=int, default=512, help="image files of the measured end-to-end file path (0: skip; fewer when the RAM disk is small)")
     ap.add_argument("--e2e-chunk", type=int, default=32, help="images per device chunk of the end-to-end leg (hesaff_params.max_batch)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
@@ -306,10 +314,12 @@ def main():
     if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
+        import datetime
+        tmo = datetime.timedelta(minutes=30)   # rank 0 alone runs the CPU legs at the end; no collective waits for them
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=tmo)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libhesaff_amd has no CPU fallback)")
     dev = torch.device("cuda", local_rank)
@@ -331,10 +341,13 @@ def main():
         # weak scaling: every rank owns --batch distinct images (global image index = rank * batch + i)
         per_rank = B = args.batch
         g_lo = rank * B
-    from hesaff_amd.synth import BANDS, BANDS_NATURAL
+    from hesaff_amd.synth import BANDS, BANDS_NATURAL, photo_mosaic_batch_torch
     bands = BANDS_NATURAL if args.density == "natural" else BANDS
     # B distinct images per rank (seeded by global image index); a rank whose share exceeds B cycles through them
-    imgs = band_noise_batch_torch(B, H, W, seed=1234 + g_lo, device=dev, bands=bands)
+    if args.density == "photo":
+        imgs = photo_mosaic_batch_torch(B, H, W, first_index=g_lo, device=dev)
+    else:
+        imgs = band_noise_batch_torch(B, H, W, seed=1234 + g_lo, device=dev, bands=bands)
     torch.cuda.synchronize()
 
     p = hesaff_amd.default_params()
@@ -387,35 +400,21 @@ def main():
     tot_hess, tot_desc, tot_imgs = [int(v) for v in counts.sum(axis=0)]
     per_rank_images = [int(v) for v in counts[:, 2]]
     ctx.close()
-    fast_modes = None
-    if rank == 0 and args.fast_steps > 0 and not args.no_host_path:
-        fast_modes = {"what": "the same device-resident step with hesaff_params.fast = 1 (same algorithm, free summation order, fused on-chip "
-                              "descriptor) and = 2 (+ windows larger than the patch sampled from the scale space); NOT bit-exact, not the headline "
-                              "value; mismatch rates in profiles/r03_fast_mode*.json",
-                      "fast_1": fast_leg(hesaff_amd, torch, imgs, local_rank, B, H, W, 1, args.fast_steps),
-                      "fast_2": fast_leg(hesaff_amd, torch, imgs, local_rank, B, H, W, 2, args.fast_steps)}
-    probe = hbm_probe(torch, dev) if rank == 0 else None
-    natural = None
-    if rank == 0 and args.natural_steps > 0 and args.density == "dense" and not args.no_host_path:
-        natural = density_leg(hesaff_amd, torch, dev, local_rank, B, H, W, 1234 + g_lo, args.natural_steps)
 
-    # ---- host-inclusive leg: host images -> hesaff_detect_batch -> host records, + text export ----
+    # ---- host-inclusive legs, EVERY rank at the same time: hesaff_detect_batch, then the file path ----
     host_path = None
-    text_export = None
     end_to_end = None
+    host_imgs = None
     if not args.no_host_path:
         hp = hesaff_amd.default_params()
         hp.max_batch = max(1, min(args.host_chunk, B))
         hctx = hesaff_amd.HesaffContext(hp, device=local_rank)
         host_imgs = list(imgs.cpu().numpy())           # B pageable host images; the library stages them through pinned memory
-        del imgs
-        torch.cuda.empty_cache()
         hctx.detect_batch_raw(host_imgs)                   # warm-up: device buffers of both pipeline slots and one pinned result block per chunk
         hsteps = max(1, min(args.steps, 2))
         barrier()
         t1 = time.perf_counter()
         hdesc = 0
-        res = None
         for _ in range(hsteps):
             res = hctx.detect_batch_raw(host_imgs)
             hdesc += sum(r.count_desc for r in res)
@@ -431,43 +430,78 @@ def main():
                      "what": "hesaff_detect_batch: pageable host images -> pinned staging -> H2D -> kernels -> D2H -> pinned host records; "
                              "chunks of %d images, H2D of chunk i+1 and D2H of chunk i-1 beside the kernels of chunk i" % hp.max_batch,
                      "h2d_bytes_per_step": B * H * W, "d2h_bytes_per_step": int(hdesc // hsteps) * 164}
-        # text export (exportKeypoints for every image) on a bounded subset, to a RAM disk when there is one
-        if rank == 0 and args.export_images > 0:
-            ne = min(args.export_images, B)
+        hctx.close()
+        # the whole file path, measured on every rank at once: image files -> decode -> device -> .hesaff.sift files (hesaff.cpp:133-180)
+        if args.e2e_images > 0:
+            def e2e(fmt):
+                r = file_path_leg(hesaff_amd, host_imgs, W, H, args.e2e_images, args.e2e_chunk, local_rank, fmt=fmt,
+                                  decode_threads=args.e2e_decode_threads, write_threads=args.e2e_write_threads, world=world, sync=barrier)
+                barrier()
+                ok = "images_per_s" in r
+                mine = [r["images"], r["rows"], r["failed_files"], r["output_bytes"], 1] if ok else [0, 0, 0, 0, 0]
+                sec = r["seconds"] if ok else 0.0
+                if grouped:
+                    t = torch.tensor([sec], device=coll_dev, dtype=torch.float64)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    sec = float(t.item())
+                g = gather_counts(mine, device=coll_dev if grouped else None)
+                if rank != 0:
+                    return None
+                if int(g[:, 4].sum()) != world or sec <= 0:
+                    return r if not ok else {"skipped": "the leg did not run on every rank"}
+                tot = g.sum(axis=0)
+                r.update({"images": int(tot[0]), "images_per_s": float(tot[0]) / sec, "value": float(tot[1]) / sec, "rows": int(tot[1]),
+                          "failed_files": int(tot[2]), "output_bytes": int(tot[3]), "output_GB": float(tot[3]) / 1e9,
+                          "output_GB_per_s": float(tot[3]) / sec / 1e9, "seconds": sec, "ranks": world,
+                          "per_rank_images": [int(v) for v in g[:, 0]],
+                          "fraction_of_host_path": (float(tot[0]) / sec) / host_path["images_per_s"]})
+                return r
+            end_to_end = e2e(1)
+            eb = e2e(2)
+            if rank == 0 and end_to_end is not None:
+                end_to_end["binary_sidecar"] = eb
+
+    # ---- from here on rank 0 alone (no collective follows: the other ranks are done) ----
+    if grouped and rank != 0:
+        dist.destroy_process_group()
+        return
+    fast_modes = None
+    if args.fast_steps > 0 and not args.no_host_path:
+        fast_modes = {"what": "the same device-resident step with hesaff_params.fast = 2 (windows larger than the 41 x 41 patch sampled from the "
+                              "scale space instead of warped and blurred, affine.cpp:114-135); NOT bit-exact, not the headline value; "
+                              "measured effect on descriptors and matching: DESIGN.md, profiles/",
+                      "fast_2": fast_leg(hesaff_amd, torch, imgs, local_rank, B, H, W, 2, args.fast_steps)}
+    del imgs
+    torch.cuda.empty_cache()
+    probe = hbm_probe(torch, dev)
+    photo = None
+    if args.photo_steps > 0 and args.density == "dense" and not args.no_host_path:
+        photo = density_leg(hesaff_amd, torch, dev, local_rank, B, H, W, g_lo, args.photo_steps)
+    # the host formatter alone (the writer of the stage API; the file path above formats on the device)
+    text_export = None
+    if not args.no_host_path and args.export_images > 0:
+        hp = hesaff_amd.default_params()
+        hp.max_batch = max(1, min(args.host_chunk, B))
+        ne = min(args.export_images, B)
+        with hesaff_amd.HesaffContext(hp, device=local_rank) as hctx:
+            res = hctx.detect_batch_raw(host_imgs[:ne])
             base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
             tmp = tempfile.mkdtemp(prefix="hesaff_bench_", dir=base)
             try:
                 paths = [os.path.join(tmp, "img%04d.hesaff.sift" % i) for i in range(ne)]
-                hctx.write_sift_batch_raw(paths, res[:ne], hp.mrSize, 0)            # warm-up (page cache, thread pool)
+                hctx.write_sift_batch_raw(paths, res, hp.mrSize, 0)            # warm-up (page cache, thread pool)
                 t2 = time.perf_counter()
-                hctx.write_sift_batch_raw(paths, res[:ne], hp.mrSize, 0)
+                hctx.write_sift_batch_raw(paths, res, hp.mrSize, 0)
                 edt = time.perf_counter() - t2
-                rows = sum(r.count_desc for r in res[:ne])
+                rows = sum(r.count_desc for r in res)
                 nbytes = sum(os.path.getsize(q) for q in paths)
-                exp_img_s = ne / edt
-                det_img_s = host_path["images_per_s"] / max(world, 1)   # per rank
-                text_export = {"images": ne, "rows_per_s": rows / edt, "images_per_s": exp_img_s, "text_GB_per_s": nbytes / edt / 1e9,
+                text_export = {"images": ne, "rows_per_s": rows / edt, "images_per_s": ne / edt, "text_GB_per_s": nbytes / edt / 1e9,
                                "bytes_per_image": nbytes / ne, "threads": int(hctx.L.hesaff_host_threads()), "target": tmp.rsplit("/", 1)[0],
-                               # a MODEL from the two legs measured one after the other (the measured pipeline is `end_to_end` below)
-                               "end_to_end_images_per_s_modelled_min_of_legs": min(exp_img_s, det_img_s),
-                               "end_to_end_images_per_s_modelled_sequential": 1.0 / (1.0 / exp_img_s + 1.0 / det_img_s),
-                               "what": "hesaff_write_sift_batch (the reference's text format, hesaff.cpp:107-130) of %d images of the batch, "
-                                       "nothing else running" % ne}
+                               "what": "hesaff_write_sift_batch (host formatter, the reference's text format, hesaff.cpp:107-130) of %d images "
+                                       "of the batch on every host thread the CPU quota allows, nothing else running" % ne}
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
-        cpu_sample = host_imgs
-        hctx.close()
-        # ---- the whole file path, measured: image files -> decode -> device -> .hesaff.sift files (hesaff.cpp:133-180) ----
-        if rank == 0 and args.e2e_images > 0:
-            end_to_end = file_path_leg(hesaff_amd, host_imgs, W, H, args.e2e_images, args.e2e_chunk, local_rank)
-            if end_to_end and host_path and "images_per_s" in end_to_end:
-                end_to_end["fraction_of_host_path"] = end_to_end["images_per_s"] / (host_path["images_per_s"] / max(world, 1))
-                eb = file_path_leg(hesaff_amd, host_imgs, W, H, args.e2e_images, args.e2e_chunk, local_rank, fmt=2)
-                if "images_per_s" in eb:
-                    eb["fraction_of_host_path"] = eb["images_per_s"] / (host_path["images_per_s"] / max(world, 1))
-                end_to_end["binary_sidecar"] = eb
-    else:
-        cpu_sample = None
+    cpu_sample = host_imgs
 
     if rank == 0:
         achieved = (bh_bytes / 1e9) / (bh_ms / 1e3) if bh_ms > 0 else 0.0
@@ -475,8 +509,7 @@ def main():
         pyr_bytes_step = tot["pyr_bytes"] / args.steps
         ex_achieved = (bh["ex_bytes"] / 1e9) / (bh["ex_ms"] / 1e3) if bh["ex_ms"] > 0 else 0.0
         if fast_modes:
-            for k in ("fast_1", "fast_2"):
-                fast_modes[k]["speed_up_over_parity_rank0"] = (dt / args.steps * 1e3) / fast_modes[k]["ms_per_step"] if per_rank == B else None
+            fast_modes["fast_2"]["speed_up_over_parity_rank0"] = (dt / args.steps * 1e3) / fast_modes["fast_2"]["ms_per_step"] if per_rank == B else None
         out = {
             "metric": "keypoints/sec (descriptors written), 4K grayscale batch",
             "value": tot_desc / dt,
@@ -493,17 +526,19 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "batch of %d x %dx%d 8-bit grey images per GPU per step%s, band-noise synthetic%s, default params"
+            "config": {"workload": "batch of %d x %dx%d 8-bit grey images per GPU per step%s, %s, default params"
                                    % (per_rank, W, H, (" (%d distinct, cycled; library calls of %d)" % (B, B)) if per_rank > B else "",
-                                      " (natural density)" if args.density == "natural" else ""),
+                                      {"dense": "band-noise synthetic", "natural": "band-noise synthetic (natural density)",
+                                       "photo": "mosaics of two photographs"}[args.density]),
                        "images_per_gpu_per_step": per_rank, "images_per_library_call": B, "images_per_step_all_ranks": tot_imgs // max(args.steps, 1),
                        "per_rank_images_timed": per_rank_images, "width": W, "height": H, "sharding": "image-level, contiguous blocks, %d rank(s), no data-path collective; one all-gather of counts" % world,
                        "descriptors_per_image": tot_desc / max(tot_imgs, 1),
+                       "descriptors_timed_all_ranks": tot_desc, "hessian_keypoints_timed_all_ranks": tot_hess,
                        "value_is": "device-resident: inputs in HBM before the timed region, records left in HBM (hesaff_detect_batch_device)"},
             "host_path": host_path,
             "text_export": text_export,
             "end_to_end": end_to_end,
-            "natural_density": natural,
+            "photo_density": photo,
             "fast_modes": fast_modes,
             "hbm_probe": probe,
             "roofline_detect": {"bound": "hbm", "kernel": "k_extrema_march (the three 3x3x3 extrema scans of an octave in one launch; SURVEY.md 8d: "
@@ -531,7 +566,8 @@ def main():
         if not args.no_cpu_baseline:   # rank 0 only, also when world > 1 (the other ranks are done)
             from tests import _oracle
             if cpu_sample is None:
-                cpu_sample = list(imgs.cpu().numpy())
+                cpu_sample = list(band_noise_batch_torch(min(B, 16), H, W, seed=1234 + g_lo, device=dev, bands=bands).cpu().numpy()) \
+                    if args.density != "photo" else list(photo_mosaic_batch_torch(min(B, 16), H, W, first_index=g_lo, device=dev).cpu().numpy())
             cpu = host_cpu_info()
             host = cpu_sample[: max(1, args.cpu_images)]
             t1 = time.perf_counter()

@@ -32,7 +32,9 @@ void validate_params(const hesaff_params &p)
    if (!(p.mrSize > 0.0f)) throw HsError(HESAFF_ERR_ARG, "mrSize must be positive");
    if (!(p.edgeEigenValueRatio > 0.0f)) throw HsError(HESAFF_ERR_ARG, "edgeEigenValueRatio must be positive");
    if (p.maxIterations < 1 || p.maxIterations > 1000) throw HsError(HESAFF_ERR_ARG, "maxIterations out of range (1..1000)");
-   if (p.fast < 0 || p.fast > 2) throw HsError(HESAFF_ERR_ARG, "fast must be 0 (parity mode), 1 or 2");
+   if (p.fast == 1)
+      throw HsError(HESAFF_ERR_ARG, "hesaff_params.fast = 1 was withdrawn in ABI version 4 (it bought 1.02x); use 0 (parity mode) or 2");
+   if (p.fast != 0 && p.fast != 2) throw HsError(HESAFF_ERR_ARG, "fast must be 0 (parity mode) or 2");
 }
 
 } // namespace
@@ -100,10 +102,9 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       if (c->par.max_kpts_per_mpx < 1000) c->par.max_kpts_per_mpx = 1000;
       validate_params(c->par);
       c->device = device;
-      c->fast = c->par.fast >= 1;
       c->fast_pyramid = c->par.fast == 2;
 #ifdef HESAFF_TUNING
-      if (const char *fm = getenv("HESAFF_FAST")) { c->fast = atoi(fm) >= 1; c->fast_pyramid = atoi(fm) == 2; }   // profile the fast kernels under bench.py
+      if (const char *fm = getenv("HESAFF_FAST")) c->fast_pyramid = atoi(fm) == 2;   // profile the fast mode under bench.py
 #endif
       bind_device(c);
       hipDeviceProp_t prop;

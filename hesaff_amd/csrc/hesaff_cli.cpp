@@ -11,8 +11,8 @@
 //       --schedule static | dynamic   static (default): one contiguous shard per device context.  dynamic: the list is cut into
 //       blocks of 256 images and every device context takes the next block when it has finished its own - for lists whose
 //       keypoint density varies strongly along the list; the output files are the same either way.
-//       --fast 1 | 2                  hesaff_params.fast: the not-bit-exact per-keypoint kernels (1: same algorithm, free summation order;
-//       2: also windows larger than the patch sampled from the scale space); default 0 = parity mode.
+//       --fast 2                      hesaff_params.fast: windows larger than the patch sampled from the scale space (NOT bit-exact,
+//       another algorithm for those keypoints); default 0 = parity mode.
 //       --output text | bin | both    what every image gets: <image>.hesaff.sift (default), the binary sidecar
 //       <image>.hesaff.bin (the same rows unprinted, include/hesaff_amd.h: hesaff_write_bin), or both.
 #include <chrono>
@@ -157,7 +157,7 @@ int main(int argc, char **argv)
          if (i + 1 >= argc) bad = true;
          else if (strcmp(argv[i], "--devices") == 0) devices = argv[i + 1];
          else if (strcmp(argv[i], "--fast") == 0) {
-            if (strcmp(argv[i + 1], "0") == 0 || strcmp(argv[i + 1], "1") == 0 || strcmp(argv[i + 1], "2") == 0) fast = atoi(argv[i + 1]);
+            if (strcmp(argv[i + 1], "0") == 0 || strcmp(argv[i + 1], "2") == 0) fast = atoi(argv[i + 1]);
             else bad = true;
          } else if (strcmp(argv[i], "--schedule") == 0) {
             if (strcmp(argv[i + 1], "dynamic") == 0) dynamic = true;
@@ -169,7 +169,7 @@ int main(int argc, char **argv)
             else bad = true;
          } else bad = true;
       }
-      if (bad) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all] [--output text|bin|both] [--schedule static|dynamic] [--fast 0|1|2]\n"); return 1; }
+      if (bad) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all] [--output text|bin|both] [--schedule static|dynamic] [--fast 0|2]\n"); return 1; }
       return run_batch_mode(argv[2], devices, out_format, dynamic, fast);
    }
    if (argc > 1) {

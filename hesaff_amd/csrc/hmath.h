@@ -17,13 +17,6 @@
 #pragma once
 #include <stdint.h>
 
-// HS_FAST: the translation unit of the fast mode (kernels_fast.hip, hesaff_params.fast = 1): contraction and approximate
-// division / square root are allowed by its compiler flags and the functions below may be replaced by cheaper ones.
-// Parity mode (the default, pipeline.hip) never defines it.
-#ifndef HS_FAST
-#define HS_FAST 0
-#endif
-
 #if defined(__HIPCC__)
 #define HM_HD __host__ __device__ __forceinline__
 #else

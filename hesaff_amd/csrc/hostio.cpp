@@ -46,7 +46,7 @@ int pnm_next_int(FILE *f, int *out)
 // ---- PNG: what cv::imread(path) with its default flag returns for a PNG
 // file - 8 bits per channel, alpha dropped, 16-bit samples reduced to their high byte, palette and
 // 1/2/4-bit grey expanded - decoded with zlib only.  PNG is lossless, so the pixels do not depend on
-// the decoder (unlike JPEG, which stays out of scope).  Interlaced files are rejected.
+// the decoder.  Adam7-interlaced files are de-interlaced pass by pass.
 inline uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
 int read_png_bytes(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *height, int *channels)
@@ -56,7 +56,7 @@ int read_png_bytes(const std::vector<uint8_t> &f, uint8_t **data, int *width, in
    size_t pos = 8;
    uint32_t W = 0, H = 0;
    int depth = 0, ctype = -1;
-   bool have_ihdr = false, done = false;
+   bool have_ihdr = false, done = false, interlaced = false;
    std::vector<uint8_t> idat, plte;
    while (!done && pos + 12 <= f.size()) {
       const uint32_t len = be32(&f[pos]);
@@ -66,7 +66,8 @@ int read_png_bytes(const std::vector<uint8_t> &f, uint8_t **data, int *width, in
       if (memcmp(type, "IHDR", 4) == 0) {
          if (len != 13 || have_ihdr) return HESAFF_ERR_IO;
          W = be32(body); H = be32(body + 4); depth = body[8]; ctype = body[9];
-         if (body[10] != 0 || body[11] != 0 || body[12] != 0) return HESAFF_ERR_IO;   // compression, filter, interlace
+         if (body[10] != 0 || body[11] != 0 || body[12] > 1) return HESAFF_ERR_IO;   // compression, filter; interlace 0 or 1 (Adam7)
+         interlaced = body[12] == 1;
          if (W < 1 || H < 1 || W > 65535u || H > 65535u) return HESAFF_ERR_IO;
          have_ihdr = true;
       } else if (memcmp(type, "PLTE", 4) == 0) plte.assign(body, body + len);
@@ -87,63 +88,83 @@ int read_png_bytes(const std::vector<uint8_t> &f, uint8_t **data, int *width, in
    const bool depth_ok = (ctype == 0) ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
                          : (ctype == 3) ? (depth == 1 || depth == 2 || depth == 4 || depth == 8) : (depth == 8 || depth == 16);
    if (!depth_ok || (ctype == 3 && (plte.empty() || plte.size() % 3 != 0))) return HESAFF_ERR_IO;
-   const size_t rowbytes = ((size_t)W * nch * depth + 7) / 8;
    const int bpp = std::max(1, nch * depth / 8);   // filter unit
+   // passes: the whole image, or the seven Adam7 sub-images (PNG specification, section 8.2): pass p holds the pixels
+   // (ys + i * dy, xs + j * dx), each pass is filtered like an image of its own
+   struct Pass { uint32_t xs, ys, dx, dy; };
+   static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+   static const Pass whole = {0, 0, 1, 1};
+   const int npass = interlaced ? 7 : 1;
+   const Pass *passes = interlaced ? adam7 : &whole;
+   auto pass_w = [&](const Pass &q) { return (W > q.xs) ? (W - q.xs + q.dx - 1) / q.dx : 0u; };
+   auto pass_h = [&](const Pass &q) { return (H > q.ys) ? (H - q.ys + q.dy - 1) / q.dy : 0u; };
+   unsigned long long rawsize = 0;
+   for (int pi = 0; pi < npass; pi++) {
+      const unsigned long long pw = pass_w(passes[pi]), ph = pass_h(passes[pi]);
+      if (pw && ph) rawsize += ph * ((pw * nch * depth + 7) / 8 + 1);
+   }
    // deflate expands by at most ~1032:1: an image the IDAT bytes cannot possibly produce is rejected before
    // anything of its claimed size is allocated (a 60-byte file may claim 65535 x 65535 RGBA16)
-   if ((unsigned long long)H * (rowbytes + 1) > (unsigned long long)idat.size() * 1040ull + 4096ull) return HESAFF_ERR_IO;
-   std::vector<uint8_t> raw((size_t)H * (rowbytes + 1));
+   if (rawsize > (unsigned long long)idat.size() * 1040ull + 4096ull) return HESAFF_ERR_IO;
+   std::vector<uint8_t> raw((size_t)rawsize);
    uLongf rawlen = (uLongf)raw.size();
    if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return HESAFF_ERR_IO;
-   // unfilter in place (PNG specification, section 9)
-   std::vector<uint8_t> zero(rowbytes, 0);
-   for (uint32_t y = 0; y < H; y++) {
-      uint8_t *row = &raw[(size_t)y * (rowbytes + 1)];
-      const int ft = row[0];
-      uint8_t *cur = row + 1;
-      const uint8_t *up = y ? cur - (rowbytes + 1) : zero.data();
-      switch (ft) {
-         case 0: break;
-         case 1: for (size_t i = bpp; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]); break;
-         case 2: for (size_t i = 0; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + up[i]); break;
-         case 3:
-            for (size_t i = 0; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + (((i >= (size_t)bpp ? cur[i - bpp] : 0) + up[i]) >> 1));
-            break;
-         case 4:
-            for (size_t i = 0; i < rowbytes; i++) {
-               const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = up[i], c = i >= (size_t)bpp ? up[i - bpp] : 0;
-               const int pq = a + b - c, pa = std::abs(pq - a), pb = std::abs(pq - b), pc = std::abs(pq - c);
-               cur[i] = (uint8_t)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)));
-            }
-            break;
-         default: return HESAFF_ERR_IO;
-      }
-   }
    const int och = (ctype == 0 || ctype == 4) ? 1 : 3;
    uint8_t *out = (uint8_t *)malloc((size_t)W * H * och);
    if (!out) return HESAFF_ERR_NOMEM;
    const int step = depth == 16 ? 2 : 1;   // 16-bit samples: the high byte (big-endian first)
-   for (uint32_t y = 0; y < H; y++) {
-      const uint8_t *cur = &raw[(size_t)y * (rowbytes + 1) + 1];
-      uint8_t *o = out + (size_t)y * W * och;
-      for (uint32_t x = 0; x < W; x++) {
-         if (depth < 8) {   // grey or palette index, packed most significant bits first
-            const int per = 8 / depth, sh = (per - 1 - (int)(x % per)) * depth;
-            const int v = (cur[x / per] >> sh) & ((1 << depth) - 1);
-            if (ctype == 3) {
+   size_t pos_raw = 0;
+   std::vector<uint8_t> zero;
+   for (int pi = 0; pi < npass; pi++) {
+      const Pass &q = passes[pi];
+      const uint32_t pw = pass_w(q), ph = pass_h(q);
+      if (!pw || !ph) continue;
+      const size_t rowbytes = ((size_t)pw * nch * depth + 7) / 8;
+      zero.assign(rowbytes, 0);
+      for (uint32_t y = 0; y < ph; y++) {
+         // unfilter in place (PNG specification, section 9)
+         uint8_t *row = &raw[pos_raw + (size_t)y * (rowbytes + 1)];
+         const int ft = row[0];
+         uint8_t *cur = row + 1;
+         const uint8_t *up = y ? cur - (rowbytes + 1) : zero.data();
+         switch (ft) {
+            case 0: break;
+            case 1: for (size_t i = bpp; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]); break;
+            case 2: for (size_t i = 0; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + up[i]); break;
+            case 3:
+               for (size_t i = 0; i < rowbytes; i++) cur[i] = (uint8_t)(cur[i] + (((i >= (size_t)bpp ? cur[i - bpp] : 0) + up[i]) >> 1));
+               break;
+            case 4:
+               for (size_t i = 0; i < rowbytes; i++) {
+                  const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = up[i], c = i >= (size_t)bpp ? up[i - bpp] : 0;
+                  const int pq = a + b - c, pa = std::abs(pq - a), pb = std::abs(pq - b), pc = std::abs(pq - c);
+                  cur[i] = (uint8_t)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)));
+               }
+               break;
+            default: free(out); return HESAFF_ERR_IO;
+         }
+         uint8_t *orow = out + (size_t)(q.ys + y * q.dy) * W * och;
+         for (uint32_t x = 0; x < pw; x++) {
+            uint8_t *o = orow + (size_t)(q.xs + x * q.dx) * och;
+            if (depth < 8) {   // grey or palette index, packed most significant bits first
+               const int per = 8 / depth, sh = (per - 1 - (int)(x % per)) * depth;
+               const int v = (cur[x / per] >> sh) & ((1 << depth) - 1);
+               if (ctype == 3) {
+                  if ((size_t)v * 3 + 2 >= plte.size()) { free(out); return HESAFF_ERR_IO; }
+                  o[0] = plte[3 * v]; o[1] = plte[3 * v + 1]; o[2] = plte[3 * v + 2];
+               } else o[0] = (uint8_t)(v * (255 / ((1 << depth) - 1)));
+            } else if (ctype == 3) {
+               const int v = cur[x];
                if ((size_t)v * 3 + 2 >= plte.size()) { free(out); return HESAFF_ERR_IO; }
-               o[3 * x] = plte[3 * v]; o[3 * x + 1] = plte[3 * v + 1]; o[3 * x + 2] = plte[3 * v + 2];
-            } else o[x] = (uint8_t)(v * (255 / ((1 << depth) - 1)));
-         } else if (ctype == 3) {
-            const int v = cur[x];
-            if ((size_t)v * 3 + 2 >= plte.size()) { free(out); return HESAFF_ERR_IO; }
-            o[3 * x] = plte[3 * v]; o[3 * x + 1] = plte[3 * v + 1]; o[3 * x + 2] = plte[3 * v + 2];
-         } else {
-            const uint8_t *px = cur + (size_t)x * nch * step;
-            if (och == 1) o[x] = px[0];
-            else { o[3 * x] = px[0]; o[3 * x + 1] = px[step]; o[3 * x + 2] = px[2 * step]; }
+               o[0] = plte[3 * v]; o[1] = plte[3 * v + 1]; o[2] = plte[3 * v + 2];
+            } else {
+               const uint8_t *px = cur + (size_t)x * nch * step;
+               if (och == 1) o[0] = px[0];
+               else { o[0] = px[0]; o[1] = px[step]; o[2] = px[2 * step]; }
+            }
          }
       }
+      pos_raw += (size_t)ph * (rowbytes + 1);
    }
    *data = out; *width = (int)W; *height = (int)H; *channels = och;
    return HESAFF_OK;
@@ -308,24 +329,84 @@ int hesaff_test_fmt_g(const float *v, int n)
 
 void hesaff_free(void *p) { big_free(p); }
 
+// cv::imread's PxM decoder (OpenCV 2.4 modules/highgui/src/grfmt_pxm.cpp, restated from its published source - OpenCV is not
+// in this image): P1..P6, maxval 1..65535.
+//   * binary 8-bit samples (P5/P6, maxval <= 255) are taken as they are, whatever maxval says;
+//   * plain samples (P2/P3) above maxval are clamped to it and mapped through i * 255 / maxval (integer division);
+//   * 16-bit samples (maxval > 255; big-endian in the binary forms) are reduced to their high byte, v >> 8;
+//   * bitmaps (P1/P4): bit 0 = white (255), bit 1 = black (0); P4 rows are padded to whole bytes.
 int hesaff_read_pnm(const char *path, uint8_t **data, int *width, int *height, int *channels)
 {
    if (!path || !data || !width || !height || !channels) return HESAFF_ERR_ARG;
    FILE *f = fopen(path, "rb");
    if (!f) return HESAFF_ERR_IO;
-   int c1 = fgetc(f), c2 = fgetc(f);
-   int w = 0, h = 0, maxv = 0;
-   if (c1 != 'P' || (c2 != '5' && c2 != '6') || pnm_next_int(f, &w) || pnm_next_int(f, &h) || pnm_next_int(f, &maxv) || w < 1 ||
-       h < 1 || maxv != 255) {
+   const int c1 = fgetc(f), c2 = fgetc(f);
+   int w = 0, h = 0, maxv = 1;
+   const bool known = c1 == 'P' && c2 >= '1' && c2 <= '6';
+   const int kind = known ? c2 - '0' : 0;
+   const bool bitmap = kind == 1 || kind == 4, plain = kind >= 1 && kind <= 3;
+   if (!known || pnm_next_int(f, &w) || pnm_next_int(f, &h) || (!bitmap && pnm_next_int(f, &maxv)) || w < 1 || h < 1 || maxv < 1 || maxv > 65535) {
       fclose(f);
       return HESAFF_ERR_IO;
    }
-   const int ch = c2 == '5' ? 1 : 3;
+   const int ch = (kind == 3 || kind == 6) ? 3 : 1;
    const size_t n = (size_t)w * h * ch;
+   // a file cannot hold more samples than it has bytes (plain: a digit and a separator each; bitmaps: a bit each):
+   // an absurd header is refused before anything of its claimed size is allocated
+   {
+      const long here = ftell(f);
+      fseek(f, 0, SEEK_END);
+      const long end = ftell(f);
+      fseek(f, here, SEEK_SET);
+      const unsigned long long avail = (here >= 0 && end >= here) ? (unsigned long long)(end - here) : 0ull;
+      const unsigned long long need = kind == 4 ? (unsigned long long)h * (((unsigned long long)w + 7) / 8)
+                                     : plain ? (kind == 1 ? n : 2 * n - 1) : n * (maxv > 255 ? 2ull : 1ull);
+      if (avail < need) { fclose(f); return HESAFF_ERR_IO; }
+   }
    uint8_t *buf = (uint8_t *)malloc(n);
    if (!buf) { fclose(f); return HESAFF_ERR_NOMEM; }
-   if (fread(buf, 1, n, f) != n) { free(buf); fclose(f); return HESAFF_ERR_IO; }
+   bool ok = true;
+   if (kind == 5 || kind == 6) {
+      if (maxv <= 255) ok = fread(buf, 1, n, f) == n;
+      else {
+         std::vector<uint8_t> row;
+         try { row.resize((size_t)w * ch * 2); } catch (...) { free(buf); fclose(f); return HESAFF_ERR_NOMEM; }
+         for (int y = 0; y < h && ok; y++) {
+            ok = fread(row.data(), 1, row.size(), f) == row.size();
+            uint8_t *o = buf + (size_t)y * w * ch;
+            for (size_t x = 0; ok && x < (size_t)w * ch; x++) o[x] = row[2 * x];   // big-endian: the first byte is the high one
+         }
+      }
+   } else if (kind == 4) {
+      const size_t rb = ((size_t)w + 7) / 8;
+      std::vector<uint8_t> row;
+      try { row.resize(rb); } catch (...) { free(buf); fclose(f); return HESAFF_ERR_NOMEM; }
+      for (int y = 0; y < h && ok; y++) {
+         ok = fread(row.data(), 1, rb, f) == rb;
+         for (int x = 0; ok && x < w; x++) buf[(size_t)y * w + x] = ((row[(size_t)x >> 3] >> (7 - (x & 7))) & 1) ? 0 : 255;
+      }
+   } else if (kind == 1) {
+      // plain bitmap: the digits need no separators
+      for (size_t i = 0; i < n && ok; i++) {
+         int c = fgetc(f);
+         for (;;) {
+            while (c == ' ' || c == '\t' || c == '\n' || c == '\r') c = fgetc(f);
+            if (c == '#') { while (c != '\n' && c != EOF) c = fgetc(f); continue; }
+            break;
+         }
+         if (c != '0' && c != '1') ok = false;
+         else buf[i] = c == '1' ? 0 : 255;
+      }
+   } else {
+      for (size_t i = 0; i < n && ok; i++) {
+         int v = 0;
+         if (pnm_next_int(f, &v)) { ok = false; break; }
+         if (v > maxv) v = maxv;
+         buf[i] = maxv > 255 ? (uint8_t)(v >> 8) : (uint8_t)(v * 255 / maxv);
+      }
+   }
    fclose(f);
+   if (!ok) { free(buf); return HESAFF_ERR_IO; }
    *data = buf; *width = w; *height = h; *channels = ch;
    return HESAFF_OK;
 }
@@ -357,7 +438,7 @@ int hesaff_read_image(const char *path, uint8_t **data, int *width, int *height,
    if (!f) return HESAFF_ERR_IO;
    const int c1 = fgetc(f), c2 = fgetc(f);
    fclose(f);
-   if (c1 == 'P' && (c2 == '5' || c2 == '6')) return hesaff_read_pnm(path, data, width, height, channels);
+   if (c1 == 'P' && c2 >= '1' && c2 <= '6') return hesaff_read_pnm(path, data, width, height, channels);
    if (c1 == 0x89 && c2 == 'P') return hesaff_read_png(path, data, width, height, channels);
    if (c1 == 0xFF && c2 == 0xD8) return hesaff_read_jpeg(path, data, width, height, channels);
    return HESAFF_ERR_IO;

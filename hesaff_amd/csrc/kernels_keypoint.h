@@ -282,138 +282,6 @@ __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, con
    }
 }
 
-#if HS_FAST
-// Fast-mode form of the iteration (kernels_fast.hip only; NOT bit-exact): the three 361-term sums of the second-moment
-// matrix are accumulated per lane (23 terms each) and combined with a shuffle tree over the 16 lanes of a group, which
-// removes the product arrays from LDS (7 KB instead of 19 KB per wavefront) and both serial stretches of the parity
-// form; invSqrt runs in float on every lane (no broadcast), multiply-adds are contracted.  The tap phase is the parity
-// kernel's: untested taps when the window's four corners are inside (hs_window_outside), the XCD-aware keypoint order.
-template <class Fetch>
-__device__ __forceinline__ void hs_affine_groups_fast(uint32_t first, uint32_t n, const float *__restrict__ mask_g, const DConsts &k, AffineOut out,
-                                                      Fetch fetch)
-{
-   __shared__ __attribute__((aligned(16))) float s_img[HS_AFF_G][HS_AFF_ARR];
-   __shared__ float s_mask[HS_AFF_ARR];
-   const int lane = threadIdx.x, grp = lane >> 4, li = lane & 15;
-   for (int i = lane; i < HS_SMM_PIX; i += 64) s_mask[i] = mask_g[i];
-   float *img = s_img[grp];
-   uint32_t hstep = gridDim.x * HS_AFF_G, h_end = n;
-   uint32_t h = first + blockIdx.x * HS_AFF_G + grp;
-   if (HS_AFF_XCD && (gridDim.x & 7u) == 0u && n > first) {
-      const uint32_t n_items = (n - first + HS_AFF_G - 1) / HS_AFF_G;
-      const uint32_t xcd = blockIdx.x & 7u, rank = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-      const uint32_t it_lo = (uint32_t)(((unsigned long long)n_items * xcd) >> 3), it_hi = (uint32_t)(((unsigned long long)n_items * (xcd + 1)) >> 3);
-      hstep = per_xcd * HS_AFF_G;
-      h_end = min(first + it_hi * HS_AFF_G, n);
-      h = first + (it_lo + rank) * HS_AFF_G + grp;
-   }
-   const float *blur = nullptr;
-   int pitch = 0, width = 0, height = 0, l = 0;
-   float lx = 0, ly = 0, ratio = 0, u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f;
-   float eigen_ratio_act = 0.0f, eigen_ratio_bef = 0.0f;
-   bool active = h < h_end;
-   auto load_kp = [&]() {
-      if (active) {
-         const AffKp q = fetch(h);
-         blur = q.blur; pitch = q.pitch; width = q.cols - 1; height = q.rows - 1;
-         lx = q.x / q.pd; ly = q.y / q.pd;
-         ratio = q.s / (k.affInitialSigma * q.pd);
-         u11 = 1.0f; u12 = 0.0f; u21 = 0.0f; u22 = 1.0f;
-         eigen_ratio_act = 0.0f; eigen_ratio_bef = 0.0f;
-         l = 0;
-      }
-   };
-   load_kp();
-   HS_WAVE_LDS_SYNC();
-   while (__ballot(active) != 0ull) {
-      bool win_in = true;
-      if (active) win_in = !hs_window_outside(height + 1, width + 1, lx, ly, u11 * ratio, u12 * ratio, u21 * ratio, u22 * ratio, HS_SMM >> 1);
-      const bool all_in = __ballot(active && !win_in) == 0ull;
-      auto sample = [&](auto inside_c) {
-         constexpr bool INSIDE = decltype(inside_c)::value;
-         const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
-#pragma unroll
-         for (int half = 0; half < 2; half++) {
-            constexpr int NB = (HS_AFF_NT + 1) / 2;
-            float sv[NB];
-#pragma unroll
-            for (int t = 0; t < NB; t++) {
-               const int idx = min(li + 16 * (half * NB + t), HS_SMM_PIX - 1);
-               const int jj = idx / HS_SMM, ii = idx - jj * HS_SMM;
-               const int j = jj - (HS_SMM >> 1), i = ii - (HS_SMM >> 1);
-               const float wx = lx + (float)j * a12 + (float)i * a11, wy = ly + (float)j * a22 + (float)i * a21;
-               if (INSIDE) sv[t] = hs_tap_inside_ptr(blur, pitch, wx, wy);
-               else { bool outside = false; sv[t] = hs_bilinear(blur, pitch, width, height, wx, wy, outside); }
-            }
-#pragma unroll
-            for (int t = 0; t < NB; t++) HS_KEEP(sv[t]);
-#pragma unroll
-            for (int t = 0; t < NB; t++) {
-               const int idx = li + 16 * (half * NB + t);
-               if (idx < HS_SMM_PIX) img[idx] = sv[t];
-            }
-         }
-      };
-      if (active) {
-         if (all_in) sample(std::true_type{});
-         else sample(std::false_type{});
-      }
-      HS_WAVE_LDS_SYNC();
-      if (active) {
-         float a = 0.0f, b = 0.0f, c = 0.0f;
-#pragma unroll
-         for (int t = 0; t < HS_AFF_NT; t++) {
-            const int idx = li + 16 * t;
-            if (idx < HS_SMM_PIX) {
-               const int r = idx / HS_SMM, cc = idx - r * HS_SMM;
-               const float gx = img[idx + (cc < HS_SMM - 1 ? 1 : 0)] - img[idx - (cc > 0 ? 1 : 0)];
-               const float gy = img[idx + (r < HS_SMM - 1 ? HS_SMM : 0)] - img[idx - (r > 0 ? HS_SMM : 0)];
-               const float v = s_mask[idx];
-               a += gx * gx * v; b += gx * gy * v; c += gy * gy * v;
-            }
-         }
-#pragma unroll
-         for (int d = 8; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 16); b += __shfl_xor(b, d, 16); c += __shfl_xor(c, d, 16); }
-         a *= 1.0f / (float)HS_SMM_PIX; b *= 1.0f / (float)HS_SMM_PIX; c *= 1.0f / (float)HS_SMM_PIX;
-         // invSqrt (helpers.cpp:149-175) in float
-         float t, r;
-         if (b != 0.0f) {
-            r = (c - a) / (2.0f * b);
-            t = (r >= 0.0f ? 1.0f : -1.0f) / (fabsf(r) + sqrtf(1.0f + r * r));
-            r = rsqrtf(1.0f + t * t);
-            t = t * r;
-         } else { r = 1.0f; t = 0.0f; }
-         float x = rsqrtf(r * r * a - 2.0f * r * t * b + t * t * c);
-         float z = rsqrtf(t * t * a + 2.0f * r * t * b + r * r * c);
-         const float d = sqrtf(x * z);
-         x /= d; z /= d;
-         float l1 = fmaxf(x, z), l2 = fminf(x, z);
-         a = r * r * x + t * t * z; b = -r * t * x + t * r * z; c = t * t * x + r * r * z;
-         eigen_ratio_bef = eigen_ratio_act;
-         eigen_ratio_act = 1.0f - l2 / l1;
-         const float n11 = a * u11 + b * u21, n12 = a * u12 + b * u22, n21 = b * u11 + c * u21, n22 = b * u12 + c * u22;
-         u11 = n11; u12 = n12; u21 = n21; u22 = n22;
-         int state = 0;   // 0 continue, 1 break (rejected), 2 converged
-         if (!hs_eigenvalues(u11, u12, u21, u22, l1, l2)) state = 1;
-         else if ((l1 / l2 > 6) || (l2 / l1 > 6)) state = 1;
-         else if (eigen_ratio_act < k.convergenceThreshold && eigen_ratio_bef < k.convergenceThreshold) state = 2;
-         if (state != 0 || l + 1 >= k.maxIterations) {
-            if (li == 0) {
-               out.converged[h] = (state == 2) ? 1 : 0;
-               out.iters[h] = (state == 2) ? l : 0;
-               out.U[4 * h + 0] = u11; out.U[4 * h + 1] = u12; out.U[4 * h + 2] = u21; out.U[4 * h + 3] = u22;
-            }
-            h += hstep;
-            active = h < h_end;
-            load_kp();
-         } else {
-            l++;
-         }
-      }
-      HS_WAVE_LDS_SYNC();
-   }
-}
-#endif
 
 #ifndef HS_AFF_WAVES
 #define HS_AFF_WAVES 0   // tuning: wavefronts per SIMD to hold the register allocation to (0: the compiler's choice)
@@ -422,11 +290,7 @@ __global__ __launch_bounds__(64, HS_AFF_WAVES) void k_affine(PlaneTab pt, HessLi
                                                KpTables tb, DConsts k, AffineOut out)
 {
    const uint32_t n = min(min(*n_ptr, hl.cap), h_hi);   // keypoints [h_lo, h_hi) of the list
-#if HS_FAST
-   hs_affine_groups_fast(
-#else
    hs_affine_groups(
-#endif
       h_lo, n, tb.smm_mask, k, out, [&](uint32_t h) {
       const int meta = hl.meta[h];
       const int b = meta >> 8, octave = (meta >> 4) & 15, level = (meta >> 2) & 3;

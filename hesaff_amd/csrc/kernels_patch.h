@@ -1034,9 +1034,8 @@ __global__ __launch_bounds__(256) void k_large_prefix(PatchWork pw, uint32_t *__
 }
 
 
-#if HS_FAST
 // ---------------------------------------------------------------------------------------------------------------------
-// k_patch_pyramid (fast level 2 only; a DIFFERENT ALGORITHM from the reference's for these windows):
+// k_patch_pyramid (hesaff_params.fast = 2 only; a DIFFERENT ALGORITHM from the reference's for these windows):
 // normalizeAffine (affine.cpp:102-144) warps a P x P window of the ORIGINAL image at unit spacing, blurs it with
 // sigma = 1.5 * P0 / 41 and takes every (P0 / 41)-th sample.  For P > 41 that is P^2 bilinear taps and a K = 0.22 P tap
 // separable blur per keypoint - bins 2-4 (15 % of the keypoints) cost 60 % of the patch stage.  The scale space already
@@ -1059,10 +1058,11 @@ __global__ __launch_bounds__(256) void k_patch_pyramid(HessList hl, PatchWork pw
          const float x = hl.x[h], y = hl.y[h];
          const float a11 = pw.A[4 * h], a12 = pw.A[4 * h + 1], a21 = pw.A[4 * h + 2], a22 = pw.A[4 * h + 3];
          const float scale = (float)pw.P0[h] / (float)HS_PATCH;
-         // level with sigma closest to 1.5 * scale: sigma(o, l) = 1.6 * 2^(o + l / 3) in pixels of the original image
-         const float t = 3.0f * log2f(fmaxf(1.5f * scale / 1.6f, 1.0f));        // octave * 3 + level, fractional
+         // level with sigma closest to 1.5 * scale: sigma(o, l) = 1.6 * 2^(o + l / 3) * pd0 in pixels of the original image
+         // (pd0 = 0.5 with upscaleInputImage: the stored planes are those of the 2x up-sampled image)
+         const float t = 3.0f * log2f(fmaxf(1.5f * scale / (1.6f * pd0), 1.0f));        // octave * 3 + level, fractional
          int ol = (int)(t + 0.5f);
-         ol = min(ol, 3 * n_octaves - 1);
+         ol = max(0, min(ol, 3 * n_octaves - 1));
          const int o = ol / 3, l = ol - 3 * o;
          const DPlane &P = pt.L[o][l];
          const float *img = P.img(b);
@@ -1091,4 +1091,3 @@ __global__ __launch_bounds__(256) void k_patch_pyramid(HessList hl, PatchWork pw
       base += cnt;
    }
 }
-#endif

@@ -143,7 +143,6 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
    }
    // this thread's pixels inside the circular mask (1245 of 1681, helpers.cpp:131): stencil neighbours (LDS byte offsets),
    // output slot and mask value come from one table row per pixel (KpTables::sgrad_*), all requested in one round
-   const int nm = tb.n_masked;
    int4 nbq[HS_SIFT_MSK_IT];
    int2 omq[HS_SIFT_MSK_IT];
 #pragma unroll
@@ -187,7 +186,6 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
       }
       __syncthreads();
       if (cur_alive) {
-         float2 *out = vo + (size_t)k * HS_VO_PITCH;
          // ND (block-uniform): the patch was photometrically normalised.  Its pixels are then 128 + fac * (v - mean) clamped
          // to [0, 255]: multiples of 2^-17, so gx and gy are zero or at least 2^-17 in magnitude (never denormal) and
          // gx^2 + gy^2 is zero or at least 2^-34: the square root and the two divisions of atan2f need no range handling
@@ -239,191 +237,6 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
    }
 }
 
-#if HS_FAST
-// ---------------------------------------------------------------------------------------------------------------------
-// k_desc_fused (fast mode only, NOT bit-exact): the whole descriptor of a keypoint on chip - computeSiftDescriptor
-// siftdesc.cpp:115-140 from the 41x41 patch to the 128 bytes in ONE kernel, one 256-thread block per keypoint (persistent
-// grid).  With the reference's summation orders given up, nothing has to leave the chip between the steps:
-//   photometric mean / variance   two block reductions over the 1245 masked pixels (helpers.cpp:253-268)
-//   normalisation                 in place in LDS (helpers.cpp:269-280)
-//   gradient, orientation         one thread per masked pixel (siftdesc.cpp:123-137), polynomial atan2 -> (mask*grad, o) in LDS
-//   samplePatch                   thread = (cell, row of the cell's 16 x 16 support): 16 pixels each into 8 thread-private LDS words
-//                                 (plain read-add-write, no atomics), then thread = (cell, bin) adds the 16 partial sums
-//                                 (siftdesc.cpp:51-81).  A first version added every pixel's 8 contributions with integer LDS
-//                                 atomics on fixed-point values: ds_add_u32 ran at about 3 lane-operations per clock and CU and
-//                                 took 60 % of the kernel (29 ms per 32 UHD images; unconditional adds for clamped cells, +25 %
-//                                 atomics, cost +15 % time).
-//   normalize / clip / quantise   two more block reductions (siftdesc.cpp:83-113)
-// HBM traffic per keypoint: the patch read once (6.7 KB) + 128 bytes out; the parity path moves 53 KB (patch read three times,
-// 12.8 KB of gradient pairs written and read).
-// ---------------------------------------------------------------------------------------------------------------------
-// orientation coordinate o = 8 (atan2(gy, gx) + 2 pi) / (2 pi) in [4, 12] without the math library: octant folding + an odd
-// minimax polynomial of degree 9 on [0, 1] (|error| < 1.2e-5 rad, orders of magnitude below what moves a quantised bin)
-__device__ __forceinline__ float hsf_orient_coord(float gy, float gx)
-{
-   const float ax = fabsf(gx), ay = fabsf(gy);
-   const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-   const float t = mn * __builtin_amdgcn_rcpf(mx);   // caller guarantees mx > 0
-   const float s2 = t * t;
-   float p = ((((0.0208351f * s2 - 0.0851330f) * s2 + 0.1801410f) * s2 - 0.3302995f) * s2 + 0.9998660f) * t;   // atan(t), t in [0, 1]
-   p = ay > ax ? 1.57079633f - p : p;
-   p = gx < 0.0f ? 3.14159265f - p : p;
-   p = gy < 0.0f ? -p : p;
-   return p * 1.27323954f + 8.0f;   // 8 / (2 pi) = 4 / pi
-}
-
-__device__ __forceinline__ float hsf_block_sum(float v, float *s_red)   // all 256 threads; s_red: 4 floats nobody else is using
-{
-#pragma unroll
-   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-   __syncthreads();
-   return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-}
-
-#define HSF_BIN_STRIDE 257   // words between a thread's consecutive private bins: odd, so that the 64 lanes of a wave spread over the banks
-
-__global__ __launch_bounds__(256) void k_desc_fused(SiftIO io, KpTables tb, DConsts kc)
-{
-   __shared__ float s_p[HS_PATCH_ARR];
-   __shared__ __attribute__((aligned(16))) float2 s_vo[HS_VO_PITCH];
-   __shared__ float s_bins[8 * HSF_BIN_STRIDE];
-   __shared__ float s_cw[64];
-   __shared__ float s_red[16];
-   const int tid = threadIdx.x;
-   const uint32_t n = io.h_hi - io.h_lo;
-   const int nm = tb.n_masked;
-   // phase A constants: this thread's five masked pixels (stencil neighbours, output slot, mask value)
-   int4 nbq[HS_SIFT_MSK_IT];
-   int2 omq[HS_SIFT_MSK_IT];
-   int m_i[HS_SIFT_MSK_IT];
-#pragma unroll
-   for (int q = 0; q < HS_SIFT_MSK_IT; q++) {
-      nbq[q] = tb.sgrad_nb[tid + 256 * q];
-      omq[q] = tb.sgrad_om[tid + 256 * q];
-      m_i[q] = tb.mask_idx[min(tid + 256 * q, nm - 1)];
-   }
-   for (int i = tid; i < HS_VO_PITCH; i += 256) s_vo[i] = make_float2(0.0f, 0.0f);   // pixels outside the mask stay (0, 0)
-   {
-      // cell weights as in k_sift_hist: spatial bin b gets w1[r] from rows with bin1 == b, w0[r] from rows with bin0 == b
-      const int b = tid >> 4, i = tid & 15, r = 8 * b + i;
-      float w = 0.0f;
-      if (tid < 64 && r < HS_PATCH) {
-         if (tb.bin0[r] == 8 * b && tb.w0[r] != 0.0f) w = tb.w0[r];
-         else if (tb.bin1[r] == 8 * b) w = tb.w1[r];
-      }
-      if (tid < 64) s_cw[tid] = w;
-   }
-   __syncthreads();
-   // phase B constants: thread = (cell, row i of the cell's 16 x 16 support)
-   const int cell = tid >> 4, ri = tid & 15, cy = cell >> 2, cx = cell & 3;
-   const float wr = s_cw[cy * 16 + ri];
-   const float2 *my_row = s_vo + (8 * cy + ri) * HS_VO_DIM + 8 * cx;
-   float *pb = s_bins + tid;
-   uint32_t k = blockIdx.x;
-   if (k >= n) return;
-   float pv[HS_PATCH_PIX_IT];
-   int alive = io.alive[io.h_lo + k];
-   {
-      const float *gp = io.patches + (size_t)k * HS_PATCH_PIX;
-#pragma unroll
-      for (int q = 0; q < HS_PATCH_PIX_IT; q++) pv[q] = gp[min(tid + 256 * q, HS_PATCH_PIX - 1)];
-   }
-   for (; k < n; k += gridDim.x) {
-      const bool cur_alive = alive != 0;
-      const uint32_t kn = k + gridDim.x;
-      if (cur_alive) {
-#pragma unroll
-         for (int q = 0; q < HS_PATCH_PIX_IT; q++) { const int i = tid + 256 * q; if (i < HS_PATCH_PIX) s_p[i] = pv[q]; }
-      }
-      // the next keypoint's patch is requested before this one is evaluated
-      if (kn < n) {
-         alive = io.alive[io.h_lo + kn];
-         const float *gp = io.patches + (size_t)kn * HS_PATCH_PIX;
-#pragma unroll
-         for (int q = 0; q < HS_PATCH_PIX_IT; q++) pv[q] = gp[min(tid + 256 * q, HS_PATCH_PIX - 1)];
-      }
-      if (!cur_alive) continue;   // block-uniform
-      __syncthreads();
-      // photometric mean / variance over the masked pixels (helpers.cpp:253-268), tree sums
-      float ps = 0.0f;
-#pragma unroll
-      for (int q = 0; q < HS_SIFT_MSK_IT; q++) if (tid + 256 * q < nm) ps += s_p[m_i[q]];
-      const float mean = hsf_block_sum(ps, s_red) / (float)nm;
-      float pq = 0.0f;
-#pragma unroll
-      for (int q = 0; q < HS_SIFT_MSK_IT; q++) if (tid + 256 * q < nm) { const float dd = mean - s_p[m_i[q]]; pq += dd * dd; }
-      const float var = sqrtf(hsf_block_sum(pq, s_red + 4) / (float)nm);
-      // every read of the raw patch happened before the barrier inside the second sum: normalise in place (helpers.cpp:269-280)
-      if (!(var < 0.0001f)) {
-         const float fac = 50.0f / var;
-#pragma unroll
-         for (int q = 0; q < HS_PATCH_PIX_IT; q++) {
-            const int i = tid + 256 * q;
-            if (i < HS_PATCH_PIX) {
-               float v = 128.0f + fac * (s_p[i] - mean);
-               v = v > 255.0f ? 255.0f : v;
-               s_p[i] = v < 0.0f ? 0.0f : v;
-            }
-         }
-      }
-      __syncthreads();
-      // phase A: gradient magnitude and orientation of the masked pixels (siftdesc.cpp:123-137) -> (mask*grad, o)
-#pragma unroll
-      for (int q = 0; q < HS_SIFT_MSK_IT; q++) {
-         if (omq[q].x >= 0) {
-            const char *sp = reinterpret_cast<const char *>(s_p);
-            const float gx = *reinterpret_cast<const float *>(sp + nbq[q].y) - *reinterpret_cast<const float *>(sp + nbq[q].x);
-            const float gy = *reinterpret_cast<const float *>(sp + nbq[q].w) - *reinterpret_cast<const float *>(sp + nbq[q].z);
-            const float g2 = gx * gx + gy * gy;
-            const float val = __int_as_float(omq[q].y) * sqrtf(g2);
-            s_vo[omq[q].x] = make_float2(val, g2 > 0.0f ? hsf_orient_coord(gy, gx) : 8.0f);
-         }
-      }
-      __syncthreads();
-      // phase B: samplePatch (siftdesc.cpp:51-81), thread-private bins
-#pragma unroll
-      for (int b = 0; b < 8; b++) pb[b * HSF_BIN_STRIDE] = 0.0f;
-      {
-         float4 cur[8];
-#pragma unroll
-         for (int m = 0; m < 8; m++) cur[m] = reinterpret_cast<const float4 *>(my_row)[m];
-#pragma unroll
-         for (int j = 0; j < 16; j++) {
-            const float qx = (j & 1) ? cur[j >> 1].z : cur[j >> 1].x;
-            const float qy = (j & 1) ? cur[j >> 1].w : cur[j >> 1].y;
-            const float v = (wr * s_cw[cx * 16 + j]) * qx;
-            const int io0 = (int)qy;
-            const int bo0 = io0 & 7, bo1 = (io0 + 1) & 7;
-            const float t1 = v * (qy - (float)io0), t0 = v - t1;
-            const float a0 = pb[bo0 * HSF_BIN_STRIDE], a1 = pb[bo1 * HSF_BIN_STRIDE];   // bo0 != bo1
-            pb[bo0 * HSF_BIN_STRIDE] = a0 + t0;
-            pb[bo1 * HSF_BIN_STRIDE] = a1 + t1;
-         }
-      }
-      __syncthreads();
-      // thread = (cell, bin): the 16 partial sums of the cell's rows; then normalize, clip, normalize, quantise (siftdesc.cpp:83-113)
-      float x = 0.0f;
-      if (tid < 128) {
-         const float *src = s_bins + (tid & 7) * HSF_BIN_STRIDE + (tid >> 3) * 16;
-#pragma unroll
-         for (int i = 0; i < 16; i++) x += src[i];
-      }
-      const float len = sqrtf(hsf_block_sum(x * x, s_red + 8));
-      x *= 1.0f / len;
-      const bool clip = x > kc.maxBinValue;
-      if (clip) x = kc.maxBinValue;
-      const float len2sq = hsf_block_sum(x * x, s_red + 12);
-      const bool any_clip = __syncthreads_or(clip ? 1 : 0) != 0;   // "changed": renormalise when any element was clipped
-      if (any_clip) x *= 1.0f / sqrtf(len2sq);
-      if (tid < 128) {
-         const float qf = 512.0f * x;
-         const int bq = (qf == qf) ? (int)qf : 0;
-         io.desc[(size_t)(io.h_lo + k) * 128 + tid] = (uint8_t)min(bq, 255);
-      }
-   }
-}
-#endif
 
 // device check (stage API): the per-pixel forms of k_sift_grad, general and range-free, on caller-supplied operands
 __global__ void k_math_sift(int n, const float *__restrict__ gy, const float *__restrict__ gx, float *__restrict__ ori_g,

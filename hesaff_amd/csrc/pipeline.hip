@@ -34,7 +34,6 @@
 #include "kernels_sift.h"
 #include "kernels_pyramid.h"
 #include "kernels_export.h"
-#include "fast_api.h"
 #include "chunk_engine.h"
 
 namespace hesaff {
@@ -242,8 +241,7 @@ struct hesaff_ctx {
    hipEvent_t ev_extract_done[HS_NSLOT] = {}, ev_sift_done[HS_NSLOT] = {};
    DevBuf b_patches2[HS_NSLOT], b_siftvec2[HS_NSLOT], b_meanvar2[HS_NSLOT], b_siftvo2[HS_NSLOT];
    hipEvent_t ev_fork = nullptr, ev_join[HS_NSIDE] = {nullptr, nullptr, nullptr, nullptr};
-   bool fast = false;              // hesaff_params.fast: per-keypoint stages on the kernels of kernels_fast.hip (not bit-exact)
-   bool fast_pyramid = false;      // hesaff_params.fast == 2: windows beyond bin 0 sampled from the scale-space level with the matching blur
+   bool fast_pyramid = false;      // hesaff_params.fast == 2: windows beyond bin 0 sampled from the scale-space level with the matching blur (not bit-exact)
    // schedule knobs: fixed in the product build, environment-driven only under -DHESAFF_TUNING
    bool no_overlap = false;        // HESAFF_OVERLAP=0: every kernel alone on the device (per-kernel profiling)
    uint32_t sift_group_kpts = 0;   // HESAFF_GROUP: keypoints per image group; 0 = by batch
@@ -441,10 +439,6 @@ void set_kernel_attrs(hesaff_ctx *c)
    // (a claim per item on an atomic counter serialises in L2 instead).  Measured per 32 UHD images, x 1 / 8 / 32:
    // k_patch_extract_small<0> 13.8 / 13.3 / 12.9 ms, <1> 6.1 / - / 5.9, k_sift_hist 13.4 / 12.0 / 11.7.
    c->g_small0 *= HS_OVERSUB; c->g_small1 *= HS_OVERSUB; c->g_shist *= HS_OVERSUB;
-   if (c->fast) {
-      const size_t lds[4] = {small_extract_lds_bytes(0), small_extract_lds_bytes(1), mid_lds_bytes(), big_lds_bytes()};
-      hsfast_set_attrs(lds, 0);
-   }
 }
 
 // Buffer plan for a batch of B images of H x W.
@@ -534,10 +528,6 @@ void plan(hesaff_ctx *c, int B, int H, int W)
       if (lg.lds > 160 * 1024) throw HsError(HESAFF_ERR_ARG, "image too large for the large-window row kernel");
       if (lg.lds > c->rows_lds_set) {
          set_dyn_lds(k_patch_large_rows, lg.lds);
-         if (c->fast) {
-            const size_t lds[4] = {small_extract_lds_bytes(0), small_extract_lds_bytes(1), mid_lds_bytes(), big_lds_bytes()};
-            hsfast_set_attrs(lds, lg.lds);
-         }
          c->rows_lds_set = lg.lds;
       }
    }
@@ -657,21 +647,6 @@ Lists make_lists(hesaff_ctx *c)
    return s;
 }
 
-FastArgs fast_args(const hesaff_ctx *c, const Lists &s, const PatchIO *io, const PlaneTab *pt, const SiftIO *so)
-{
-   FastArgs a;
-   memset(&a, 0, sizeof a);
-   a.hl = &s.hl; a.sz_hl = sizeof s.hl;
-   a.pw = &s.pw; a.sz_pw = sizeof s.pw;
-   a.ao = &s.ao; a.sz_ao = sizeof s.ao;
-   a.tb = &c->tables; a.sz_tb = sizeof c->tables;
-   a.kc = &c->consts; a.sz_kc = sizeof c->consts;
-   a.io = io; a.sz_io = sizeof(PatchIO);
-   a.pt = pt; a.sz_pt = sizeof(PlaneTab);
-   a.so = so; a.sz_so = sizeof(SiftIO);
-   return a;
-}
-
 // normalizeAffine for every keypoint k_prepare_patch left alive and binned.  Every launch is a persistent grid of
 // fixed size that reads its work-list length from the device-side bin counters: the host never waits for them.
 // large_rows_bound: upper bound of the large bin's T' rows in this group (from k_image_large_rows).
@@ -684,8 +659,8 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
    io.image = image;
    io.patches = patches_out;
    io.h_base = h_base;
-   if (c->fast && c->fast_pyramid && pt) {
-      // fast level 2: bin 0 (P <= 41) on the LDS-window kernel, every larger window from the pyramid (k_patch_pyramid)
+   if (c->fast_pyramid && pt) {
+      // hesaff_params.fast = 2: bin 0 (P <= 41) on the parity kernel, every larger window from the pyramid (k_patch_pyramid)
       hipStream_t s0 = st;
       const bool forked = c->side_streams[0] && !c->no_overlap;
       if (forked) {
@@ -693,9 +668,9 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
          HIP_TRY(hipStreamWaitEvent(c->side_streams[0], c->ev_fork, 0));
          s0 = c->side_streams[0];
       }
-      hsfast_patch_bin0(s0, fast_args(c, s, &io, nullptr, nullptr), c->g_small0, small_extract_lds_bytes(0));
+      hipLaunchKernelGGL(k_patch_extract_small<0>, dim3(c->g_small0), dim3(256), small_extract_lds_bytes(0), s0, s.hl, s.pw, io, c->tables);
       if (forked) HIP_TRY(hipEventRecord(c->ev_join[0], s0));
-      hsfast_patch_pyramid(st, fast_args(c, s, &io, pt, nullptr), (int)c->oct.size(), c->consts.pd0, 1, (uint32_t)c->n_cu * 32u);
+      hipLaunchKernelGGL(k_patch_pyramid, dim3((uint32_t)c->n_cu * 32u), dim3(256), 0, st, s.hl, s.pw, io, *pt, (int)c->oct.size(), c->consts.pd0, 1);
       if (forked) HIP_TRY(hipStreamWaitEvent(st, c->ev_join[0], 0));
       return;
    }
@@ -716,16 +691,10 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
       io2.trows = c->b_trows2.as<float>();
       PatchIO io3 = io;
       io3.trows = c->b_trows3.as<float>();
-      if (c->fast) {
-         const uint32_t grids[4] = {c->g_small0, c->g_small1, c->g_mid, c->g_big};
-         const size_t lds[4] = {small_extract_lds_bytes(0), small_extract_lds_bytes(1), mid_lds_bytes(), big_lds_bytes()};
-         hsfast_patch_bins(s0, s1, s2, s3, fast_args(c, s, &io, nullptr, nullptr), &io2, &io3, grids, lds);
-      } else {
-         hipLaunchKernelGGL(k_patch_extract_small<0>, dim3(c->g_small0), dim3(256), small_extract_lds_bytes(0), s0, s.hl, s.pw, io, c->tables);
-         hipLaunchKernelGGL(k_patch_extract_small<1>, dim3(c->g_small1), dim3(256), small_extract_lds_bytes(1), s1, s.hl, s.pw, io, c->tables);
-         hipLaunchKernelGGL(k_patch_mid<HS_MID_PMAX>, dim3(c->g_mid), dim3(256), mid_lds_bytes(), s2, s.hl, s.pw, io2, c->tables);
-         hipLaunchKernelGGL(k_patch_mid<HS_BIN3_PMAX>, dim3(c->g_big), dim3(256), big_lds_bytes(), s3, s.hl, s.pw, io3, c->tables);
-      }
+      hipLaunchKernelGGL(k_patch_extract_small<0>, dim3(c->g_small0), dim3(256), small_extract_lds_bytes(0), s0, s.hl, s.pw, io, c->tables);
+      hipLaunchKernelGGL(k_patch_extract_small<1>, dim3(c->g_small1), dim3(256), small_extract_lds_bytes(1), s1, s.hl, s.pw, io, c->tables);
+      hipLaunchKernelGGL(k_patch_mid<HS_MID_PMAX>, dim3(c->g_mid), dim3(256), mid_lds_bytes(), s2, s.hl, s.pw, io2, c->tables);
+      hipLaunchKernelGGL(k_patch_mid<HS_BIN3_PMAX>, dim3(c->g_big), dim3(256), big_lds_bytes(), s3, s.hl, s.pw, io3, c->tables);
    }
    if (forked)
       for (int i = 0; i < HS_NSIDE; i++) HIP_TRY(hipEventRecord(c->ev_join[i], c->side_streams[i]));
@@ -740,12 +709,9 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
       io.trows_cap = rows_cap;
       io.overflow = s.counters + 6;
       const uint32_t gblocks = std::min<uint32_t>((large_rows_bound + 4 * HS_LARGE_CHUNK - 1) / (4 * HS_LARGE_CHUNK), 256 * 16);
-      if (c->fast) hsfast_patch_large(st, fast_args(c, s, &io, nullptr, nullptr), c->b_rowprefix.as<uint32_t>(), gblocks, lg.lds, lg.srow_stride, lg.tap_stride, c->g_lfin);
-      else {
-         hipLaunchKernelGGL(k_large_prefix, dim3(1), dim3(256), 0, st, s.pw, c->b_rowprefix.as<uint32_t>());
-         hipLaunchKernelGGL(k_patch_large_rows, dim3(gblocks), dim3(256), lg.lds, st, s.hl, s.pw, io, c->tables, lg.srow_stride, lg.tap_stride);
-         hipLaunchKernelGGL(k_patch_large_finish, dim3(c->g_lfin), dim3(256), 0, st, s.pw, io, c->tables);
-      }
+      hipLaunchKernelGGL(k_large_prefix, dim3(1), dim3(256), 0, st, s.pw, c->b_rowprefix.as<uint32_t>());
+      hipLaunchKernelGGL(k_patch_large_rows, dim3(gblocks), dim3(256), lg.lds, st, s.hl, s.pw, io, c->tables, lg.srow_stride, lg.tap_stride);
+      hipLaunchKernelGGL(k_patch_large_finish, dim3(c->g_lfin), dim3(256), 0, st, s.pw, io, c->tables);
    }
    if (forked)
       for (int i = 0; i < HS_NSIDE; i++) HIP_TRY(hipStreamWaitEvent(st, c->ev_join[i], 0));
@@ -928,12 +894,6 @@ void collect_timings(hesaff_ctx *c, StageTimer &tm, int B)
 // The descriptor kernels (kernels_sift.h) over n patches in HBM.
 void launch_sift(hesaff_ctx *c, hipStream_t ss, const SiftIO &so, uint32_t n, float2 *vo)
 {
-   if (c->fast) {
-      Lists none;
-      memset(&none, 0, sizeof none);
-      hsfast_sift(ss, fast_args(c, none, nullptr, nullptr, &so), n, vo, c->sgrad_grid ? c->sgrad_grid : c->n_cu * 6u, c->g_shist);
-      return;
-   }
    const uint32_t nb64 = (n + 63) / 64;
    hipLaunchKernelGGL(k_sift_meanvar, dim3((n + SM_KP - 1) / SM_KP), dim3(64), 0, ss, so, c->tables);
    hipLaunchKernelGGL(k_sift_grad, dim3(c->sgrad_grid ? std::min(n, c->sgrad_grid) : n), dim3(256), 0, ss, so, c->tables, vo);
@@ -1026,8 +986,7 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       auto launch_affine = [&](size_t gi) {
          const int ta = tm.begin(T_AFF, 0, as);
          const uint32_t agrid = std::min<uint32_t>((groups[gi].hi - groups[gi].lo + HS_AFFP_G - 1) / HS_AFFP_G, (uint32_t)c->n_cu * c->aff_blocks_per_cu);
-         if (c->fast) hsfast_affine(as, std::min<uint32_t>((groups[gi].hi - groups[gi].lo + 3) / 4, (uint32_t)c->n_cu * 12u), fast_args(c, s, nullptr, &pt, nullptr), groups[gi].lo, groups[gi].hi, (const uint32_t *)(cnt + 3));
-         else hipLaunchKernelGGL(k_affine, dim3(agrid), dim3(64), 0, as, pt, s.hl, groups[gi].lo, groups[gi].hi, (const uint32_t *)(cnt + 3), c->tables, c->consts, s.ao);
+         hipLaunchKernelGGL(k_affine, dim3(agrid), dim3(64), 0, as, pt, s.hl, groups[gi].lo, groups[gi].hi, (const uint32_t *)(cnt + 3), c->tables, c->consts, s.ao);
          tm.end(ta);
          if (as != st) HIP_TRY(hipEventRecord(c->ev_aff[gi], as));
       };

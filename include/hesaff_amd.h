@@ -57,12 +57,13 @@ typedef struct hesaff_params {
    int max_batch;              /* images processed together on the device (default 64; hesaff_detect_batch pipelines chunks of this size) */
    int max_kpts_per_mpx;       /* candidate/keypoint capacity per megapixel (default 40000) */
    /* 0 (default): parity mode, results bit-identical to the reference's arithmetic.
-    * 1: fast mode: contracted multiply-adds, reassociated sums and approximate
-    *    division / square root / atan2 in the per-keypoint kernels; NOT bit-exact, see DESIGN.md for the
-    *    measured mismatch rate.
-    * 2: fast mode + a different algorithm for the windows larger than the 41 x 41 patch: their samples are taken from the
-    *    scale-space level whose blur matches (1681 taps) instead of warping and blurring a P x P window of the original
-    *    (affine.cpp:114-135); descriptors of those keypoints differ visibly, see DESIGN.md for the measured effect. */
+    * 2: a different algorithm for the windows larger than the 41 x 41 patch (27 % of the keypoints, 3/4 of the patch stage's
+    *    time): their samples are taken from the scale-space level whose blur matches (1681 taps) instead of warping and
+    *    blurring a P x P window of the original (affine.cpp:114-135).  Detection, affine shapes, the set of described keypoints
+    *    and the descriptors of the small windows stay those of parity mode; the other descriptors differ visibly, see DESIGN.md
+    *    for the measured effect on descriptors and matching.
+    * 1 was "the same algorithm with free summation order and approximate division" (ABI versions 2-3).  It bought 1.02x
+    *    and is withdrawn: hesaff_create refuses it. */
    int fast;
 } hesaff_params;
 
@@ -210,12 +211,14 @@ int hesaff_host_threads(void);
 int hesaff_test_fmt_g(const float *v, int n);
 void hesaff_free(void *p);
 
-/* replaces: cv::imread(argv[1]) hesaff.cpp:137 for binary PGM/PPM (P5/P6, maxval 255).
+/* replaces: cv::imread(argv[1]) hesaff.cpp:137 for PBM / PGM / PPM files, plain and binary (P1..P6), maxval 1..65535, the way
+ * OpenCV's PxM decoder delivers them at imread's default flag: binary 8-bit samples as they are, plain samples scaled by
+ * 255 / maxval, 16-bit samples reduced to the high byte, bitmaps as 255 / 0.
  * *data is malloc'ed (free with hesaff_free), tightly packed, channels 1 or 3. */
 int hesaff_read_pnm(const char *path, uint8_t **data, int *width, int *height, int *channels);
 /* the same for PNG files (decoded with zlib): what cv::imread returns with its default flag - 8 bits per
  * channel, alpha dropped, 16-bit samples reduced to the high byte, palette / 1-2-4-bit grey expanded;
- * channels = 1 for grey files, 3 (R,G,B order) otherwise.  Interlaced files: HESAFF_ERR_IO. */
+ * channels = 1 for grey files, 3 (R,G,B order) otherwise.  Adam7-interlaced files are read too. */
 int hesaff_read_png(const char *path, uint8_t **data, int *width, int *height, int *channels);
 /* Huffman-coded 8-bit JPEG, sequential or progressive, grey or YCbCr: the integer algorithms of libjpeg at
  * cv::imread's settings (JDCT_ISLOW inverse DCT, "fancy" chroma up-sampling, JFIF colour conversion), pixel for pixel

@@ -4,7 +4,8 @@
 // ChunkIO::next / staged one chunk ahead, the caller's thread that "computes" a chunk, delivers the previous one and takes a
 // result block from the ring of three - and fabricates records from the pixels it was handed (so every decoded byte is read
 // while the engine says it is alive, and every record is read by a writer while its block is marked busy).
-//   engine_sanitize <max_batch> <decode_threads> <write_threads> <format> <file>...
+//   engine_sanitize <max_batch> <decode_threads> <write_threads> <format> <file>...      (format + 4: the mock hands over rows that
+//                   are already text / packed - ChunkDone::text, text_off, bin - like the device formatter of kernels_export.h)
 // prints "files=<n> written=<w> unreadable=<u> rows=<r>"; exit code 0 unless the pipeline misbehaved.
 #include <cstdio>
 #include <cstdlib>
@@ -20,13 +21,15 @@ struct State {
    std::vector<int32_t> nh, nd;
    std::vector<size_t> off;
    std::vector<uint32_t> sum;
+   std::vector<unsigned long long> toff;
    int total = 0, block = -1;
 };
 
 int main(int argc, char **argv)
 {
    if (argc < 6) return 2;
-   const int max_batch = atoi(argv[1]), dt = atoi(argv[2]), wt = atoi(argv[3]), fmt = atoi(argv[4]);
+   const int max_batch = atoi(argv[1]), dt = atoi(argv[2]), wt = atoi(argv[3]), fmt = atoi(argv[4]) & 3;
+   const bool device_format = (atoi(argv[4]) & 4) != 0;
    const int n = argc - 5;
    std::vector<const char *> paths((size_t)n);
    for (int i = 0; i < n; i++) paths[(size_t)i] = argv[5 + i];
@@ -35,9 +38,10 @@ int main(int argc, char **argv)
    BlockRing ring;
    ring.reset(3);
    std::vector<std::vector<hesaff_keypoint>> blocks(3);
+   std::vector<std::vector<char>> text_blocks(3), bin_blocks(3);
    long long rows = 0;
    {
-      FileIO io(&ring, max_batch, 5.196152f, fmt, n, paths.data(), nullptr, status.data(), dt, wt);
+      FileIO io(&ring, max_batch, 5.196152f, fmt, n, paths.data(), nullptr, status.data(), dt, wt, device_format);
       auto stage = [&]() -> std::unique_ptr<State> {
          std::unique_ptr<State> s(new State());
          if (!io.next(s->q)) return nullptr;
@@ -57,6 +61,11 @@ int main(int argc, char **argv)
          ChunkDone d;
          d.chunk = &s.q; d.count_hessian = s.nh.data(); d.count_desc = s.nd.data(); d.key_off = s.off.data();
          d.keys = blocks[(size_t)s.block].data(); d.block = s.block;
+         if (device_format) {
+            d.keys = nullptr;
+            if (io.wants() & WANT_TEXT) { d.text = text_blocks[(size_t)s.block].data(); d.text_off = s.toff.data(); }
+            if (io.wants() & WANT_BIN) d.bin = bin_blocks[(size_t)s.block].data();
+         }
          io.done(d);
       };
       for (;;) {
@@ -81,6 +90,31 @@ int main(int argc, char **argv)
                k.a11 = 1.25f; k.a12 = 0.0f; k.a21 = 0.1f; k.a22 = 0.8f; k.response = 30.0f; k.type = r & 1;
                for (int j = 0; j < 128; j++) k.desc[j] = (uint8_t)(cur->sum[b] + (uint32_t)(r * 131 + j));
             }
+         if (device_format) {
+            // the "device formatter": every image's rows through the host formatter, headers cut off, back to back
+            std::vector<char> &tb = text_blocks[(size_t)cur->block], &bb = bin_blocks[(size_t)cur->block];
+            tb.assign(1, 0); bb.assign((size_t)cur->total * 148 + 1, 0);
+            cur->toff.assign(B + 1, 0ull);
+            size_t to = 0;
+            for (size_t b = 0; b < B; b++) {
+               char *txt = nullptr; size_t len = 0;
+               if (hesaff_format_sift(blk.data() + cur->off[b], cur->nd[b], 5.196152f, &txt, &len) != HESAFF_OK) return 4;
+               size_t skip = 0;
+               for (int nl = 0; nl < 2; skip++) if (txt[skip] == '\n') nl++;
+               tb.resize(to + (len - skip) + 1);
+               memcpy(tb.data() + to, txt + skip, len - skip);
+               cur->toff[b] = to; to += len - skip;
+               hesaff_free(txt);
+               for (int r = 0; r < cur->nd[b]; r++) {
+                  const hesaff_keypoint &k = blk[cur->off[b] + (size_t)r];
+                  float v[5] = {k.x, k.y, 0, 0, 0};
+                  hesaff_ellipse(&k, 5.196152f, &v[2], &v[3], &v[4]);
+                  memcpy(bb.data() + (cur->off[b] + (size_t)r) * 148, v, 20);
+                  memcpy(bb.data() + (cur->off[b] + (size_t)r) * 148 + 20, k.desc, 128);
+               }
+            }
+            cur->toff[B] = to;
+         }
          rows += cur->total;
          prev = std::move(cur);
       }

@@ -143,7 +143,7 @@ def test_oversubscribed_huffman_table_is_refused(driver, tmp_path):
 
 def test_readers_refuse_damaged_files_without_memory_errors(driver, tmp_path):
     import numpy as np
-    from tests.test_host_side import _png_bytes
+    from tests.test_host_side import _adam7_png_bytes, _png_bytes
     rng = random.Random(20260202)
     nrng = np.random.default_rng(5)
     seeds = [f for f in sorted(os.listdir(GOLDEN)) if f.rsplit(".", 1)[-1] in ("pgm", "ppm", "jpg")]
@@ -156,7 +156,16 @@ def test_readers_refuse_damaged_files_without_memory_errors(driver, tmp_path):
               ("rgba.png", _png_bytes(nrng.integers(0, 256, (9, 13, 4), dtype=np.uint8), 6)),
               ("g16.png", _png_bytes(nrng.integers(0, 65536, (11, 7, 1), dtype=np.uint16), 0, depth=16)),
               ("g2.png", _png_bytes(nrng.integers(0, 4, (10, 21, 1), dtype=np.uint8), 0, depth=2, filters=(0, 2))),
-              ("pal4.png", _png_bytes(nrng.integers(0, 16, (12, 15, 1), dtype=np.uint8), 3, depth=4, palette=pal, filters=(0,)))]
+              ("pal4.png", _png_bytes(nrng.integers(0, 16, (12, 15, 1), dtype=np.uint8), 3, depth=4, palette=pal, filters=(0,))),
+              # round 4: Adam7-interlaced PNG and the other PNM forms imread reads (plain, 16-bit, bitmaps, maxval != 255)
+              ("a7_rgb.png", _adam7_png_bytes(nrng.integers(0, 256, (19, 23, 3), dtype=np.uint8), 2)),
+              ("a7_g1.png", _adam7_png_bytes(nrng.integers(0, 2, (17, 29, 1), dtype=np.uint8), 0, depth=1)),
+              ("a7_pal4.png", _adam7_png_bytes(nrng.integers(0, 16, (9, 9, 1), dtype=np.uint8), 3, depth=4, palette=pal)),
+              ("p2.pgm", b"P2\n# c\n13 9\n200\n" + b" ".join(b"%d" % v for v in nrng.integers(0, 256, 13 * 9)) + b"\n"),
+              ("p3.ppm", b"P3 5 4 1023 " + b" ".join(b"%d" % v for v in nrng.integers(0, 1024, 60))),
+              ("p5_16.pgm", b"P5 11 7 65535\n" + nrng.integers(0, 65536, 77, dtype=np.uint16).astype(">u2").tobytes()),
+              ("p4.pbm", b"P4 13 6\n" + nrng.integers(0, 256, 12, dtype=np.uint8).tobytes()),
+              ("p1.pbm", b"P1 7 5\n" + b"".join(b"%d" % v for v in nrng.integers(0, 2, 35)))]
     paths = []
     for f, data in blobs:
         p0 = str(tmp_path / ("intact_" + f)); open(p0, "wb").write(data); paths.append(p0)   # the intact file too
@@ -211,7 +220,8 @@ def test_file_pipeline_threads_under_sanitizers(san, tmp_path):
     bad = tmp_path / "bad.pgm"; bad.write_bytes(b"P5\n9 9\n255\nxx")
     names.insert(7, str(bad)); names.append(str(bad))
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1")
-    for max_batch, dt, wt, fmt in ((1, 1, 1, 1), (4, 3, 3, 3), (64, 8, 2, 2), (3, 2, 8, 1)):
+    # fmt + 4: the mock device hands the writers finished rows (ChunkDone::text / bin) like the GPU formatter does
+    for max_batch, dt, wt, fmt in ((1, 1, 1, 1), (4, 3, 3, 3), (64, 8, 2, 2), (3, 2, 8, 1), (4, 2, 3, 7), (2, 1, 2, 5)):
         for n_ in names:
             for ext in (".hesaff.sift", ".hesaff.bin"):
                 if os.path.exists(n_ + ext):
@@ -220,6 +230,7 @@ def test_file_pipeline_threads_under_sanitizers(san, tmp_path):
         assert r.returncode == 0, (max_batch, dt, wt, fmt, r.stdout[-500:], r.stderr[-4000:])
         assert "files=47 written=45 unreadable=2 other=0" in r.stdout, r.stdout
         rows = int(r.stdout.strip().rsplit("rows=", 1)[1])
+        fmt &= 3
         got = 0
         for n_ in names:
             if n_ == str(bad):

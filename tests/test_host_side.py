@@ -271,6 +271,117 @@ def test_read_png_matches_imread_semantics(tmp_path):
         hesaff_amd.read_image(str(tmp_path / "x.jpg"))
 
 
+def _adam7_png_bytes(pix, ctype, depth=8, palette=None):
+    """An Adam7-interlaced PNG of pix [H, W, samples] (Pillow cannot write one): each of the seven passes is the sub-image
+    of the PNG specification's section 8.2, filtered and packed like an image of its own."""
+    import struct, zlib
+    H, W, nch = pix.shape
+    raw = bytearray()
+    for xs, ys, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        sub = pix[ys::dy, xs::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        # the filtered rows of this pass = the raw stream of a stand-alone (non-interlaced) PNG of the sub-image
+        one = _png_bytes(sub, ctype, depth=depth, palette=palette, idat_split=1)
+        i = one.index(b"IDAT")
+        n = struct.unpack(">I", one[i - 4:i])[0]
+        raw += zlib.decompress(one[i + 4:i + 4 + n])
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    b = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, depth, ctype, 0, 0, 1))
+    if palette is not None:
+        b += chunk(b"PLTE", palette.astype(np.uint8).tobytes())
+    z = zlib.compress(bytes(raw), 6)
+    return b + chunk(b"IDAT", z[: len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:]) + chunk(b"IEND", b"")
+
+
+def test_read_png_adam7_interlaced(tmp_path):
+    """cv::imread reads interlaced PNG files (hesaff.cpp:137); the pixels are lossless, so the in-tree reader must return what
+    Pillow (libpng) returns and what was encoded: sizes around the 8 x 8 Adam7 cell (empty passes), every colour type and depth."""
+    from PIL import Image
+    rng = np.random.default_rng(23)
+    for (H, W) in ((1, 1), (2, 3), (5, 4), (8, 8), (9, 17), (23, 37), (64, 50)):
+        cases = [("g8", rng.integers(0, 256, (H, W, 1), dtype=np.uint8), 0, 8, None),
+                 ("rgb", rng.integers(0, 256, (H, W, 3), dtype=np.uint8), 2, 8, None),
+                 ("rgba", rng.integers(0, 256, (H, W, 4), dtype=np.uint8), 6, 8, None),
+                 ("g16", rng.integers(0, 65536, (H, W, 1), dtype=np.uint16), 0, 16, None),
+                 ("g2", rng.integers(0, 4, (H, W, 1), dtype=np.uint8), 0, 2, None),
+                 ("g1", rng.integers(0, 2, (H, W, 1), dtype=np.uint8), 0, 1, None),
+                 ("pal4", rng.integers(0, 16, (H, W, 1), dtype=np.uint8), 3, 4, rng.integers(0, 256, (16, 3), dtype=np.uint8))]
+        for name, pix, ctype, depth, pal in cases:
+            q = tmp_path / ("%s_%dx%d.png" % (name, W, H))
+            q.write_bytes(_adam7_png_bytes(pix, ctype, depth, pal))
+            got = hesaff_amd.read_image(str(q))
+            if ctype == 3:
+                want = pal[pix[:, :, 0]]
+            elif depth == 16:
+                want = (pix[:, :, 0] >> 8).astype(np.uint8)
+            elif depth < 8:
+                want = pix[:, :, 0] * (255 // ((1 << depth) - 1))
+            elif ctype == 0:
+                want = pix[:, :, 0]
+            else:
+                want = pix[:, :, :3]
+            assert np.array_equal(got, want), (name, H, W)
+            if depth == 8 and ctype in (0, 2):     # ... and libpng agrees that this is what the file holds
+                assert np.array_equal(np.asarray(Image.open(str(q))), want), (name, H, W)
+    # a truncated pass stream is an error
+    bad = _adam7_png_bytes(rng.integers(0, 256, (9, 9, 1), dtype=np.uint8), 0)
+    (tmp_path / "cut.png").write_bytes(bad[:-40] + bad[-12:])
+    with pytest.raises(hesaff_amd.HesaffError):
+        hesaff_amd.read_image(str(tmp_path / "cut.png"))
+
+
+def test_read_pnm_every_form_imread_reads(tmp_path):
+    """hesaff_read_pnm follows OpenCV's PxM decoder (cv::imread, hesaff.cpp:137): plain and binary PBM / PGM / PPM, any maxval."""
+    from PIL import Image
+    rng = np.random.default_rng(29)
+    H, W = 7, 11
+
+    def rd(name, data):
+        q = tmp_path / name
+        q.write_bytes(data)
+        return hesaff_amd.read_image(str(q)), str(q)
+
+    g = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    c = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    # plain forms at maxval 255 = the binary forms, = Pillow
+    got, q = rd("p2.pgm", b"P2\n# made by hand\n%d %d\n255\n" % (W, H) + b"\n".join(b" ".join(b"%d" % v for v in row) for row in g) + b"\n")
+    assert np.array_equal(got, g) and np.array_equal(np.asarray(Image.open(q)), g)
+    got, q = rd("p3.ppm", b"P3 %d %d 255 " % (W, H) + b" ".join(b"%d" % v for v in c.ravel()))
+    assert np.array_equal(got, c) and np.array_equal(np.asarray(Image.open(q)), c)
+    # plain samples with another maxval: clamped to it, then i * 255 / maxval (integer division, grfmt_pxm.cpp)
+    v = rng.integers(0, 40, (H, W))
+    got, _ = rd("p2_31.pgm", b"P2 %d %d 31\n" % (W, H) + b" ".join(b"%d" % x for x in v.ravel()) + b"\n")
+    assert np.array_equal(got, (np.minimum(v, 31) * 255 // 31).astype(np.uint8))
+    # binary 8-bit samples are taken as they are, whatever maxval says
+    got, _ = rd("p5_100.pgm", b"P5 %d %d 100\n" % (W, H) + g.tobytes())
+    assert np.array_equal(got, g)
+    # 16-bit samples: the high byte (binary: big-endian)
+    g16 = rng.integers(0, 65536, (H, W), dtype=np.uint16)
+    got, _ = rd("p5_16.pgm", b"P5 %d %d 65535\n" % (W, H) + g16.astype(">u2").tobytes())
+    assert np.array_equal(got, (g16 >> 8).astype(np.uint8))
+    c16 = rng.integers(0, 1024, (H, W, 3), dtype=np.uint16)
+    got, _ = rd("p6_16.ppm", b"P6 %d %d 1023\n" % (W, H) + c16.astype(">u2").tobytes())
+    assert np.array_equal(got, (c16 >> 8).astype(np.uint8))
+    got, _ = rd("p2_16.pgm", b"P2 %d %d 65535\n" % (W, H) + b" ".join(b"%d" % x for x in g16.ravel()))
+    assert np.array_equal(got, (g16 >> 8).astype(np.uint8))
+    # bitmaps: 1 = black
+    bits = rng.integers(0, 2, (H, W), dtype=np.uint8)
+    packed = np.packbits(bits, axis=1).tobytes()
+    got, q = rd("p4.pbm", b"P4 %d %d\n" % (W, H) + packed)
+    assert np.array_equal(got, (1 - bits) * 255) and np.array_equal(np.asarray(Image.open(q).convert("L")), (1 - bits) * 255)
+    got, _ = rd("p1.pbm", b"P1\n%d %d\n" % (W, H) + b"\n".join(b"".join(b"%d" % x for x in row) for row in bits))
+    assert np.array_equal(got, (1 - bits) * 255)
+    # damaged: too few samples, a header that promises more than the file holds, maxval out of range
+    for name, data in (("short.pgm", b"P2 4 4 255 1 2 3"), ("huge.pgm", b"P5 60000 60000 255\n" + bytes(100)), ("mv.pgm", b"P5 2 2 70000\n" + bytes(8)),
+                       ("p7.pam", b"P7\nWIDTH 2\n")):
+        (tmp_path / name).write_bytes(data)
+        with pytest.raises(hesaff_amd.HesaffError):
+            hesaff_amd.read_image(str(tmp_path / name))
+
+
 # ------------------------------------------------------------------------------------------
 # JPEG (SURVEY.md 8f rank 2): hesaff_read_jpeg restates libjpeg's integer algorithms at cv::imread's settings
 # ------------------------------------------------------------------------------------------

@@ -196,17 +196,22 @@ def synthetic_sequence(width=800, height=640, angles=(10, 20, 30, 40, 50), seed=
                     "(the Oxford sequences are not available offline)" % (width, height), "pairs": out}
 
 
-def write_sequence_files(out_dir, width=800, height=640, angles=(10, 20, 30, 40, 50), seed=1234, quality=92):
+def write_sequence_files(out_dir, width=800, height=640, angles=(10, 20, 30, 40, 50), seed=1234, quality=92, photo=None):
     """A graf-like sequence on disk, laid out like the Oxford sets: img1.jpg .. imgN.jpg (colour JPEG, 4:2:0, so that the
     library's own JPEG decoder is on the path exactly as with the real data) and H1to2p .. H1toNp (3x3 text).
+    photo: an HxWx3 uint8 photograph to warp instead of the band-noise image (width / height are then its size).
     -> (image paths, homographies)."""
     from PIL import Image
     from hesaff_amd.synth import band_noise_image
-    g = band_noise_image(height, width, seed).astype(np.float32)
-    t1 = band_noise_image(height, width, seed + 1).astype(np.float32)
-    t2 = band_noise_image(height, width, seed + 2).astype(np.float32)
-    base = np.stack([g, 0.75 * g + 0.25 * t1, 0.75 * g + 0.25 * t2], axis=2)
-    base = np.clip(np.rint(base), 0, 255).astype(np.uint8)
+    if photo is not None:
+        base = np.ascontiguousarray(photo, np.uint8)
+        height, width = base.shape[:2]
+    else:
+        g = band_noise_image(height, width, seed).astype(np.float32)
+        t1 = band_noise_image(height, width, seed + 1).astype(np.float32)
+        t2 = band_noise_image(height, width, seed + 2).astype(np.float32)
+        base = np.stack([g, 0.75 * g + 0.25 * t1, 0.75 * g + 0.25 * t2], axis=2)
+        base = np.clip(np.rint(base), 0, 255).astype(np.uint8)
     os.makedirs(out_dir, exist_ok=True)
     paths, Hs = [], []
     for k, a in enumerate((0,) + tuple(angles)):
@@ -234,11 +239,20 @@ def evaluate_sequence_files(paths, Hs, size, angles=None):
     return out
 
 
-def sequence_through_cli(out_dir, width=800, height=640, angles=(10, 20, 30, 40, 50), fast=0):
+def sequence_through_cli(out_dir, width=800, height=640, angles=(10, 20, 30, 40, 50), fast=0, photo=None):
     """BASELINE.json config 5 on the synthetic stand-in: the sequence as JPEG files -> `hesaff --batch` (decode threads,
-    device, writer threads) -> the evaluation above."""
+    device, writer threads) -> the evaluation above.  photo: index of one of scikit-learn's sample photographs (0: china.jpg,
+    1: flower.jpg) to warp instead of the band-noise image: a planar scene under a viewpoint change, like graf."""
     import subprocess
-    paths, Hs = write_sequence_files(out_dir, width, height, angles)
+    pic = None
+    if photo is not None:
+        from hesaff_amd.synth import load_sample_photos
+        pics = load_sample_photos()
+        if not pics:
+            raise RuntimeError("scikit-learn's sample photographs are not installed")
+        pic = pics[photo]
+        height, width = pic.shape[:2]
+    paths, Hs = write_sequence_files(out_dir, width, height, angles, photo=pic)
     lst = os.path.join(out_dir, "list.txt")
     with open(lst, "w") as f:
         f.write("\n".join(paths) + "\n")
@@ -246,10 +260,13 @@ def sequence_through_cli(out_dir, width=800, height=640, angles=(10, 20, 30, 40,
     r = subprocess.run([exe, "--batch", lst] + (["--fast", str(fast)] if fast else []), capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hesaff --batch failed: " + r.stderr[-2000:])
-    return {"data": "synthetic graf-like sequence: %dx%d colour band-noise image and %d copies warped by a camera rotation about the "
+    return {"data": "graf-like sequence: %s (%dx%d) and %d copies warped by a camera rotation about the "
                     "vertical axis, stored as JPEG (quality 92, 4:2:0) and read back by the library's JPEG decoder; the Oxford "
-                    "sequences are not available offline" % (width, height, len(angles)),
-            "command": "python tools/repeatability.py --synthetic-files DIR%s   (hesaff --batch list.txt, then the evaluation)" % ((" --fast %d" % fast) if fast else ""),
+                    "sequences are not available offline" % ("a colour band-noise image" if photo is None else
+                                                              "the photograph %s of scikit-learn's sample images" % ("china.jpg", "flower.jpg")[photo],
+                                                              width, height, len(angles)),
+            "command": "python tools/repeatability.py --synthetic-files DIR%s%s   (hesaff --batch list.txt, then the evaluation)"
+                       % ((" --fast %d" % fast) if fast else "", (" --photo %d" % photo) if photo is not None else ""),
             "fast": fast,
             "cli_stdout_tail": r.stdout.strip().splitlines()[-1],
             "pairs": evaluate_sequence_files(paths, Hs, (width, height), list(angles))}
@@ -264,9 +281,10 @@ def main():
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--synthetic-files", metavar="DIR", help="write the synthetic sequence as JPEG files into DIR, run `hesaff --batch` on it, evaluate")
     ap.add_argument("--fast", type=int, default=0, help="with --synthetic-files: hesaff_params.fast (0 = parity mode through the CLI)")
+    ap.add_argument("--photo", type=int, default=None, help="with --synthetic-files: warp this sample photograph (0: china.jpg, 1: flower.jpg) instead of band noise")
     args = ap.parse_args()
     if args.synthetic_files:
-        print(json.dumps(sequence_through_cli(args.synthetic_files, fast=args.fast), indent=1))
+        print(json.dumps(sequence_through_cli(args.synthetic_files, fast=args.fast, photo=args.photo), indent=1))
         return
     if args.synthetic:
         print(json.dumps(synthetic_sequence()))
