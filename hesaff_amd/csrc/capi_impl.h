@@ -714,7 +714,7 @@ int hesaff_stage_find_affine_shape(hesaff_ctx *c, const float *blur, int rows, i
    HIP_TRY(hipMemcpyAsync(d_kp, kp, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
    AffineOut ao; ao.converged = d_conv; ao.iters = d_iters; ao.U = d_U;
    DPlane P = make_plane(d_plane, rows, cols, cols);
-   hipLaunchKernelGGL(k_affine_stage, dim3(std::min((n + HS_AFF_KP_PER_BLOCK - 1) / HS_AFF_KP_PER_BLOCK, 256 * 2)), dim3(HS_AFF_THREADS), 0, c->stream, P, (const float *)d_kp, n, c->tables, c->consts, ao);
+   hipLaunchKernelGGL(k_affine_stage, dim3(std::min((n + HS_AFFP_G - 1) / HS_AFFP_G, 256 * 6)), dim3(64), 0, c->stream, P, (const float *)d_kp, n, c->tables, c->consts, ao);
    if (converged) HIP_TRY(hipMemcpyAsync(converged, d_conv, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
    if (iters) HIP_TRY(hipMemcpyAsync(iters, d_iters, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
    if (U) HIP_TRY(hipMemcpyAsync(U, d_U, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));

@@ -283,221 +283,14 @@ __device__ __forceinline__ void hs_affine_groups(uint32_t first, uint32_t n, con
 }
 
 
-// ---------------------------------------------------------------------------------------
-// hs_affine_block: the same iteration with SIXTEEN keypoints per 256-thread block.  Four wavefronts
-// sample and form the products of four keypoints each exactly like hs_affine_groups; then ONE wavefront - a different
-// one every round, so that the four SIMDs share the work - adds the 48 sums of the block (16 keypoints x a, b, c) in the
-// reference's order on 48 lanes and runs the double-precision invSqrt of the 16 keypoints on 16 lanes.  The serial
-// stretches of a round (about 650 wavefront instructions: 361 dependent adds and the double-precision tail) are paid once
-// per 16 keypoints instead of once per 4.  Two block barriers per round; LDS 16 x 3 x 364 floats (72 KB): two blocks per CU.
-// ---------------------------------------------------------------------------------------
-#ifndef HS_AFFB_W
-#define HS_AFFB_W 4
-#endif
-#define HS_AFFB_KP (HS_AFFB_W * 4)
-template <class Fetch>
-__device__ __forceinline__ void hs_affine_block(uint32_t first, uint32_t n, const float *__restrict__ mask_g, const DConsts &k, AffineOut out,
-                                                Fetch fetch)
-{
-   __shared__ __attribute__((aligned(16))) float s_arr[HS_AFFB_KP][3][HS_AFF_ARR];   // img, then a terms | b terms | c terms
-   __shared__ float s_mask[HS_AFF_ARR];
-   __shared__ float s_in[HS_AFFB_KP][8];    // owner -> summer: u11, u12, u21, u22, eigen_ratio_act, active
-   __shared__ float s_bc[HS_AFFB_KP][12];   // summer -> owner: a, b, c | new U | state | new eigen_ratio_act
-   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, li = lane & 15;
-   const int kq = wave * 4 + grp;           // this 16-lane group's keypoint slot in the block
-   for (int i = tid; i < HS_SMM_PIX; i += 64 * HS_AFFB_W) s_mask[i] = mask_g[i];
-   float *s_img = s_arr[kq][0], *s_pa = s_arr[kq][0], *s_pb = s_arr[kq][1], *s_pc = s_arr[kq][2];
-   // XCD-aware order as in hs_affine_groups, in items of 16 keypoints
-   uint32_t hstep = gridDim.x * HS_AFFB_KP, h_end = n;
-   uint32_t h = first + blockIdx.x * HS_AFFB_KP + kq;
-   if (HS_AFF_XCD && (gridDim.x & 7u) == 0u && n > first) {
-      const uint32_t n_items = (n - first + HS_AFFB_KP - 1) / HS_AFFB_KP;
-      const uint32_t xcd = blockIdx.x & 7u, rank = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-      const uint32_t it_lo = (uint32_t)(((unsigned long long)n_items * xcd) >> 3), it_hi = (uint32_t)(((unsigned long long)n_items * (xcd + 1)) >> 3);
-      hstep = per_xcd * HS_AFFB_KP;
-      h_end = min(first + it_hi * HS_AFFB_KP, n);
-      h = first + (it_lo + rank) * HS_AFFB_KP + kq;
-   }
-   if (k.maxIterations <= 0) {   // no iteration: U = identity, not converged
-      for (; h < h_end; h += hstep)
-         if (li == 0) {
-            out.converged[h] = 0; out.iters[h] = 0;
-            out.U[4 * h + 0] = 1.0f; out.U[4 * h + 1] = 0.0f; out.U[4 * h + 2] = 0.0f; out.U[4 * h + 3] = 1.0f;
-         }
-      return;
-   }
-   const float *blur = nullptr;
-   int pitch = 0, width = 0, height = 0, l = 0;
-   float lx = 0, ly = 0, ratio = 0, u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f;
-   float eigen_ratio_act = 0.0f;
-   bool active = h < h_end;
-   auto load_kp = [&]() {
-      if (active) {
-         const AffKp q = fetch(h);
-         blur = q.blur; pitch = q.pitch; width = q.cols - 1; height = q.rows - 1;
-         lx = q.x / q.pd; ly = q.y / q.pd;
-         ratio = q.s / (k.affInitialSigma * q.pd);
-         u11 = 1.0f; u12 = 0.0f; u21 = 0.0f; u22 = 1.0f;
-         eigen_ratio_act = 0.0f;
-         l = 0;
-      }
-   };
-   load_kp();
-   __syncthreads();   // s_mask
-   for (uint32_t round = 0;; round++) {
-      bool win_in = true;
-      if (active) {
-         const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
-         win_in = !hs_window_outside(height + 1, width + 1, lx, ly, a11, a12, a21, a22, HS_SMM >> 1);
-      }
-      const bool all_in = __ballot(active && !win_in) == 0ull;   // one decision per wavefront, see hs_affine_groups
-      auto sample = [&](auto inside_c) {
-         constexpr bool INSIDE = decltype(inside_c)::value;
-         const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
-#pragma unroll
-         for (int half = 0; half < HS_AFF_BATCHES; half++) {
-            constexpr int NB = (HS_AFF_NT + HS_AFF_BATCHES - 1) / HS_AFF_BATCHES;
-            float sv[NB];
-#pragma unroll
-            for (int t = 0; t < NB; t++) {
-               const int idx = min(li + 16 * (half * NB + t), HS_SMM_PIX - 1);
-               const int jj = idx / HS_SMM, ii = idx - jj * HS_SMM;
-               const int j = jj - (HS_SMM >> 1), i = ii - (HS_SMM >> 1);
-               const float rx = lx + (float)j * a12;
-               const float ry = ly + (float)j * a22;
-               const float wx = rx + (float)i * a11;
-               const float wy = ry + (float)i * a21;
-               if (INSIDE) {
-                  sv[t] = hs_tap_inside_ptr(blur, pitch, wx, wy);
-               } else {
-                  bool outside = false;
-                  sv[t] = hs_bilinear(blur, pitch, width, height, wx, wy, outside);
-               }
-            }
-#pragma unroll
-            for (int t = 0; t < NB; t++) HS_KEEP(sv[t]);
-#pragma unroll
-            for (int t = 0; t < NB; t++) {
-               const int idx = li + 16 * (half * NB + t);
-               if (idx < HS_SMM_PIX) s_img[idx] = sv[t];
-            }
-         }
-      };
-      if (active) {
-         if (all_in) sample(std::true_type{});
-         else sample(std::false_type{});
-      }
-      HS_WAVE_LDS_SYNC();
-      if (active) {
-         // computeGradient affine.cpp:14-33 + products affine.cpp:62-68 (hs_affine_groups)
-         float pa[HS_AFF_NT];
-#pragma unroll
-         for (int t = 0; t < HS_AFF_NT; t++) {
-            const int idx = min(li + 16 * t, HS_SMM_PIX - 1);
-            const int r = idx / HS_SMM, c = idx - r * HS_SMM;
-            const float gxx = s_img[idx + (c < HS_SMM - 1 ? 1 : 0)] - s_img[idx - (c > 0 ? 1 : 0)];
-            const float gyy = s_img[idx + (r < HS_SMM - 1 ? HS_SMM : 0)] - s_img[idx - (r > 0 ? HS_SMM : 0)];
-            const float v = s_mask[idx];
-            const float gxy = gxx * gyy;
-            pa[t] = gxx * gxx * v;
-            if (li + 16 * t < HS_SMM_PIX) {
-               s_pb[idx] = gxy * v;
-               s_pc[idx] = gyy * gyy * v;
-            }
-         }
-         HS_WAVE_LDS_SYNC();
-#pragma unroll
-         for (int t = 0; t < HS_AFF_NT; t++) {
-            const int idx = li + 16 * t;
-            if (idx < HS_SMM_PIX) s_pa[idx] = pa[t];
-         }
-      }
-      if (li == 0) {
-         s_in[kq][0] = u11; s_in[kq][1] = u12; s_in[kq][2] = u21; s_in[kq][3] = u22;
-         s_in[kq][4] = eigen_ratio_act; s_in[kq][5] = active ? 1.0f : 0.0f;
-      }
-      if (__syncthreads_or(active ? 1 : 0) == 0) break;   // products and s_in of the whole block are visible; nobody left: done
-      if (wave == (int)(round & (HS_AFFB_W - 1))) {
-         // this round's summer: lanes 0..47 = (which, keypoint slot), 361 terms each in index order (affine.cpp:57-68)
-         const int sk = lane % HS_AFFB_KP, which = lane / HS_AFFB_KP;
-         if (lane < 3 * HS_AFFB_KP && s_in[sk][5] != 0.0f) {
-            const float *pp = s_arr[sk][which];
-            const float4 *p4 = reinterpret_cast<const float4 *>(pp);
-            float acc = 0.0f;
-            for (int i0 = 0; i0 < HS_SMM_PIX / 4; i0 += 10) {   // 90 = 9 x 10 float4, ten reads in flight
-               float4 q[10];
-#pragma unroll
-               for (int u = 0; u < 10; u++) q[u] = p4[i0 + u];
-#pragma unroll
-               for (int u = 0; u < 10; u++) { acc += q[u].x; acc += q[u].y; acc += q[u].z; acc += q[u].w; }
-            }
-            acc += pp[HS_SMM_PIX - 1];   // 361 = 4 * 90 + 1
-            s_bc[sk][which] = acc / (float)HS_SMM_PIX;
-         }
-         HS_WAVE_LDS_SYNC();
-         if (lane < HS_AFFB_KP && s_in[lane][5] != 0.0f) {
-            float a = s_bc[lane][0], b = s_bc[lane][1], c = s_bc[lane][2];
-            float l1, l2;
-            hs_inv_sqrt(a, b, c, l1, l2);
-            const float bef = s_in[lane][4];
-            const float act = 1 - l2 / l1;
-            const float o11 = s_in[lane][0], o12 = s_in[lane][1], o21 = s_in[lane][2], o22 = s_in[lane][3];
-            const float n11 = a * o11 + b * o21, n12 = a * o12 + b * o22;
-            const float n21 = b * o11 + c * o21, n22 = b * o12 + c * o22;
-            int state = 0;   // 0 continue, 1 break (rejected), 2 converged
-            if (!hs_eigenvalues(n11, n12, n21, n22, l1, l2)) state = 1;
-            else if ((l1 / l2 > 6) || (l2 / l1 > 6)) state = 1;
-            else if (act < k.convergenceThreshold && bef < k.convergenceThreshold) state = 2;
-            s_bc[lane][3] = n11; s_bc[lane][4] = n12; s_bc[lane][5] = n21; s_bc[lane][6] = n22;
-            s_bc[lane][7] = __int_as_float(state);
-            s_bc[lane][8] = act;
-         }
-      }
-      __syncthreads();
-      if (active) {
-         u11 = s_bc[kq][3]; u12 = s_bc[kq][4]; u21 = s_bc[kq][5]; u22 = s_bc[kq][6];
-         const int state = __float_as_int(s_bc[kq][7]);
-         eigen_ratio_act = s_bc[kq][8];
-         if (state != 0 || l + 1 >= k.maxIterations) {
-            // affine.cpp:88-99: converged -> onAffineShapeFound(..., l); otherwise the keypoint is dropped
-            if (li == 0) {
-               out.converged[h] = (state == 2) ? 1 : 0;
-               out.iters[h] = (state == 2) ? l : 0;
-               out.U[4 * h + 0] = u11; out.U[4 * h + 1] = u12; out.U[4 * h + 2] = u21; out.U[4 * h + 3] = u22;
-            }
-            h += hstep;
-            active = h < h_end;
-            load_kp();
-         } else {
-            l++;
-         }
-      }
-   }
-}
-
-#ifndef HS_AFF_BLOCK16
-#define HS_AFF_BLOCK16 1   // 1: k_affine = 16 keypoints per 256-thread block (hs_affine_block); 0: 4 per wavefront (hs_affine_groups)
-#endif
-#if HS_AFF_BLOCK16
-#define HS_AFF_THREADS (64 * HS_AFFB_W)
-#define HS_AFF_KP_PER_BLOCK HS_AFFB_KP
-#else
-#define HS_AFF_THREADS 64
-#define HS_AFF_KP_PER_BLOCK HS_AFFP_G
-#endif
-
 #ifndef HS_AFF_WAVES
 #define HS_AFF_WAVES 0   // tuning: wavefronts per SIMD to hold the register allocation to (0: the compiler's choice)
 #endif
-__global__ __launch_bounds__(HS_AFF_THREADS, HS_AFF_WAVES) void k_affine(PlaneTab pt, HessList hl, uint32_t h_lo, uint32_t h_hi, const uint32_t *__restrict__ n_ptr,
+__global__ __launch_bounds__(64, HS_AFF_WAVES) void k_affine(PlaneTab pt, HessList hl, uint32_t h_lo, uint32_t h_hi, const uint32_t *__restrict__ n_ptr,
                                                KpTables tb, DConsts k, AffineOut out)
 {
    const uint32_t n = min(min(*n_ptr, hl.cap), h_hi);   // keypoints [h_lo, h_hi) of the list
-#if HS_AFF_BLOCK16
-   hs_affine_block(
-#else
    hs_affine_groups(
-#endif
       h_lo, n, tb.smm_mask, k, out, [&](uint32_t h) {
       const int meta = hl.meta[h];
       const int b = meta >> 8, octave = (meta >> 4) & 15, level = (meta >> 2) & 3;
@@ -510,15 +303,10 @@ __global__ __launch_bounds__(HS_AFF_THREADS, HS_AFF_WAVES) void k_affine(PlaneTa
 }
 
 // stage API flavour: n keypoints on a single plane, pixelDistance given explicitly
-__global__ __launch_bounds__(HS_AFF_THREADS) void k_affine_stage(DPlane P, const float *__restrict__ kp /*n x 4*/, int n, KpTables tb, DConsts k,
+__global__ __launch_bounds__(64) void k_affine_stage(DPlane P, const float *__restrict__ kp /*n x 4*/, int n, KpTables tb, DConsts k,
                                                      AffineOut out)
 {
-#if HS_AFF_BLOCK16
-   hs_affine_block(
-#else
-   hs_affine_groups(
-#endif
-      0u, (uint32_t)n, tb.smm_mask, k, out, [&](uint32_t h) {
+   hs_affine_groups(0u, (uint32_t)n, tb.smm_mask, k, out, [&](uint32_t h) {
       AffKp q;
       q.blur = P.img(0); q.rows = P.rows; q.cols = P.cols; q.pitch = P.pitch;
       q.x = kp[4 * h]; q.y = kp[4 * h + 1]; q.s = kp[4 * h + 2]; q.pd = kp[4 * h + 3];

@@ -246,7 +246,7 @@ struct hesaff_ctx {
    bool no_overlap = false;        // HESAFF_OVERLAP=0: every kernel alone on the device (per-kernel profiling)
    uint32_t sift_group_kpts = 0;   // HESAFF_GROUP: keypoints per image group; 0 = by batch
    bool taper_groups = false;      // HESAFF_TAPER: small groups at both ends of a batch (pipeline fill / drain)
-   int aff_blocks_per_cu = HS_AFF_BLOCK16 ? 8 / HS_AFFB_W : 8;      // HESAFF_AFF_BLOCKS: persistent k_affine blocks per CU (19 KB of LDS each: 8 resident).  Alone on the device
+   int aff_blocks_per_cu = 8;      // HESAFF_AFF_BLOCKS: persistent k_affine blocks per CU (19 KB of LDS each: 8 resident).  Alone on the device
                                    // 64 / 128 blocks per CU are 4 % faster (20.7 / 20.6 vs 21.6 ms), beside the other stages' kernels they
                                    // make the step 3.5 % slower (453 vs 438 ms at B = 128): the queued blocks take every slot that frees up
    int side_mask = 15;             // HESAFF_SIDE: bit i = window-size bin i runs on its own side stream
@@ -985,8 +985,8 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       if (as != st) HIP_TRY(hipStreamWaitEvent(as, c->ev_detect_done, 0));
       auto launch_affine = [&](size_t gi) {
          const int ta = tm.begin(T_AFF, 0, as);
-         const uint32_t agrid = std::min<uint32_t>((groups[gi].hi - groups[gi].lo + HS_AFF_KP_PER_BLOCK - 1) / HS_AFF_KP_PER_BLOCK, (uint32_t)c->n_cu * c->aff_blocks_per_cu);
-         hipLaunchKernelGGL(k_affine, dim3(agrid), dim3(HS_AFF_THREADS), 0, as, pt, s.hl, groups[gi].lo, groups[gi].hi, (const uint32_t *)(cnt + 3), c->tables, c->consts, s.ao);
+         const uint32_t agrid = std::min<uint32_t>((groups[gi].hi - groups[gi].lo + HS_AFFP_G - 1) / HS_AFFP_G, (uint32_t)c->n_cu * c->aff_blocks_per_cu);
+         hipLaunchKernelGGL(k_affine, dim3(agrid), dim3(64), 0, as, pt, s.hl, groups[gi].lo, groups[gi].hi, (const uint32_t *)(cnt + 3), c->tables, c->consts, s.ao);
          tm.end(ta);
          if (as != st) HIP_TRY(hipEventRecord(c->ev_aff[gi], as));
       };
