@@ -81,7 +81,10 @@ struct ChunkIO {
    virtual ~ChunkIO() {}
 };
 
-// hesaff_process_files: decoder threads -> chunks -> device -> writer threads
+// hesaff_process_files: decode -> chunks -> device -> write.  ONE pool of decode_threads + write_threads host threads serves both
+// ends: a worker decodes the next image whenever the look-ahead window has room (cheap for PNM, and what keeps the device fed) and
+// otherwise writes a finished image.  With separate pools the decoders of a PGM list idle while the writers - one write() per
+// image, tens of MB into the page cache - are the slowest stage of the whole pipeline.
 struct FileIO : ChunkIO {
    BlockRing *ring;
    int max_batch;
@@ -94,7 +97,7 @@ struct FileIO : ChunkIO {
    struct Img { uint8_t *data = nullptr; int w = 0, h = 0, ch = 0; int state = 0; };   // 0 pending, 1 decoded, 2 unreadable, 3 handed on
    std::vector<Img> imgs;
    std::mutex mu;
-   std::condition_variable cv_dec, cv_img, cv_task;
+   std::condition_variable cv_work, cv_img, cv_done;   // workers: a job may be available; next(): an image changed state; wait_writers()
    int next_decode = 0, consumed = 0, window = 0, pos = 0;
    bool stop = false;
    struct Task { int index; const hesaff_keypoint *keys; int n; int chunk; const char *text; size_t text_len; const char *bin; };
@@ -102,7 +105,7 @@ struct FileIO : ChunkIO {
    struct Open { int left; int block; };
    std::vector<Open> open_chunks;
    int tasks_in_flight = 0;
-   std::vector<std::thread> decoders, writers;
+   std::vector<std::thread> workers;
 
    FileIO(BlockRing *ring_, int max_batch_, float mrSize_, int fmt_, int n_, const char *const *p, const char *const *o, hesaff_file_status *st,
           int dec_threads, int wr_threads, bool device_format_ = false)
@@ -111,46 +114,50 @@ struct FileIO : ChunkIO {
    {
       window = 2 * max_batch + dec_threads;
       try {
-         for (int t = 0; t < dec_threads; t++) decoders.emplace_back([this] { decode_loop(); });
-         for (int t = 0; t < wr_threads; t++) writers.emplace_back([this] { write_loop(); });
+         for (int t = 0; t < dec_threads + wr_threads; t++) workers.emplace_back([this] { work_loop(); });
       } catch (...) {
-         shutdown();
-         throw;
+         if (workers.empty()) { shutdown(); throw; }   // not one thread: give up; fewer than asked for: go on with those
       }
    }
    ~FileIO() override { shutdown(); }
    void shutdown()
    {
       { std::lock_guard<std::mutex> lk(mu); stop = true; }
-      cv_dec.notify_all(); cv_img.notify_all(); cv_task.notify_all();
-      for (auto &t : decoders) if (t.joinable()) t.join();
-      for (auto &t : writers) if (t.joinable()) t.join();
+      cv_work.notify_all(); cv_img.notify_all(); cv_done.notify_all();
+      for (auto &t : workers) if (t.joinable()) t.join();
       for (Img &im : imgs) if (im.data) { hesaff_free(im.data); im.data = nullptr; }
    }
-   void decode_loop()
+   bool decode_ready() const { return !stop && next_decode < n && next_decode < consumed + window; }   // under mu
+   void work_loop()
    {
       for (;;) {
-         int i;
+         int i = -1;
+         Task t{};
          {
             std::unique_lock<std::mutex> lk(mu);
-            cv_dec.wait(lk, [&] { return stop || next_decode >= n || next_decode < consumed + window; });
-            if (stop || next_decode >= n) return;
-            i = next_decode++;
+            cv_work.wait(lk, [&] { return stop || decode_ready() || !tasks.empty(); });
+            if (decode_ready()) i = next_decode++;
+            else if (!tasks.empty()) { t = tasks.front(); tasks.pop_front(); }
+            else return;   // stop, nothing left to write
          }
-         Img im;
-         int rc = paths[i] ? hesaff_read_image(paths[i], &im.data, &im.w, &im.h, &im.ch) : HESAFF_ERR_ARG;
-         int stage = HESAFF_FILE_UNREADABLE;
-         if (rc == HESAFF_OK && (im.w > 65535 || im.h > 65535)) {   // the device plans 16-bit pixel coordinates (plan(), pipeline.hip)
-            hesaff_free(im.data); im.data = nullptr;
-            rc = HESAFF_ERR_ARG; stage = HESAFF_FILE_REJECTED;
-         }
-         {
-            std::lock_guard<std::mutex> lk(mu);
-            if (rc == HESAFF_OK) { im.state = 1; imgs[(size_t)i] = im; }
-            else { imgs[(size_t)i].state = 2; status[i].rc = rc; status[i].stage = stage; }
-         }
-         cv_img.notify_all();
+         if (i >= 0) decode_one(i); else write_one(t);
       }
+   }
+   void decode_one(int i)
+   {
+      Img im;
+      int rc = paths[i] ? hesaff_read_image(paths[i], &im.data, &im.w, &im.h, &im.ch) : HESAFF_ERR_ARG;
+      int stage = HESAFF_FILE_UNREADABLE;
+      if (rc == HESAFF_OK && (im.w > 65535 || im.h > 65535)) {   // the device plans 16-bit pixel coordinates (plan(), pipeline.hip)
+         hesaff_free(im.data); im.data = nullptr;
+         rc = HESAFF_ERR_ARG; stage = HESAFF_FILE_REJECTED;
+      }
+      {
+         std::lock_guard<std::mutex> lk(mu);
+         if (rc == HESAFF_OK) { im.state = 1; imgs[(size_t)i] = im; }
+         else { imgs[(size_t)i].state = 2; status[i].rc = rc; status[i].stage = stage; }
+      }
+      cv_img.notify_all();
    }
    // the next run of consecutive readable images of one geometry
    bool next(HostChunk &out) override
@@ -161,7 +168,7 @@ struct FileIO : ChunkIO {
          cv_img.wait(lk, [&] { return stop || imgs[(size_t)pos].state != 0; });
          if (stop) break;
          Img &im = imgs[(size_t)pos];
-         if (im.state == 2) { pos++; consumed = pos; cv_dec.notify_all(); continue; }
+         if (im.state == 2) { pos++; consumed = pos; cv_work.notify_all(); continue; }
          if (out.data.empty()) { out.W = im.w; out.H = im.h; out.ch = im.ch; }
          else if (im.w != out.W || im.h != out.H || im.ch != out.ch) break;
          out.data.push_back(im.data);
@@ -180,7 +187,7 @@ struct FileIO : ChunkIO {
          for (int i : q.index) { hesaff_free(imgs[(size_t)i].data); imgs[(size_t)i].data = nullptr; }
          consumed = std::max(consumed, q.index.back() + 1);
       }
-      cv_dec.notify_all();
+      cv_work.notify_all();
    }
    void done(const ChunkDone &d) override
    {
@@ -201,7 +208,7 @@ struct FileIO : ChunkIO {
             tasks_in_flight++;
          }
       }
-      cv_task.notify_all();
+      cv_work.notify_all();
    }
    int wants() const override
    {
@@ -214,45 +221,35 @@ struct FileIO : ChunkIO {
       for (int i : q.index) { status[i].rc = rc; status[i].stage = HESAFF_FILE_REJECTED; }
       return true;
    }
-   void write_loop()
+   void write_one(const Task &t)
    {
-      for (;;) {
-         Task t;
-         {
-            std::unique_lock<std::mutex> lk(mu);
-            cv_task.wait(lk, [&] { return stop || !tasks.empty(); });
-            if (tasks.empty()) return;   // stop
-            t = tasks.front();
-            tasks.pop_front();
-         }
-         const char *o = out_paths ? out_paths[t.index] : nullptr;
-         int rc = HESAFF_OK;
-         if (fmt & HESAFF_OUT_TEXT) {
-            const std::string name = o ? std::string(o) : std::string(paths[t.index]) + ".hesaff.sift";   // hesaff.cpp:170-173
-            if (device_format) rc = hesaff_write_sift_rows(name.c_str(), t.text, t.text_len, t.n);
-            else rc = hesaff_write_sift_mt(name.c_str(), t.keys, t.n, mrSize, 1);
-         }
-         if ((fmt & HESAFF_OUT_BIN) && rc == HESAFF_OK) {
-            const std::string name = o ? (std::string(o) + ((fmt & HESAFF_OUT_TEXT) ? ".bin" : "")) : std::string(paths[t.index]) + ".hesaff.bin";
-            if (device_format) rc = hesaff_write_bin_rows(name.c_str(), t.bin, t.n);
-            else rc = hesaff_write_bin(name.c_str(), t.keys, t.n, mrSize);
-         }
-         int blk = -1;
-         {
-            std::lock_guard<std::mutex> lk(mu);
-            status[t.index].rc = rc;
-            if (rc == HESAFF_OK) status[t.index].stage = HESAFF_FILE_WRITTEN;
-            if (--open_chunks[(size_t)t.chunk].left == 0) blk = open_chunks[(size_t)t.chunk].block;
-            tasks_in_flight--;
-         }
-         if (blk >= 0) ring->release(blk);
-         cv_task.notify_all();
+      const char *o = out_paths ? out_paths[t.index] : nullptr;
+      int rc = HESAFF_OK;
+      if (fmt & HESAFF_OUT_TEXT) {
+         const std::string name = o ? std::string(o) : std::string(paths[t.index]) + ".hesaff.sift";   // hesaff.cpp:170-173
+         if (device_format) rc = hesaff_write_sift_rows(name.c_str(), t.text, t.text_len, t.n);
+         else rc = hesaff_write_sift_mt(name.c_str(), t.keys, t.n, mrSize, 1);
       }
+      if ((fmt & HESAFF_OUT_BIN) && rc == HESAFF_OK) {
+         const std::string name = o ? (std::string(o) + ((fmt & HESAFF_OUT_TEXT) ? ".bin" : "")) : std::string(paths[t.index]) + ".hesaff.bin";
+         if (device_format) rc = hesaff_write_bin_rows(name.c_str(), t.bin, t.n);
+         else rc = hesaff_write_bin(name.c_str(), t.keys, t.n, mrSize);
+      }
+      int blk = -1;
+      {
+         std::lock_guard<std::mutex> lk(mu);
+         status[t.index].rc = rc;
+         if (rc == HESAFF_OK) status[t.index].stage = HESAFF_FILE_WRITTEN;
+         if (--open_chunks[(size_t)t.chunk].left == 0) blk = open_chunks[(size_t)t.chunk].block;
+         tasks_in_flight--;
+      }
+      if (blk >= 0) ring->release(blk);
+      cv_done.notify_all();
    }
    void wait_writers()
    {
       std::unique_lock<std::mutex> lk(mu);
-      cv_task.wait(lk, [&] { return tasks_in_flight == 0; });
+      cv_done.wait(lk, [&] { return tasks_in_flight == 0; });
    }
 };
 

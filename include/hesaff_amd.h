@@ -143,7 +143,9 @@ int hesaff_detect_batch_cb(hesaff_ctx *ctx, int n, const uint8_t *const *images,
  * size through the device (copy in / kernels / copy out overlapped) -> writer threads.  Host memory stays bounded
  * (about 2 max_batch decoded images and three result blocks).  out_paths may be NULL (or hold NULLs): the reference's
  * name.  status[i].rc = HESAFF_OK, or why file i was skipped (unreadable input, unwritable output); one bad file does
- * not stop the others.  decode_threads / write_threads: 0 = auto (hesaff_host_threads). */
+ * not stop the others.  decode_threads / write_threads: 0 = auto (hesaff_host_threads); the two counts add up to ONE pool of
+ * host threads that decode when the look-ahead window has room and write otherwise.  The rows of the output files are formatted
+ * on the device (hesaff.cpp:124-128 as a kernel): a writer only write()s what the copy engine delivered. */
 #define HESAFF_FILE_PENDING 0   /* never reached (the run stopped on a device error before this file) */
 #define HESAFF_FILE_UNREADABLE 1
 #define HESAFF_FILE_DETECTED 2  /* detected and described, but the output file could not be written (rc says why) */
