@@ -198,9 +198,25 @@ __global__ __launch_bounds__(256) void k_blur_cols_generic(DPlane tmp, DPlane ou
 
 // Candidates of one octave: findLevelKeypoints pyramid.cpp:206-222 appends (img,level,r,c) for every pixel that
 // passes isMax / isMin (:39-61); unordered here, the order is restored by the bitmask ranks in k_scatter_ordered.
+// A candidate carries the 19 response values localizeKeypoint's first iteration reads (pyramid.cpp:132-150): k_extrema_march has
+// them in registers when it finds the extremum, and 89 % of the candidates converge in that iteration - so k_localize reads one
+// 96-byte record per candidate instead of nine scattered cache lines of three response planes (33 M candidates per 256 UHD
+// images: 3 GB written + 3 GB read instead of 19-38 GB of line fetches).
+struct CandRec {
+   uint32_t id0, id1;   // img<<2 | level, r<<16 | c;  id0 == HS_CAND_HOLE: an unused slot of a wavefront's block of 64
+   float v[19];         // cur 3x3 row-major (rows r-1..r+1, columns c-1..c+1) | low: centre, left, right, up, down | high: the same five
+   uint32_t pad[3];
+};
+#define HS_CAND_HOLE 0xffffffffu
+#ifndef HS_CAND_PAYLOAD
+#define HS_CAND_PAYLOAD 1   // 0 (A/B only): candidates carry their id alone and k_localize reads every neighbourhood from the planes
+#endif
+#ifndef HS_CAND_BLOCK
+#define HS_CAND_BLOCK 64u   // slots a wavefront reserves at a time (one global atomic per 64 candidates)
+#endif
 struct CandList {
-   uint32_t *count;   // device counter
-   uint2 *items;      // x = img<<2 | level, y = r<<16 | c
+   uint32_t *count;   // device counter (slots handed out, holes included)
+   CandRec *items;
    uint32_t cap;
    uint32_t *overflow;   // set to 1 when a list ran out of capacity
 };
@@ -240,36 +256,67 @@ __global__ __launch_bounds__(256) void k_localize(OctaveCtx oc, CandList cl, Rec
    const uint32_t n = min(*cl.count, cl.cap);
    if (blockIdx.x == 0 && threadIdx.x == 0 && *cl.count > cl.cap) *cl.overflow = 1u;
    const int rows = oc.R[0].rows, cols = oc.R[0].cols, pitch = oc.R[0].pitch;
-   for (uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x; ci < n; ci += gridDim.x * blockDim.x) {
-      const uint2 it = cl.items[ci];
-      const int b = (int)(it.x >> 2), level = (int)(it.x & 3u);
-      const int r0 = (int)(it.y >> 16), c0 = (int)(it.y & 0xffffu);
+   __shared__ uint32_t s_cnt, s_base;
+   // uniform trip count: the survivors of a round take their record slots with ONE global atomic per block (a returning atomic
+   // per wavefront on one address - 100 k of them per 32 UHD images - was most of this kernel's time)
+   for (uint32_t ci0 = blockIdx.x * blockDim.x; ci0 < n; ci0 += gridDim.x * blockDim.x) {
+      const uint32_t ci = ci0 + threadIdx.x;
+      if (threadIdx.x == 0) s_cnt = 0;
+      __syncthreads();
+      bool keep = false;
+      float o_x = 0, o_y = 0, o_s = 0, o_val = 0;
+      int o_meta = 0;
+      uint32_t o_cell = 0, o_key = 0, o_bit = 0, o_map = 0, rank = 0;
+      long long o_word = 0;
+      do {
+      if (ci >= n) break;
+      const float4 *rec = reinterpret_cast<const float4 *>(cl.items + ci);
+      const float4 q0 = rec[0];
+      const uint32_t id0 = __float_as_uint(q0.x), id1 = __float_as_uint(q0.y);
+      if (id0 == HS_CAND_HOLE) break;
+#if HS_CAND_PAYLOAD
+      const float4 q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5];
+#else
+      const float4 q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0;
+#endif
+      const int b = (int)(id0 >> 2), level = (int)(id0 & 3u);
+      const int r0 = (int)(id1 >> 16), c0 = (int)(id1 & 0xffffu);
       // level = i-2 : low = R[level], cur = R[level+1], high = R[level+2]
       const float *low = oc.R[level].img(b), *cur = oc.R[level + 1].img(b), *high = oc.R[level + 2].img(b);
       float bb[3] = {0.0f, 0.0f, 0.0f};
       float val = 0.0f;
       int r = r0, c = c0, nr = r0, nc = c0;
       bool dead = false;
+      // the neighbourhood of the current centre: cur 3x3 (m = row - 1, centre, row + 1), low / high crosses
+      float m00 = q0.z, m01 = q0.w, m02 = q1.x, c10 = q1.y, c00 = q1.z, c12 = q1.w, p20 = q2.x, p21 = q2.y, p22 = q2.z;
+      float lc = q2.w, ll = q3.x, lr = q3.y, lu = q3.z, ld = q3.w;
+      float hc = q4.x, hl = q4.y, hr = q4.z, hu = q4.w, hd = q5.x;
       for (int iter = 0; iter < 5; iter++) {
          r = nr; c = nc;
-         const float *pc = cur + (long long)r * pitch + c;
-         const float *pl = low + (long long)r * pitch + c;
-         const float *ph = high + (long long)r * pitch + c;
-         const float c00 = pc[0];
-         const float dxx = pc[-1] - 2.0f * c00 + pc[1];
-         const float dyy = pc[-pitch] - 2.0f * c00 + pc[pitch];
-         const float dss = pl[0] - 2.0f * c00 + ph[0];
-         const float dxy = 0.25f * (pc[pitch + 1] - pc[pitch - 1] - pc[-pitch + 1] + pc[-pitch - 1]);
+         if (iter > 0 || !HS_CAND_PAYLOAD) {   // the centre moved (one candidate in nine): its neighbourhood comes from the planes
+            const float *pc = cur + (long long)r * pitch + c;
+            const float *pl = low + (long long)r * pitch + c;
+            const float *ph = high + (long long)r * pitch + c;
+            m00 = pc[-pitch - 1]; m01 = pc[-pitch]; m02 = pc[-pitch + 1];
+            c10 = pc[-1]; c00 = pc[0]; c12 = pc[1];
+            p20 = pc[pitch - 1]; p21 = pc[pitch]; p22 = pc[pitch + 1];
+            lc = pl[0]; ll = pl[-1]; lr = pl[1]; lu = pl[-pitch]; ld = pl[pitch];
+            hc = ph[0]; hl = ph[-1]; hr = ph[1]; hu = ph[-pitch]; hd = ph[pitch];
+         }
+         const float dxx = c10 - 2.0f * c00 + c12;
+         const float dyy = m01 - 2.0f * c00 + p21;
+         const float dss = lc - 2.0f * c00 + hc;
+         const float dxy = 0.25f * (p22 - p20 - m02 + m00);
          if (iter == 0) {
             const float edgeScore = (dxx + dyy) * (dxx + dyy) / (dxx * dyy - dxy * dxy);
             if (edgeScore >= k.edgeScoreThreshold || edgeScore < 0) { dead = true; break; }
          }
-         const float dxs = 0.25f * (ph[1] - ph[-1] - pl[1] + pl[-1]);
-         const float dys = 0.25f * (ph[pitch] - ph[-pitch] - pl[pitch] + pl[-pitch]);
+         const float dxs = 0.25f * (hr - hl - lr + ll);
+         const float dys = 0.25f * (hd - hu - ld + lu);
          float A[9] = {dxx, dxy, dxs, dxy, dyy, dys, dxs, dys, dss};
-         const float dx = 0.5f * (pc[1] - pc[-1]);
-         const float dy = 0.5f * (pc[pitch] - pc[-pitch]);
-         const float ds = 0.5f * (ph[0] - pl[0]);
+         const float dx = 0.5f * (c12 - c10);
+         const float dy = 0.5f * (p21 - m01);
+         const float ds = 0.5f * (hc - lc);
          bb[0] = -dx; bb[1] = -dy; bb[2] = -ds;
          hs_solve3x3(A, bb);
          if (bb[0] != bb[0] || bb[1] != bb[1] || bb[2] != bb[2]) { dead = true; break; }
@@ -281,8 +328,8 @@ __global__ __launch_bounds__(256) void k_localize(OctaveCtx oc, CandList cl, Rec
          if ((double)bb[1] < -0.6) { if (r > 3) nr--; else { dead = true; break; } }
          if (nr == r && nc == c) break;
       }
-      if (dead) continue;
-      if (fabsf(bb[0]) > 1.5f || fabsf(bb[1]) > 1.5f || fabsf(bb[2]) > 1.5f || fabsf(val) < k.finalThreshold) continue;
+      if (dead) break;
+      if (fabsf(bb[0]) > 1.5f || fabsf(bb[1]) > 1.5f || fabsf(bb[2]) > 1.5f || fabsf(val) < k.finalThreshold) break;
       const float curScale = oc.sigma[level + 1];
       const float scale = curScale * hm_pow2f(bb[2] / (float)HS_NSCALES);
       int type;
@@ -292,22 +339,39 @@ __global__ __launch_bounds__(256) void k_localize(OctaveCtx oc, CandList cl, Rec
          const float Lxx = (p[-1] - 2 * p[0] + p[1]);
          type = (Lxx < 0) ? 0 : 1;
       }
-      const uint32_t slot = atomicAdd(rl.count, 1u);
-      if (slot >= rl.cap) { *cl.overflow = 1u; continue; }
       const float pd = oc.pixelDistance;
-      rl.x[slot] = pd * ((float)c + bb[0]);
-      rl.y[slot] = pd * ((float)r + bb[1]);
-      rl.s[slot] = pd * scale;
-      rl.response[slot] = val;
-      rl.meta[slot] = (b << 8) | (oc.octave << 4) | (level << 2) | type;
-      const uint32_t cell = (uint32_t)(r * cols + c);
-      const uint32_t key = (uint32_t)level * (uint32_t)(rows * cols) + (uint32_t)(r0 * cols + c0);
-      rl.cell[slot] = cell;
-      rl.key[slot] = key;
-      rl.word[slot] = (long long)b * oc.words_per_image + oc.word_base +
-                      ((long long)level * rows + r0) * oc.words_per_row + (c0 >> 6);
-      rl.bit[slot] = (uint32_t)(c0 & 63);
-      atomicMin(oc.map + (long long)b * rows * cols + cell, key);
+      o_x = pd * ((float)c + bb[0]);
+      o_y = pd * ((float)r + bb[1]);
+      o_s = pd * scale;
+      o_val = val;
+      o_meta = (b << 8) | (oc.octave << 4) | (level << 2) | type;
+      o_cell = (uint32_t)(r * cols + c);
+      o_key = (uint32_t)level * (uint32_t)(rows * cols) + (uint32_t)(r0 * cols + c0);
+      o_word = (long long)b * oc.words_per_image + oc.word_base + ((long long)level * rows + r0) * oc.words_per_row + (c0 >> 6);
+      o_bit = (uint32_t)(c0 & 63);
+      o_map = (uint32_t)b;
+      keep = true;
+      } while (false);
+      if (keep) rank = atomicAdd(&s_cnt, 1u);
+      __syncthreads();
+      if (threadIdx.x == 0 && s_cnt > 0) s_base = atomicAdd(rl.count, s_cnt);
+      __syncthreads();
+      if (keep) {
+         const uint32_t slot = s_base + rank;
+         if (slot >= rl.cap) { *cl.overflow = 1u; }
+         else {
+            rl.x[slot] = o_x;
+            rl.y[slot] = o_y;
+            rl.s[slot] = o_s;
+            rl.response[slot] = o_val;
+            rl.meta[slot] = o_meta;
+            rl.cell[slot] = o_cell;
+            rl.key[slot] = o_key;
+            rl.word[slot] = o_word;
+            rl.bit[slot] = o_bit;
+            atomicMin(oc.map + (long long)o_map * rows * cols + o_cell, o_key);
+         }
+      }
    }
 }
 
@@ -323,6 +387,16 @@ __global__ __launch_bounds__(256) void k_dedupe(OctaveCtx oc, RecList rl, const 
       if (oc.map[(long long)b * N + rl.cell[i]] == rl.key[i]) atomicOr(bitmask + rl.word[i], 1ull << rl.bit[i]);
       else rl.word[i] = -1;   // lost the octaveMap race
    }
+}
+
+// the octave's records give their map cells back (all records: the losers of a cell reset it as well as its winner)
+__global__ __launch_bounds__(256) void k_map_reset(OctaveCtx oc, RecList rl, const uint32_t *__restrict__ start_ptr)
+{
+   const uint32_t start = *start_ptr;
+   const uint32_t n = min(*rl.count, rl.cap);
+   const long long N = (long long)oc.R[0].rows * oc.R[0].cols;
+   for (uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+      oc.map[(long long)(rl.meta[i] >> 8) * N + rl.cell[i]] = 0xffffffffu;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -760,9 +834,7 @@ struct FivePlanes { DPlane R[5]; };
 // grid (ceil(cols/248), ceil(rows/band), B), block 64.
 // ---------------------------------------------------------------------------------------
 #define EXM_STRIP 248
-#define EXM_CAP 2048
 #define EXM_RS 5
-#define EXM_ROWMAX (3 * EXM_STRIP)   // candidates one row step can add
 
 __device__ __forceinline__ float hs_max3(float a, float b, float c)
 {
@@ -777,10 +849,19 @@ __device__ __forceinline__ float hs_min3(float a, float b, float c)
    return r;
 }
 
+// value of the lane below / above (wavefront shift by one lane: one VALU move with a DPP control, no trip through the LDS crossbar);
+// lane 0 / lane 63 keep their own value
+__device__ __forceinline__ float hs_from_lane_below(float v)
+{
+   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float hs_from_lane_above(float v)
+{
+   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
 __global__ __launch_bounds__(64) void k_extrema_march(FivePlanes fp, float posThr, float negThr, CandList cl, int band)
 {
-   __shared__ uint2 s_list[EXM_CAP];
-   __shared__ uint32_t s_n;
    const int lane = threadIdx.x, b = blockIdx.z;
    const int rows = fp.R[0].rows, cols = fp.R[0].cols, pitch = fp.R[0].pitch;
    const int ya = max((int)blockIdx.y * band, HS_BORDER), yb = min(((int)blockIdx.y + 1) * band, rows - HS_BORDER);   // scanned rows
@@ -797,8 +878,9 @@ __global__ __launch_bounds__(64) void k_extrema_march(FivePlanes fp, float posTh
    const float *base[5];
 #pragma unroll
    for (int p = 0; p < 5; p++) base[p] = fp.R[p].img(b) + xc;
-   if (lane == 0) s_n = 0;
-   __syncthreads();
+   // candidate slots: the wavefront reserves blocks of HS_CAND_BLOCK slots of the octave's list (one global atomic per block) and
+   // fills them in the order it finds its candidates; what is left of a block is marked as holes
+   uint32_t wbase = 0, wused = HS_CAND_BLOCK;   // wave-uniform: no block yet
 
    float4 ring[5][EXM_RS];
    const int nsteps = yb - ya + 2;   // step k brings row ya - 1 + k; rows ya .. yb-1 are tested at steps 2 .. nsteps-1
@@ -819,7 +901,6 @@ __global__ __launch_bounds__(64) void k_extrema_march(FivePlanes fp, float posTh
 #pragma unroll
             for (int p = 0; p < 5; p++) ring[p][(u + 2) % EXM_RS] = HS_NT_EXT ? hs_load_nt4(reinterpret_cast<const float4 *>(base[p] + off)) : *reinterpret_cast<const float4 *>(base[p] + off);
          }
-         const uint32_t n_lagged = s_n;   // count before the previous step's candidates are all in
          const int y = ya - 2 + k;        // row under test: slots (u-2, u-1, u) = rows y-1, y, y+1
          const int s0 = (u + EXM_RS - 2) % EXM_RS, s1 = (u + EXM_RS - 1) % EXM_RS, s2 = u;
          float A[3][4], I[3][4];   // per level: max / min over 3 rows x 3 planes, per column
@@ -844,8 +925,8 @@ __global__ __launch_bounds__(64) void k_extrema_march(FivePlanes fp, float posTh
          uint32_t hits = 0;   // bit 4 * l + c
 #pragma unroll
          for (int l = 0; l < 3; l++) {
-            const float Al = __shfl_up(A[l][3], 1, 64), Ar = __shfl_down(A[l][0], 1, 64);
-            const float Il = __shfl_up(I[l][3], 1, 64), Ir = __shfl_down(I[l][0], 1, 64);
+            const float Al = hs_from_lane_below(A[l][3]), Ar = hs_from_lane_above(A[l][0]);
+            const float Il = hs_from_lane_below(I[l][3]), Ir = hs_from_lane_above(I[l][0]);
             const float M[4] = {hs_max3(Al, A[l][0], A[l][1]), hs_max3(A[l][0], A[l][1], A[l][2]), hs_max3(A[l][1], A[l][2], A[l][3]), hs_max3(A[l][2], A[l][3], Ar)};
             const float N[4] = {hs_min3(Il, I[l][0], I[l][1]), hs_min3(I[l][0], I[l][1], I[l][2]), hs_min3(I[l][1], I[l][2], I[l][3]), hs_min3(I[l][2], I[l][3], Ir)};
             const float v[4] = {ring[l + 1][s1].x, ring[l + 1][s1].y, ring[l + 1][s1].z, ring[l + 1][s1].w};
@@ -858,36 +939,64 @@ __global__ __launch_bounds__(64) void k_extrema_march(FivePlanes fp, float posTh
          }
          hits &= colmask * 0x111u;
          if (k < 2 || k >= nsteps) hits = 0;
-         if (n_lagged > EXM_CAP - 2 * EXM_ROWMAX) {
-            // flush (wave-uniform): everything the earlier steps collected goes out with one global atomic
-            __syncthreads();
-            const uint32_t n = min(s_n, (uint32_t)EXM_CAP);
-            uint32_t gbase = 0;
-            if (lane == 0) { gbase = atomicAdd(cl.count, n); s_n = 0; }
-            gbase = __shfl(gbase, 0, 64);
-            for (uint32_t i = lane; i < n; i += 64)
-               if (gbase + i < cl.cap) cl.items[gbase + i] = s_list[i];
-            __syncthreads();
-         }
-         while (hits) {
-            const int bit = __ffs(hits) - 1;
-            hits &= hits - 1;
-            const int l = bit >> 2, c = bit & 3;
-            const uint2 item = make_uint2(((uint32_t)b << 2) | (uint32_t)l, ((uint32_t)y << 16) | (uint32_t)(x + c));
-            const uint32_t ls = atomicAdd(&s_n, 1u);
-            if (ls < EXM_CAP) s_list[ls] = item;
-            else {
-               const uint32_t slot = atomicAdd(cl.count, 1u);
-               if (slot < cl.cap) cl.items[slot] = item;
+         if (__ballot(hits != 0u) != 0ull) {
+            // The candidates of this row leave with the 19 values localizeKeypoint's first iteration reads.
+#pragma unroll
+            for (int l = 0; l < 3; l++) {
+               if (__ballot(((hits >> (4 * l)) & 15u) != 0u) == 0ull) continue;   // wave-uniform: nothing at this level
+               // columns x - 1 and x + 4 belong to the neighbouring lanes: the level's own plane (l + 1) in the three rows, the planes
+               // below and above it in the middle row
+#if HS_CAND_PAYLOAD
+               const float lowL = hs_from_lane_below(ring[l][s1].w), lowR = hs_from_lane_above(ring[l][s1].x);
+               const float highL = hs_from_lane_below(ring[l + 2][s1].w), highR = hs_from_lane_above(ring[l + 2][s1].x);
+               const float cL0 = hs_from_lane_below(ring[l + 1][s0].w), cR0 = hs_from_lane_above(ring[l + 1][s0].x);
+               const float cL1 = hs_from_lane_below(ring[l + 1][s1].w), cR1 = hs_from_lane_above(ring[l + 1][s1].x);
+               const float cL2 = hs_from_lane_below(ring[l + 1][s2].w), cR2 = hs_from_lane_above(ring[l + 1][s2].x);
+#else
+               const float lowL = 0, lowR = 0, highL = 0, highR = 0, cL0 = 0, cR0 = 0, cL1 = 0, cR1 = 0, cL2 = 0, cR2 = 0;
+#endif
+               const float cu[3][6] = {
+                  {cL0, ring[l + 1][s0].x, ring[l + 1][s0].y, ring[l + 1][s0].z, ring[l + 1][s0].w, cR0},
+                  {cL1, ring[l + 1][s1].x, ring[l + 1][s1].y, ring[l + 1][s1].z, ring[l + 1][s1].w, cR1},
+                  {cL2, ring[l + 1][s2].x, ring[l + 1][s2].y, ring[l + 1][s2].z, ring[l + 1][s2].w, cR2}};
+               const float lo1[6] = {lowL, ring[l][s1].x, ring[l][s1].y, ring[l][s1].z, ring[l][s1].w, lowR};
+               const float hi1[6] = {highL, ring[l + 2][s1].x, ring[l + 2][s1].y, ring[l + 2][s1].z, ring[l + 2][s1].w, highR};
+               const float lo0[4] = {ring[l][s0].x, ring[l][s0].y, ring[l][s0].z, ring[l][s0].w}, lo2[4] = {ring[l][s2].x, ring[l][s2].y, ring[l][s2].z, ring[l][s2].w};
+               const float hi0[4] = {ring[l + 2][s0].x, ring[l + 2][s0].y, ring[l + 2][s0].z, ring[l + 2][s0].w}, hi2[4] = {ring[l + 2][s2].x, ring[l + 2][s2].y, ring[l + 2][s2].z, ring[l + 2][s2].w};
+#pragma unroll
+               for (int c = 0; c < 4; c++) {
+                  const bool h = (hits >> (4 * l + c)) & 1u;
+                  const unsigned long long m = __ballot(h);
+                  if (m == 0ull) continue;   // wave-uniform
+                  const uint32_t total = (uint32_t)__popcll(m);
+                  if (wused + total > HS_CAND_BLOCK) {
+                     if (wused < HS_CAND_BLOCK && (uint32_t)lane < HS_CAND_BLOCK - wused && wbase + wused + lane < cl.cap) cl.items[wbase + wused + lane].id0 = HS_CAND_HOLE;
+                     uint32_t nb = 0;
+                     if (lane == 0) nb = atomicAdd(cl.count, HS_CAND_BLOCK);
+                     wbase = __builtin_amdgcn_readfirstlane(nb);
+                     wused = 0;
+                  }
+                  if (h) {
+                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                     const uint32_t slot = wbase + wused + rank;
+                     if (slot < cl.cap) {
+                        float4 *dst = reinterpret_cast<float4 *>(cl.items + slot);
+                        dst[0] = make_float4(__uint_as_float(((uint32_t)b << 2) | (uint32_t)l), __uint_as_float(((uint32_t)y << 16) | (uint32_t)(x + c)), cu[0][c], cu[0][c + 1]);
+#if HS_CAND_PAYLOAD
+                        dst[1] = make_float4(cu[0][c + 2], cu[1][c], cu[1][c + 1], cu[1][c + 2]);
+                        dst[2] = make_float4(cu[2][c], cu[2][c + 1], cu[2][c + 2], lo1[c + 1]);
+                        dst[3] = make_float4(lo1[c], lo1[c + 2], lo0[c], lo2[c]);
+                        dst[4] = make_float4(hi1[c + 1], hi1[c], hi1[c + 2], hi0[c]);
+                        dst[5] = make_float4(hi2[c], 0.0f, 0.0f, 0.0f);
+#endif
+                     }
+                  }
+                  wused += total;
+               }
             }
          }
       }
    }
-   __syncthreads();
-   const uint32_t n = min(s_n, (uint32_t)EXM_CAP);
-   uint32_t gbase = 0;
-   if (lane == 0 && n > 0) gbase = atomicAdd(cl.count, n);
-   gbase = __shfl(gbase, 0, 64);
-   for (uint32_t i = lane; i < n; i += 64)
-      if (gbase + i < cl.cap) cl.items[gbase + i] = s_list[i];
+   // the unused rest of the last block
+   if (wused < HS_CAND_BLOCK && (uint32_t)lane < HS_CAND_BLOCK - wused && wbase + wused + lane < cl.cap) cl.items[wbase + wused + lane].id0 = HS_CAND_HOLE;
 }

@@ -178,7 +178,9 @@ struct hesaff_ctx {
    int B = 0, H = 0, W = 0;
    std::vector<OctGeom> oct;
    long long words_per_image = 0;
-   uint32_t cap = 0;      // keypoint / candidate capacity of a batch
+   uint32_t cap = 0;      // keypoint capacity of a batch
+   uint32_t cand_cap = 0; // candidate slots of one octave (k_extrema_march -> k_localize)
+   bool map_clean = false;   // every cell of b_map is 0xFFFFFFFF (free): k_map_reset puts back what an octave's records touched
 
    // planes
    DevBuf b_gray, b_up, b_L, b_L3, b_R, b_map, b_bitmask, b_prefix, b_blocksums, b_generic;
@@ -442,7 +444,27 @@ void set_kernel_attrs(hesaff_ctx *c)
 }
 
 // Buffer plan for a batch of B images of H x W.
+void plan_buffers(hesaff_ctx *c, int B, int H, int W);
 void plan(hesaff_ctx *c, int B, int H, int W)
+{
+   try {
+      plan_buffers(c, B, H, W);
+   } catch (const HsError &e) {
+      if (e.code == HESAFF_ERR_NOMEM) {
+         // a plan the device cannot hold must not keep what it managed to allocate on the way (hundreds of GB for an absurd
+         // capacity request): every geometry-sized buffer goes back, the next plan starts from nothing
+         DevBuf *bufs[] = {&c->b_gray, &c->b_up, &c->b_L, &c->b_L3, &c->b_R, &c->b_map, &c->b_bitmask, &c->b_prefix, &c->b_blocksums, &c->b_cand,
+                           &c->b_rec_f, &c->b_rec_i, &c->b_rec_w, &c->b_hess_f, &c->b_hess_i, &c->b_aff, &c->b_pw, &c->b_bins, &c->b_rank, &c->b_desc,
+                           &c->b_out, &c->b_starts};
+         (void)hipStreamSynchronize(c->stream);
+         for (DevBuf *b : bufs) b->release();
+         c->map_clean = false;
+      }
+      throw;
+   }
+}
+
+void plan_buffers(hesaff_ctx *c, int B, int H, int W)
 {
    if (B <= c->B && H == c->H && W == c->W) return;
    if (H < 1 || W < 1 || (H << c->up) > 65535 || (W << c->up) > 65535) throw HsError(HESAFF_ERR_ARG, "image size out of range (1..65535 at the first pyramid level)");
@@ -490,7 +512,11 @@ void plan(hesaff_ctx *c, int B, int H, int W)
    }
    c->b_L3.ensure(pplane0 * 4);
    c->b_R.ensure(pplane0 * 4 * 5);
-   c->b_map.ensure(std::max<size_t>((size_t)B * PH * PW * 4, 16));
+   {
+      const void *before = c->b_map.p;
+      c->b_map.ensure(std::max<size_t>((size_t)B * PH * PW * 4, 16));
+      if (c->b_map.p != before) c->map_clean = false;   // a new block: filled once before its first use (run_detection)
+   }
    const long long total_words = (long long)B * words;
    c->b_bitmask.ensure(std::max<size_t>((size_t)total_words * 8, 16));
    c->b_prefix.ensure(std::max<size_t>((size_t)(total_words + 1) * 4, 16));
@@ -503,7 +529,15 @@ void plan(hesaff_ctx *c, int B, int H, int W)
    const long long scan_items = std::max<long long>(total_words, (long long)cap);
    c->b_blocksums.ensure((size_t)((scan_items + SCAN_BLOCK - 1) / SCAN_BLOCK + 1) * 4);
    c->b_counters.ensure(64 * 4);
-   c->b_cand.ensure(cap * sizeof(uint2));
+   {
+      // candidate slots: the keypoint capacity + what the wavefronts of k_extrema_march may leave unused of their blocks of 64
+      // (octave 0 has the most wavefronts: one per 248-column strip and 32-row band at least)
+      const unsigned long long waves0 = (unsigned long long)((PW + EXM_STRIP - 1) / EXM_STRIP) * (unsigned long long)(PH / 32 + 1) * (unsigned long long)B;
+      const unsigned long long cc = (unsigned long long)cap + HS_CAND_BLOCK * waves0;
+      if (cc > 0xfffffff0ull) throw HsError(HESAFF_ERR_ARG, "batch too large for 32-bit candidate indices");
+      c->cand_cap = (uint32_t)cc;
+      c->b_cand.ensure((size_t)cc * sizeof(CandRec));
+   }
    c->b_rec_f.ensure(cap * 4 * 4);
    c->b_rec_i.ensure(cap * 4 * 4);
    c->b_rec_w.ensure(cap * 8);
@@ -628,7 +662,7 @@ Lists make_lists(hesaff_ctx *c)
    uint32_t *cnt = c->b_counters.as<uint32_t>();
    const size_t cap = c->cap;
    s.counters = cnt;
-   s.cl.count = cnt + 0; s.cl.items = c->b_cand.as<uint2>(); s.cl.cap = c->cap; s.cl.overflow = cnt + 2;
+   s.cl.count = cnt + 0; s.cl.items = c->b_cand.as<CandRec>(); s.cl.cap = c->cand_cap; s.cl.overflow = cnt + 2;
    s.rl.count = cnt + 1; s.rl.cap = c->cap;
    float *rf = c->b_rec_f.as<float>();
    s.rl.x = rf; s.rl.y = rf + cap; s.rl.s = rf + 2 * cap; s.rl.response = rf + 3 * cap;
@@ -728,6 +762,10 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
    const float *ptaps = c->t_pyr_taps.as<float>();
    HIP_TRY(hipMemsetAsync(cnt, 0, 64 * 4, st));
    HIP_TRY(hipMemsetAsync(c->b_bitmask.p, 0, std::max<size_t>((size_t)B * c->words_per_image * 8, 8), st));
+   // octaveMap (pyramid.cpp:226: zeroed per octave): the order-key map is filled with "free" once; after an octave's dedupe the
+   // cells its records touched are set back (k_map_reset) - 0.1 GB of scattered stores per 256 UHD images instead of an 11 GB fill
+   if (!c->map_clean) HIP_TRY(hipMemsetAsync(c->b_map.p, 0xFF, c->b_map.bytes, st));
+   c->map_clean = false;
 
    int t = tm.begin(T_PYR);
    DPlane none = make_plane(nullptr, 0, 0, 0);
@@ -813,7 +851,6 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
       }
       // ---- detection on this octave ----
       t = tm.begin(T_DET);
-      HIP_TRY(hipMemsetAsync(c->b_map.p, 0xFF, (size_t)B * g.rows * g.cols * 4, st));
       HIP_TRY(hipMemsetAsync(cnt + 0, 0, 4, st));
       HIP_TRY(hipMemcpyAsync(cnt + 32 + o, cnt + 1, 4, hipMemcpyDeviceToDevice, st));
       OctaveCtx oc;
@@ -837,6 +874,7 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
          hipLaunchKernelGGL(k_localize, dim3(HS_GRID_LOC), dim3(256), 0, st, oc, s.cl, s.rl, c->consts);
          hipLaunchKernelGGL(k_dedupe, dim3(HS_GRID_DED), dim3(256), 0, st, oc, s.rl, (const uint32_t *)(cnt + 32 + o),
                             c->b_bitmask.as<unsigned long long>());
+         hipLaunchKernelGGL(k_map_reset, dim3(HS_GRID_DED), dim3(256), 0, st, oc, s.rl, (const uint32_t *)(cnt + 32 + o));
       }
       tm.end(t);
    }
@@ -854,6 +892,7 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
    hipLaunchKernelGGL(k_image_large_rows, dim3(512), dim3(256), 0, st, s.hl, (const uint32_t *)(cnt + 3), c->consts.mrSize,
                       c->b_starts.as<uint32_t>() + 2 * (B + 1));
    tm.end(t);
+   c->map_clean = true;   // (in stream order; a HIP error on the way leaves the flag false)
 }
 
 __global__ void k_desc_starts(const int32_t *__restrict__ hess_starts, int nimg, const uint32_t *__restrict__ rank,
