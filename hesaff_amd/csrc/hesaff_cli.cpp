@@ -149,12 +149,17 @@ int main(int argc, char **argv)
       fprintf(stderr, "hesaff: libhesaff_amd.so has ABI version %d, this program was built for %d\n", hesaff_abi_version(), HESAFF_ABI_VERSION);
       return 1;
    }
-   if (argc > 2 && strcmp(argv[1], "--batch") == 0) {
-      const char *devices = nullptr;
+   // batch mode: "--batch <list>" and the other options in any order (the reference has no options: a first argument that does
+   // not start with "--" is an image, as in hesaff.cpp:133-137)
+   bool batch = false;
+   for (int i = 1; i < argc; i++) batch = batch || strcmp(argv[i], "--batch") == 0;
+   if (batch) {
+      const char *devices = nullptr, *list = nullptr;
       int out_format = HESAFF_OUT_TEXT, fast = 0;
       bool bad = false, dynamic = false;
-      for (int i = 3; i < argc && !bad; i += 2) {
+      for (int i = 1; i < argc && !bad; i += 2) {
          if (i + 1 >= argc) bad = true;
+         else if (strcmp(argv[i], "--batch") == 0) list = argv[i + 1];
          else if (strcmp(argv[i], "--devices") == 0) devices = argv[i + 1];
          else if (strcmp(argv[i], "--fast") == 0) {
             if (strcmp(argv[i + 1], "0") == 0 || strcmp(argv[i + 1], "2") == 0) fast = atoi(argv[i + 1]);
@@ -169,8 +174,8 @@ int main(int argc, char **argv)
             else bad = true;
          } else bad = true;
       }
-      if (bad) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all] [--output text|bin|both] [--schedule static|dynamic] [--fast 0|2]\n"); return 1; }
-      return run_batch_mode(argv[2], devices, out_format, dynamic, fast);
+      if (bad || !list) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all] [--output text|bin|both] [--schedule static|dynamic] [--fast 0|2]\n"); return 1; }
+      return run_batch_mode(list, devices, out_format, dynamic, fast);
    }
    if (argc > 1) {
       uint8_t *data = nullptr;

@@ -196,6 +196,17 @@ __global__ __launch_bounds__(256) void k_blur_cols_generic(DPlane tmp, DPlane ou
    out.img(b)[(long long)y * out.pitch + x] = d;
 }
 
+// value of the lane below / above (wavefront shift by one lane: one VALU move with a DPP control, no trip through the LDS crossbar);
+// lane 0 / lane 63 keep their own value
+__device__ __forceinline__ float hs_from_lane_below(float v)
+{
+   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float hs_from_lane_above(float v)
+{
+   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
 // Candidates of one octave: findLevelKeypoints pyramid.cpp:206-222 appends (img,level,r,c) for every pixel that
 // passes isMax / isMin (:39-61); unordered here, the order is restored by the bitmask ranks in k_scatter_ordered.
 // A candidate carries the 19 response values localizeKeypoint's first iteration reads (pyramid.cpp:132-150): k_extrema_march has
@@ -728,8 +739,8 @@ __global__ __launch_bounds__(256, (K == 15 ? HS_MARCH15_WAVES : 0)) void k_blur_
                la = la + qa;
                lb = lb + qb;
             }
-            const float left = __shfl_up(lb.y, 1, 64);      // column x-1
-            const float right = __shfl_down(la.x, 1, 64);   // column x+4
+            const float left = hs_from_lane_below(lb.y);    // column x-1
+            const float right = hs_from_lane_above(la.x);   // column x+4
             v2f P0[5];
             P0[0].x = left; P0[0].y = la.x;
             P0[1] = la;
@@ -782,7 +793,7 @@ __global__ __launch_bounds__(256, (K == 15 ? HS_MARCH15_WAVES : 0)) void k_blur_
          if (WRITE_R0) {
             auto row_pairs = [&](int buf, v2f *Q) {
                const float4 m = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(s_rows[wave][buf] + 4 * lane + 8, 16));
-               const float e0 = __shfl_up(m.w, 1, 64), e5 = __shfl_down(m.x, 1, 64);
+               const float e0 = hs_from_lane_below(m.w), e5 = hs_from_lane_above(m.x);
                Q[0].x = e0; Q[0].y = m.x;
                Q[1].x = m.x; Q[1].y = m.y;
                Q[2].x = m.y; Q[2].y = m.z;
@@ -847,17 +858,6 @@ __device__ __forceinline__ float hs_min3(float a, float b, float c)
    float r;
    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
    return r;
-}
-
-// value of the lane below / above (wavefront shift by one lane: one VALU move with a DPP control, no trip through the LDS crossbar);
-// lane 0 / lane 63 keep their own value
-__device__ __forceinline__ float hs_from_lane_below(float v)
-{
-   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float hs_from_lane_above(float v)
-{
-   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
 }
 
 __global__ __launch_bounds__(64) void k_extrema_march(FivePlanes fp, float posThr, float negThr, CandList cl, int band)

@@ -236,6 +236,13 @@ def test_cli_batch_mode(tmp_path):
         r1 = subprocess.run([exe, n], capture_output=True, text=True)
         assert r1.returncode == 0, r1.stderr
         assert open(n + ".hesaff.sift", "rb").read() == want and len(want) > 1000
+    # options in any order, before or after the list (they were only accepted after it)
+    for n in names:
+        os.remove(n + ".hesaff.sift")
+    r = subprocess.run([exe, "--output", "both", "--devices", "0", "--batch", str(lst), "--schedule", "dynamic"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert [open(n + ".hesaff.sift", "rb").read() for n in names] == batch_out and all(os.path.exists(n + ".hesaff.bin") for n in names)
+    assert subprocess.run([exe, "--devices", "0", "--batch"], capture_output=True, text=True).returncode == 1
 
 
 def test_cli_multi_device_shards_and_isolates_bad_files(tmp_path):
