@@ -111,6 +111,8 @@ def load_library():
     L.hesaff_write_sift_mt.argtypes = [C.c_char_p, vp, C.c_int, C.c_float, C.c_int]
     L.hesaff_write_bin.argtypes = [C.c_char_p, vp, C.c_int, C.c_float]
     L.hesaff_set_output_format.argtypes = [vp, C.c_int]
+    L.hesaff_set_resume.argtypes = [vp, C.c_int]
+    L.hesaff_output_is_complete.argtypes = [C.c_char_p, C.c_int]
     L.hesaff_detect_batch_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, _i32p, _i32p, C.POINTER(vp), C.POINTER(C.c_int64)]
     L.hesaff_set_profiling.argtypes = [vp, C.c_int]
     L.hesaff_get_timings.argtypes = [vp, C.POINTER(Timings)]
@@ -164,7 +166,8 @@ ABI_SYMBOLS = [
     "hesaff_read_png", "hesaff_read_image", "hesaff_device_count", "hesaff_shard_range", "hesaff_read_jpeg",
     "hesaff_host_threads", "hesaff_abi_version", "hesaff_sizeof_params", "hesaff_sizeof_timings", "hesaff_detect_batch_cb",
     "hesaff_process_files", "hesaff_write_sift_mt", "hesaff_write_bin", "hesaff_set_output_format",
-    "hesaff_write_sift_rows", "hesaff_write_bin_rows", "hesaff_stage_export", "hesaff_stage_fmt_g",
+    "hesaff_write_sift_rows", "hesaff_write_bin_rows", "hesaff_stage_export", "hesaff_stage_fmt_g", "hesaff_set_resume",
+    "hesaff_output_is_complete",
 ]
 
 
@@ -399,6 +402,10 @@ class HesaffContext:
     def set_output_format(self, fmt):
         """1 = text (.hesaff.sift, default), 2 = binary sidecar (.hesaff.bin), 3 = both."""
         self._check(self.L.hesaff_set_output_format(self.h, fmt))
+
+    def set_resume(self, on=True):
+        """hesaff_process_files skips images whose complete output exists."""
+        self._check(self.L.hesaff_set_resume(self.h, 1 if on else 0))
 
     def process_files(self, paths, out_paths=None, decode_threads=0, write_threads=0):
         """hesaff_process_files: image files -> <name>.hesaff.sift through the decode / device / write pipeline.

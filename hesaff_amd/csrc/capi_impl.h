@@ -527,6 +527,13 @@ int hesaff_set_output_format(hesaff_ctx *c, int format)
    return HESAFF_OK;
 }
 
+int hesaff_set_resume(hesaff_ctx *c, int on)
+{
+   if (!c) return HESAFF_ERR_ARG;
+   c->resume = on != 0;
+   return HESAFF_OK;
+}
+
 int hesaff_process_files(hesaff_ctx *c, int n, const char *const *paths, const char *const *out_paths, int decode_threads,
                          int write_threads, hesaff_file_status *status)
 {
@@ -537,7 +544,7 @@ int hesaff_process_files(hesaff_ctx *c, int n, const char *const *paths, const c
    const int dt = std::max(1, std::min(decode_threads > 0 ? decode_threads : std::max(2, host / 4), 64));
    const int wt = std::max(1, std::min(write_threads > 0 ? write_threads : host, 256));
    // the rows are formatted on the device (kernels_export.h): the writer threads only write()
-   FileIO io(&c->ring, c->par.max_batch, c->par.mrSize, c->out_format, n, paths, out_paths, status, dt, wt, true);
+   FileIO io(&c->ring, c->par.max_batch, c->par.mrSize, c->out_format, n, paths, out_paths, status, dt, wt, true, c->resume);
    c->stage_threads = std::max(1, std::min(4, dt));
    try {
       run_chunks(c, io, 3);

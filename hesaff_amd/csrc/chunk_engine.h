@@ -94,6 +94,7 @@ struct FileIO : ChunkIO {
    float mrSize;
    int fmt;
    bool device_format;   // rows arrive formatted (ChunkDone::text / bin): the writers only write()
+   bool resume;          // hesaff_set_resume: an image whose complete output exists is not read
    struct Img { uint8_t *data = nullptr; int w = 0, h = 0, ch = 0; int state = 0; };   // 0 pending, 1 decoded, 2 unreadable, 3 handed on
    std::vector<Img> imgs;
    std::mutex mu;
@@ -108,9 +109,9 @@ struct FileIO : ChunkIO {
    std::vector<std::thread> workers;
 
    FileIO(BlockRing *ring_, int max_batch_, float mrSize_, int fmt_, int n_, const char *const *p, const char *const *o, hesaff_file_status *st,
-          int dec_threads, int wr_threads, bool device_format_ = false)
+          int dec_threads, int wr_threads, bool device_format_ = false, bool resume_ = false)
       : ring(ring_), max_batch(max_batch_), n(n_), paths(p), out_paths(o), status(st), mrSize(mrSize_), fmt(fmt_), device_format(device_format_),
-        imgs((size_t)n_)
+        resume(resume_), imgs((size_t)n_)
    {
       window = 2 * max_batch + dec_threads;
       try {
@@ -143,8 +144,29 @@ struct FileIO : ChunkIO {
          if (i >= 0) decode_one(i); else write_one(t);
       }
    }
+   std::string out_name(int i, bool bin) const
+   {
+      const char *o = out_paths ? out_paths[i] : nullptr;
+      if (!bin) return o ? std::string(o) : std::string(paths[i]) + ".hesaff.sift";   // hesaff.cpp:170-173
+      return o ? (std::string(o) + ((fmt & HESAFF_OUT_TEXT) ? ".bin" : "")) : std::string(paths[i]) + ".hesaff.bin";
+   }
    void decode_one(int i)
    {
+      if (resume && paths[i]) {
+         int n_text = 0, n_bin = 0;
+         if (fmt & HESAFF_OUT_TEXT) n_text = hesaff_output_is_complete(out_name(i, false).c_str(), HESAFF_OUT_TEXT);
+         if (fmt & HESAFF_OUT_BIN) n_bin = hesaff_output_is_complete(out_name(i, true).c_str(), HESAFF_OUT_BIN);
+         if (n_text >= 0 && n_bin >= 0 && (fmt != (HESAFF_OUT_TEXT | HESAFF_OUT_BIN) || n_text == n_bin)) {
+            {
+               std::lock_guard<std::mutex> lk(mu);
+               imgs[(size_t)i].state = 2;
+               status[i].rc = HESAFF_OK; status[i].stage = HESAFF_FILE_SKIPPED;
+               status[i].count_hessian = -1; status[i].count_desc = (fmt & HESAFF_OUT_TEXT) ? n_text : n_bin;
+            }
+            cv_img.notify_all();
+            return;
+         }
+      }
       Img im;
       int rc = paths[i] ? hesaff_read_image(paths[i], &im.data, &im.w, &im.h, &im.ch) : HESAFF_ERR_ARG;
       int stage = HESAFF_FILE_UNREADABLE;
@@ -223,15 +245,14 @@ struct FileIO : ChunkIO {
    }
    void write_one(const Task &t)
    {
-      const char *o = out_paths ? out_paths[t.index] : nullptr;
       int rc = HESAFF_OK;
       if (fmt & HESAFF_OUT_TEXT) {
-         const std::string name = o ? std::string(o) : std::string(paths[t.index]) + ".hesaff.sift";   // hesaff.cpp:170-173
+         const std::string name = out_name(t.index, false);
          if (device_format) rc = hesaff_write_sift_rows(name.c_str(), t.text, t.text_len, t.n);
          else rc = hesaff_write_sift_mt(name.c_str(), t.keys, t.n, mrSize, 1);
       }
       if ((fmt & HESAFF_OUT_BIN) && rc == HESAFF_OK) {
-         const std::string name = o ? (std::string(o) + ((fmt & HESAFF_OUT_TEXT) ? ".bin" : "")) : std::string(paths[t.index]) + ".hesaff.bin";
+         const std::string name = out_name(t.index, true);
          if (device_format) rc = hesaff_write_bin_rows(name.c_str(), t.bin, t.n);
          else rc = hesaff_write_bin(name.c_str(), t.keys, t.n, mrSize);
       }

@@ -13,6 +13,8 @@
 //       keypoint density varies strongly along the list; the output files are the same either way.
 //       --fast 2                      hesaff_params.fast: windows larger than the patch sampled from the scale space (NOT bit-exact,
 //       another algorithm for those keypoints); default 0 = parity mode.
+//       --resume                      skip every image whose complete output (of the selected format) already exists; outputs are written
+//       under a temporary name and renamed, so an interrupted run leaves no torn file (checkpoint / resume).
 //       --output text | bin | both    what every image gets: <image>.hesaff.sift (default), the binary sidecar
 //       <image>.hesaff.bin (the same rows unprinted, include/hesaff_amd.h: hesaff_write_bin), or both.
 #include <chrono>
@@ -63,7 +65,7 @@ bool parse_devices(const char *spec, std::vector<int> &out)
 
 // hesaff --batch: the list is cut into contiguous shards, one per device context (hesaff_shard_range); every shard runs
 // through hesaff_process_files - decode threads -> device -> writer threads, bounded memory - on its own host thread.
-int run_batch_mode(const char *list_path, const char *devices_spec, int out_format, bool dynamic, int fast)
+int run_batch_mode(const char *list_path, const char *devices_spec, int out_format, bool dynamic, int fast, bool resume)
 {
    std::ifstream lf(list_path);
    if (!lf) { fprintf(stderr, "hesaff: cannot read list '%s'\n", list_path); return 1; }
@@ -99,6 +101,7 @@ int run_batch_mode(const char *list_path, const char *devices_spec, int out_form
       hesaff_ctx *ctx = nullptr;
       if (hesaff_create(&ctx, &par, devices[(size_t)rank]) != HESAFF_OK) { errs[(size_t)rank] = hesaff_last_error(nullptr); return; }
       hesaff_set_output_format(ctx, out_format);
+      hesaff_set_resume(ctx, resume ? 1 : 0);
       const int host = hesaff_host_threads();
       const int wt = std::max(1, host / world), dt = std::max(1, std::min(16, host / (2 * world)));
       for (;;) {
@@ -120,12 +123,15 @@ int run_batch_mode(const char *list_path, const char *devices_spec, int out_form
    }
    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
    long long tot_h = 0, tot_d = 0;
-   int n_ok = 0;
+   int n_ok = 0, n_skipped = 0;
    for (int r = 0; r < world; r++)
       if (!errs[(size_t)r].empty()) { fprintf(stderr, "hesaff: device %d: %s\n", devices[(size_t)r], errs[(size_t)r].c_str()); rc = 1; }
    for (int i = 0; i < n; i++) {
       const hesaff_file_status &st = status[(size_t)i];
-      if (st.rc == HESAFF_OK) {
+      if (st.rc == HESAFF_OK && st.stage == HESAFF_FILE_SKIPPED) {
+         std::cout << names[(size_t)i] << ": output exists (" << st.count_desc << " rows), skipped" << std::endl;
+         n_skipped++;
+      } else if (st.rc == HESAFF_OK) {
          std::cout << names[(size_t)i] << ": Detected " << st.count_hessian << " keypoints and " << st.count_desc << " affine shapes" << std::endl;
          tot_h += st.count_hessian; tot_d += st.count_desc; n_ok++;
       } else {
@@ -136,6 +142,7 @@ int run_batch_mode(const char *list_path, const char *devices_spec, int out_form
       }
    }
    std::cout << "Detected " << tot_h << " keypoints and " << tot_d << " affine shapes in " << n_ok << " images in " << dt << " sec.";
+   if (n_skipped) std::cout << " (" << n_skipped << " more skipped: complete outputs exist)";
    if (world > 1) std::cout << " (" << world << " device contexts)";
    std::cout << std::endl;
    return rc;
@@ -156,8 +163,9 @@ int main(int argc, char **argv)
    if (batch) {
       const char *devices = nullptr, *list = nullptr;
       int out_format = HESAFF_OUT_TEXT, fast = 0;
-      bool bad = false, dynamic = false;
+      bool bad = false, dynamic = false, resume = false;
       for (int i = 1; i < argc && !bad; i += 2) {
+         if (strcmp(argv[i], "--resume") == 0) { resume = true; i--; continue; }
          if (i + 1 >= argc) bad = true;
          else if (strcmp(argv[i], "--batch") == 0) list = argv[i + 1];
          else if (strcmp(argv[i], "--devices") == 0) devices = argv[i + 1];
@@ -174,8 +182,8 @@ int main(int argc, char **argv)
             else bad = true;
          } else bad = true;
       }
-      if (bad || !list) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all] [--output text|bin|both] [--schedule static|dynamic] [--fast 0|2]\n"); return 1; }
-      return run_batch_mode(list, devices, out_format, dynamic, fast);
+      if (bad || !list) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all] [--output text|bin|both] [--schedule static|dynamic] [--fast 0|2] [--resume]\n"); return 1; }
+      return run_batch_mode(list, devices, out_format, dynamic, fast, resume);
    }
    if (argc > 1) {
       uint8_t *data = nullptr;

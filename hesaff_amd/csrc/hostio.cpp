@@ -627,31 +627,76 @@ static bool write_all(int fd, const char *q, size_t left)
 
 // The file of hesaff.cpp:109-128 from rows that are already text (formatted on the device, kernels_export.h): the two header
 // lines, then the rows as they are.
+// (written under "<path>.part" and renamed when complete: a killed run leaves no torn file under the final name)
+static int finish_part(int fd, bool ok, const std::string &part, const char *path)
+{
+   if (close(fd) != 0) ok = false;
+   if (ok && rename(part.c_str(), path) != 0) ok = false;
+   if (!ok) unlink(part.c_str());
+   return ok ? HESAFF_OK : HESAFF_ERR_IO;
+}
+
 int hesaff_write_sift_rows(const char *path, const char *rows, size_t len, int n)
 {
    if (!path || n < 0 || (len > 0 && !rows)) return HESAFF_ERR_ARG;
-   const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+   HOSTIO_TRY
+   const std::string part = std::string(path) + ".part";
+   const int fd = open(part.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
    if (fd < 0) return HESAFF_ERR_IO;
    char head[64];
    const int hl = snprintf(head, sizeof head, "%d\n%d\n", 128, n);
-   bool ok = write_all(fd, head, (size_t)hl) && write_all(fd, rows, len);
-   if (close(fd) != 0) ok = false;
-   return ok ? HESAFF_OK : HESAFF_ERR_IO;
+   const bool ok = write_all(fd, head, (size_t)hl) && write_all(fd, rows, len);
+   return finish_part(fd, ok, part, path);
+   HOSTIO_CATCH
+}
+
+// Is `path` the complete output of an earlier run?  text (format HESAFF_OUT_TEXT): "128\n<n>\n", then rows, the last byte a newline
+// (n == 0: nothing after the header); sidecar: magic, dim 128, size == 16 + 148 n.  -> n, or -1
+int hesaff_output_is_complete(const char *path, int format)
+{
+   if (!path) return -1;
+   const int fd = open(path, O_RDONLY | O_CLOEXEC);
+   if (fd < 0) return -1;
+   int result = -1;
+   const off_t size = lseek(fd, 0, SEEK_END);
+   char head[64] = {0};
+   const ssize_t got = size > 0 ? pread(fd, head, sizeof head - 1, 0) : 0;
+   if (format == HESAFF_OUT_BIN) {
+      uint32_t dim = 0, cnt = 0;
+      if (got >= 16 && memcmp(head, "HESAFFB1", 8) == 0) {
+         memcpy(&dim, head + 8, 4); memcpy(&cnt, head + 12, 4);
+         if (dim == 128 && cnt <= 0x7fffffffu && (unsigned long long)size == 16ull + 148ull * cnt) result = (int)cnt;
+      }
+   } else if (got >= 6 && memcmp(head, "128\n", 4) == 0) {
+      long n = 0;
+      int i = 4;
+      while (i < got && head[i] >= '0' && head[i] <= '9' && n < 100000000) n = n * 10 + (head[i++] - '0');
+      if (i > 4 && i < got && head[i] == '\n') {
+         const off_t body = size - (off_t)(i + 1);
+         char last = 0;
+         // a row is at least 5 * 2 + 128 * 2 characters; the text must end with the newline of its last row
+         if (n == 0 ? body == 0 : (body >= (off_t)n * 266 && pread(fd, &last, 1, size - 1) == 1 && last == '\n')) result = (int)n;
+      }
+   }
+   close(fd);
+   return result;
 }
 
 // hesaff_write_bin's file from rows that are already packed (148 bytes each)
 int hesaff_write_bin_rows(const char *path, const char *rows, int n)
 {
    if (!path || n < 0 || (n > 0 && !rows)) return HESAFF_ERR_ARG;
-   const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+   HOSTIO_TRY
+   const std::string part = std::string(path) + ".part";
+   const int fd = open(part.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
    if (fd < 0) return HESAFF_ERR_IO;
    char head[16];
    memcpy(head, "HESAFFB1", 8);
    const uint32_t dim = 128, cnt = (uint32_t)n;
    memcpy(head + 8, &dim, 4); memcpy(head + 12, &cnt, 4);
-   bool ok = write_all(fd, head, 16) && write_all(fd, rows, (size_t)n * 148);
-   if (close(fd) != 0) ok = false;
-   return ok ? HESAFF_OK : HESAFF_ERR_IO;
+   const bool ok = write_all(fd, head, 16) && write_all(fd, rows, (size_t)n * 148);
+   return finish_part(fd, ok, part, path);
+   HOSTIO_CATCH
 }
 
 // One file per image of a batch (exportKeypoints once per image, hesaff.cpp:170-176), images

@@ -233,6 +233,7 @@ struct hesaff_ctx {
    hesaff_timings tm;
    int profiling = 0;
    int out_format = HESAFF_OUT_TEXT;   // hesaff_set_output_format
+   bool resume = false;                // hesaff_set_resume
    int stage_threads = 4;              // host threads that copy a chunk's pixels into pinned memory (hesaff_process_files: within its thread budget)
    hipStream_t side_streams[HS_NSIDE] = {nullptr, nullptr, nullptr, nullptr};
    hipStream_t sift_stream = nullptr, sift_stream2 = nullptr;   // descriptor kernels of even / odd groups (sift2: HESAFF_SIFT2)

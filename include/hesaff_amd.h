@@ -153,6 +153,8 @@ int hesaff_detect_batch_cb(hesaff_ctx *ctx, int n, const uint8_t *const *images,
 #define HESAFF_FILE_REJECTED 4  /* decoded, but the device refused it: a side above 65535 pixels or a window the kernels cannot hold
                                    (rc = HESAFF_ERR_ARG), more keypoints than max_kpts_per_mpx plans for (HESAFF_ERR_CAPACITY); the other
                                    files of the list are not affected */
+#define HESAFF_FILE_SKIPPED 5   /* hesaff_set_resume: the complete output of an earlier run exists; the image was not read (rc = HESAFF_OK,
+                                   count_desc = the row count that output states, count_hessian = -1: not known) */
 typedef struct hesaff_file_status {
    int32_t rc;                 /* HESAFF_OK only in stage HESAFF_FILE_WRITTEN */
    int32_t stage;              /* how far this file got: HESAFF_FILE_* */
@@ -167,6 +169,12 @@ int hesaff_process_files(hesaff_ctx *ctx, int n, const char *const *paths, const
 #define HESAFF_OUT_TEXT 1
 #define HESAFF_OUT_BIN 2
 int hesaff_set_output_format(hesaff_ctx *ctx, int format);
+/* Resume a list that was interrupted (checkpoint / resume; no counterpart in the reference, which handles one
+ * image per process): with on != 0 hesaff_process_files skips every image whose output file(s) of the selected format exist and
+ * are complete - a .hesaff.sift with its two header lines and a final newline, a .hesaff.bin whose size matches its row count.
+ * hesaff_process_files writes every output under a temporary name and renames it when it is complete, so a run that is killed
+ * never leaves a torn file under the final name. */
+int hesaff_set_resume(hesaff_ctx *ctx, int on);
 
 /* Same path with inputs already resident in device memory (bench / pipelines that decode
  * on the GPU): d_gray = n contiguous height x width 8-bit grey planes (device pointer).
@@ -196,6 +204,9 @@ int hesaff_write_bin(const char *path, const hesaff_keypoint *keys, int n, float
  * n rows of 148 bytes; the header lines (hesaff.cpp:109-110) / the 16-byte sidecar header are added here. */
 int hesaff_write_sift_rows(const char *path, const char *rows, size_t len, int n);
 int hesaff_write_bin_rows(const char *path, const char *rows, int n);
+/* the row count of `path` when it is the complete output (format HESAFF_OUT_TEXT or HESAFF_OUT_BIN) of an earlier run, -1
+ * otherwise: what hesaff_set_resume goes by */
+int hesaff_output_is_complete(const char *path, int format);
 /* formats into a malloc'ed buffer (*out, *len); caller frees with hesaff_free */
 int hesaff_format_sift(const hesaff_keypoint *keys, int n, float mrSize, char **out, size_t *len);
 /* the same bytes, rows formatted by `threads` host threads (0 = one per core, at most 64);

@@ -1200,3 +1200,41 @@ def test_photograph_mosaic_4k_against_the_oracle(ctx, oracle):
     assert ctx.export(k0) == o.export_text()
     P0 = 2 * np.ceil(k0["s"] * np.float32(ctx.params.mrSize)).astype(np.int64) + 1
     assert 25 <= np.median(P0) <= 45 and P0.max() > 150, (float(np.median(P0)), int(P0.max()))
+
+
+def test_process_files_resume_skips_complete_outputs(tmp_path, oracle):
+    """hesaff_set_resume (checkpoint / resume): a second run over the same list reads no image whose complete
+    output exists, re-does the ones whose output is missing or torn, and leaves identical files; outputs are written under a
+    temporary name and renamed, so nothing but complete files ever carries the final name."""
+    import hesaff_amd
+    from tests import _oracle
+    paths, texts = [], []
+    for i in range(6):
+        img = band_noise_image(120, 160, 700 + i, SMALL_BANDS)
+        q = tmp_path / ("r%d.pgm" % i)
+        q.write_bytes(b"P5\n160 120\n255\n" + img.tobytes())
+        paths.append(str(q)); texts.append(_oracle.OracleRun(_oracle.gray_from_u8(img)).export_text())
+    p = hesaff_amd.default_params(); p.max_batch = 2
+    with hesaff_amd.HesaffContext(p, device=0) as ctx:
+        ctx.set_output_format(3)
+        ctx.set_resume(True)
+        st = ctx.process_files(paths)
+        assert all((rc, stage) == (0, 3) for rc, stage, _, _ in st)
+        assert not [f for f in os.listdir(tmp_path) if f.endswith(".part")]
+        os.remove(paths[1] + ".hesaff.sift")                                              # missing
+        open(paths[3] + ".hesaff.sift", "wb").write(texts[3][: len(texts[3]) // 2])       # torn: no final newline
+        open(paths[4] + ".hesaff.bin", "ab").write(b"\0")                                 # size does not match the row count
+        for q in (paths[0], paths[2], paths[5]):
+            os.remove(q)                                                                  # complete outputs: the image is not even opened
+        st = ctx.process_files(paths)
+        for i, (rc, stage, nh, nd) in enumerate(st):
+            if i in (0, 2, 5):
+                assert (rc, stage, nh) == (0, 5, -1) and nd == int(texts[i].split(b"\n")[1]), (i, rc, stage, nh, nd)   # HESAFF_FILE_SKIPPED
+            else:
+                assert (rc, stage) == (0, 3) and nh > 0, (i, rc, stage)
+        for q, t in zip(paths, texts):
+            assert open(q + ".hesaff.sift", "rb").read() == t
+            assert hesaff_amd.load_library().hesaff_output_is_complete(os.fsencode(q + ".hesaff.bin"), 2) == int(t.split(b"\n")[1])
+        ctx.set_resume(False)
+        st = ctx.process_files(paths[1:2])
+        assert st[0][1] == 3
