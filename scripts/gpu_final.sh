@@ -1,6 +1,7 @@
 # usage (through gpurun): bash scripts/gpu_final.sh <tag>
-# round-end evidence: GPU test suite, default bench line, rocprofv3 stats + HBM traffic of the bench command, per-kernel PMC tables,
-# per-kernel serial times (parity, fast, natural density), fast-mode report, config-5 sequence table
+# round-end evidence, ONE pass: GPU test suite, default bench line, rocprofv3 stats + HBM traffic of the bench command, per-kernel PMC tables,
+# per-kernel serial times (parity, fast = 2, photographs), fast-mode reports, config-5 sequence tables (band noise and photograph, fast 0 / 2),
+# end-to-end thread sweep
 cd $GRAFT_REPO_ROOT
 TAG=$1
 mkdir -p gpurun_out
@@ -10,8 +11,22 @@ bash scripts/gpu_profile_round.sh ${TAG}_prof > gpurun_out/${TAG}_prof.log 2>&1;
 bash scripts/gpu_pmc2.sh ${TAG} 8 > gpurun_out/${TAG}_pmc.md 2>&1; cat gpurun_out/${TAG}_pmc.md
 bash scripts/gpu_pmc_lds.sh ${TAG} 8 > gpurun_out/${TAG}_pmc_lds.md 2>&1; cat gpurun_out/${TAG}_pmc_lds.md
 bash scripts/gpu_pmc_mem.sh ${TAG} 8 > gpurun_out/${TAG}_pmc_mem.md 2>&1; cat gpurun_out/${TAG}_pmc_mem.md
-bash scripts/gpu_kernels.sh ${TAG} 32 > gpurun_out/${TAG}_kernels_serial.txt 2>&1; head -16 gpurun_out/${TAG}_kernels_serial.txt
-HESAFF_FAST=1 bash scripts/gpu_kernels.sh ${TAG}_fast 32 > gpurun_out/${TAG}_kernels_serial_fast.txt 2>&1; head -12 gpurun_out/${TAG}_kernels_serial_fast.txt
-BENCH_EXTRA="--density natural" bash scripts/gpu_kernels.sh ${TAG}_nat 32 > gpurun_out/${TAG}_kernels_serial_natural.txt 2>&1; head -12 gpurun_out/${TAG}_kernels_serial_natural.txt
+bash scripts/gpu_kernels.sh ${TAG} 32 > gpurun_out/${TAG}_kernels_serial.txt 2>&1; head -30 gpurun_out/${TAG}_kernels_serial.txt
+HESAFF_FAST=2 bash scripts/gpu_kernels.sh ${TAG}_fast2 32 > gpurun_out/${TAG}_kernels_serial_fast2.txt 2>&1; head -12 gpurun_out/${TAG}_kernels_serial_fast2.txt
+BENCH_EXTRA="--density photo" bash scripts/gpu_kernels.sh ${TAG}_photo 32 > gpurun_out/${TAG}_kernels_serial_photo.txt 2>&1; head -12 gpurun_out/${TAG}_kernels_serial_photo.txt
 timeout 900 python tools/fast_mode_report.py --batch 32 > gpurun_out/${TAG}_fast_mode.json 2> gpurun_out/${TAG}_fast_mode.err; tail -1 gpurun_out/${TAG}_fast_mode.json | cut -c1-600
-rm -rf /tmp/seq_${TAG}; timeout 900 python tools/repeatability.py --synthetic-files /tmp/seq_${TAG} > gpurun_out/${TAG}_repeatability_sequence.json 2> gpurun_out/${TAG}_repeatability.err; head -c 1500 gpurun_out/${TAG}_repeatability_sequence.json
+timeout 900 python tools/fast_mode_report.py --batch 32 --photo > gpurun_out/${TAG}_fast_mode_photo.json 2>> gpurun_out/${TAG}_fast_mode.err; tail -1 gpurun_out/${TAG}_fast_mode_photo.json | cut -c1-600
+for f in 0 2; do
+  rm -rf /tmp/seq_${TAG}; timeout 900 python tools/repeatability.py --synthetic-files /tmp/seq_${TAG} --fast $f > gpurun_out/${TAG}_repeatability_sequence_fast$f.json 2> gpurun_out/${TAG}_repeatability.err
+  for ph in 0 1; do rm -rf /tmp/seqp_${TAG}; timeout 900 python tools/repeatability.py --synthetic-files /tmp/seqp_${TAG} --photo $ph --fast $f > gpurun_out/${TAG}_repeatability_photo${ph}_fast$f.json 2>> gpurun_out/${TAG}_repeatability.err; done
+done
+python - <<PY
+import json, glob
+for q in sorted(glob.glob("gpurun_out/${TAG}_repeatability_*.json")):
+    try:
+        d = json.load(open(q))
+        print(q.rsplit("/", 1)[1], [(e.get("viewpoint_deg"), round(e["repeatability"], 4), round(e["matching_score"], 4)) for e in d["pairs"]])
+    except Exception as e:
+        print(q, "unreadable", e)
+PY
+timeout 900 python scripts/e2e_thread_sweep.py 384 > gpurun_out/${TAG}_e2e_thread_sweep.txt 2>&1; tail -12 gpurun_out/${TAG}_e2e_thread_sweep.txt | cut -c1-300
