@@ -778,10 +778,11 @@ int hesaff_stage_normalize_affine(hesaff_ctx *c, const float *img, int rows, int
    HIP_TRY(hipMemsetAsync(c->b_patches.p, 0, (size_t)n * HS_PATCH_PIX * 4, st));
    // T' rows of the huge windows: bounded by the sum of their sides
    unsigned long long large_rows = 0;
+   c->batch_max_p = 0;
    for (int i = 0; i < n; i++) {
       const float mrScale = ceilf(sc[i] * c->consts.mrSize);
       const long long P = (mrScale < 1.0e6f) ? 2 * (long long)mrScale + 3 : 0;
-      if (P > HS_BIN3_PMAX && P <= c->max_p0 + 2) large_rows += (unsigned long long)P;
+      if (P > HS_BIN3_PMAX && P <= c->max_p0 + 2) { large_rows += (unsigned long long)P; c->batch_max_p = std::max(c->batch_max_p, (int)P); }
    }
    if (large_rows > 0xffffffffull) throw HsError(HESAFF_ERR_NOMEM, "too many huge windows in one call");
    run_patch_stage(c, s, c->gray, c->b_patches.as<float>(), 0, (uint32_t)large_rows);

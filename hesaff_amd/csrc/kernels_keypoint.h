@@ -346,7 +346,9 @@ __device__ __forceinline__ int hs_window_p0(float s, float mrSize)
 // Upper bound, per image, of the T' rows the huge windows (last bin) of its keypoints need: depends on the scales
 // only, so it is known right after detection and the host can size / group the patch stage without waiting for the
 // affine iteration.  rows[b] += P for every Hessian keypoint whose window falls into the last bin.
-__global__ __launch_bounds__(256) void k_image_large_rows(HessList hl, const uint32_t *__restrict__ n_ptr, float mrSize, uint32_t *__restrict__ rows);
+// rows[nimg + 1] (one past the per-image sums) receives the largest such P of the batch: the row kernel's LDS is sized for the
+// windows that exist, not for the largest the image could hold.
+__global__ __launch_bounds__(256) void k_image_large_rows(HessList hl, const uint32_t *__restrict__ n_ptr, float mrSize, uint32_t *__restrict__ rows, int nimg);
 
 template <bool RECTIFY>
 __device__ __forceinline__ void hs_prepare_patch_body(const HessList &hl, uint32_t h_lo, uint32_t n, const AffineOut &aff, int imRows, int imCols,
@@ -399,14 +401,17 @@ __device__ __forceinline__ void hs_prepare_patch_body(const HessList &hl, uint32
    }
 }
 
-__global__ __launch_bounds__(256) void k_image_large_rows(HessList hl, const uint32_t *__restrict__ n_ptr, float mrSize, uint32_t *__restrict__ rows)
+__global__ __launch_bounds__(256) void k_image_large_rows(HessList hl, const uint32_t *__restrict__ n_ptr, float mrSize, uint32_t *__restrict__ rows, int nimg)
 {
    const uint32_t n = min(*n_ptr, hl.cap);
    for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < n; h += gridDim.x * blockDim.x) {
       const int P0 = hs_window_p0(hl.s[h], mrSize);
       const float scale = (float)P0 / (float)HS_PATCH;
       const int P = ((double)scale > 0.4) ? P0 + 2 : 0;
-      if (hs_patch_bin(P) == HS_NBINS - 1 && P0 < (1 << 20)) atomicAdd(rows + (hl.meta[h] >> 8), (uint32_t)P);
+      if (hs_patch_bin(P) == HS_NBINS - 1 && P0 < (1 << 20)) {
+         atomicAdd(rows + (hl.meta[h] >> 8), (uint32_t)P);
+         atomicMax(rows + nimg + 1, (uint32_t)P);
+      }
    }
 }
 

@@ -170,6 +170,7 @@ struct hesaff_ctx {
    int pyr_tap_off[5];
    bool pyr_march = false;   // the four octave blurs have K = 9, 11, 13, 15 (default initialSigma): marching kernel
    int max_p0 = 0;        // tap table covers odd P0 <= max_p0
+   int batch_max_p = 0;   // largest window side P of the current batch's huge windows (known after detection)
    int n_masked = 0;
    KpTables tables;
 
@@ -550,7 +551,7 @@ void plan_buffers(hesaff_ctx *c, int B, int H, int W)
    c->b_rank.ensure((cap + 1) * 4);
    c->b_desc.ensure(cap * 128);
    c->b_out.ensure(cap * sizeof(KeyRec));
-   c->b_starts.ensure((size_t)(B + 1) * 3 * 4);
+   c->b_starts.ensure(((size_t)(B + 1) * 3 + 2) * 4);   // hessian starts | descriptor starts | huge-window rows per image, + their largest side
    // patch taps: P <= sqrt(W*H) + small (the det-1 window must fit)
    const int max_p0 = (int)std::floor(std::sqrt((double)W * (double)H)) + 3;
    ensure_patch_taps(c, max_p0);
@@ -738,7 +739,10 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
       const uint32_t rows_cap = std::max(large_rows_bound, c->trows_rows);
       c->b_trows.ensure((size_t)rows_cap * HS_NEED * 4);
       c->b_rowprefix.ensure(((size_t)c->cap + 1) * 4);
-      const LargeGeom lg = large_geom(c->max_p0 + 2);
+      // LDS per wavefront for the largest window that exists in this batch (rounded up so that few distinct launch shapes occur),
+      // not for the largest the image could hold: 2 -> 5 resident blocks per CU on UHD images
+      const int pmax = std::min(c->max_p0 + 2, std::max(HS_BIN3_PMAX + 1, (c->batch_max_p > 0 ? c->batch_max_p : c->max_p0 + 2)));
+      const LargeGeom lg = large_geom(std::min(c->max_p0 + 2, (pmax + 255) / 256 * 256));
       io.trows = c->b_trows.as<float>();
       io.row_prefix = c->b_rowprefix.as<uint32_t>();
       io.trows_cap = rows_cap;
@@ -889,9 +893,9 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
    hipLaunchKernelGGL(k_image_counts, dim3((B + 1 + 63) / 64), dim3(64), 0, st, (const uint32_t *)c->b_prefix.p,
                       c->words_per_image, B, (const uint32_t *)(cnt + 3), c->b_starts.as<int32_t>());
    // per image: upper bound of the T' rows its huge windows (P > 512) need, known from the scales alone
-   HIP_TRY(hipMemsetAsync(c->b_starts.as<int32_t>() + 2 * (B + 1), 0, (size_t)(B + 1) * 4, st));
+   HIP_TRY(hipMemsetAsync(c->b_starts.as<int32_t>() + 2 * (B + 1), 0, (size_t)(B + 2) * 4, st));
    hipLaunchKernelGGL(k_image_large_rows, dim3(512), dim3(256), 0, st, s.hl, (const uint32_t *)(cnt + 3), c->consts.mrSize,
-                      c->b_starts.as<uint32_t>() + 2 * (B + 1));
+                      c->b_starts.as<uint32_t>() + 2 * (B + 1), B);
    tm.end(t);
    c->map_clean = true;   // (in stream order; a HIP error on the way leaves the flag false)
 }
@@ -979,12 +983,13 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       // The one host round trip of a batch: per-image Hessian counts + large-window row bounds.  The bin kernels
       // only extract the 41x41 patches (to HBM); the descriptor runs as four kernels with the parallel axis each
       // part wants (kernels_sift.h).  Images are processed in groups so that the patch buffers stay bounded.
-      std::vector<int32_t> hs(3 * (B + 1));
-      HIP_TRY(hipMemcpyAsync(hs.data(), c->b_starts.p, (size_t)3 * (B + 1) * 4, hipMemcpyDeviceToHost, st));
+      std::vector<int32_t> hs(3 * (B + 1) + 1);
+      HIP_TRY(hipMemcpyAsync(hs.data(), c->b_starts.p, ((size_t)3 * (B + 1) + 1) * 4, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipEventRecord(c->ev_detect_done, st));
       HIP_TRY(hipEventSynchronize(c->ev_detect_done));   // blocking-sync event: no core spins while the detection stage runs
       if ((uint32_t)hs[B] > c->cap) throw HsError(HESAFF_ERR_CAPACITY, "keypoint capacity exceeded; raise hesaff_params.max_kpts_per_mpx");
       const uint32_t *lrows = (const uint32_t *)hs.data() + 2 * (B + 1);
+      c->batch_max_p = (int)lrows[B + 1];   // largest huge window of the batch (0: none)
       // image groups [h_lo, h_hi) of at most group_kpts keypoints: about 16 groups per batch keep the
       // three-stage pipeline full, between 300 k (launch overheads) and 1.2 M keypoints (buffer size);
       // the T' rows of a group's huge windows must fit the row buffer (a single image may exceed it: the buffer grows)
