@@ -245,15 +245,13 @@ int hesaff_detect_batch_device(hesaff_ctx *c, int n, const void *d_gray, int wid
 //    caller's thread:  kernels of chunk k (run_batch) ; io.done(chunk k-1) ; D2D + D2H of chunk k on a third stream
 // so the copy in of chunk k+1 and the copy out of chunk k-1 run beside the kernels of chunk k.  Pinned result memory:
 // ring == 0 keeps one block per chunk until the next call (hesaff_detect_batch's contract: every results[i].keys stays
-// valid); ring == N > 0 cycles through N blocks, and the consumer gives a block back with release_block() when it
+// valid); ring == N > 0 cycles through N blocks, and the consumer gives a block back (BlockRing::release) when it
 // has finished with the chunk (bounded host memory however long the list is).
 // ------------------------------------------------------------------------------------------------------------------
 } // extern "C"
 
 namespace {
 using namespace hesaff_engine;
-
-void release_block(hesaff_ctx *c, int block) { c->ring.release(block); }
 
 void ensure_copy_streams(hesaff_ctx *c)
 {
@@ -418,80 +416,16 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
    HIP_TRY(hipStreamSynchronize(c->stream));
 }
 
-// chunks of a caller-supplied image list: images of equal (width, height, channels) grouped in input order
-struct ArrayIO : ChunkIO {
-   std::vector<HostChunk> chunks;
-   size_t pos = 0;
-   hesaff_ctx *c = nullptr;
-   hesaff_result *results = nullptr;             // hesaff_detect_batch: filled in place
-   hesaff_chunk_sink sink = nullptr;             // hesaff_detect_batch_cb
-   void *user = nullptr;
-   std::atomic<int> sink_rc{0};                 // written by done() on the caller's thread, read by next() on the staging thread
-   ArrayIO(hesaff_ctx *ctx, int n, const uint8_t *const *images, const int *widths, const int *heights, const int *strides, const int *channels)
-      : c(ctx)
-   {
-      std::vector<char> done((size_t)n, 0);
-      for (int i = 0; i < n; i++) {
-         if (done[(size_t)i]) continue;
-         const int W = widths[i], H = heights[i], ch = channels ? channels[i] : 1;
-         if (ch != 1 && ch != 3) throw HsError(HESAFF_ERR_ARG, "channels must be 1 or 3");
-         std::vector<int> grp;
-         for (int j = i; j < n; j++)
-            if (!done[(size_t)j] && widths[j] == W && heights[j] == H && (channels ? channels[j] : 1) == ch) {
-               if (!images[j] || W < 1 || H < 1) throw HsError(HESAFF_ERR_ARG, "bad image");
-               if (strides && (long long)strides[j] < (long long)W * ch) throw HsError(HESAFF_ERR_ARG, "row stride smaller than width * channels");
-               grp.push_back(j);
-               done[(size_t)j] = 1;
-            }
-         // chunk sizes: max_batch, except that a long run starts and ends with smaller chunks (1/4, 1/2 of it): the first chunk's
-         // copy in and the last chunk's copy out are the pipeline's fill and drain - nothing overlaps them
-         const size_t mb = (size_t)c->par.max_batch, N = grp.size();
-         std::vector<size_t> sizes;
-         if (N >= 4 * mb && mb >= 8) {
-            sizes.push_back(mb / 4); sizes.push_back(mb / 2);
-            size_t left = N - mb / 4 - mb / 2 - (mb / 2 + mb / 4);
-            while (left > 0) { const size_t t = std::min(mb, left); sizes.push_back(t); left -= t; }
-            sizes.push_back(mb / 2); sizes.push_back(mb / 4);
-         } else {
-            for (size_t left = N; left > 0;) { const size_t t = std::min(mb, left); sizes.push_back(t); left -= t; }
-         }
-         size_t g0 = 0;
-         for (size_t sz : sizes) {
-            HostChunk k;
-            k.W = W; k.H = H; k.ch = ch;
-            for (size_t g = g0; g < g0 + sz; g++) {
-               const int j = grp[g];
-               k.index.push_back(j);
-               k.data.push_back(images[j]);
-               k.stride.push_back(strides ? (size_t)strides[j] : (size_t)W * ch);
-            }
-            chunks.push_back(std::move(k));
-            g0 += sz;
-         }
-      }
+// what ArrayIO (chunk_engine.h) takes for granted
+void validate_image_list(int n, const uint8_t *const *images, const int *widths, const int *heights, const int *strides, const int *channels)
+{
+   for (int j = 0; j < n; j++) {
+      const int W = widths[j], H = heights[j], ch = channels ? channels[j] : 1;
+      if (ch != 1 && ch != 3) throw HsError(HESAFF_ERR_ARG, "channels must be 1 or 3");
+      if (!images[j] || W < 1 || H < 1) throw HsError(HESAFF_ERR_ARG, "bad image");
+      if (strides && (long long)strides[j] < (long long)W * ch) throw HsError(HESAFF_ERR_ARG, "row stride smaller than width * channels");
    }
-   bool next(HostChunk &out) override
-   {
-      if (pos >= chunks.size() || sink_rc.load() != 0) return false;
-      out = chunks[pos++];
-      return true;
-   }
-   void done(const ChunkDone &d) override
-   {
-      const size_t B = d.chunk->index.size();
-      if (results) {
-         for (size_t b = 0; b < B; b++) {
-            hesaff_result &r = results[d.chunk->index[b]];
-            r.count_hessian = d.count_hessian[b]; r.count_desc = d.count_desc[b]; r.keys = d.keys + d.key_off[b];
-         }
-         return;
-      }
-      std::vector<hesaff_result> tmp(B);
-      for (size_t b = 0; b < B; b++) { tmp[b].count_hessian = d.count_hessian[b]; tmp[b].count_desc = d.count_desc[b]; tmp[b].keys = d.keys + d.key_off[b]; }
-      if (sink_rc.load() == 0) sink_rc.store(sink(user, (int)B, d.chunk->index.data(), tmp.data()));
-      release_block(c, d.block);
-   }
-};
+}
 
 } // namespace
 
@@ -502,7 +436,8 @@ int hesaff_detect_batch(hesaff_ctx *c, int n, const uint8_t *const *images, cons
 {
    if (!c || n < 0 || (n > 0 && (!images || !widths || !heights || !results))) return HESAFF_ERR_ARG;
    HS_API_BEGIN
-   ArrayIO io(c, n, images, widths, heights, strides, channels);
+   validate_image_list(n, images, widths, heights, strides, channels);
+   ArrayIO io(&c->ring, c->par.max_batch, n, images, widths, heights, strides, channels);
    io.results = results;
    run_chunks(c, io, 0);
    HS_API_END(c)
@@ -513,7 +448,8 @@ int hesaff_detect_batch_cb(hesaff_ctx *c, int n, const uint8_t *const *images, c
 {
    if (!c || n < 0 || !sink || (n > 0 && (!images || !widths || !heights))) return HESAFF_ERR_ARG;
    HS_API_BEGIN
-   ArrayIO io(c, n, images, widths, heights, strides, channels);
+   validate_image_list(n, images, widths, heights, strides, channels);
+   ArrayIO io(&c->ring, c->par.max_batch, n, images, widths, heights, strides, channels);
    io.sink = sink; io.user = user;
    run_chunks(c, io, 3);
    if (io.sink_rc.load() != 0) throw HsError(HESAFF_ERR_IO, "the result sink reported an error");

@@ -3,6 +3,8 @@
 // mutex, condition variable and hand-over between threads of the file pipeline - also runs under ThreadSanitizer and
 // AddressSanitizer on a CPU with a mock device loop (tests/native/engine_sanitize.cpp, tests/test_host_sanitize.py).
 #pragma once
+#include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
@@ -79,6 +81,80 @@ struct ChunkIO {
    // planned for).  true: noted per image, go on with the next chunk; false: the whole call fails with rc
    virtual bool failed(const HostChunk &, int /*rc*/) { return false; }
    virtual ~ChunkIO() {}
+};
+
+// hesaff_detect_batch / hesaff_detect_batch_cb: chunks of a caller-supplied image list, images of equal (width, height, channels)
+// grouped in input order.  The arguments are validated by the caller (capi_impl.h: validate_image_list).
+struct ArrayIO : ChunkIO {
+   std::vector<HostChunk> chunks;
+   size_t pos = 0;
+   BlockRing *ring = nullptr;
+   hesaff_result *results = nullptr;             // hesaff_detect_batch: filled in place
+   hesaff_chunk_sink sink = nullptr;             // hesaff_detect_batch_cb
+   void *user = nullptr;
+   std::atomic<int> sink_rc{0};                 // written by done() on the caller's thread, read by next() on the staging thread
+   ArrayIO(BlockRing *ring_, int max_batch, int n, const uint8_t *const *images, const int *widths, const int *heights, const int *strides,
+           const int *channels)
+      : ring(ring_)
+   {
+      std::vector<char> taken((size_t)n, 0);
+      for (int i = 0; i < n; i++) {
+         if (taken[(size_t)i]) continue;
+         const int W = widths[i], H = heights[i], ch = channels ? channels[i] : 1;
+         std::vector<int> grp;
+         for (int j = i; j < n; j++)
+            if (!taken[(size_t)j] && widths[j] == W && heights[j] == H && (channels ? channels[j] : 1) == ch) {
+               grp.push_back(j);
+               taken[(size_t)j] = 1;
+            }
+         // chunk sizes: max_batch, except that a long run starts and ends with smaller chunks (1/4, 1/2 of it): the first chunk's
+         // copy in and the last chunk's copy out are the pipeline's fill and drain - nothing overlaps them
+         const size_t mb = (size_t)(max_batch > 0 ? max_batch : 1), N = grp.size();
+         std::vector<size_t> sizes;
+         if (N >= 4 * mb && mb >= 8) {
+            sizes.push_back(mb / 4); sizes.push_back(mb / 2);
+            size_t left = N - mb / 4 - mb / 2 - (mb / 2 + mb / 4);
+            while (left > 0) { const size_t t = std::min(mb, left); sizes.push_back(t); left -= t; }
+            sizes.push_back(mb / 2); sizes.push_back(mb / 4);
+         } else {
+            for (size_t left = N; left > 0;) { const size_t t = std::min(mb, left); sizes.push_back(t); left -= t; }
+         }
+         size_t g0 = 0;
+         for (size_t sz : sizes) {
+            HostChunk k;
+            k.W = W; k.H = H; k.ch = ch;
+            for (size_t g = g0; g < g0 + sz; g++) {
+               const int j = grp[g];
+               k.index.push_back(j);
+               k.data.push_back(images[j]);
+               k.stride.push_back(strides ? (size_t)strides[j] : (size_t)W * ch);
+            }
+            chunks.push_back(std::move(k));
+            g0 += sz;
+         }
+      }
+   }
+   bool next(HostChunk &out) override
+   {
+      if (pos >= chunks.size() || sink_rc.load() != 0) return false;
+      out = chunks[pos++];
+      return true;
+   }
+   void done(const ChunkDone &d) override
+   {
+      const size_t B = d.chunk->index.size();
+      if (results) {
+         for (size_t b = 0; b < B; b++) {
+            hesaff_result &r = results[d.chunk->index[b]];
+            r.count_hessian = d.count_hessian[b]; r.count_desc = d.count_desc[b]; r.keys = d.keys + d.key_off[b];
+         }
+         return;
+      }
+      std::vector<hesaff_result> tmp(B);
+      for (size_t b = 0; b < B; b++) { tmp[b].count_hessian = d.count_hessian[b]; tmp[b].count_desc = d.count_desc[b]; tmp[b].keys = d.keys + d.key_off[b]; }
+      if (sink_rc.load() == 0) sink_rc.store(sink(user, (int)B, d.chunk->index.data(), tmp.data()));
+      ring->release(d.block);
+   }
 };
 
 // hesaff_process_files: decode -> chunks -> device -> write.  ONE pool of decode_threads + write_threads host threads serves both

@@ -6,6 +6,9 @@
 // while the engine says it is alive, and every record is read by a writer while its block is marked busy).
 //   engine_sanitize <max_batch> <decode_threads> <write_threads> <format> <file>...      (format + 4: the mock hands over rows that
 //                   are already text / packed - ChunkDone::text, text_off, bin - like the device formatter of kernels_export.h)
+//   engine_sanitize array <max_batch> <n_images>      ArrayIO (hesaff_detect_batch_cb's chunk source: a sink called per chunk with records
+//                   that live in a ring block, the sink's return code read by the staging thread) under the same mock loop; the sink
+//                   fails on the last third of a second run
 // prints "files=<n> written=<w> unreadable=<u> rows=<r>"; exit code 0 unless the pipeline misbehaved.
 #include <cstdio>
 #include <cstdlib>
@@ -25,8 +28,83 @@ struct State {
    int total = 0, block = -1;
 };
 
+struct SinkState { long long rows = 0; int calls = 0; int fail_after = -1; uint32_t acc = 0; };
+static int array_sink(void *user, int n_images, const int *image_index, const hesaff_result *results)
+{
+   SinkState *s = (SinkState *)user;
+   for (int i = 0; i < n_images; i++) {
+      for (int r = 0; r < results[i].count_desc; r++) s->acc = s->acc * 31u + results[i].keys[r].desc[(r + image_index[i]) & 127];   // read the block
+      s->rows += results[i].count_desc;
+   }
+   s->calls++;
+   return (s->fail_after >= 0 && s->calls > s->fail_after) ? 1 : 0;
+}
+
+// ArrayIO under the mock device loop: staging thread one chunk ahead (next), caller's thread computes, delivers the previous chunk (done ->
+// sink -> ring release) and takes a block
+static int run_array(int max_batch, int n, int fail_after, long long *rows_out)
+{
+   std::vector<std::vector<uint8_t>> pix((size_t)n);
+   std::vector<const uint8_t *> ptr((size_t)n);
+   std::vector<int> w((size_t)n), h((size_t)n), ch((size_t)n);
+   for (int i = 0; i < n; i++) {
+      w[(size_t)i] = (i % 3 == 1) ? 20 : 32; h[(size_t)i] = 16; ch[(size_t)i] = (i % 5 == 4) ? 3 : 1;
+      pix[(size_t)i].assign((size_t)w[(size_t)i] * h[(size_t)i] * ch[(size_t)i], (uint8_t)(i * 7));
+      ptr[(size_t)i] = pix[(size_t)i].data();
+   }
+   BlockRing ring;
+   ring.reset(3);
+   std::vector<std::vector<hesaff_keypoint>> blocks(3);
+   ArrayIO io(&ring, max_batch, n, ptr.data(), w.data(), h.data(), nullptr, ch.data());
+   SinkState st;
+   st.fail_after = fail_after;
+   io.sink = array_sink; io.user = &st;
+   struct AState { HostChunk q; std::vector<int32_t> nh, nd; std::vector<size_t> off; int total = 0, block = -1; };
+   auto stage = [&]() -> std::unique_ptr<AState> {
+      std::unique_ptr<AState> s(new AState());
+      if (!io.next(s->q)) return nullptr;
+      io.staged(s->q);
+      return s;
+   };
+   std::future<std::unique_ptr<AState>> staged = std::async(std::launch::async, stage);
+   std::unique_ptr<AState> prev;
+   auto deliver = [&](AState &s) {
+      ChunkDone d;
+      d.chunk = &s.q; d.count_hessian = s.nh.data(); d.count_desc = s.nd.data(); d.key_off = s.off.data();
+      d.keys = blocks[(size_t)s.block].data(); d.block = s.block;
+      io.done(d);
+   };
+   for (;;) {
+      std::unique_ptr<AState> cur = staged.get();
+      if (!cur) break;
+      staged = std::async(std::launch::async, stage);
+      for (size_t b = 0; b < cur->q.data.size(); b++) {
+         const int cnt = (cur->q.index[b] * 37) % 200;
+         cur->nh.push_back(cnt + 1); cur->nd.push_back(cnt); cur->off.push_back((size_t)cur->total);
+         cur->total += cnt;
+      }
+      if (prev) { deliver(*prev); prev.reset(); }
+      cur->block = ring.acquire();
+      blocks[(size_t)cur->block].assign((size_t)cur->total + 1, hesaff_keypoint());
+      for (auto &k : blocks[(size_t)cur->block]) for (int j = 0; j < 128; j++) k.desc[j] = (uint8_t)(j + cur->block);
+      prev = std::move(cur);
+   }
+   if (prev) { deliver(*prev); prev.reset(); }
+   *rows_out = st.rows;
+   return io.sink_rc.load();
+}
+
 int main(int argc, char **argv)
 {
+   if (argc == 4 && !strcmp(argv[1], "array")) {
+      const int max_batch = atoi(argv[2]), n = atoi(argv[3]);
+      long long rows = 0, want = 0, rows2 = 0;
+      for (int i = 0; i < n; i++) want += (i * 37) % 200;
+      const int rc = run_array(max_batch, n, -1, &rows);
+      const int rc2 = run_array(max_batch, n, 2, &rows2);     // the sink reports failure on its third call: the run stops early
+      printf("array images=%d rows=%lld want=%lld rc=%d failing_run_rc=%d rows=%lld\n", n, rows, want, rc, rc2, rows2);
+      return (rc == 0 && rows == want && rc2 != 0 && rows2 < want) ? 0 : 3;
+   }
    if (argc < 6) return 2;
    const int max_batch = atoi(argv[1]), dt = atoi(argv[2]), wt = atoi(argv[3]), fmt = atoi(argv[4]) & 3;
    const bool device_format = (atoi(argv[4]) & 4) != 0;

@@ -240,3 +240,8 @@ def test_file_pipeline_threads_under_sanitizers(san, tmp_path):
             if fmt & 2:
                 assert (os.path.getsize(n_ + ".hesaff.bin") - 16) % 148 == 0
         assert (fmt & 1) == 0 or got == rows
+    # ArrayIO (hesaff_detect_batch_cb): chunk source + sink hand-over, with a sink that fails mid-run (sink_rc is read by the
+    # staging thread while the caller's thread writes it)
+    for max_batch, n_img in ((1, 7), (4, 45), (8, 64)):
+        r = subprocess.run([exe, "array", str(max_batch), str(n_img)], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, (max_batch, n_img, r.stdout[-500:], r.stderr[-4000:])
