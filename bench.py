@@ -194,7 +194,12 @@ def file_path_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, fmt=1, de
         # inputs 1 byte per pixel, outputs about 5.3 bytes per pixel at the dense images' 14 k descriptors per Mpx
         per_image = W * H * 7
         free = shutil.disk_usage(tmp).free
-        n = int(max(0, min(n_files, (free * 0.6 / max(world, 1)) // per_image)))
+        try:   # a RAM disk's pages are host memory: never plan for more than a quarter of what is available, over all ranks
+            avail = [int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable:")][0]
+            free = min(free, avail)
+        except (OSError, IndexError, ValueError):
+            pass
+        n = int(max(0, min(n_files, (free * (0.6 if world == 1 else 0.25) / max(world, 1)) // per_image)))
         if n < 2 * chunk:
             if sync:
                 sync()
