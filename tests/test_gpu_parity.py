@@ -1211,6 +1211,8 @@ def test_process_files_resume_skips_complete_outputs(tmp_path, oracle):
     paths, texts = [], []
     for i in range(6):
         img = band_noise_image(120, 160, 700 + i, SMALL_BANDS)
+        if i == 4:
+            img = np.full((120, 160), 77, np.uint8)      # featureless: "128\n0\n" (a chunk whose text is empty)
         q = tmp_path / ("r%d.pgm" % i)
         q.write_bytes(b"P5\n160 120\n255\n" + img.tobytes())
         paths.append(str(q)); texts.append(_oracle.OracleRun(_oracle.gray_from_u8(img)).export_text())
@@ -1231,7 +1233,8 @@ def test_process_files_resume_skips_complete_outputs(tmp_path, oracle):
             if i in (0, 2, 5):
                 assert (rc, stage, nh) == (0, 5, -1) and nd == int(texts[i].split(b"\n")[1]), (i, rc, stage, nh, nd)   # HESAFF_FILE_SKIPPED
             else:
-                assert (rc, stage) == (0, 3) and nh > 0, (i, rc, stage)
+                assert (rc, stage) == (0, 3) and (nh > 0 or i == 4), (i, rc, stage)
+        assert texts[4] == b"128\n0\n"
         for q, t in zip(paths, texts):
             assert open(q + ".hesaff.sift", "rb").read() == t
             assert hesaff_amd.load_library().hesaff_output_is_complete(os.fsencode(q + ".hesaff.bin"), 2) == int(t.split(b"\n")[1])
