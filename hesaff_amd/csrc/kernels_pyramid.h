@@ -705,24 +705,34 @@ __global__ __launch_bounds__(256, (K == 15 ? HS_MARCH15_WAVES : 0)) void k_blur_
          // to a multiple of U; padded steps read clamped rows and store nothing.
          const int t = t0 + u;           // t & 1 == u & 1
          load_row(t + 2, pre[u & 1]);    // row t's registers are free (staged during step t-1)
-         // ---- row pass of input row t: acc = k[0]*S[x-R]; acc += k[j]*S[x-R+j], two columns per op ----
+         // ---- row pass of input row t: acc = k[0]*S[x-R]; acc += k[j]*S[x-R+j] (RowFilter order), this lane's four columns ----
          {
-            const float *rb = s_rows[wave][R0L3 ? (t % 3) : (u & 1)] + 4 * lane + W0;
-            v2f G[K + 2];                // G[i] = (S[x-R+i], S[x-R+i+1]), x = this lane's first column
+            // The K + 3 samples the four chains read come in as the aligned 16-byte quads that cover them (3 or 5 conflict-free
+            // ds_read_b128 at a lane stride of 16 bytes; rounds 1-3 read them as K + 2 overlapping pairs at a 2-way bank conflict each:
+            // 49 % conflict cycles, the LDS 72 % busy under the 15-tap launch), and the chains run as scalar operations on them.
+            // Measured neutral on the launch time (profiles/r04_notes.md: these launches are held by the power limit, the clock
+            // falls to 1.6-1.9 GHz under them), kept for the registers (K = 15: 124 instead of 133) and the idle LDS.
+            constexpr int QF = (W0 / 4) * 4;                            // first quad, in floats relative to 4 * lane
+            constexpr int NQ = (W0 + K + 2) / 4 - W0 / 4 + 1;
+            constexpr int O = W0 - QF;                                  // S[O + c + j] = tap j of column c
+            const float4 *qb = reinterpret_cast<const float4 *>(__builtin_assume_aligned(s_rows[wave][R0L3 ? (t % 3) : (u & 1)] + 4 * lane + QF, 16));
+            float S[4 * NQ];
 #pragma unroll
-            for (int i = 0; i < K + 2; i++) {
-               if (((W0 + i) & 1) == 0) G[i] = *reinterpret_cast<const v2f *>(__builtin_assume_aligned(rb + i, 8));
-               else { G[i].x = rb[i]; G[i].y = rb[i + 1]; }
+            for (int q = 0; q < NQ; q++) {
+               float4 v = qb[q];
+               // all four components count as used: the compiler otherwise narrows the first and last quad to the floats the chains
+               // read and splits every quad into ds_read2_b32 pairs again
+               HS_KEEP(v.x); HS_KEEP(v.y); HS_KEEP(v.z); HS_KEEP(v.w);
+               S[4 * q] = v.x; S[4 * q + 1] = v.y; S[4 * q + 2] = v.z; S[4 * q + 3] = v.w;
             }
-            v2f a = kk[0] * G[0], bq = kk[0] * G[2];
+            float a0 = kk[0] * S[O], a1 = kk[0] * S[O + 1], a2 = kk[0] * S[O + 2], a3 = kk[0] * S[O + 3];
 #pragma unroll
             for (int j = 1; j < K; j++) {
-               // products first, then the two independent accumulations: a packed multiply may not be
-               // consumed by the very next instruction (1 wait state), interleaving A and B hides it
-               const v2f pa = kk[j] * G[j], pb = kk[j] * G[j + 2];
-               a = a + pa;
-               bq = bq + pb;
+               const float p0 = kk[j] * S[O + j], p1 = kk[j] * S[O + 1 + j], p2 = kk[j] * S[O + 2 + j], p3 = kk[j] * S[O + 3 + j];
+               a0 += p0; a1 += p1; a2 += p2; a3 += p3;
             }
+            v2f a, bq;
+            a.x = a0; a.y = a1; bq.x = a2; bq.y = a3;
             ringA[u] = a;
             ringB[u] = bq;
          }

@@ -23,7 +23,7 @@ for r in csv.DictReader(open(f)):
     dur[n] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6; calls[n] += 1
 print('| %-40s | %5s | %8s | %9s | %6s | %7s | %7s | %7s | %6s | %5s |' % ('kernel', 'calls', 'ms', 'VALU inst', 'VALU %', 'parked%', 'stall%', 'active%', 'waves/SIMD', 'GHz'))
 print('|---|---|---|---|---|---|---|---|---|---|')
-for n in sorted(dur, key=lambda k: -dur[k])[:16]:
+for n in sorted(dur, key=lambda k: -dur[k])[:int(__import__("os").environ.get("PMC_ROWS", "16"))]:
     if not n.startswith('k_'): continue
     a = agg[n]; ms = dur[n]
     wc = max(a['SQ_WAVE_CYCLES'], 1.0)

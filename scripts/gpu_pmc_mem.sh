@@ -24,7 +24,7 @@ for r in csv.DictReader(open(f)):
     dur[n] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6; calls[n] += 1
 print('| %-40s | %5s | %8s | %8s | %10s | %12s | %12s |' % ('kernel', 'calls', 'ms', 'TA busy%', 'TA waves', 'L1 accesses', 'L1->L2 reads'))
 print('|---|---|---|---|---|---|---|')
-for n in sorted(dur, key=lambda k: -dur[k])[:16]:
+for n in sorted(dur, key=lambda k: -dur[k])[:int(__import__("os").environ.get("PMC_ROWS", "16"))]:
     if not n.startswith('k_'): continue
     a = agg[n]; ms = dur[n]
     cyc = a['GRBM_GUI_ACTIVE'] / 8.0 if a['GRBM_GUI_ACTIVE'] > 0 else 2.4e6 * ms
