@@ -4,8 +4,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/batch_ranks.py list.txt
 
 Rank r takes the contiguous block shard_range(n, r, world) of the list (the rule of hesaff_shard_range and of the
-multi-device CLI), detects it on device LOCAL_RANK (--one-device: every rank on device 0, for a box with one GPU) and
-writes <image>.hesaff.sift next to every image (hesaff.cpp:170-176).  No feature data crosses ranks; the only collective
+multi-device CLI), runs it through hesaff_process_files on device LOCAL_RANK (--one-device: every rank on device 0, for a box with
+one GPU), which writes <image>.hesaff.sift next to every image (hesaff.cpp:170-176).  No feature data crosses ranks; the only collective
 is the all-gather of [Hessian keypoints, descriptors, images] (RCCL; BENCH_DIST_BACKEND=gloo moves it to CPU tensors).
 Rank 0 prints one JSON line with the totals."""
 import argparse
@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("list")
     ap.add_argument("--one-device", action="store_true")
-    ap.add_argument("--chunk", type=int, default=32, help="images per hesaff_detect_batch call")
+    ap.add_argument("--chunk", type=int, default=32, help="images per device chunk (hesaff_params.max_batch)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     backend = None
@@ -35,20 +35,17 @@ def main():
         dist.init_process_group(backend=backend)
     names = [ln.strip() for ln in open(args.list) if ln.strip() and not ln.startswith("#")]
     lo, hi = shard_range(len(names), rank, world)
-    ctx = hesaff_amd.HesaffContext(device=0 if args.one_device else local)
-    mr = ctx.params.mrSize
-    nh = nd = 0
-    for i in range(lo, hi, args.chunk):
-        part = names[i:min(hi, i + args.chunk)]
-        # images of different sizes go through separate calls (a batch call takes equally sized images)
-        imgs = [hesaff_amd.read_image(p) for p in part]
-        groups = {}
-        for k, im in enumerate(imgs):
-            groups.setdefault(im.shape[:2], []).append(k)
-        for idx in groups.values():
-            res = ctx.detect_batch_raw([imgs[k] for k in idx])
-            ctx.write_sift_batch_raw([part[k] + ".hesaff.sift" for k in idx], res, mr, 0)
-            nh += sum(r.count_hessian for r in res); nd += sum(r.count_desc for r in res)
+    p = hesaff_amd.default_params()
+    p.max_batch = max(1, args.chunk)
+    ctx = hesaff_amd.HesaffContext(p, device=0 if args.one_device else local)
+    # the rank's shard through hesaff_process_files (what `hesaff --batch` runs per device): decode ahead, device, rows formatted
+    # on the device, write behind - with this rank's share of the host threads
+    threads = max(1, int(ctx.L.hesaff_host_threads()) // max(world, 1))
+    st = ctx.process_files(names[lo:hi], decode_threads=max(1, threads // 2), write_threads=max(1, threads - threads // 2))
+    bad = [names[lo + i] for i, s_ in enumerate(st) if s_[0] != 0]
+    if bad:
+        print("rank %d: %d file(s) failed, first: %s" % (rank, len(bad), bad[0]), file=sys.stderr)
+    nh = sum(s_[2] for s_ in st if s_[0] == 0); nd = sum(s_[3] for s_ in st if s_[0] == 0)
     device = None
     if world > 1 and backend == "nccl":
         import torch
