@@ -216,6 +216,7 @@ def file_path_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, fmt=1, de
         ext = ".hesaff.sift" if fmt == 1 else ".hesaff.bin"
         with hesaff_amd.HesaffContext(p, device=device) as ctx:
             ctx.set_output_format(fmt)
+            ctx.set_profiling(1)
             warm = ctx.process_files(paths[: 3 * chunk], decode_threads=decode_threads, write_threads=write_threads)   # buffers (all three pinned blocks), page cache, thread start-up
             for q in paths[: 3 * chunk]:
                 os.remove(q + ext)
@@ -225,6 +226,7 @@ def file_path_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, fmt=1, de
             st = ctx.process_files(paths, decode_threads=decode_threads, write_threads=write_threads)
             dt = time.perf_counter() - t0
             threads = int(ctx.L.hesaff_host_threads())
+            tmx = ctx.timings()
         bad = [i for i, s_ in enumerate(st) if s_[0] != 0 or s_[1] != 3] + [i for i, s_ in enumerate(warm) if s_[0] != 0]
         nbytes = sum(os.path.getsize(q + ext) for q in paths)
         rows = sum(s_[3] for s_ in st)
@@ -232,6 +234,7 @@ def file_path_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, fmt=1, de
                 "output": "text (.hesaff.sift, the reference's format)" if fmt == 1 else "binary sidecar (.hesaff.bin, 148 bytes per row)",
                 "failed_files": len(bad), "output_GB_per_s": nbytes / dt / 1e9, "input_GB": n * (W * H + len(hdr)) / 1e9, "output_GB": nbytes / 1e9,
                 "rows": rows, "output_bytes": nbytes,
+                "device_export_ms_last_chunk": tmx.export_ms, "device_export_rows_last_chunk": tmx.export_rows,
                 "decode_threads": decode_threads, "write_threads": write_threads, "host_threads_available": threads, "target": tmp.rsplit("/", 1)[0],
                 "what": "hesaff_process_files: %d binary PGM files (%dx%d, the bench images) on a RAM disk -> %d decode threads -> chunks of %d "
                         "images through the device (copy in, kernels, rows of the output files formatted on the device, copy out, all overlapped) "

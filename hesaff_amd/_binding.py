@@ -40,6 +40,7 @@ class Timings(C.Structure):
         ("sift_ms", C.c_float), ("pack_ms", C.c_float), ("total_ms", C.c_float), ("blur_hess_ms", C.c_float), ("blur_hess_launches", C.c_int32),
         ("blur_hess_bytes", C.c_double), ("pyramid_bytes", C.c_double),
         ("extrema_ms", C.c_float), ("extrema_launches", C.c_int32), ("extrema_bytes", C.c_double),
+        ("export_ms", C.c_float), ("export_rows", C.c_int32),
     ]
 
 

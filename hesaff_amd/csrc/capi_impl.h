@@ -194,6 +194,7 @@ void hesaff_destroy(hesaff_ctx *c)
       if (c->ev_in_free[i]) (void)hipEventDestroy(c->ev_in_free[i]);
       if (c->ev_out_ready[i]) (void)hipEventDestroy(c->ev_out_ready[i]);
       if (c->ev_d2h[i]) (void)hipEventDestroy(c->ev_d2h[i]);
+      for (int q = 0; q < 2; q++) if (c->ev_exp[i][q]) (void)hipEventDestroy(c->ev_exp[i][q]);
    }
    for (auto &pb : c->pin_out) pb.release();
    if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
@@ -263,6 +264,8 @@ void ensure_copy_streams(hesaff_ctx *c)
       HIP_TRY(hipEventCreateWithFlags(&c->ev_in_free[i], hipEventDisableTiming | hipEventBlockingSync));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_out_ready[i], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_d2h[i], hipEventDisableTiming | hipEventBlockingSync));
+      HIP_TRY(hipEventCreate(&c->ev_exp[i][0]));
+      HIP_TRY(hipEventCreate(&c->ev_exp[i][1]));
    }
 }
 
@@ -323,6 +326,11 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
    };
    auto deliver = [&](State &s) {
       if (s.total > 0) HIP_TRY(hipEventSynchronize(c->ev_d2h[s.no & 1]));
+      if (s.total > 0 && c->profiling && (wants & (WANT_TEXT | WANT_BIN))) {
+         float ms = 0.0f;   // (includes the host's short wait for the byte counts between the length pass and the write pass)
+         if (hipEventElapsedTime(&ms, c->ev_exp[s.no & 1][0], c->ev_exp[s.no & 1][1]) == hipSuccess) { c->export_ms = ms; c->export_rows = s.total; c->tm.export_ms = ms; c->tm.export_rows = s.total; }
+         else (void)hipGetLastError();
+      }
       ChunkDone d;
       const char *blk = (const char *)c->pin_out[(size_t)s.block].p;
       d.chunk = &s.q; d.count_hessian = s.nh.data(); d.count_desc = s.nd.data(); d.key_off = s.off.data();
@@ -372,6 +380,8 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
          auto place = [&at](size_t bytes) { const size_t o = at; at = (at + bytes + 255) & ~(size_t)255; return o; };
          const size_t keys_at = (wants & WANT_KEYS) ? place(n_rows * sizeof(hesaff_keypoint)) : 0;
          unsigned long long text_bytes = 0;
+         const bool time_export = c->profiling && (wants & (WANT_TEXT | WANT_BIN)) && n_rows > 0;
+         if (time_export) HIP_TRY(hipEventRecord(c->ev_exp[slot][0], c->stream));
          if (wants & WANT_TEXT) {   // row lengths and offsets first: the host needs the byte count (a short wait on the main stream)
             text_bytes = export_text_prepare(c, d_keys, (uint32_t)n_rows, c->b_starts.as<int32_t>() + (B + 1), B, cur->toff);
             cur->text_at = place((size_t)text_bytes);
@@ -397,6 +407,7 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
             if (wants & WANT_KEYS) HIP_TRY(hipMemcpyAsync(stg + keys_at, c->b_out.p, n_rows * sizeof(hesaff_keypoint), hipMemcpyDeviceToDevice, c->stream));
             if (wants & WANT_TEXT) export_text_write(c, d_keys, (uint32_t)n_rows, stg + cur->text_at);
             if (wants & WANT_BIN) export_bin_rows(c, d_keys, (uint32_t)n_rows, stg + cur->bin_at);
+            if (time_export) HIP_TRY(hipEventRecord(c->ev_exp[slot][1], c->stream));
             HIP_TRY(hipEventRecord(c->ev_out_ready[slot], c->stream));
             HIP_TRY(hipStreamWaitEvent(c->d2h_stream, c->ev_out_ready[slot], 0));
             HIP_TRY(hipMemcpyAsync(c->pin_out[(size_t)cur->block].p, stg, bytes, hipMemcpyDeviceToHost, c->d2h_stream));

@@ -220,6 +220,8 @@ struct hesaff_ctx {
    std::vector<Pinned> pin_out;       // result blocks: one per chunk of the current call (hesaff_detect_batch), or a ring of three
    hesaff_engine::BlockRing ring;     // (hesaff_detect_batch_cb, hesaff_process_files: a block returns to the ring when its consumer is done with it)
    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+   hipEvent_t ev_exp[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // profiling: brackets of a chunk's export kernels, per staging slot
+   float export_ms = 0.0f; int32_t export_rows = 0;
    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_in_free[2] = {nullptr, nullptr}, ev_out_ready[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
    std::vector<int32_t> h_starts;
    DevBuf t_mask_idx, t_sgrad_nb, t_sgrad_om, b_rowprefix, b_trows, b_trows2, b_trows3;
@@ -932,7 +934,8 @@ void collect_timings(hesaff_ctx *c, StageTimer &tm, int B)
    }
    double sumN = 0;
    for (const OctGeom &g : c->oct) sumN += (double)g.rows * g.cols;
-   t.pyramid_bytes = (double)B * (5.0 * c->H * c->W + 58.0 * sumN);   // (+ the up-sampling pass when upscaleInputImage is set: not counted)
+   t.pyramid_bytes = (double)B * (5.0 * c->H * c->W + 58.0 * sumN);
+   t.export_ms = c->export_ms; t.export_rows = c->export_rows;   // (run_chunks keeps them across the batches of a list)   // (+ the up-sampling pass when upscaleInputImage is set: not counted)
 }
 
 // The descriptor kernels (kernels_sift.h) over n patches in HBM.

@@ -107,6 +107,9 @@ typedef struct hesaff_timings {
    float extrema_ms;           /* sum of the k_extrema_march launches (3x3x3 extrema of the three scans of an octave) */
    int32_t extrema_launches;
    double extrema_bytes;       /* algorithmic bytes of those launches: 20 N per octave (five response planes read once), SURVEY.md 8d B_ext */
+   /* appended in ABI version 4 */
+   float export_ms;            /* hesaff_process_files: the export kernels (row lengths, offsets, text / sidecar rows) of the last chunk delivered */
+   int32_t export_rows;        /* ... and the rows they formatted */
 } hesaff_timings;
 
 int hesaff_default_params(hesaff_params *p);
