@@ -119,6 +119,7 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
          HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
       }
       HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+      // (the eight compute streams stay on the default priority: every other assignment measured 1.5-6 % slower, profiles/r04_notes.md)
       HIP_TRY(hipStreamCreateWithFlags(&c->sift_stream, hipStreamNonBlocking));
       HIP_TRY(hipStreamCreateWithFlags(&c->sift_stream2, hipStreamNonBlocking));
       HIP_TRY(hipStreamCreateWithFlags(&c->aff_stream, hipStreamNonBlocking));
@@ -257,8 +258,14 @@ using namespace hesaff_engine;
 void ensure_copy_streams(hesaff_ctx *c)
 {
    if (c->h2d_stream) return;
-   HIP_TRY(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
-   HIP_TRY(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+   // The copy streams get a priority of their own: the runtime multiplexes the streams of one priority onto a few hardware queues
+   // (four by default; this context has eight compute streams), and a copy command holds its queue until the copy engine is done -
+   // 23 ms for the 1.3 GB of text of a chunk, during which the patch kernels of whatever stream shared that queue did not start
+   // (measured: +19 ms on the patch stage of every chunk, profiles/r04_notes.md).  Streams of another priority live on other queues.
+   int prio_least = 0, prio_greatest = 0;
+   HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+   HIP_TRY(hipStreamCreateWithPriority(&c->h2d_stream, hipStreamNonBlocking, prio_greatest));
+   HIP_TRY(hipStreamCreateWithPriority(&c->d2h_stream, hipStreamNonBlocking, prio_greatest));
    for (int i = 0; i < 2; i++) {
       HIP_TRY(hipEventCreateWithFlags(&c->ev_h2d[i], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_in_free[i], hipEventDisableTiming | hipEventBlockingSync));
@@ -344,8 +351,10 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
    std::unique_ptr<State> prev;
    try {
       for (int k = 0;; k++) {
+         const auto dbg_t0 = std::chrono::steady_clock::now();
          std::unique_ptr<State> cur = staged.get();           // H2D of chunk k is enqueued
          if (!cur) break;
+         const auto dbg_t1 = std::chrono::steady_clock::now();
          cur->no = k;
          staged = std::async(std::launch::async, stage, k + 1);
          const HostChunk &q = cur->q;
@@ -365,6 +374,7 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
             continue;
          }
          HIP_TRY(hipEventRecord(c->ev_in_free[slot], c->stream));
+         const auto dbg_t2 = std::chrono::steady_clock::now();
          const int32_t *hs = c->h_starts.data(), *ds = c->h_starts.data() + (B + 1);
          cur->total = ds[B];
          cur->nh.resize((size_t)B); cur->nd.resize((size_t)B); cur->off.resize((size_t)B);
@@ -388,8 +398,10 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
          }
          if (wants & WANT_BIN) cur->bin_at = place(n_rows * EX_BIN_ROW);
          const size_t bytes = at;
+         const auto dbg_t3 = std::chrono::steady_clock::now();
          // chunk k-1: its copy out was enqueued before the kernels of chunk k and has long finished
          if (prev) { deliver(*prev); prev.reset(); }
+         const auto dbg_t4 = std::chrono::steady_clock::now();
          // a pinned block for chunk k
          if (ring > 0) {
             cur->block = c->ring.acquire();
@@ -412,6 +424,12 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
             HIP_TRY(hipStreamWaitEvent(c->d2h_stream, c->ev_out_ready[slot], 0));
             HIP_TRY(hipMemcpyAsync(c->pin_out[(size_t)cur->block].p, stg, bytes, hipMemcpyDeviceToHost, c->d2h_stream));
             HIP_TRY(hipEventRecord(c->ev_d2h[slot], c->d2h_stream));
+         }
+         if (c->debug) {
+            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            const auto dbg_t5 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[hesaff] chunk %d: wait staged %.1f  run_batch %.1f  export prepare %.1f  deliver prev %.1f  acquire+enqueue %.1f ms | device: pyramid %.1f detect %.1f affine %.1f patch %.1f sift %.1f pack %.1f total %.1f\n", k, ms(dbg_t0, dbg_t1),
+                    ms(dbg_t1, dbg_t2), ms(dbg_t2, dbg_t3), ms(dbg_t3, dbg_t4), ms(dbg_t4, dbg_t5), c->tm.pyramid_ms, c->tm.detect_ms, c->tm.affine_ms, c->tm.patch_ms, c->tm.sift_ms, c->tm.pack_ms, c->tm.total_ms);
          }
          prev = std::move(cur);
       }
