@@ -113,16 +113,21 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
          std::string m = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
          throw HsError(HESAFF_ERR_DEVICE, m);
       }
-      HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-      for (int i = 0; i < HS_NSIDE; i++) {
-         HIP_TRY(hipStreamCreateWithFlags(&c->side_streams[i], hipStreamNonBlocking));
-         HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+      {
+         // creation order decides which streams share a hardware queue (round robin over four queues): main, side 0-3, descriptor,
+         // descriptor 2, affine.  Tuning build: HESAFF_ORDER = a permutation of "01234567".
+         hipStream_t *slots[8] = {&c->stream, &c->side_streams[0], &c->side_streams[1], &c->side_streams[2], &c->side_streams[3], &c->sift_stream,
+                                  &c->sift_stream2, &c->aff_stream};
+         int order[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+#ifdef HESAFF_TUNING
+         if (const char *od = getenv("HESAFF_ORDER"))
+            if (strlen(od) == 8) for (int i = 0; i < 8; i++) order[i] = (od[i] - '0') & 7;
+#endif
+         for (int i = 0; i < 8; i++) HIP_TRY(hipStreamCreateWithFlags(slots[order[i]], hipStreamNonBlocking));
       }
+      for (int i = 0; i < HS_NSIDE; i++) HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
       // (the eight compute streams stay on the default priority: every other assignment measured 1.5-6 % slower, profiles/r04_notes.md)
-      HIP_TRY(hipStreamCreateWithFlags(&c->sift_stream, hipStreamNonBlocking));
-      HIP_TRY(hipStreamCreateWithFlags(&c->sift_stream2, hipStreamNonBlocking));
-      HIP_TRY(hipStreamCreateWithFlags(&c->aff_stream, hipStreamNonBlocking));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_detect_done, hipEventDisableTiming | hipEventBlockingSync));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_batch_done, hipEventDisableTiming | hipEventBlockingSync));
       for (int i = 0; i < HS_NSLOT; i++) {
