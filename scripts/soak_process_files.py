@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--chunk", type=int, default=64)
     ap.add_argument("--distinct", type=int, default=32)
+    ap.add_argument("--format", type=int, default=2, help="1 text, 2 binary sidecar, 3 both")
     a = ap.parse_args()
     import torch
     import hesaff_amd
@@ -46,7 +47,7 @@ def main():
         p.max_batch = a.chunk
         rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
         with hesaff_amd.HesaffContext(p, device=0) as ctx:
-            ctx.set_output_format(2)
+            ctx.set_output_format(a.format)
             ctx.process_files(paths[: 2 * a.chunk])
             rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
             t0 = time.perf_counter()
@@ -55,7 +56,7 @@ def main():
         rss2 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
         ok = sum(1 for s in st if s[0] == 0 and s[1] == 3)
         rows = sum(s[3] for s in st)
-        out_bytes = sum(os.path.getsize(q + ".hesaff.bin") for q in paths)
+        out_bytes = sum(os.path.getsize(q + e) for q in paths for e in ((".hesaff.sift",) if a.format == 1 else (".hesaff.bin",) if a.format == 2 else (".hesaff.sift", ".hesaff.bin")))
         print({"files": a.files, "size": "%dx%d" % (a.width, a.height), "chunk": a.chunk, "written": ok, "images_per_s": a.files / dt,
                "descriptors_per_s": rows / dt, "seconds": dt, "output_GB": out_bytes / 1e9,
                "peak_rss_GB_before": rss0 / 1e6, "peak_rss_GB_after_warmup_of_%d_files" % (2 * a.chunk): rss1 / 1e6,
