@@ -114,16 +114,36 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
          throw HsError(HESAFF_ERR_DEVICE, m);
       }
       {
-         // creation order decides which streams share a hardware queue (round robin over four queues): main, side 0-3, descriptor,
-         // descriptor 2, affine.  Tuning build: HESAFF_ORDER = a permutation of "01234567".
+         // The HIP runtime runs the streams of one priority on FOUR hardware queues, and kernels of streams that share a queue do not
+         // overlap.  Which of a context's eight logical streams (main, patch bins 0-3, descriptor, descriptor 2, affine) end up together
+         // moves the step by up to 8 %, and with eight HIP streams it depends on what else the process has created.  So the pairing is
+         // made explicit: four HIP streams, each serving the two logical streams that measured best together
+         // (profiles/r04_notes.md):   main + bin 3 | bin 0 + bin 1 | bin 2 + affine | descriptor + descriptor 2.
+         // Tuning build: HESAFF_MERGE=0 gives every logical stream a HIP stream of its own again, created in HESAFF_ORDER.
          hipStream_t *slots[8] = {&c->stream, &c->side_streams[0], &c->side_streams[1], &c->side_streams[2], &c->side_streams[3], &c->sift_stream,
                                   &c->sift_stream2, &c->aff_stream};
+         bool merge = true;
          int order[8] = {0, 1, 2, 3, 4, 5, 6, 7};
 #ifdef HESAFF_TUNING
+         if (const char *mg = getenv("HESAFF_MERGE")) merge = atoi(mg) != 0;
          if (const char *od = getenv("HESAFF_ORDER"))
             if (strlen(od) == 8) for (int i = 0; i < 8; i++) order[i] = (od[i] - '0') & 7;
 #endif
-         for (int i = 0; i < 8; i++) HIP_TRY(hipStreamCreateWithFlags(slots[order[i]], hipStreamNonBlocking));
+         if (merge) {
+            // logical stream -> group: 0 main, 1-4 patch bins 0-3, 5 descriptor, 6 descriptor 2, 7 affine
+            int group[8] = {0, 1, 1, 2, 0, 3, 3, 2};
+#ifdef HESAFF_TUNING
+            if (const char *gr = getenv("HESAFF_GROUPS"))   // e.g. "01120332": eight digits, the group of each logical stream
+               if (strlen(gr) == 8) for (int i = 0; i < 8; i++) group[i] = (gr[i] - '0') & 7;
+#endif
+            hipStream_t made[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            for (int i = 0; i < 8; i++) {
+               if (!made[group[i]]) HIP_TRY(hipStreamCreateWithFlags(&made[group[i]], hipStreamNonBlocking));
+               *slots[i] = made[group[i]];
+            }
+         } else {
+            for (int i = 0; i < 8; i++) HIP_TRY(hipStreamCreateWithFlags(slots[order[i]], hipStreamNonBlocking));
+         }
       }
       for (int i = 0; i < HS_NSIDE; i++) HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -178,14 +198,17 @@ void hesaff_destroy(hesaff_ctx *c)
                      &c->b_ex_len, &c->b_ex_sums, &c->b_ex_off, &c->b_ex_imgoff, &c->b_ex_starts};
    for (DevBuf *b : bufs) b->release();
    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-   for (int i = 0; i < HS_NSIDE; i++) {
-      if (c->side_streams[i]) { (void)hipStreamSynchronize(c->side_streams[i]); (void)hipStreamDestroy(c->side_streams[i]); }
-      if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+   {
+      // logical streams may be aliases of one HIP stream (hesaff_create): every HIP stream is destroyed once; c->stream goes last, below
+      hipStream_t all[7] = {c->side_streams[0], c->side_streams[1], c->side_streams[2], c->side_streams[3], c->sift_stream, c->sift_stream2, c->aff_stream};
+      for (int i = 0; i < 7; i++) {
+         bool seen = all[i] == nullptr || all[i] == c->stream;
+         for (int j = 0; j < i; j++) seen = seen || all[j] == all[i];
+         if (!seen) { (void)hipStreamSynchronize(all[i]); (void)hipStreamDestroy(all[i]); }
+      }
+      for (int i = 0; i < HS_NSIDE; i++) if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
    }
    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-   if (c->sift_stream) { (void)hipStreamSynchronize(c->sift_stream); (void)hipStreamDestroy(c->sift_stream); }
-   if (c->sift_stream2) { (void)hipStreamSynchronize(c->sift_stream2); (void)hipStreamDestroy(c->sift_stream2); }
-   if (c->aff_stream) { (void)hipStreamSynchronize(c->aff_stream); (void)hipStreamDestroy(c->aff_stream); }
    if (c->ev_detect_done) (void)hipEventDestroy(c->ev_detect_done);
    if (c->ev_batch_done) (void)hipEventDestroy(c->ev_batch_done);
    for (hipEvent_t e : c->ev_aff) (void)hipEventDestroy(e);

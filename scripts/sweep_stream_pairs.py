@@ -1,6 +1,6 @@
-"""Which compute streams should share a hardware queue?  The HIP runtime puts the i-th stream created (per priority) on hardware queue
-i mod 4; kernels of streams on one queue do not overlap.  This sweeps all 105 ways to pair the context's eight compute streams
-(0 main, 1-4 patch bins 0-3, 5 descriptor, 6 descriptor 2, 7 affine) through the tuning build's HESAFF_ORDER and times the step.
+"""Which logical streams of a context should share a HIP stream (= a hardware queue: the runtime has four per priority, and kernels on one
+queue do not overlap)?  This sweeps all 105 ways to pair the eight logical streams (0 main, 1-4 patch bins 0-3, 5 descriptor,
+6 descriptor 2, 7 affine) through the tuning build's HESAFF_GROUPS (eight digits: the group of each logical stream) and times the step.
 usage on the GPU box: HESAFF_AMD_LIB=hesaff_amd/libhesaff_amd_tuning.so python scripts/sweep_stream_pairs.py [batch] [steps]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,7 +26,7 @@ def pairings(items):
 
 
 def run(order):
-    os.environ["HESAFF_ORDER"] = order
+    os.environ["HESAFF_GROUPS"] = order
     p = hesaff_amd.default_params(); p.max_batch = B
     with hesaff_amd.HesaffContext(p, device=0) as ctx:
         ctx.detect_batch_device(imgs.data_ptr(), B, W, H)
@@ -39,14 +39,17 @@ def run(order):
 
 names = ["main", "bin0", "bin1", "bin2", "bin3", "desc", "desc2", "affine"]
 res = []
-base = run("01234567")
+base = run("01120332")
 for pr in pairings(list(range(8))):
-    order = "".join(str(a) for a, _ in pr) + "".join(str(b) for _, b in pr)
+    g = [0] * 8
+    for gi, (a, b) in enumerate(pr):
+        g[a] = gi; g[b] = gi
+    order = "".join(str(x) for x in g)
     ms = run(order)
     res.append((ms, order, pr))
     print("%.1f ms  %s  %s" % (ms, order, " | ".join("%s+%s" % (names[a], names[b]) for a, b in pr)), flush=True)
 res.sort()
-print("default order 01234567: %.1f ms (again: %.1f)" % (base, run("01234567")))
+print("grouping in use 01120332: %.1f ms (again: %.1f)" % (base, run("01120332")))
 print("best five:")
 for ms, order, pr in res[:5]:
     print("  %.1f ms  %s  %s" % (ms, order, " | ".join("%s+%s" % (names[a], names[b]) for a, b in pr)))
