@@ -136,9 +136,18 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
             if (const char *gr = getenv("HESAFF_GROUPS"))   // e.g. "01120332": eight digits, the group of each logical stream
                if (strlen(gr) == 8) for (int i = 0; i < 8; i++) group[i] = (gr[i] - '0') & 7;
 #endif
+            int ctx_prio = 0;   // tuning build, HESAFF_CTX_PRIO: 1 = this context's streams at the high priority (queues apart from a normal context's)
+#ifdef HESAFF_TUNING
+            if (const char *cp = getenv("HESAFF_CTX_PRIO")) ctx_prio = atoi(cp);
+#endif
+            int p_least = 0, p_greatest = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&p_least, &p_greatest));
             hipStream_t made[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             for (int i = 0; i < 8; i++) {
-               if (!made[group[i]]) HIP_TRY(hipStreamCreateWithFlags(&made[group[i]], hipStreamNonBlocking));
+               if (!made[group[i]]) {
+                  if (ctx_prio == 0) HIP_TRY(hipStreamCreateWithFlags(&made[group[i]], hipStreamNonBlocking));
+                  else HIP_TRY(hipStreamCreateWithPriority(&made[group[i]], hipStreamNonBlocking, ctx_prio == 1 ? p_greatest : p_least));
+               }
                *slots[i] = made[group[i]];
             }
          } else {

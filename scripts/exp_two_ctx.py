@@ -13,6 +13,8 @@ for nctx in (1, 2, 1, 2):
     ctxs = []
     for i in range(nctx):
         p = hesaff_amd.default_params(); p.max_batch = per
+        # tuning build: the second context's streams at another priority = hardware queues of their own (CTX_PRIOS="0,1")
+        os.environ["HESAFF_CTX_PRIO"] = os.environ.get("CTX_PRIOS", "0,0").split(",")[i]
         ctxs.append(hesaff_amd.HesaffContext(p, device=0))
     res = [0] * nctx
     def work(i, steps):
