@@ -952,8 +952,13 @@ void launch_sift(hesaff_ctx *c, hipStream_t ss, const SiftIO &so, uint32_t n, fl
 // per-group patch / descriptor buffers (two slots): sized once per batch for the largest group
 void ensure_group_buffers(hesaff_ctx *c, uint32_t n)
 {
+   // The patch buffers rotate over HS_NSLOT slots (the patch stage fills one while the descriptor stage reads the others).  The
+   // descriptor stage's own intermediates - gradient pairs (12.8 KB per keypoint), histograms, mean / variance - live and die on its
+   // stream: when both descriptor streams are one HIP stream (the product), one copy of them serves every group.
+   const int dslots = (c->sift_stream == c->sift_stream2 && !c->no_overlap) ? 1 : HS_NSLOT;
    for (int slot = 0; slot < HS_NSLOT; slot++) {
       c->b_patches2[slot].ensure((size_t)n * HS_PATCH_PIX * 4);
+      if (slot >= dslots) continue;
       c->b_siftvec2[slot].ensure((size_t)n * 128 * 4);
       c->b_meanvar2[slot].ensure((size_t)n * 2 * 4);
       // the (mask*grad, o) pairs of pixels outside the circular mask stay (0, 0): zero-fill on (re)allocation
@@ -997,6 +1002,8 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       // image groups [h_lo, h_hi) of at most group_kpts keypoints: about 16 groups per batch keep the
       // three-stage pipeline full, between 300 k (launch overheads) and 1.2 M keypoints (buffer size);
       // the T' rows of a group's huge windows must fit the row buffer (a single image may exceed it: the buffer grows)
+      // (the group size itself hardly matters: 0.6 / 0.9 / 1.2 / 1.8 / 2.4 M keypoints per group at B = 256, shuffled: 810 / 823 / 816 /
+      //  818 / 816 ms; what matters is that the buffers of a group stay modest: 33 KB per keypoint of a group)
       const uint32_t group_kpts = c->sift_group_kpts ? c->sift_group_kpts : std::min<uint32_t>(std::max<uint32_t>((uint32_t)hs[B] / 16u, 300000u), 1200000u);
       struct Group { uint32_t lo, hi, large_rows; };
       std::vector<Group> groups;
@@ -1059,10 +1066,11 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
          hipStream_t ss = c->no_overlap ? st : ((c->sift2 && (gi & 1)) ? c->sift_stream2 : c->sift_stream);
          if (ss != st) HIP_TRY(hipStreamWaitEvent(ss, c->ev_extract_done[slot], 0));
          SiftIO so;
-         so.patches = c->b_patches2[slot].as<float>(); so.alive = s.pw.alive; so.meanvar = c->b_meanvar2[slot].as<float>();
-         so.vec = c->b_siftvec2[slot].as<float>(); so.desc = c->b_desc.as<uint8_t>(); so.h_lo = h_lo; so.h_hi = h_hi;
+         const int dslot = (c->sift_stream == c->sift_stream2 && !c->no_overlap) ? 0 : slot;   // ensure_group_buffers
+         so.patches = c->b_patches2[slot].as<float>(); so.alive = s.pw.alive; so.meanvar = c->b_meanvar2[dslot].as<float>();
+         so.vec = c->b_siftvec2[dslot].as<float>(); so.desc = c->b_desc.as<uint8_t>(); so.h_lo = h_lo; so.h_hi = h_hi;
          const int ts = tm.begin(T_SIFT, 0, ss);
-         launch_sift(c, ss, so, n, c->b_siftvo2[slot].as<float2>());
+         launch_sift(c, ss, so, n, c->b_siftvo2[dslot].as<float2>());
          tm.end(ts);
          HIP_TRY(hipEventRecord(c->ev_sift_done[slot], ss));
          slot_used[slot] = true;
