@@ -132,9 +132,10 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
          if (merge) {
             // logical stream -> group: 0 main, 1-4 patch bins 0-3, 5 descriptor, 6 descriptor 2, 7 affine
             int group[8] = {0, 1, 1, 2, 0, 3, 3, 2};
+            bool custom_groups = false;
 #ifdef HESAFF_TUNING
             if (const char *gr = getenv("HESAFF_GROUPS"))   // e.g. "01120332": eight digits, the group of each logical stream
-               if (strlen(gr) == 8) for (int i = 0; i < 8; i++) group[i] = (gr[i] - '0') & 7;
+               if (strlen(gr) == 8) { for (int i = 0; i < 8; i++) group[i] = (gr[i] - '0') & 7; custom_groups = true; }
 #endif
             int ctx_prio = 0;   // tuning build, HESAFF_CTX_PRIO: 1 = this context's streams at the high priority (queues apart from a normal context's)
 #ifdef HESAFF_TUNING
@@ -143,6 +144,13 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
             int p_least = 0, p_greatest = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&p_least, &p_greatest));
             hipStream_t made[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            // The HIP streams of a context outlive it: the next context on this device takes the same ones (take_stream_set).  A stream
+            // created later lands on whichever hardware queue has the fewest users at that moment, so the second and third context of
+            // a process used to get another - often worse - sharing of queues than the first (the chunks of bench.py's file leg, third
+            // context of its process: 110-135 ms each against 107-110 in a process of their own).
+            c->pooled_streams = ctx_prio == 0 && !custom_groups;
+            if (c->pooled_streams && take_stream_set(device, c->sset))
+               for (int g = 0; g < 4; g++) made[g] = c->sset.comp[g];
             for (int i = 0; i < 8; i++) {
                if (!made[group[i]]) {
                   if (ctx_prio == 0) HIP_TRY(hipStreamCreateWithFlags(&made[group[i]], hipStreamNonBlocking));
@@ -150,6 +158,8 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
                }
                *slots[i] = made[group[i]];
             }
+            if (c->pooled_streams)
+               for (int g = 0; g < 4; g++) c->sset.comp[g] = made[g];
          } else {
             for (int i = 0; i < 8; i++) HIP_TRY(hipStreamCreateWithFlags(slots[order[i]], hipStreamNonBlocking));
          }
@@ -213,7 +223,7 @@ void hesaff_destroy(hesaff_ctx *c)
       for (int i = 0; i < 7; i++) {
          bool seen = all[i] == nullptr || all[i] == c->stream;
          for (int j = 0; j < i; j++) seen = seen || all[j] == all[i];
-         if (!seen) { (void)hipStreamSynchronize(all[i]); (void)hipStreamDestroy(all[i]); }
+         if (!seen) { (void)hipStreamSynchronize(all[i]); if (!c->pooled_streams) (void)hipStreamDestroy(all[i]); }
       }
       for (int i = 0; i < HS_NSIDE; i++) if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
    }
@@ -235,9 +245,16 @@ void hesaff_destroy(hesaff_ctx *c)
       for (int q = 0; q < 2; q++) if (c->ev_exp[i][q]) (void)hipEventDestroy(c->ev_exp[i][q]);
    }
    for (auto &pb : c->pin_out) pb.release();
-   if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
-   if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
-   if (c->stream) (void)hipStreamDestroy(c->stream);
+   if (c->h2d_stream) (void)hipStreamSynchronize(c->h2d_stream);
+   if (c->d2h_stream) (void)hipStreamSynchronize(c->d2h_stream);
+   if (c->pooled_streams) {
+      c->sset.h2d = c->h2d_stream; c->sset.d2h = c->d2h_stream;
+      give_stream_set(c->device, c->sset);   // idle now; the next context of this device runs on them
+   } else {
+      if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
+      if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
+      if (c->stream) (void)hipStreamDestroy(c->stream);
+   }
    delete c;
 }
 
@@ -301,8 +318,12 @@ void ensure_copy_streams(hesaff_ctx *c)
    // (measured: +19 ms on the patch stage of every chunk, profiles/r04_notes.md).  Streams of another priority live on other queues.
    int prio_least = 0, prio_greatest = 0;
    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-   HIP_TRY(hipStreamCreateWithPriority(&c->h2d_stream, hipStreamNonBlocking, prio_greatest));
-   HIP_TRY(hipStreamCreateWithPriority(&c->d2h_stream, hipStreamNonBlocking, prio_greatest));
+   if (c->pooled_streams && c->sset.h2d && c->sset.d2h) {   // the copy streams of the context that had this set before
+      c->h2d_stream = c->sset.h2d; c->d2h_stream = c->sset.d2h;
+   } else {
+      HIP_TRY(hipStreamCreateWithPriority(&c->h2d_stream, hipStreamNonBlocking, prio_greatest));
+      HIP_TRY(hipStreamCreateWithPriority(&c->d2h_stream, hipStreamNonBlocking, prio_greatest));
+   }
    for (int i = 0; i < 2; i++) {
       HIP_TRY(hipEventCreateWithFlags(&c->ev_h2d[i], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_in_free[i], hipEventDisableTiming | hipEventBlockingSync));
@@ -323,11 +344,17 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
       std::vector<size_t> off;
       std::vector<unsigned long long> toff;   // WANT_TEXT: byte offset of every image's rows
       size_t text_at = 0, bin_at = 0;         // where the text / sidecar rows start inside the result block
-      int total = 0, block = -1, no = 0;
+      int total = 0, block = -1, no = 0, largest = 0;
    };
    const int wants = io.wants();
    c->ring.reset(ring);
    if (ring > 0 && (int)c->pin_out.size() < ring) c->pin_out.resize((size_t)ring);
+   std::vector<std::future<void>> presize((size_t)std::max(ring, 0));   // ring blocks being pinned on a helper thread
+   bool presized = false;
+   struct JoinPresize {   // no helper outlives this call
+      std::vector<std::future<void>> &f;
+      ~JoinPresize() { for (auto &x : f) if (x.valid()) x.wait(); }
+   } join_presize{presize};
 
    // stage(k): chunk k -> pinned buffer -> device input buffer (k & 1) on the H2D stream; runs while chunk k-1 computes
    auto stage = [&](int k) -> std::unique_ptr<State> {
@@ -338,8 +365,9 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
       const int slot = k & 1;
       const size_t row_bytes = (size_t)q.W * q.ch, img_bytes = row_bytes * q.H, total = img_bytes * q.data.size();
       HIP_TRY(hipEventSynchronize(c->ev_in_free[slot]));   // chunk k-2 no longer reads this input buffer (never recorded: returns at once)
-      c->pin_in[slot].ensure(total);
-      c->b_in2[slot].ensure(total);
+      s->largest = std::max<int>((int)q.data.size(), std::min(io.largest_chunk((int)q.data.size()), c->par.max_batch));
+      c->pin_in[slot].ensure(img_bytes * (size_t)s->largest);   // sized once, for the large chunks that follow a small first one
+      c->b_in2[slot].ensure(img_bytes * (size_t)s->largest);
       // pixels into the pinned buffer: a chunk of 64 UHD images is 0.5 GB - on four threads when it is worth it (the first chunk's
       // copy is the pipeline's fill: nothing runs on the device meanwhile)
       auto copy_images = [&](size_t b0, size_t b1) {
@@ -399,7 +427,7 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
          const size_t row_bytes = (size_t)q.W * q.ch, img_bytes = row_bytes * q.H;
          HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_h2d[slot], 0));
          try {
-            plan(c, std::min<int>(c->par.max_batch, B), q.H, q.W);
+            plan(c, std::max(std::min<int>(c->par.max_batch, B), cur->largest), q.H, q.W);
             run_batch(c, (const uint8_t *)c->b_in2[slot].p, q.ch, (long long)img_bytes, (int)row_bytes, B, q.H, q.W);
          } catch (const HsError &e) {
             // this chunk's images cannot be planned (geometry) or exceed the planned keypoint capacity: that is about these
@@ -447,8 +475,26 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
             cur->block = k;
          }
          // device copy / formatting into the staging slot (frees b_out for the next chunk), then D2H beside the next chunk
-         if (ring > 0) c->pin_out[(size_t)cur->block].ensure_grow(std::max<size_t>(bytes, 16));
-         else c->pin_out[(size_t)cur->block].ensure(std::max<size_t>(bytes, 16));
+         if (ring > 0) {
+            // Every block of the ring is sized for a FULL chunk of this density the first time one is needed (the list may start with
+            // small chunks), the other blocks on a helper thread beside the next chunk's kernels: pinning 1.5 GB takes 150 ms, and a
+            // block that is sized - or grown - when its chunk is already waiting leaves the device idle for that long.
+            const size_t full = (bytes * (size_t)std::max(c->par.max_batch, B) + (size_t)B - 1) / (size_t)B;
+            if (presize[(size_t)cur->block].valid()) presize[(size_t)cur->block].get();
+            hesaff_ctx::Pinned &pb = c->pin_out[(size_t)cur->block];
+            if (bytes > pb.bytes) pb.ensure_grow(std::max<size_t>(full, 16));
+            if (!presized) {
+               presized = true;
+               for (int r = 0; r < ring; r++)
+                  if (r != cur->block && c->pin_out[(size_t)r].bytes == 0)
+                     presize[(size_t)r] = std::async(std::launch::async, [c, r, full] {
+                        if (hipSetDevice(c->device) != hipSuccess) return;
+                        try { c->pin_out[(size_t)r].ensure_grow(std::max<size_t>(full, 16)); } catch (const HsError &) {}   // asked for again, and reported, when the block is needed
+                     });
+            }
+         } else {
+            c->pin_out[(size_t)cur->block].ensure(std::max<size_t>(bytes, 16));
+         }
          if (cur->total > 0) {
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_d2h[slot], 0));      // D2H of chunk k-2 has left this staging slot
             if (bytes > c->b_outstage[slot].bytes) c->b_outstage[slot].ensure(bytes + bytes / 4);

@@ -77,6 +77,9 @@ struct ChunkIO {
    virtual void staged(const HostChunk &) {}    // staging thread: the chunk's pixels are in pinned memory, its sources may go
    virtual void done(const ChunkDone &) = 0;    // caller's thread, in order
    virtual int wants() const { return WANT_KEYS; }
+   // images of the largest chunk that a chunk of `this_chunk` images with this geometry may be followed by (a list that starts with
+   // small chunks says so here: the device plan and the pinned input buffers are then made once, for the large chunks)
+   virtual int largest_chunk(int this_chunk) const { return this_chunk; }
    // caller's thread: the device refused this chunk (rc = HESAFF_ERR_ARG: image geometry, HESAFF_ERR_CAPACITY: more keypoints than
    // planned for).  true: noted per image, go on with the next chunk; false: the whole call fails with rc
    virtual bool failed(const HostChunk &, int /*rc*/) { return false; }
@@ -140,6 +143,14 @@ struct ArrayIO : ChunkIO {
       out = chunks[pos++];
       return true;
    }
+   int largest_chunk(int this_chunk) const override
+   {
+      if (pos == 0 || pos > chunks.size()) return this_chunk;
+      const HostChunk &q = chunks[pos - 1];   // the chunk next() handed out last (staging thread, like next())
+      size_t m = (size_t)this_chunk;
+      for (size_t i = pos; i < chunks.size() && chunks[i].W == q.W && chunks[i].H == q.H && chunks[i].ch == q.ch; i++) m = std::max(m, chunks[i].data.size());
+      return (int)m;
+   }
    void done(const ChunkDone &d) override
    {
       const size_t B = d.chunk->index.size();
@@ -175,7 +186,7 @@ struct FileIO : ChunkIO {
    std::vector<Img> imgs;
    std::mutex mu;
    std::condition_variable cv_work, cv_img, cv_done;   // workers: a job may be available; next(): an image changed state; wait_writers()
-   int next_decode = 0, consumed = 0, window = 0, pos = 0;
+   int next_decode = 0, consumed = 0, window = 0, pos = 0, chunks_out = 0;
    bool stop = false;
    struct Task { int index; const hesaff_keypoint *keys; int n; int chunk; const char *text; size_t text_len; const char *bin; };
    std::deque<Task> tasks;
@@ -257,10 +268,25 @@ struct FileIO : ChunkIO {
       }
       cv_img.notify_all();
    }
-   // the next run of consecutive readable images of one geometry
+   // the next run of consecutive readable images of one geometry.  Like ArrayIO's chunks, a long list starts and ends with smaller
+   // chunks (1/4, 1/2 of max_batch): the device waits for the first chunk's images to be read and copied in, and the writers for the
+   // last chunk's rows - nothing overlaps either
+   int chunk_limit() const   // under mu
+   {
+      const int mb = max_batch, left = n - pos, tail = mb / 2 + mb / 4;
+      if (n < 4 * mb || mb < 8) return mb;
+      if (chunks_out == 0) return mb / 4;
+      if (chunks_out == 1) return mb / 2;
+      if (left <= mb / 4) return left;
+      if (left <= tail) return left - mb / 4;
+      if (left < tail + mb) return left - tail;
+      return mb;
+   }
+   int largest_chunk(int this_chunk) const override { return (n >= 4 * max_batch && max_batch >= 8) ? std::max(this_chunk, max_batch) : this_chunk; }
    bool next(HostChunk &out) override
    {
       std::unique_lock<std::mutex> lk(mu);
+      const int limit = chunk_limit();
       for (;;) {
          if (stop || pos >= n) break;
          cv_img.wait(lk, [&] { return stop || imgs[(size_t)pos].state != 0; });
@@ -274,8 +300,9 @@ struct FileIO : ChunkIO {
          out.index.push_back(pos);
          im.state = 3;
          pos++;
-         if ((int)out.data.size() >= max_batch) break;
+         if ((int)out.data.size() >= limit) break;
       }
+      if (!out.data.empty()) chunks_out++;
       return !out.data.empty();
    }
    void staged(const HostChunk &q) override

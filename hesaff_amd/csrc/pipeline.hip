@@ -24,6 +24,7 @@
 #include <condition_variable>
 #include <deque>
 #include <future>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -114,6 +115,14 @@ struct DevBuf {
       p = q;
       bytes = need;
    }
+   // for buffers whose size follows the data (keypoints of a group, rows of a chunk): a new maximum is allocated with head-room, so
+   // that hipFree + hipMalloc - tens of ms for the group buffers, with the device idle - become rare instead of "every denser chunk"
+   void ensure_grow(size_t need)
+   {
+      if (need <= bytes) return;
+      try { ensure(need + need / 8); }
+      catch (const HsError &) { ensure(need); }
+   }
    void release()
    {
       if (p) (void)hipFree(p);
@@ -157,9 +166,32 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 #ifndef HS_NSLOT
 #define HS_NSLOT 3   // patch / descriptor buffer slots of the group pipeline
 #endif
+// The HIP streams a context runs on (four compute streams, two copy streams).  They are created once per device and handed from a
+// destroyed context to the next one (capi_impl.h): which hardware queues a NEW stream shares depends on everything the process has
+// created before, so only reuse keeps the queue pairing of the first context.  Contexts alive at the same time get sets of their own.
+struct StreamSet { hipStream_t comp[4] = {nullptr, nullptr, nullptr, nullptr}; hipStream_t h2d = nullptr, d2h = nullptr; };
+static std::mutex g_sets_mu;
+static std::map<int, std::vector<StreamSet>> g_idle_sets;   // per device: the sets no context is using
+static bool take_stream_set(int device, StreamSet &out)
+{
+   std::lock_guard<std::mutex> lk(g_sets_mu);
+   std::vector<StreamSet> &v = g_idle_sets[device];
+   if (v.empty()) return false;
+   out = v.back();
+   v.pop_back();
+   return true;
+}
+static void give_stream_set(int device, const StreamSet &s)
+{
+   std::lock_guard<std::mutex> lk(g_sets_mu);
+   g_idle_sets[device].push_back(s);
+}
+
 struct hesaff_ctx {
    hesaff_params par;
    int device = 0;
+   StreamSet sset;
+   bool pooled_streams = false;
    hipStream_t stream = nullptr;
    std::string err;
    hesaff::OctaveSchedule sched;
@@ -957,14 +989,14 @@ void ensure_group_buffers(hesaff_ctx *c, uint32_t n)
    // stream: when both descriptor streams are one HIP stream (the product), one copy of them serves every group.
    const int dslots = (c->sift_stream == c->sift_stream2 && !c->no_overlap) ? 1 : HS_NSLOT;
    for (int slot = 0; slot < HS_NSLOT; slot++) {
-      c->b_patches2[slot].ensure((size_t)n * HS_PATCH_PIX * 4);
+      c->b_patches2[slot].ensure_grow((size_t)n * HS_PATCH_PIX * 4);
       if (slot >= dslots) continue;
-      c->b_siftvec2[slot].ensure((size_t)n * 128 * 4);
-      c->b_meanvar2[slot].ensure((size_t)n * 2 * 4);
+      c->b_siftvec2[slot].ensure_grow((size_t)n * 128 * 4);
+      c->b_meanvar2[slot].ensure_grow((size_t)n * 2 * 4);
       // the (mask*grad, o) pairs of pixels outside the circular mask stay (0, 0): zero-fill on (re)allocation
       const void *before = c->b_siftvo2[slot].p;
       const size_t bytes_before = c->b_siftvo2[slot].bytes;
-      c->b_siftvo2[slot].ensure((size_t)n * HS_VO_PITCH * 8 + 64);
+      c->b_siftvo2[slot].ensure_grow((size_t)n * HS_VO_PITCH * 8 + 64);
       if (c->b_siftvo2[slot].p != before || c->b_siftvo2[slot].bytes != bytes_before)
          HIP_TRY(hipMemsetAsync(c->b_siftvo2[slot].p, 0, c->b_siftvo2[slot].bytes, c->stream));
    }
@@ -1114,9 +1146,9 @@ unsigned long long export_text_prepare(hesaff_ctx *c, const KeyRec *keys, uint32
    if (n == 0) return 0ull;
    hipStream_t st = c->stream;
    const uint32_t nblk = (n + EX_ROWS - 1) / EX_ROWS;
-   c->b_ex_len.ensure(((size_t)n + 64) * 2);
-   c->b_ex_sums.ensure((size_t)nblk * 4);
-   c->b_ex_off.ensure(((size_t)nblk + 1) * 8);
+   c->b_ex_len.ensure_grow(((size_t)n + 64) * 2);
+   c->b_ex_sums.ensure_grow((size_t)nblk * 4);
+   c->b_ex_off.ensure_grow(((size_t)nblk + 1) * 8);
    c->b_ex_imgoff.ensure(((size_t)B + 1) * 8);
    hipLaunchKernelGGL(k_text_len, dim3((n + 255) / 256), dim3(256), 0, st, keys, n, c->par.mrSize, c->b_ex_len.as<uint16_t>(), c->b_ex_sums.as<uint32_t>());
    hipLaunchKernelGGL(k_text_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)c->b_ex_sums.p, nblk, c->b_ex_off.as<unsigned long long>());

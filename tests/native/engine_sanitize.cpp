@@ -9,12 +9,13 @@
 //   engine_sanitize array <max_batch> <n_images>      ArrayIO (hesaff_detect_batch_cb's chunk source: a sink called per chunk with records
 //                   that live in a ring block, the sink's return code read by the staging thread) under the same mock loop; the sink
 //                   fails on the last third of a second run
-// prints "files=<n> written=<w> unreadable=<u> rows=<r>"; exit code 0 unless the pipeline misbehaved.
+// prints "chunks=<images per chunk, ...>" and "files=<n> written=<w> unreadable=<u> rows=<r>"; exit code 0 unless the pipeline misbehaved.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <future>
 #include <memory>
+#include <string>
 #include "../../hesaff_amd/csrc/chunk_engine.h"
 
 using namespace hesaff_engine;
@@ -118,6 +119,7 @@ int main(int argc, char **argv)
    std::vector<std::vector<hesaff_keypoint>> blocks(3);
    std::vector<std::vector<char>> text_blocks(3), bin_blocks(3);
    long long rows = 0;
+   std::string chunk_sizes;
    {
       FileIO io(&ring, max_batch, 5.196152f, fmt, n, paths.data(), nullptr, status.data(), dt, wt, device_format);
       auto stage = [&]() -> std::unique_ptr<State> {
@@ -151,6 +153,7 @@ int main(int argc, char **argv)
          if (!cur) break;
          staged = std::async(std::launch::async, stage);
          const size_t B = cur->q.data.size();
+         chunk_sizes += (chunk_sizes.empty() ? "" : ",") + std::to_string(B);
          for (size_t b = 0; b < B; b++) {
             const int cnt = (int)(cur->sum[b] % 700u);     // rows of this image, 0 included
             cur->nh.push_back(cnt + 3); cur->nd.push_back(cnt); cur->off.push_back((size_t)cur->total);
@@ -206,6 +209,7 @@ int main(int argc, char **argv)
       else if (status[(size_t)i].stage == HESAFF_FILE_UNREADABLE) unreadable++;
       else other++;
    }
+   printf("chunks=%s\n", chunk_sizes.c_str());
    printf("files=%d written=%d unreadable=%d other=%d rows=%lld\n", n, written, unreadable, other, rows);
    return other == 0 ? 0 : 3;
 }

@@ -221,7 +221,7 @@ def test_file_pipeline_threads_under_sanitizers(san, tmp_path):
     names.insert(7, str(bad)); names.append(str(bad))
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1")
     # fmt + 4: the mock device hands the writers finished rows (ChunkDone::text / bin) like the GPU formatter does
-    for max_batch, dt, wt, fmt in ((1, 1, 1, 1), (4, 3, 3, 3), (64, 8, 2, 2), (3, 2, 8, 1), (4, 2, 3, 7), (2, 1, 2, 5)):
+    for max_batch, dt, wt, fmt in ((1, 1, 1, 1), (4, 3, 3, 3), (64, 8, 2, 2), (3, 2, 8, 1), (4, 2, 3, 7), (2, 1, 2, 5), (8, 2, 2, 6)):
         for n_ in names:
             for ext in (".hesaff.sift", ".hesaff.bin"):
                 if os.path.exists(n_ + ext):
@@ -240,6 +240,15 @@ def test_file_pipeline_threads_under_sanitizers(san, tmp_path):
             if fmt & 2:
                 assert (os.path.getsize(n_ + ".hesaff.bin") - 16) % 148 == 0
         assert (fmt & 1) == 0 or got == rows
+    # a long list of one geometry starts and ends with smaller chunks (pipeline fill and drain), FileIO::chunk_limit
+    same = []
+    for i in range(64):
+        q = tmp_path / ("s%02d.pgm" % i)
+        q.write_bytes(b"P5\n16 12\n255\n" + rng.integers(0, 256, (12, 16), dtype=np.uint8).tobytes())
+        same.append(str(q))
+    r = subprocess.run([exe, "8", "2", "2", "2"] + same, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-4000:])
+    assert "chunks=2,4,8,8,8,8,8,8,4,4,2\n" in r.stdout and "files=64 written=64" in r.stdout, r.stdout
     # ArrayIO (hesaff_detect_batch_cb): chunk source + sink hand-over, with a sink that fails mid-run (sink_rc is read by the
     # staging thread while the caller's thread writes it)
     for max_batch, n_img in ((1, 7), (4, 45), (8, 64)):
