@@ -19,6 +19,8 @@ from ._binding import (  # noqa: F401
     BIN_ROW_DTYPE,
     read_image,
     read_pnm,
+    read_jpeg_coefficients,
+    JpegLayout,
     ellipse,
     lib_path,
     load_library,

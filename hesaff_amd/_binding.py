@@ -55,7 +55,13 @@ _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
-ABI_VERSION = 4   # HESAFF_ABI_VERSION of the include/hesaff_amd.h these ctypes structs mirror
+ABI_VERSION = 5   # HESAFF_ABI_VERSION of the include/hesaff_amd.h these ctypes structs mirror
+
+
+class JpegLayout(C.Structure):
+    """hesaff_jpeg_layout: what the JPEG images of one device chunk share."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32)] + \
+               [(n, C.c_int32 * 3) for n in ("h", "v", "hx", "vx", "bw", "bh", "cw", "chgt")]
 
 
 class FileStatus(C.Structure):
@@ -144,6 +150,8 @@ def load_library():
     L.hesaff_stage_math_sift.argtypes = [vp, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
     L.hesaff_stage_export.argtypes = [vp, vp, C.c_int, C.c_float, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.hesaff_stage_fmt_g.argtypes = [vp, C.c_int, _f32p, vp, _i32p]
+    L.hesaff_read_jpeg_coefficients.argtypes = [C.c_char_p, C.POINTER(JpegLayout), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.hesaff_stage_jpeg_pixels.argtypes = [vp, C.POINTER(JpegLayout), C.c_int, vp, C.c_size_t, vp]
     L.hesaff_write_sift_rows.argtypes = [C.c_char_p, vp, C.c_size_t, C.c_int]
     L.hesaff_write_bin_rows.argtypes = [C.c_char_p, vp, C.c_int]
     L.hesaff_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -168,7 +176,7 @@ ABI_SYMBOLS = [
     "hesaff_host_threads", "hesaff_abi_version", "hesaff_sizeof_params", "hesaff_sizeof_timings", "hesaff_detect_batch_cb",
     "hesaff_process_files", "hesaff_write_sift_mt", "hesaff_write_bin", "hesaff_set_output_format",
     "hesaff_write_sift_rows", "hesaff_write_bin_rows", "hesaff_stage_export", "hesaff_stage_fmt_g", "hesaff_set_resume",
-    "hesaff_output_is_complete",
+    "hesaff_output_is_complete", "hesaff_read_jpeg_coefficients", "hesaff_stage_jpeg_pixels",
 ]
 
 
@@ -295,6 +303,20 @@ def read_bin(path):
 def read_image(path):
     """PGM/PPM or PNG by magic number -> uint8 array HxW (grey) or HxWx3."""
     return read_pnm(path, _fn="hesaff_read_image")
+
+
+def read_jpeg_coefficients(path):
+    """The host half of the JPEG reader (entropy decoding only) -> (JpegLayout, blob as a uint8 array)."""
+    L = load_library()
+    lay = JpegLayout(); blob = C.c_void_p(); nb = C.c_size_t()
+    rc = L.hesaff_read_jpeg_coefficients(os.fsencode(path), C.byref(lay), C.byref(blob), C.byref(nb))
+    if rc != 0:
+        raise HesaffError(rc, "hesaff_read_jpeg_coefficients(%s)" % path)
+    try:
+        arr = np.frombuffer(C.string_at(blob.value, nb.value), dtype=np.uint8).copy()
+    finally:
+        L.hesaff_free(blob)
+    return lay, arr
 
 
 def read_pnm(path, _fn="hesaff_read_pnm"):
@@ -530,6 +552,17 @@ class HesaffContext:
         text = np.zeros((len(v), 16), np.uint8); lens = np.zeros(len(v), np.int32)
         self._check(self.L.hesaff_stage_fmt_g(self.h, len(v), v, text.ctypes.data, lens))
         return text, lens
+
+    def jpeg_pixels(self, layout, blobs):
+        """The device half of the JPEG reader: blobs [n, blob_bytes] uint8 of one layout -> pixels [n, H, W(, 3)] uint8."""
+        blobs = np.ascontiguousarray(blobs, np.uint8)
+        if blobs.ndim == 1:
+            blobs = blobs[None]
+        n = blobs.shape[0]
+        shape = (n, layout.height, layout.width) + ((3,) if layout.channels == 3 else ())
+        out = np.zeros(shape, np.uint8)
+        self._check(self.L.hesaff_stage_jpeg_pixels(self.h, C.byref(layout), n, blobs.ctypes.data, blobs.shape[1], out.ctypes.data))
+        return out
 
     def math(self, a, b):
         a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)

@@ -214,7 +214,7 @@ void hesaff_destroy(hesaff_ctx *c)
                      &c->b_blocksums, &c->b_generic, &c->b_counters, &c->b_cand, &c->b_rec_f, &c->b_rec_i, &c->b_rec_w, &c->b_hess_f, &c->b_hess_i,
                      &c->b_aff, &c->b_pw, &c->b_bins, &c->b_rank, &c->b_desc, &c->b_out, &c->b_starts, &c->b_patches,
                      &c->b_stage, &c->b_input, &c->t_mask_idx, &c->t_sgrad_nb, &c->t_sgrad_om, &c->b_rowprefix, &c->b_trows, &c->b_trows2, &c->b_trows3,
-                     &c->b_ex_len, &c->b_ex_sums, &c->b_ex_off, &c->b_ex_imgoff, &c->b_ex_starts};
+                     &c->b_ex_len, &c->b_ex_sums, &c->b_ex_off, &c->b_ex_imgoff, &c->b_ex_starts, &c->b_jcoef[0], &c->b_jcoef[1], &c->b_jplane};
    for (DevBuf *b : bufs) b->release();
    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
    {
@@ -363,17 +363,21 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
       if (!io.next(s->q)) return nullptr;
       const HostChunk &q = s->q;
       const int slot = k & 1;
-      const size_t row_bytes = (size_t)q.W * q.ch, img_bytes = row_bytes * q.H, total = img_bytes * q.data.size();
+      const size_t row_bytes = (size_t)q.W * q.ch, img_bytes = row_bytes * q.H;
+      // what travels per image: its pixels, or - a JPEG file - its coefficient blob (the pixels are then made in b_in2 by the device)
+      const size_t unit = q.blob_bytes ? q.blob_bytes : img_bytes, total = unit * q.data.size();
       HIP_TRY(hipEventSynchronize(c->ev_in_free[slot]));   // chunk k-2 no longer reads this input buffer (never recorded: returns at once)
       s->largest = std::max<int>((int)q.data.size(), std::min(io.largest_chunk((int)q.data.size()), c->par.max_batch));
-      c->pin_in[slot].ensure(img_bytes * (size_t)s->largest);   // sized once, for the large chunks that follow a small first one
+      c->pin_in[slot].ensure(unit * (size_t)s->largest);   // sized once, for the large chunks that follow a small first one
       c->b_in2[slot].ensure(img_bytes * (size_t)s->largest);
+      if (q.blob_bytes) c->b_jcoef[slot].ensure(unit * (size_t)s->largest);
       // pixels into the pinned buffer: a chunk of 64 UHD images is 0.5 GB - on four threads when it is worth it (the first chunk's
       // copy is the pipeline's fill: nothing runs on the device meanwhile)
       auto copy_images = [&](size_t b0, size_t b1) {
          for (size_t b = b0; b < b1; b++) {
+            uint8_t *dst = (uint8_t *)c->pin_in[slot].p + unit * b;
+            if (q.blob_bytes) { memcpy(dst, q.data[b], unit); continue; }
             const size_t stride = q.stride[b];
-            uint8_t *dst = (uint8_t *)c->pin_in[slot].p + img_bytes * b;
             if (stride == row_bytes) memcpy(dst, q.data[b], img_bytes);
             else for (int y = 0; y < q.H; y++) memcpy(dst + row_bytes * y, q.data[b] + stride * y, row_bytes);
          }
@@ -391,7 +395,7 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
          if (t < nthr) copy_images(nimg * t / nthr, nimg);
          for (auto &x : th) x.join();
       }
-      HIP_TRY(hipMemcpyAsync(c->b_in2[slot].p, c->pin_in[slot].p, total, hipMemcpyHostToDevice, c->h2d_stream));
+      HIP_TRY(hipMemcpyAsync(q.blob_bytes ? c->b_jcoef[slot].p : c->b_in2[slot].p, c->pin_in[slot].p, total, hipMemcpyHostToDevice, c->h2d_stream));
       HIP_TRY(hipEventRecord(c->ev_h2d[slot], c->h2d_stream));
       io.staged(q);
       return s;
@@ -428,6 +432,8 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
          HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_h2d[slot], 0));
          try {
             plan(c, std::max(std::min<int>(c->par.max_batch, B), cur->largest), q.H, q.W);
+            // a chunk of JPEG files: inverse DCT, up-sampling and colour conversion of all its images (kernels_jpeg.h) into the input slot
+            if (q.blob_bytes) jpeg_pixels(c, c->b_jcoef[slot].as<uint8_t>(), make_jpeg_geom(q.jpeg), B, (uint8_t *)c->b_in2[slot].p, img_bytes, c->stream);
             run_batch(c, (const uint8_t *)c->b_in2[slot].p, q.ch, (long long)img_bytes, (int)row_bytes, B, q.H, q.W);
          } catch (const HsError &e) {
             // this chunk's images cannot be planned (geometry) or exceed the planned keypoint capacity: that is about these
@@ -592,7 +598,7 @@ int hesaff_process_files(hesaff_ctx *c, int n, const char *const *paths, const c
    const int dt = std::max(1, std::min(decode_threads > 0 ? decode_threads : std::max(2, host / 4), 64));
    const int wt = std::max(1, std::min(write_threads > 0 ? write_threads : host, 256));
    // the rows are formatted on the device (kernels_export.h): the writer threads only write()
-   FileIO io(&c->ring, c->par.max_batch, c->par.mrSize, c->out_format, n, paths, out_paths, status, dt, wt, true, c->resume);
+   FileIO io(&c->ring, c->par.max_batch, c->par.mrSize, c->out_format, n, paths, out_paths, status, dt, wt, true, c->resume, true);
    c->stage_threads = std::max(1, std::min(4, dt));
    try {
       run_chunks(c, io, 3);
@@ -939,6 +945,25 @@ int hesaff_stage_fmt_g(hesaff_ctx *c, int n, const float *v, char *text, int32_t
    hipLaunchKernelGGL(k_fmt_g_test, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, (const float *)d_v, d_text, d_len);
    HIP_TRY(hipMemcpyAsync(text, d_text, N * 16, hipMemcpyDeviceToHost, c->stream));
    HIP_TRY(hipMemcpyAsync(lens, d_len, N * 4, hipMemcpyDeviceToHost, c->stream));
+   HIP_TRY(hipStreamSynchronize(c->stream));
+   HIP_TRY(hipGetLastError());
+   HS_API_END(c)
+}
+
+int hesaff_stage_jpeg_pixels(hesaff_ctx *c, const hesaff_jpeg_layout *layout, int n, const uint8_t *blobs, size_t blob_bytes, uint8_t *pixels)
+{
+   if (!c || !layout || n < 0 || (n > 0 && (!blobs || !pixels))) return HESAFF_ERR_ARG;
+   HS_API_BEGIN
+   bind_device(c);
+   if (n == 0) return HESAFF_OK;
+   const JpegGeom g = make_jpeg_geom(*layout);
+   if ((size_t)g.blob_bytes != blob_bytes) throw HsError(HESAFF_ERR_ARG, "blob size does not match the layout");
+   const size_t img = (size_t)g.W * g.H * g.nc;
+   c->b_jcoef[0].ensure(blob_bytes * (size_t)n);
+   c->b_stage.ensure(img * (size_t)n);
+   HIP_TRY(hipMemcpyAsync(c->b_jcoef[0].p, blobs, blob_bytes * (size_t)n, hipMemcpyHostToDevice, c->stream));
+   jpeg_pixels(c, c->b_jcoef[0].as<uint8_t>(), g, n, c->b_stage.as<uint8_t>(), img, c->stream);
+   HIP_TRY(hipMemcpyAsync(pixels, c->b_stage.p, img * (size_t)n, hipMemcpyDeviceToHost, c->stream));
    HIP_TRY(hipStreamSynchronize(c->stream));
    HIP_TRY(hipGetLastError());
    HS_API_END(c)

@@ -54,7 +54,12 @@ struct HostChunk {                // at most max_batch images of one geometry
    std::vector<const uint8_t *> data;
    std::vector<size_t> stride;    // bytes between rows
    std::vector<int> index;        // the caller's image numbers
+   // JPEG files travel as entropy-decoded coefficients (hesaff_read_jpeg_coefficients): data[b] is then image b's blob of blob_bytes
+   // bytes, all images of the chunk have the layout `jpeg`, and the device makes the W x H x ch pixels (kernels_jpeg.h)
+   size_t blob_bytes = 0;         // 0: data[b] are pixels
+   hesaff_jpeg_layout jpeg = {};
 };
+inline bool same_jpeg_layout(const hesaff_jpeg_layout &a, const hesaff_jpeg_layout &b) { return memcmp(&a, &b, sizeof a) == 0; }
 
 // what a consumer wants copied to the host for every chunk
 enum { WANT_KEYS = 1,    // the hesaff_keypoint records (hesaff.cpp:41-48)
@@ -182,7 +187,11 @@ struct FileIO : ChunkIO {
    int fmt;
    bool device_format;   // rows arrive formatted (ChunkDone::text / bin): the writers only write()
    bool resume;          // hesaff_set_resume: an image whose complete output exists is not read
-   struct Img { uint8_t *data = nullptr; int w = 0, h = 0, ch = 0; int state = 0; };   // 0 pending, 1 decoded, 2 unreadable, 3 handed on
+   bool device_jpeg;     // JPEG files: entropy decoding only on the pool's threads, the pixels are made on the device
+   struct Img {          // state: 0 pending, 1 decoded, 2 unreadable, 3 handed on
+      uint8_t *data = nullptr; int w = 0, h = 0, ch = 0; int state = 0;
+      size_t blob_bytes = 0; hesaff_jpeg_layout jpeg = {};   // blob_bytes != 0: data is a coefficient blob
+   };
    std::vector<Img> imgs;
    std::mutex mu;
    std::condition_variable cv_work, cv_img, cv_done;   // workers: a job may be available; next(): an image changed state; wait_writers()
@@ -196,9 +205,9 @@ struct FileIO : ChunkIO {
    std::vector<std::thread> workers;
 
    FileIO(BlockRing *ring_, int max_batch_, float mrSize_, int fmt_, int n_, const char *const *p, const char *const *o, hesaff_file_status *st,
-          int dec_threads, int wr_threads, bool device_format_ = false, bool resume_ = false)
+          int dec_threads, int wr_threads, bool device_format_ = false, bool resume_ = false, bool device_jpeg_ = false)
       : ring(ring_), max_batch(max_batch_), n(n_), paths(p), out_paths(o), status(st), mrSize(mrSize_), fmt(fmt_), device_format(device_format_),
-        resume(resume_), imgs((size_t)n_)
+        resume(resume_), device_jpeg(device_jpeg_), imgs((size_t)n_)
    {
       window = 2 * max_batch + dec_threads;
       try {
@@ -237,6 +246,15 @@ struct FileIO : ChunkIO {
       if (!bin) return o ? std::string(o) : std::string(paths[i]) + ".hesaff.sift";   // hesaff.cpp:170-173
       return o ? (std::string(o) + ((fmt & HESAFF_OUT_TEXT) ? ".bin" : "")) : std::string(paths[i]) + ".hesaff.bin";
    }
+   static bool is_jpeg_file(const char *path)   // SOI marker, like hesaff_read_image's choice of reader
+   {
+      FILE *f = fopen(path, "rb");
+      if (!f) return false;
+      unsigned char m[2] = {0, 0};
+      const bool ok = fread(m, 1, 2, f) == 2 && m[0] == 0xFF && m[1] == 0xD8;
+      fclose(f);
+      return ok;
+   }
    void decode_one(int i)
    {
       if (resume && paths[i]) {
@@ -255,7 +273,13 @@ struct FileIO : ChunkIO {
          }
       }
       Img im;
-      int rc = paths[i] ? hesaff_read_image(paths[i], &im.data, &im.w, &im.h, &im.ch) : HESAFF_ERR_ARG;
+      int rc = HESAFF_ERR_ARG;
+      if (paths[i] && device_jpeg && is_jpeg_file(paths[i])) {
+         rc = hesaff_read_jpeg_coefficients(paths[i], &im.jpeg, &im.data, &im.blob_bytes);
+         if (rc == HESAFF_OK) { im.w = im.jpeg.width; im.h = im.jpeg.height; im.ch = im.jpeg.channels; }
+      } else if (paths[i]) {
+         rc = hesaff_read_image(paths[i], &im.data, &im.w, &im.h, &im.ch);
+      }
       int stage = HESAFF_FILE_UNREADABLE;
       if (rc == HESAFF_OK && (im.w > 65535 || im.h > 65535)) {   // the device plans 16-bit pixel coordinates (plan(), pipeline.hip)
          hesaff_free(im.data); im.data = nullptr;
@@ -293,8 +317,9 @@ struct FileIO : ChunkIO {
          if (stop) break;
          Img &im = imgs[(size_t)pos];
          if (im.state == 2) { pos++; consumed = pos; cv_work.notify_all(); continue; }
-         if (out.data.empty()) { out.W = im.w; out.H = im.h; out.ch = im.ch; }
-         else if (im.w != out.W || im.h != out.H || im.ch != out.ch) break;
+         if (out.data.empty()) { out.W = im.w; out.H = im.h; out.ch = im.ch; out.blob_bytes = im.blob_bytes; out.jpeg = im.jpeg; }
+         else if (im.w != out.W || im.h != out.H || im.ch != out.ch || im.blob_bytes != out.blob_bytes ||
+                  (im.blob_bytes && !same_jpeg_layout(im.jpeg, out.jpeg))) break;
          out.data.push_back(im.data);
          out.stride.push_back((size_t)im.w * im.ch);
          out.index.push_back(pos);

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -202,8 +203,14 @@ struct Comp {
    int bw = 0, bh = 0;            // blocks allocated (multiple of the sampling factors: full MCUs)
    int pred = 0;
    std::vector<uint8_t> plane;    // bw*8 x bh*8 samples
-   std::vector<int16_t> coef;     // progressive: bw x bh blocks of 64 coefficients (natural order), filled scan by scan
+   std::vector<int16_t> coef;     // progressive (and every file when only the coefficients are wanted): bw x bh blocks of 64
+                                  // coefficients in natural order, filled scan by scan
+   int16_t *cf = nullptr;         // = coef.data(), or the component's place in the blob that is handed to the device
+   uint16_t q[64];                // coefficients-only mode: the quantisation table the pixel stage has to use for this component
 };
+
+// what decode_jpeg hands over instead of pixels (hesaff_read_jpeg_coefficients): the device transforms the blocks (kernels_jpeg.h)
+struct CoefOut { hesaff_jpeg_layout *layout; uint8_t **blob; size_t *blob_bytes; };
 
 inline uint16_t be16(const uint8_t *p) { return (uint16_t)((p[0] << 8) | p[1]); }
 
@@ -294,8 +301,12 @@ void upsample_replicate(const uint8_t *in, int w, int h, int stride, int hx, int
    }
 }
 
-int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *height, int *channels)
+int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *height, int *channels, const CoefOut *co = nullptr)
 {
+   const bool keep = co != nullptr;   // entropy decoding only: no inverse DCT, no planes, no pixels
+   struct FreeDel { void operator()(uint8_t *p) const { free(p); } };
+   std::unique_ptr<uint8_t, FreeDel> blob;
+   size_t blob_bytes = 0;
    const size_t n = f.size();
    if (n < 4 || f[0] != 0xFF || f[1] != 0xD8) return HESAFF_ERR_IO;
    uint16_t qt[4][64];
@@ -373,8 +384,18 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
                // the AC scans only), so a file of n bytes holds at most 8 n blocks per component.  The bound below is eight
                // times more generous and still keeps a 100-byte file from asking for gigabytes of coefficients and planes.
                if ((unsigned long long)c.bw * c.bh > (unsigned long long)n * 64ull + 4096ull) return HESAFF_ERR_IO;
-               c.plane.assign((size_t)c.bw * 8 * c.bh * 8, 0);
-               if (progressive) c.coef.assign((size_t)c.bw * c.bh * 64, 0);
+               if (!keep) c.plane.assign((size_t)c.bw * 8 * c.bh * 8, 0);
+               if (progressive && !keep) { c.coef.assign((size_t)c.bw * c.bh * 64, 0); c.cf = c.coef.data(); }
+               memset(c.q, 0, sizeof c.q);
+            }
+            if (keep) {   // the blocks are decoded in place: calloc'ed pages, no second copy
+               size_t blocks = 0;
+               for (Comp &c : comps) blocks += (size_t)c.bw * c.bh;
+               blob_bytes = HESAFF_JPEG_BLOB_HEADER + blocks * 128;
+               blob.reset((uint8_t *)calloc(1, blob_bytes));
+               if (!blob) return HESAFF_ERR_NOMEM;
+               size_t at = HESAFF_JPEG_BLOB_HEADER;
+               for (Comp &c : comps) { c.cf = reinterpret_cast<int16_t *>(blob.get() + at); at += (size_t)c.bw * c.bh * 128; }
             }
             have_sof = true;
             break;
@@ -398,6 +419,7 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
                if (c->td > 3 || c->ta > 3 || !qt_def[c->tq]) return HESAFF_ERR_IO;
                if (!progressive && (!hdc[c->td].defined || !hac[c->ta].defined)) return HESAFF_ERR_IO;
                c->pred = 0;
+               memcpy(c->q, qt[c->tq], sizeof c->q);   // sequential: the table in force when the component's scan starts
                sc.push_back(c);
             }
             BitReader br;
@@ -432,7 +454,7 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
                         for (int bx = 0; bx < nbh; bx++) {
                            const int bxx = mc * nbh + bx, byy = mr * nbv + by;
                            int16_t dummy[64];
-                           int16_t *blk = (bxx < c->bw && byy < c->bh) ? &c->coef[((size_t)byy * c->bw + bxx) * 64] : dummy;
+                           int16_t *blk = (bxx < c->bw && byy < c->bh) ? c->cf + ((size_t)byy * c->bw + bxx) * 64 : dummy;
                            if (blk == dummy) memset(dummy, 0, sizeof dummy);
                            if (Ss == 0) {
                               if (Ah == 0) {   // DC, first pass: the difference coding of the sequential mode, value scaled by 2^Al
@@ -505,7 +527,7 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
             const bool inter = ns > 1;
             if (inter) { mx = (W + 8 * hmax - 1) / (8 * hmax); my = (H + 8 * vmax - 1) / (8 * vmax); }
             else { mx = (sc[0]->w + 7) / 8; my = (sc[0]->hgt + 7) / 8; }
-            int16_t blk[64];
+            int16_t blk_local[64];
             int to_go = restart;
             for (int mcu = 0; mcu < mx * my; mcu++) {
                if (restart && to_go == 0) {
@@ -522,7 +544,11 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
                   const int nbh = inter ? c->h : 1, nbv = inter ? c->v : 1;
                   for (int by = 0; by < nbv; by++)
                      for (int bx = 0; bx < nbh; bx++) {
-                        memset(blk, 0, sizeof blk);
+                        const int bxx = mc * nbh + bx, byy = mr * nbv + by;
+                        const bool inside = bxx < c->bw && byy < c->bh;
+                        int16_t *blk = (keep && inside) ? c->cf + ((size_t)byy * c->bw + bxx) * 64 : blk_local;
+                        // (a block visited twice - a damaged file with two scans of one component - starts from zeros again)
+                        memset(blk, 0, 128);
                         const int t = decode_huff(br, hdc[c->td]);
                         const int diff = t ? extend(br.get(t), t) : 0;
                         c->pred = (int)((unsigned)c->pred + (unsigned)diff);   // a damaged stream may run the predictor past 32 bits: wrap
@@ -539,9 +565,7 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
                            blk[kZigZag[k]] = (int16_t)extend(br.get(s), s);
                            k++;
                         }
-                        const int bxx = mc * nbh + bx, byy = mr * nbv + by;
-                        if (bxx < c->bw && byy < c->bh)
-                           idct_islow(blk, qt[c->tq], &c->plane[((size_t)byy * 8) * ((size_t)c->bw * 8) + (size_t)bxx * 8], c->bw * 8);
+                        if (inside && !keep) idct_islow(blk, qt[c->tq], &c->plane[((size_t)byy * 8) * ((size_t)c->bw * 8) + (size_t)bxx * 8], c->bw * 8);
                      }
                }
                if (restart) to_go--;
@@ -557,12 +581,38 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
       pos += (size_t)len;
    }
    if (!have_sof) return HESAFF_ERR_IO;
+   if (keep) {
+      const int nc = (int)comps.size();
+      hesaff_jpeg_layout L;
+      memset(&L, 0, sizeof L);
+      L.width = W; L.height = H; L.channels = nc == 1 ? 1 : 3;
+      size_t blocks = 0;
+      for (int i = 0; i < nc; i++) {
+         Comp &c = comps[i];
+         if (hmax % c.h || vmax % c.v) return HESAFF_ERR_IO;   // fractional sampling ratios: not supported by libjpeg either
+         if (progressive) {   // like the pixel path below: the tables as they stand after the last scan
+            if (!qt_def[c.tq]) return HESAFF_ERR_IO;
+            memcpy(c.q, qt[c.tq], sizeof c.q);
+         }
+         L.h[i] = c.h; L.v[i] = c.v; L.bw[i] = c.bw; L.bh[i] = c.bh; L.cw[i] = c.w; L.chgt[i] = c.hgt;
+         L.hx[i] = hmax / c.h; L.vx[i] = vmax / c.v;
+         if (nc == 3 && (c.w * L.hx[i] < W || c.hgt * L.vx[i] < H)) return HESAFF_ERR_IO;
+         blocks += (size_t)c.bw * c.bh;
+      }
+      if (!blob || blob_bytes != HESAFF_JPEG_BLOB_HEADER + blocks * 128) return HESAFF_ERR_IO;
+      uint8_t *b = blob.get();
+      for (int i = 0; i < nc; i++) memcpy(b + (size_t)i * 128, comps[i].q, 128);
+      const int32_t ycc = nc == 3 && (adobe ? adobe_transform != 0 : true) ? 1 : 0;   // JFIF / no marker: YCbCr; Adobe transform 0: RGB
+      memcpy(b + 384, &ycc, 4);
+      *co->layout = L; *co->blob = blob.release(); *co->blob_bytes = blob_bytes;
+      return HESAFF_OK;
+   }
    if (progressive)   // all scans are in: one IDCT per block (a complete file gets no inter-block smoothing in libjpeg either)
       for (Comp &c : comps) {
          if (!qt_def[c.tq]) return HESAFF_ERR_IO;
          for (int byy = 0; byy < c.bh; byy++)
             for (int bxx = 0; bxx < c.bw; bxx++)
-               idct_islow(&c.coef[((size_t)byy * c.bw + bxx) * 64], qt[c.tq], &c.plane[((size_t)byy * 8) * ((size_t)c.bw * 8) + (size_t)bxx * 8], c.bw * 8);
+               idct_islow(c.cf + ((size_t)byy * c.bw + bxx) * 64, qt[c.tq], &c.plane[((size_t)byy * 8) * ((size_t)c.bw * 8) + (size_t)bxx * 8], c.bw * 8);
       }
    const int nc = (int)comps.size();
    uint8_t *out = (uint8_t *)malloc((size_t)W * H * (nc == 1 ? 1 : 3));
@@ -626,6 +676,37 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
 }
 
 } // namespace
+
+static int read_all(const char *path, std::vector<uint8_t> &bytes)
+{
+   FILE *fp = fopen(path, "rb");
+   if (!fp) return HESAFF_ERR_IO;
+   try {
+      uint8_t chunk[1 << 16];
+      for (size_t k; (k = fread(chunk, 1, sizeof chunk, fp)) > 0;) bytes.insert(bytes.end(), chunk, chunk + k);
+   } catch (...) {
+      fclose(fp);
+      throw;
+   }
+   fclose(fp);
+   return HESAFF_OK;
+}
+
+extern "C" int hesaff_read_jpeg_coefficients(const char *path, hesaff_jpeg_layout *layout, uint8_t **blob, size_t *blob_bytes)
+{
+   if (!path || !layout || !blob || !blob_bytes) return HESAFF_ERR_ARG;
+   try {
+      std::vector<uint8_t> bytes;
+      const int rc = read_all(path, bytes);
+      if (rc != HESAFF_OK) return rc;
+      const CoefOut co = {layout, blob, blob_bytes};
+      return decode_jpeg(bytes, nullptr, nullptr, nullptr, nullptr, &co);
+   } catch (const std::bad_alloc &) {
+      return HESAFF_ERR_NOMEM;
+   } catch (...) {
+      return HESAFF_ERR_IO;
+   }
+}
 
 extern "C" int hesaff_read_jpeg(const char *path, uint8_t **data, int *width, int *height, int *channels)
 {

@@ -36,6 +36,7 @@
 #include "kernels_sift.h"
 #include "kernels_pyramid.h"
 #include "kernels_export.h"
+#include "kernels_jpeg.h"
 #include "chunk_engine.h"
 
 namespace hesaff {
@@ -258,6 +259,7 @@ struct hesaff_ctx {
    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_in_free[2] = {nullptr, nullptr}, ev_out_ready[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
    std::vector<int32_t> h_starts;
    DevBuf t_mask_idx, t_sgrad_nb, t_sgrad_om, b_rowprefix, b_trows, b_trows2, b_trows3;
+   DevBuf b_jcoef[2], b_jplane;   // JPEG chunks: the images' coefficient blobs per input slot, the component planes after the inverse DCT (kernels_jpeg.h)
    DevBuf b_ex_len, b_ex_sums, b_ex_off, b_ex_imgoff, b_ex_starts;   // device export (kernels_export.h): row lengths, sums / offsets per 64 rows, offsets per image
    size_t rows_lds_set = 0;            // dynamic LDS opt-in of k_patch_large_rows on THIS device
    // persistent grids of the LDS-window kernels: exactly as many blocks as the device holds at once (CUs x resident
@@ -1166,6 +1168,47 @@ void export_text_write(hesaff_ctx *c, const KeyRec *keys, uint32_t n, char *d_te
    if (n == 0) return;
    hipLaunchKernelGGL(k_text_write, dim3((n + EX_ROWS - 1) / EX_ROWS), dim3(EX_ROWS), 0, c->stream, keys, n, c->par.mrSize, (const uint16_t *)c->b_ex_len.p,
                       (const unsigned long long *)c->b_ex_off.p, d_text);
+}
+
+// hesaff_jpeg_layout (what the host's entropy stage reports; from a caller, so checked) -> the kernels' geometry
+JpegGeom make_jpeg_geom(const hesaff_jpeg_layout &L)
+{
+   JpegGeom g;
+   memset(&g, 0, sizeof g);
+   if (L.width < 1 || L.height < 1 || L.width > 65535 || L.height > 65535 || (L.channels != 1 && L.channels != 3))
+      throw HsError(HESAFF_ERR_ARG, "bad JPEG layout");
+   g.W = L.width; g.H = L.height; g.nc = L.channels;
+   unsigned long long coef = HESAFF_JPEG_BLOB_HEADER, plane = 0, blocks = 0;
+   for (int i = 0; i < g.nc; i++) {
+      const long long bw = L.bw[i], bh = L.bh[i], cw = L.cw[i], chgt = L.chgt[i], hx = L.hx[i], vx = L.vx[i];
+      if (bw < 1 || bh < 1 || bw > 8192 || bh > 8192 || cw < 1 || chgt < 1 || cw > bw * 8 || chgt > bh * 8 || hx < 1 || hx > 4 || vx < 1 || vx > 4 ||
+          cw * hx < L.width || chgt * vx < L.height || (g.nc == 1 && (hx != 1 || vx != 1)))
+         throw HsError(HESAFF_ERR_ARG, "bad JPEG layout");
+      g.bw[i] = (int)bw; g.bh[i] = (int)bh; g.cw[i] = (int)cw; g.chgt[i] = (int)chgt; g.hx[i] = (int)hx; g.vx[i] = (int)vx;
+      // jdsample.c's choice of method (jpeg_decode.cpp)
+      g.mode[i] = (hx == 1 && vx == 1) ? JPEG_UP_NONE : (hx == 2 && vx == 1 && cw > 2) ? JPEG_UP_H2V1 : (hx == 2 && vx == 2 && cw > 2) ? JPEG_UP_H2V2
+                  : (hx == 1 && vx == 2) ? JPEG_UP_H1V2 : JPEG_UP_REPLICATE;
+      g.blocks[i] = (unsigned int)(bw * bh);
+      g.coef_off[i] = coef; g.plane_off[i] = plane;
+      coef += (unsigned long long)(bw * bh) * 128;
+      plane += (unsigned long long)(bw * bh) * 64;
+      blocks += (unsigned long long)(bw * bh);
+   }
+   if (blocks > 0x7fffffffull) throw HsError(HESAFF_ERR_ARG, "bad JPEG layout");
+   g.blob_bytes = coef; g.plane_bytes = plane; g.blocks_per_image = (unsigned int)blocks;
+   return g;
+}
+
+// coefficient blobs of B images of one layout (device) -> their pixels, W x H x channels bytes each, out_img_stride apart
+void jpeg_pixels(hesaff_ctx *c, const uint8_t *d_blobs, const JpegGeom &g, int B, uint8_t *d_out, size_t out_img_stride, hipStream_t st)
+{
+   if (B < 1) return;
+   c->b_jplane.ensure_grow((size_t)g.plane_bytes * (size_t)B);
+   const unsigned long long total = (unsigned long long)B * g.blocks_per_image;
+   hipLaunchKernelGGL(k_jpeg_idct, dim3((unsigned)std::min<unsigned long long>((total + 255) / 256, 1u << 20)), dim3(256), 0, st, d_blobs,
+                      c->b_jplane.as<uint8_t>(), g, B);
+   hipLaunchKernelGGL(k_jpeg_pixels, dim3(((g.W + 3) / 4 + 255) / 256, g.H, B), dim3(256), 0, st, d_blobs, (const uint8_t *)c->b_jplane.as<uint8_t>(), d_out, g,
+                      (unsigned long long)out_img_stride);
 }
 
 void export_bin_rows(hesaff_ctx *c, const KeyRec *keys, uint32_t n, char *d_bin)

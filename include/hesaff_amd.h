@@ -31,8 +31,9 @@ extern "C" {
  * compare hesaff_abi_version() (and, if they wish, the two sizeof functions) with the header they were compiled against
  * before the first hesaff_create - hesaff.hpp and the Python binding do.  New fields are appended at the END of a
  * struct and bump this number.   1: round 1;  2: + upscaleInputImage, fast, pack_ms (inserted mid-struct);  3: + extrema_*;
- * 4: this header (hesaff_params.fast = 1 withdrawn, HESAFF_FILE_REJECTED, rows formatted on the device). */
-#define HESAFF_ABI_VERSION 4
+ * 4: hesaff_params.fast = 1 withdrawn, HESAFF_FILE_REJECTED, rows formatted on the device;
+ * 5: this header (+ hesaff_jpeg_layout, hesaff_read_jpeg_coefficients, hesaff_stage_jpeg_pixels: JPEG pixels made on the device). */
+#define HESAFF_ABI_VERSION 5
 int hesaff_abi_version(void);
 size_t hesaff_sizeof_params(void);
 size_t hesaff_sizeof_timings(void);
@@ -244,6 +245,23 @@ int hesaff_read_jpeg(const char *path, uint8_t **data, int *width, int *height, 
 /* PGM/PPM, PNG or JPEG by magic number */
 int hesaff_read_image(const char *path, uint8_t **data, int *width, int *height, int *channels);
 
+/* The host half of cv::imread (hesaff.cpp:137) for a JPEG file when the pixels are made on the device (hesaff_process_files does this
+ * for every JPEG of its list): markers and entropy decoding only - Huffman, sequential or progressive - which is the part of a JPEG
+ * decoder that has to run in order.  The inverse DCT, the chroma up-sampling and the colour conversion of hesaff_read_jpeg (the same
+ * integer algorithms, so the same bytes) run in kernels_jpeg.h over all blocks / pixels of a chunk of images at once.
+ * layout: what images must share to travel in one chunk.  blob (malloc'ed, hesaff_free): HESAFF_JPEG_BLOB_HEADER bytes - the
+ * components' quantisation tables, uint16[3][64] in natural order, at byte 0; int32 "YCbCr, convert to RGB" flag at byte 384 - then
+ * the coefficients, int16, natural order, 64 per block, blocks row by row (bw x bh per component), component after component. */
+#define HESAFF_JPEG_BLOB_HEADER 1024
+typedef struct hesaff_jpeg_layout {
+   int32_t width, height, channels;   /* channels: 1 (grey file) or 3 (R,G,B after conversion) */
+   int32_t h[3], v[3];                /* sampling factors of the components */
+   int32_t hx[3], vx[3];              /* up-sampling ratios to full resolution (hmax / h, vmax / v) */
+   int32_t bw[3], bh[3];              /* blocks per row / column of a component's coefficient array (whole MCUs) */
+   int32_t cw[3], chgt[3];            /* component size in samples: ceil(image size * factor / largest factor) */
+} hesaff_jpeg_layout;
+int hesaff_read_jpeg_coefficients(const char *path, hesaff_jpeg_layout *layout, uint8_t **blob, size_t *blob_bytes);
+
 /* ---- stage entry points (host pointers in/out; used by the parity tests and by callers
  *      that want one operator of the reference at a time) ---- */
 
@@ -286,6 +304,9 @@ int hesaff_stage_export(hesaff_ctx *ctx, const hesaff_keypoint *keys, int n, flo
 /* the device's "%g" print of n floats: 16 bytes per value in text (unused bytes 0) and its length in lens; for testing that
  * it equals the host's over the whole binary32 range */
 int hesaff_stage_fmt_g(hesaff_ctx *ctx, int n, const float *v, char *text, int32_t *lens);
+/* the device half of the JPEG reader for n images of one layout (blobs back to back, blob_bytes each, from
+ * hesaff_read_jpeg_coefficients): pixels[n][height][width][channels] == what hesaff_read_jpeg returns for the files */
+int hesaff_stage_jpeg_pixels(hesaff_ctx *ctx, const hesaff_jpeg_layout *layout, int n, const uint8_t *blobs, size_t blob_bytes, uint8_t *pixels);
 /* device evaluation of the pinned libm restatements (hmath.h) for testing */
 int hesaff_stage_math(hesaff_ctx *ctx, int n, const float *a, const float *b, float *atan2_out, float *pow2_out);
 /* the per-pixel forms of the descriptor gradient (helpers.cpp:269-280, siftdesc.cpp:123-137): orientation atan2f(gy, gx) and

@@ -1008,6 +1008,60 @@ def _fmt_g_inputs():
     return np.ascontiguousarray(np.concatenate(parts), np.float32)
 
 
+def test_device_jpeg_pixels_equal_the_host_reader(ctx, tmp_path):
+    """The device half of the JPEG reader (kernels_jpeg.h: inverse DCT, fancy / replicating up-sampling, colour conversion, run by
+    hesaff_process_files on the coefficients of every JPEG of its list) delivers the bytes of hesaff_read_jpeg - which
+    tests/test_host_side.py pins to libjpeg-turbo's - for 4:4:4, 4:2:2, 4:2:0, 4:4:0 and grey files, odd sizes down to 1 x 1, restart
+    intervals, sequential and progressive, several images of one layout per call, the committed fixtures and the photographs."""
+    Image = pytest.importorskip("PIL.Image")
+    import hesaff_amd
+    rng = np.random.default_rng(3)
+
+    def synth(h, w, color):
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = np.stack([127 + 100 * np.sin(xx / 7.0 + yy / 11.0), 127 + 100 * np.cos(xx / 5.0 - yy / 13.0),
+                         127 + 90 * np.sin(xx / 3.0) * np.cos(yy / 4.0)], -1) + rng.normal(0, 25, (h, w, 3))
+        a = np.clip(base, 0, 255).astype(np.uint8)
+        return a if color else a[..., 0]
+    n = 0
+    p = str(tmp_path / "t.jpg")
+    for (h, w) in [(64, 64), (61, 83), (7, 9), (1, 1), (17, 3), (120, 211), (33, 2), (1, 40)]:
+        for sub in [0, 1, 2, "4:4:0", "gray"]:
+            for q, extra in [(30, {}), (75, {"restart_marker_blocks": 3}), (100, {}), (85, {"progressive": True, "restart_marker_blocks": 2})]:
+                kw = dict(quality=q, **extra)
+                if sub != "gray":
+                    kw["subsampling"] = sub
+                try:
+                    Image.fromarray(synth(h, w, sub != "gray")).save(p, "JPEG", **kw)
+                except Exception:   # noqa: BLE001  (an encoder option this Pillow does not know)
+                    continue
+                want = hesaff_amd.read_image(p)
+                lay, blob = hesaff_amd.read_jpeg_coefficients(p)
+                got = ctx.jpeg_pixels(lay, blob)[0]
+                assert got.shape == want.shape and np.array_equal(got, want), (h, w, sub, q, extra)
+                n += 1
+    assert n >= 120
+    # several images of one layout in one call (what a chunk is), a size that is no multiple of the MCU
+    blobs, wants = [], []
+    for k in range(5):
+        Image.fromarray(synth(203, 317, True)).save(p, "JPEG", quality=70 + 5 * k, subsampling=2)
+        lay, blob = hesaff_amd.read_jpeg_coefficients(p)
+        blobs.append(blob); wants.append(hesaff_amd.read_image(p))
+    got = ctx.jpeg_pixels(lay, np.stack(blobs))
+    assert np.array_equal(got, np.stack(wants))
+    files = [os.path.join(GOLD, f) for f in sorted(os.listdir(GOLD)) if f.endswith(".jpg")]
+    from hesaff_amd.synth import sample_photo_paths
+    files += list(sample_photo_paths())
+    assert len(files) >= 5
+    for f in files:
+        lay, blob = hesaff_amd.read_jpeg_coefficients(f)
+        assert np.array_equal(ctx.jpeg_pixels(lay, blob)[0], hesaff_amd.read_image(f)), f
+    # a layout that does not describe the blob is refused, not read
+    lay.bw[0] += 1
+    with pytest.raises(hesaff_amd.HesaffError):
+        ctx.jpeg_pixels(lay, blob)
+
+
 def test_device_float_print_equals_printf_g(ctx):
     """The device's "%g" (export_fmt.h compiled for gfx950: 128-bit fast path, 256-bit division everywhere else) prints every
     float like snprintf("%g") on the host does - the format of operator<<(ostream&, float), hesaff.cpp:125."""

@@ -440,6 +440,57 @@ def test_read_jpeg_equals_libjpeg_on_many_encodings(tmp_path):
             pass
 
 
+def test_jpeg_coefficients_for_the_device_pixel_stage(tmp_path):
+    """hesaff_read_jpeg_coefficients (the host half of the JPEG reader when the device makes the pixels): layout of every sampling
+    scheme, blob size, and the SAME quantised coefficients and tables from the sequential and the progressive encoding of an
+    image (libjpeg codes identical coefficient arrays either way) - i.e. the progressive scans (spectral selection, successive
+    approximation) assemble exactly what the sequential decoder reads.  The pixel half is checked on the GPU against
+    hesaff_read_jpeg (tests/test_gpu_parity.py)."""
+    Image = pytest.importorskip("PIL.Image")
+    import hesaff_amd
+    rng = np.random.default_rng(5)
+    p = str(tmp_path / "t.jpg")
+    n = 0
+    for (h, w) in [(64, 64), (61, 83), (7, 9), (1, 1), (120, 211)]:
+        a = np.clip(rng.normal(128, 60, (h, w, 3)), 0, 255).astype(np.uint8)
+        for sub, hv in [(0, (1, 1)), (1, (2, 1)), (2, (2, 2)), ("4:4:0", (1, 2)), ("gray", (1, 1))]:
+            blobs = []
+            for prog in (False, True):
+                im = Image.fromarray(a if sub != "gray" else a[..., 0])
+                kw = dict(quality=80, progressive=prog)
+                if sub != "gray":
+                    kw["subsampling"] = sub
+                try:
+                    im.save(p, "JPEG", **kw)
+                except Exception:   # noqa: BLE001
+                    break
+                lay, blob = hesaff_amd.read_jpeg_coefficients(p)
+                nc = 1 if sub == "gray" else 3
+                assert (lay.width, lay.height, lay.channels) == (w, h, nc)
+                if nc == 3:
+                    assert (lay.hx[1], lay.vx[1]) == hv and (lay.hx[0], lay.vx[0]) == (1, 1)
+                    assert lay.cw[1] == -(-w // hv[0]) and lay.chgt[1] == -(-h // hv[1]) and lay.cw[0] == w
+                blocks = sum(lay.bw[i] * lay.bh[i] for i in range(nc))
+                assert blob.size == 1024 + 128 * blocks
+                assert all(lay.bw[i] * 8 >= lay.cw[i] and lay.bh[i] * 8 >= lay.chgt[i] for i in range(nc))
+                assert int(blob[384:388].view(np.int32)[0]) == (1 if nc == 3 else 0)
+                q = blob[:128 * nc].view(np.uint16)
+                assert q.min() >= 1
+                blobs.append(blob)
+            if len(blobs) == 2:
+                assert np.array_equal(blobs[0], blobs[1]), (h, w, sub)
+                n += 1
+    assert n >= 20
+    # not a JPEG, truncated JPEG: an error or a blob, never a crash
+    raw = open(os.path.join(GOLD, "jpeg_420_q85.jpg"), "rb").read()
+    for cut in (0, 2, 20, 200, len(raw) // 2, len(raw) - 3):
+        open(p, "wb").write(raw[:cut])
+        try:
+            hesaff_amd.read_jpeg_coefficients(p)
+        except hesaff_amd.HesaffError:
+            pass
+
+
 def test_binary_sidecar_holds_the_rows_of_the_text_file(tmp_path):
     """hesaff_write_bin (optional sidecar): the same rows as the text export - x, y, the ellipse (a, b, c)
     and the 128 bytes - unprinted; the text file is the 6-significant-digit print of exactly these floats."""
