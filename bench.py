@@ -183,6 +183,50 @@ def density_leg(hesaff_amd, torch, dev, device, B, H, W, seed, steps):
             "what": "the same device-resident step on " + what + "; not the headline workload"}
 
 
+def jpeg_path_leg(hesaff_amd, W, H, n_files, chunk, device, decode_threads, write_threads):
+    """hesaff_process_files on a list of COLOUR JPEG photographs (mosaics of the two sample photographs, 4:2:0, quality 90) on a RAM
+    disk, binary sidecars written there: the host threads do the entropy decoding only (hesaff_read_jpeg_coefficients), the inverse
+    DCT, chroma up-sampling and colour conversion of a chunk run on the device (kernels_jpeg.h).  cv::imread + the detector,
+    hesaff.cpp:137-180, for the format of the Oxford / graf images."""
+    try:
+        from PIL import Image
+    except ImportError:
+        return {"skipped": "Pillow is not installed (it only writes the test files)"}
+    from hesaff_amd import synth
+    photos = synth.load_sample_photos()
+    if not photos:
+        return {"skipped": "scikit-learn's sample photographs are not installed"}
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="hesaff_jpg_", dir=base)
+    try:
+        paths = []
+        for i in range(n_files):
+            q = os.path.join(tmp, "p%04d.jpg" % i)
+            Image.fromarray(synth.photo_mosaic(H, W, i, photos=photos)).save(q, quality=90, subsampling=2)
+            paths.append(q)
+        p = hesaff_amd.default_params()
+        p.max_batch = chunk
+        with hesaff_amd.HesaffContext(p, device=device) as ctx:
+            ctx.set_output_format(2)
+            ctx.process_files(paths[:2 * chunk], decode_threads=decode_threads, write_threads=write_threads)   # warm-up: plan, pinned blocks
+            for q in paths:
+                if os.path.exists(q + ".hesaff.bin"):
+                    os.remove(q + ".hesaff.bin")
+            t = time.perf_counter()
+            st = ctx.process_files(paths, decode_threads=decode_threads, write_threads=write_threads)
+            dt = time.perf_counter() - t
+        bad = [s for s in st if s[0] != 0]
+        return {"images": n_files, "images_per_s": n_files / dt, "value": sum(s[3] for s in st) / dt, "unit": "keypoints/s", "seconds": dt,
+                "failed_files": len(bad), "input_bytes_per_file": os.path.getsize(paths[0]), "chunk_images": chunk,
+                "decode_threads": decode_threads, "write_threads": write_threads, "output": "binary sidecar",
+                "what": "hesaff_process_files: %d colour JPEG files (%dx%d mosaics of two photographs, 4:2:0, quality 90) on a RAM disk -> %d host "
+                        "threads (entropy decoding only) -> coefficient blobs to the device -> inverse DCT, up-sampling, colour conversion, "
+                        "grey conversion and the whole hot path there -> sidecar files; one timed run, fill and drain included"
+                        % (n_files, W, H, decode_threads + write_threads)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def file_path_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, fmt=1, decode_threads=2, write_threads=2, world=1, sync=None):
     """hesaff_process_files (what `hesaff --batch` runs: decode threads -> chunks through the device, rows formatted there ->
     writer threads that only write) on n_files binary PGM files of the bench images on a RAM disk, every <name>.hesaff.sift
@@ -289,6 +333,7 @@ def main():
     ap.add_argument("--e2e-decode-threads", type=int, default=2, help="decoder threads of the end-to-end leg, per rank")
     ap.add_argument("--e2e-write-threads", type=int, default=2, help="writer threads of the end-to-end leg, per rank (2 + 2 = one device's share of 16 CPUs over 8 GPUs)")
     ap.add_argument("--e2e-images", type=int, default=512, help="image files of the measured end-to-end file path (0: skip; fewer when the RAM disk is small)")
+    ap.add_argument("--jpeg-images", type=int, default=128, help="colour JPEG photographs of the JPEG file-path leg (0: skip)")
     ap.add_argument("--e2e-chunk", type=int, default=32, help="images per device chunk of the end-to-end leg (hesaff_params.max_batch)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: every rank owns --batch images per step; strong: --global-images images per step in total, "
@@ -509,6 +554,9 @@ def main():
                                        "of the batch on every host thread the CPU quota allows, nothing else running" % ne}
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
+    jpeg_path = None
+    if args.jpeg_images > 0 and not args.no_host_path and args.density == "dense":
+        jpeg_path = jpeg_path_leg(hesaff_amd, W, H, args.jpeg_images, args.e2e_chunk, local_rank, args.e2e_decode_threads, args.e2e_write_threads)
     cpu_sample = host_imgs
 
     if rank == 0:
@@ -547,6 +595,7 @@ def main():
             "text_export": text_export,
             "end_to_end": end_to_end,
             "photo_density": photo,
+            "jpeg_path": jpeg_path,
             "fast_modes": fast_modes,
             "hbm_probe": probe,
             "roofline_detect": {"bound": "hbm", "kernel": "k_extrema_march (the three 3x3x3 extrema scans of an octave in one launch; SURVEY.md 8d: "

@@ -598,7 +598,11 @@ int hesaff_process_files(hesaff_ctx *c, int n, const char *const *paths, const c
    const int dt = std::max(1, std::min(decode_threads > 0 ? decode_threads : std::max(2, host / 4), 64));
    const int wt = std::max(1, std::min(write_threads > 0 ? write_threads : host, 256));
    // the rows are formatted on the device (kernels_export.h): the writer threads only write()
-   FileIO io(&c->ring, c->par.max_batch, c->par.mrSize, c->out_format, n, paths, out_paths, status, dt, wt, true, c->resume, true);
+   bool device_jpeg = true;
+#ifdef HESAFF_TUNING
+   if (const char *dj = getenv("HESAFF_DEVICE_JPEG")) device_jpeg = atoi(dj) != 0;   // A/B: 0 = whole JPEG decode on the host threads (hesaff_read_jpeg)
+#endif
+   FileIO io(&c->ring, c->par.max_batch, c->par.mrSize, c->out_format, n, paths, out_paths, status, dt, wt, true, c->resume, device_jpeg);
    c->stage_threads = std::max(1, std::min(4, dt));
    try {
       run_chunks(c, io, 3);

@@ -35,6 +35,9 @@ struct Huff {
    bool defined = false;
    uint8_t look_len[512];    // 9-bit lookahead: code length (0 = longer than 9 bits)
    uint8_t look_val[512];
+   // AC tables: when the code AND the value bits that follow it fit into the 9 looked-ahead bits (most coefficients of a photograph),
+   // one entry gives everything: (EXTENDed value << 8) | (run << 4) | bits to skip; 0: take the general path
+   int16_t fast_ac[512];
    // false: the code-length counts do not describe a prefix code (more codes of some length than that length has left;
    // libjpeg: JERR_BAD_HUFF_TABLE).  Such a table must be refused before the lookahead fill below, whose index
    // code << (9 - l) would leave the 512 entries.
@@ -64,6 +67,16 @@ struct Huff {
          }
          code <<= 1;
       }
+      for (int i = 0; i < 512; i++) {
+         fast_ac[i] = 0;
+         const int len = look_len[i];
+         if (!len) continue;
+         const int rs = look_val[i], run = rs >> 4, mag = rs & 15;
+         if (mag == 0 || len + mag > 9) continue;
+         int k = ((i << len) & 511) >> (9 - mag);                   // the mag bits after the code
+         if (k < (1 << (mag - 1))) k = k - (1 << mag) + 1;          // F.2.2.1 EXTEND
+         if (k >= -128 && k <= 127) fast_ac[i] = (int16_t)(k * 256 + run * 16 + len + mag);
+      }
       defined = true;
       return true;
    }
@@ -71,12 +84,26 @@ struct Huff {
 
 struct BitReader {
    const uint8_t *p, *end;
-   uint32_t acc = 0;
+   uint64_t acc = 0;     // the next bits of the stream, first bit at bit 63
    int nbits = 0;
    bool hit_marker = false;
    void fill()
    {
-      while (nbits <= 24) {
+      // eight bytes at once while none of them is 0xFF (no stuffed byte, no marker): the common case in entropy-coded data
+      if (!hit_marker && nbits <= 32 && end - p >= 8) {
+         uint64_t v;
+         memcpy(&v, p, 8);
+         v = __builtin_bswap64(v);
+         const uint64_t inv = ~v;   // a byte of v is 0xFF <=> that byte of inv is 0
+         if (((inv - 0x0101010101010101ull) & ~inv & 0x8080808080808080ull) == 0) {
+            const int take = (64 - nbits) >> 3;   // whole bytes that fit (4..8)
+            acc |= (v >> (64 - 8 * take)) << (64 - nbits - 8 * take);
+            p += take;
+            nbits += 8 * take;
+            return;
+         }
+      }
+      while (nbits <= 56) {
          int b = 0;
          if (!hit_marker && p < end) {
             b = *p;
@@ -85,11 +112,11 @@ struct BitReader {
                else { hit_marker = true; b = 0; }               // a marker: feed zeros (libjpeg does the same at the end of a segment)
             } else p++;
          }
-         acc |= (uint32_t)b << (24 - nbits);
+         acc |= (uint64_t)b << (56 - nbits);
          nbits += 8;
       }
    }
-   int peek(int n) { if (nbits < n) fill(); return (int)(acc >> (32 - n)); }
+   int peek(int n) { if (nbits < n) fill(); return (int)(acc >> (64 - n)); }   // n in 1..16
    void skip(int n) { acc <<= n; nbits -= n; }
    int get(int n) { if (n == 0) return 0; const int v = peek(n); skip(n); return v; }
    void reset() { acc = 0; nbits = 0; hit_marker = false; }
@@ -384,7 +411,7 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
                // the AC scans only), so a file of n bytes holds at most 8 n blocks per component.  The bound below is eight
                // times more generous and still keeps a 100-byte file from asking for gigabytes of coefficients and planes.
                if ((unsigned long long)c.bw * c.bh > (unsigned long long)n * 64ull + 4096ull) return HESAFF_ERR_IO;
-               if (!keep) c.plane.assign((size_t)c.bw * 8 * c.bh * 8, 0);
+               if (!keep) c.plane.assign((size_t)c.bw * 8 * c.bh * 8, 128);   // a block no scan reaches (damaged file): the transform of zeros, as on the device
                if (progressive && !keep) { c.coef.assign((size_t)c.bw * c.bh * 64, 0); c.cf = c.coef.data(); }
                memset(c.q, 0, sizeof c.q);
             }
@@ -553,8 +580,18 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
                         const int diff = t ? extend(br.get(t), t) : 0;
                         c->pred = (int)((unsigned)c->pred + (unsigned)diff);   // a damaged stream may run the predictor past 32 bits: wrap
                         blk[0] = (int16_t)c->pred;
+                        const Huff &ac = hac[c->ta];
                         for (int k = 1; k < 64;) {
-                           const int rs = decode_huff(br, hac[c->ta]);
+                           const int fa = ac.fast_ac[br.peek(9)];
+                           if (fa) {   // run, size and value in one look-up
+                              k += (fa >> 4) & 15;
+                              br.skip(fa & 15);
+                              if (k > 63) break;
+                              blk[kZigZag[k]] = (int16_t)(fa >> 8);
+                              k++;
+                              continue;
+                           }
+                           const int rs = decode_huff(br, ac);
                            const int r = rs >> 4, s = rs & 15;
                            if (s == 0) {
                               if (r == 15) { k += 16; continue; }

@@ -1056,6 +1056,23 @@ def test_device_jpeg_pixels_equal_the_host_reader(ctx, tmp_path):
     for f in files:
         lay, blob = hesaff_amd.read_jpeg_coefficients(f)
         assert np.array_equal(ctx.jpeg_pixels(lay, blob)[0], hesaff_amd.read_image(f)), f
+    # damaged files: whatever the host reader makes of them, the device path makes the same (hesaff <file> and hesaff --batch agree)
+    raw = open(os.path.join(GOLD, "jpeg_420_q85.jpg"), "rb").read()
+    praw = open(os.path.join(GOLD, "jpeg_prog_420_q80.jpg"), "rb").read()
+    n_damaged = 0
+    for data in (raw, praw):
+        for cut in (len(data) // 3, len(data) // 2, len(data) - 3):
+            open(p, "wb").write(data[:cut])
+            try:
+                want = hesaff_amd.read_image(p)
+            except hesaff_amd.HesaffError:
+                with pytest.raises(hesaff_amd.HesaffError):
+                    hesaff_amd.read_jpeg_coefficients(p)
+                continue
+            lay, blob = hesaff_amd.read_jpeg_coefficients(p)
+            assert np.array_equal(ctx.jpeg_pixels(lay, blob)[0], want), cut
+            n_damaged += 1
+    assert n_damaged >= 3
     # a layout that does not describe the blob is refused, not read
     lay.bw[0] += 1
     with pytest.raises(hesaff_amd.HesaffError):
