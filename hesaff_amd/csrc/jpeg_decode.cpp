@@ -16,6 +16,7 @@
 // Progressive files (SOF2: spectral selection + successive approximation, jdphuff.c) are collected scan by scan into
 // coefficient arrays and transformed once at the end; a COMPLETE file gets no inter-block smoothing in libjpeg, so the
 // pixels are again identical.  Not decoded (HESAFF_ERR_IO): lossless / arithmetic-coded / 12-bit / CMYK files.
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -233,11 +234,17 @@ struct Comp {
    std::vector<int16_t> coef;     // progressive (and every file when only the coefficients are wanted): bw x bh blocks of 64
                                   // coefficients in natural order, filled scan by scan
    int16_t *cf = nullptr;         // = coef.data(), or the component's place in the blob that is handed to the device
+   int covered = 0;               // sequential scans seen: 0 none, 1 of this component alone (ceil(w/8) x ceil(h/8) blocks), 2 interleaved (all blocks)
    uint16_t q[64];                // coefficients-only mode: the quantisation table the pixel stage has to use for this component
 };
 
 // what decode_jpeg hands over instead of pixels (hesaff_read_jpeg_coefficients): the device transforms the blocks (kernels_jpeg.h)
-struct CoefOut { hesaff_jpeg_layout *layout; uint8_t **blob; size_t *blob_bytes; };
+// alloc (optional): where the blob comes from - a caller that decodes many files hands back blobs it is done with instead of paying
+// for 25 MB of fresh zero pages per photograph; *zeroed tells whether the memory is already zero
+struct CoefOut {
+   hesaff_jpeg_layout *layout; uint8_t **blob; size_t *blob_bytes;
+   hesaff_blob_alloc alloc; void *user;
+};
 
 inline uint16_t be16(const uint8_t *p) { return (uint16_t)((p[0] << 8) | p[1]); }
 
@@ -334,6 +341,7 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
    struct FreeDel { void operator()(uint8_t *p) const { free(p); } };
    std::unique_ptr<uint8_t, FreeDel> blob;
    size_t blob_bytes = 0;
+   bool blob_dirty = false;   // a recycled blob of a sequential file: blocks that no scan decoded are cleared at the end
    const size_t n = f.size();
    if (n < 4 || f[0] != 0xFF || f[1] != 0xD8) return HESAFF_ERR_IO;
    uint16_t qt[4][64];
@@ -419,8 +427,12 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
                size_t blocks = 0;
                for (Comp &c : comps) blocks += (size_t)c.bw * c.bh;
                blob_bytes = HESAFF_JPEG_BLOB_HEADER + blocks * 128;
-               blob.reset((uint8_t *)calloc(1, blob_bytes));
+               int zeroed = 1;
+               blob.reset(co->alloc ? (uint8_t *)co->alloc(blob_bytes, &zeroed, co->user) : (uint8_t *)calloc(1, blob_bytes));
                if (!blob) return HESAFF_ERR_NOMEM;
+               // a sequential scan clears every block it decodes; progressive scans add to what is there, and blocks no scan reaches must read zero
+               if (!zeroed) memset(blob.get(), 0, progressive ? blob_bytes : (size_t)HESAFF_JPEG_BLOB_HEADER);
+               blob_dirty = !zeroed && !progressive;
                size_t at = HESAFF_JPEG_BLOB_HEADER;
                for (Comp &c : comps) { c.cf = reinterpret_cast<int16_t *>(blob.get() + at); at += (size_t)c.bw * c.bh * 128; }
             }
@@ -555,6 +567,7 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
             if (inter) { mx = (W + 8 * hmax - 1) / (8 * hmax); my = (H + 8 * vmax - 1) / (8 * vmax); }
             else { mx = (sc[0]->w + 7) / 8; my = (sc[0]->hgt + 7) / 8; }
             int16_t blk_local[64];
+            for (Comp *c : sc) c->covered = std::max(c->covered, inter ? 2 : 1);
             int to_go = restart;
             for (int mcu = 0; mcu < mx * my; mcu++) {
                if (restart && to_go == 0) {
@@ -637,6 +650,14 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
          blocks += (size_t)c.bw * c.bh;
       }
       if (!blob || blob_bytes != HESAFF_JPEG_BLOB_HEADER + blocks * 128) return HESAFF_ERR_IO;
+      if (blob_dirty)   // recycled memory: the blocks that no scan of this (sequential) file decoded still hold another image
+         for (Comp &c : comps) {
+            const int cbw = c.covered == 2 ? c.bw : (c.covered == 1 ? (c.w + 7) / 8 : 0), cbh = c.covered == 2 ? c.bh : (c.covered == 1 ? (c.hgt + 7) / 8 : 0);
+            for (int by = 0; by < c.bh; by++) {
+               const int x0 = by < cbh ? std::min(cbw, c.bw) : 0;
+               if (x0 < c.bw) memset(c.cf + ((size_t)by * c.bw + x0) * 64, 0, (size_t)(c.bw - x0) * 128);
+            }
+         }
       uint8_t *b = blob.get();
       for (int i = 0; i < nc; i++) memcpy(b + (size_t)i * 128, comps[i].q, 128);
       const int32_t ycc = nc == 3 && (adobe ? adobe_transform != 0 : true) ? 1 : 0;   // JFIF / no marker: YCbCr; Adobe transform 0: RGB
@@ -731,12 +752,18 @@ static int read_all(const char *path, std::vector<uint8_t> &bytes)
 
 extern "C" int hesaff_read_jpeg_coefficients(const char *path, hesaff_jpeg_layout *layout, uint8_t **blob, size_t *blob_bytes)
 {
+   return hesaff_read_jpeg_coefficients_alloc(path, layout, blob, blob_bytes, nullptr, nullptr);
+}
+
+extern "C" int hesaff_read_jpeg_coefficients_alloc(const char *path, hesaff_jpeg_layout *layout, uint8_t **blob, size_t *blob_bytes,
+                                                   hesaff_blob_alloc alloc, void *user)
+{
    if (!path || !layout || !blob || !blob_bytes) return HESAFF_ERR_ARG;
    try {
       std::vector<uint8_t> bytes;
       const int rc = read_all(path, bytes);
       if (rc != HESAFF_OK) return rc;
-      const CoefOut co = {layout, blob, blob_bytes};
+      const CoefOut co = {layout, blob, blob_bytes, alloc, user};
       return decode_jpeg(bytes, nullptr, nullptr, nullptr, nullptr, &co);
    } catch (const std::bad_alloc &) {
       return HESAFF_ERR_NOMEM;

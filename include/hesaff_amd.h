@@ -261,6 +261,12 @@ typedef struct hesaff_jpeg_layout {
    int32_t cw[3], chgt[3];            /* component size in samples: ceil(image size * factor / largest factor) */
 } hesaff_jpeg_layout;
 int hesaff_read_jpeg_coefficients(const char *path, hesaff_jpeg_layout *layout, uint8_t **blob, size_t *blob_bytes);
+/* the same with the blob's memory from the caller: alloc(bytes, &zeroed, user) returns memory that free() accepts (or NULL) and says
+ * whether it is already zero.  hesaff_process_files hands back the blobs of images that have gone to the device - a decoder thread
+ * then writes into warm memory instead of 25 MB of fresh zero pages per photograph.  The blob's content does not depend on it. */
+typedef void *(*hesaff_blob_alloc)(size_t bytes, int *zeroed, void *user);
+int hesaff_read_jpeg_coefficients_alloc(const char *path, hesaff_jpeg_layout *layout, uint8_t **blob, size_t *blob_bytes,
+                                        hesaff_blob_alloc alloc, void *user);
 
 /* ---- stage entry points (host pointers in/out; used by the parity tests and by callers
  *      that want one operator of the reference at a time) ---- */

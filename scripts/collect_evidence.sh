@@ -16,6 +16,7 @@ cp $G/${T}_fast_mode.json profiles/${R}_fast_mode.json
 cp $G/${T}_fast_mode_photo.json profiles/${R}_fast_mode_photographs.json
 grep -v '^{"metric' $G/${T}_e2e_thread_sweep.txt > profiles/${R}_e2e_thread_sweep.txt
 tail -4 $G/${T}_tests.log > profiles/${R}_gpu_tests.log
+grep -v amdgpu.ids $G/${T}_jpeg_list_rate.txt > profiles/${R}_jpeg_list_rate.txt
 python3 - $T $R <<'PY'
 import json, glob, sys
 t, r = sys.argv[1], sys.argv[2]

@@ -1,7 +1,7 @@
 # usage (through gpurun): bash scripts/gpu_final.sh <tag>
 # round-end evidence, ONE pass: GPU test suite, default bench line, rocprofv3 stats + HBM traffic of the bench command, per-kernel PMC tables,
 # per-kernel serial times (parity, fast = 2, photographs), fast-mode reports, config-5 sequence tables (band noise and photograph, fast 0 / 2),
-# end-to-end thread sweep
+# end-to-end thread sweep, JPEG lists (UHD and 1024x768; pixels on the device / on the host)
 cd $GRAFT_REPO_ROOT
 TAG=$1
 mkdir -p gpurun_out
@@ -30,3 +30,4 @@ for q in sorted(glob.glob("gpurun_out/${TAG}_repeatability_*.json")):
         print(q, "unreadable", e)
 PY
 timeout 900 python scripts/e2e_thread_sweep.py 384 > gpurun_out/${TAG}_e2e_thread_sweep.txt 2>&1; tail -12 gpurun_out/${TAG}_e2e_thread_sweep.txt | cut -c1-300
+timeout 600 python scripts/jpeg_list_rate.py 256 > gpurun_out/${TAG}_jpeg_list_rate.txt 2>&1; timeout 600 python scripts/jpeg_list_rate.py 1024 1024 768 >> gpurun_out/${TAG}_jpeg_list_rate.txt 2>&1; cut -c1-220 gpurun_out/${TAG}_jpeg_list_rate.txt

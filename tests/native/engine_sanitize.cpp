@@ -5,7 +5,8 @@
 // result block from the ring of three - and fabricates records from the pixels it was handed (so every decoded byte is read
 // while the engine says it is alive, and every record is read by a writer while its block is marked busy).
 //   engine_sanitize <max_batch> <decode_threads> <write_threads> <format> <file>...      (format + 4: the mock hands over rows that
-//                   are already text / packed - ChunkDone::text, text_off, bin - like the device formatter of kernels_export.h)
+//                   are already text / packed - ChunkDone::text, text_off, bin - like the device formatter of kernels_export.h;
+//                   format + 8: JPEG files arrive as coefficient blobs from the pool of recycled blobs, like hesaff_process_files)
 //   engine_sanitize array <max_batch> <n_images>      ArrayIO (hesaff_detect_batch_cb's chunk source: a sink called per chunk with records
 //                   that live in a ring block, the sink's return code read by the staging thread) under the same mock loop; the sink
 //                   fails on the last third of a second run
@@ -108,7 +109,7 @@ int main(int argc, char **argv)
    }
    if (argc < 6) return 2;
    const int max_batch = atoi(argv[1]), dt = atoi(argv[2]), wt = atoi(argv[3]), fmt = atoi(argv[4]) & 3;
-   const bool device_format = (atoi(argv[4]) & 4) != 0;
+   const bool device_format = (atoi(argv[4]) & 4) != 0, device_jpeg = (atoi(argv[4]) & 8) != 0;
    const int n = argc - 5;
    std::vector<const char *> paths((size_t)n);
    for (int i = 0; i < n; i++) paths[(size_t)i] = argv[5 + i];
@@ -121,14 +122,14 @@ int main(int argc, char **argv)
    long long rows = 0;
    std::string chunk_sizes;
    {
-      FileIO io(&ring, max_batch, 5.196152f, fmt, n, paths.data(), nullptr, status.data(), dt, wt, device_format);
+      FileIO io(&ring, max_batch, 5.196152f, fmt, n, paths.data(), nullptr, status.data(), dt, wt, device_format, false, device_jpeg);
       auto stage = [&]() -> std::unique_ptr<State> {
          std::unique_ptr<State> s(new State());
          if (!io.next(s->q)) return nullptr;
          // "copy to pinned memory": read every pixel of every image of the chunk
          for (size_t b = 0; b < s->q.data.size(); b++) {
             uint32_t acc = 0;
-            const size_t bytes = (size_t)s->q.W * s->q.H * s->q.ch;
+            const size_t bytes = s->q.blob_bytes ? s->q.blob_bytes : (size_t)s->q.W * s->q.H * s->q.ch;   // a JPEG file's coefficient blob (recycled by the pool afterwards)
             for (size_t k = 0; k < bytes; k++) acc = acc * 31u + s->q.data[b][k];
             s->sum.push_back(acc);
          }

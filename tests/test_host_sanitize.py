@@ -249,6 +249,20 @@ def test_file_pipeline_threads_under_sanitizers(san, tmp_path):
     r = subprocess.run([exe, "8", "2", "2", "2"] + same, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-4000:])
     assert "chunks=2,4,8,8,8,8,8,8,4,4,2\n" in r.stdout and "files=64 written=64" in r.stdout, r.stdout
+    # JPEG files as coefficient blobs (hesaff_read_jpeg_coefficients_alloc + FileIO's pool of recycled blobs), mixed with PGM files
+    gold = os.path.join(ROOT, "tests", "golden")
+    jpgs = [os.path.join(gold, f) for f in sorted(os.listdir(gold)) if f.endswith(".jpg")]
+    assert len(jpgs) >= 5
+    mixed = []
+    for k in range(6):
+        for j in jpgs:
+            q = tmp_path / ("j%d_%s" % (k, os.path.basename(j)))
+            q.write_bytes(open(j, "rb").read())
+            mixed.append(str(q))
+        mixed.append(same[k])
+    r = subprocess.run([exe, "4", "3", "2", str(2 + 4 + 8)] + mixed, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-4000:])
+    assert "files=%d written=%d unreadable=0" % (len(mixed), len(mixed)) in r.stdout, r.stdout
     # ArrayIO (hesaff_detect_batch_cb): chunk source + sink hand-over, with a sink that fails mid-run (sink_rc is read by the
     # staging thread while the caller's thread writes it)
     for max_batch, n_img in ((1, 7), (4, 45), (8, 64)):
