@@ -200,9 +200,12 @@ def jpeg_path_leg(hesaff_amd, W, H, n_files, chunk, device, decode_threads, writ
     tmp = tempfile.mkdtemp(prefix="hesaff_jpg_", dir=base)
     try:
         paths = []
-        for i in range(n_files):
+        for i in range(n_files):   # 32 distinct mosaics, cycled (encoding them is the slow part of this leg)
             q = os.path.join(tmp, "p%04d.jpg" % i)
-            Image.fromarray(synth.photo_mosaic(H, W, i, photos=photos)).save(q, quality=90, subsampling=2)
+            if i < 32:
+                Image.fromarray(synth.photo_mosaic(H, W, i, photos=photos)).save(q, quality=90, subsampling=2)
+            else:
+                shutil.copyfile(paths[i % 32], q)
             paths.append(q)
         p = hesaff_amd.default_params()
         p.max_batch = chunk
@@ -219,7 +222,7 @@ def jpeg_path_leg(hesaff_amd, W, H, n_files, chunk, device, decode_threads, writ
         return {"images": n_files, "images_per_s": n_files / dt, "value": sum(s[3] for s in st) / dt, "unit": "keypoints/s", "seconds": dt,
                 "failed_files": len(bad), "input_bytes_per_file": os.path.getsize(paths[0]), "chunk_images": chunk,
                 "decode_threads": decode_threads, "write_threads": write_threads, "output": "binary sidecar",
-                "what": "hesaff_process_files: %d colour JPEG files (%dx%d mosaics of two photographs, 4:2:0, quality 90) on a RAM disk -> %d host "
+                "what": "hesaff_process_files: %d colour JPEG files (%dx%d mosaics of two photographs, 32 distinct, 4:2:0, quality 90) on a RAM disk -> %d host "
                         "threads (entropy decoding only) -> coefficient blobs to the device -> inverse DCT, up-sampling, colour conversion, "
                         "grey conversion and the whole hot path there -> sidecar files; one timed run, fill and drain included"
                         % (n_files, W, H, decode_threads + write_threads)}
@@ -333,7 +336,7 @@ def main():
     ap.add_argument("--e2e-decode-threads", type=int, default=2, help="decoder threads of the end-to-end leg, per rank")
     ap.add_argument("--e2e-write-threads", type=int, default=2, help="writer threads of the end-to-end leg, per rank (2 + 2 = one device's share of 16 CPUs over 8 GPUs)")
     ap.add_argument("--e2e-images", type=int, default=512, help="image files of the measured end-to-end file path (0: skip; fewer when the RAM disk is small)")
-    ap.add_argument("--jpeg-images", type=int, default=128, help="colour JPEG photographs of the JPEG file-path leg (0: skip)")
+    ap.add_argument("--jpeg-images", type=int, default=384, help="colour JPEG photographs of the JPEG file-path leg (0: skip)")
     ap.add_argument("--e2e-chunk", type=int, default=32, help="images per device chunk of the end-to-end leg (hesaff_params.max_batch)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: every rank owns --batch images per step; strong: --global-images images per step in total, "

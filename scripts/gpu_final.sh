@@ -30,4 +30,4 @@ for q in sorted(glob.glob("gpurun_out/${TAG}_repeatability_*.json")):
         print(q, "unreadable", e)
 PY
 timeout 900 python scripts/e2e_thread_sweep.py 384 > gpurun_out/${TAG}_e2e_thread_sweep.txt 2>&1; tail -12 gpurun_out/${TAG}_e2e_thread_sweep.txt | cut -c1-300
-timeout 600 python scripts/jpeg_list_rate.py 256 > gpurun_out/${TAG}_jpeg_list_rate.txt 2>&1; timeout 600 python scripts/jpeg_list_rate.py 1024 1024 768 >> gpurun_out/${TAG}_jpeg_list_rate.txt 2>&1; cut -c1-220 gpurun_out/${TAG}_jpeg_list_rate.txt
+timeout 600 python scripts/jpeg_list_rate.py 512 > gpurun_out/${TAG}_jpeg_list_rate.txt 2>&1; timeout 600 python scripts/jpeg_list_rate.py 2048 1024 768 >> gpurun_out/${TAG}_jpeg_list_rate.txt 2>&1; cut -c1-220 gpurun_out/${TAG}_jpeg_list_rate.txt

@@ -1,4 +1,4 @@
-# usage (through gpurun): python scripts/jpeg_list_rate.py [files=192] [width=3840] [height=2160]
+# usage (through gpurun): python scripts/jpeg_list_rate.py [files=512] [width=3840] [height=2160]
 # hesaff_process_files on a list of colour JPEG photographs (mosaics of the two sample photographs, 4:2:0, quality 90, on a RAM disk)
 # with 2+2, 4+4 and 8+8 host threads: images/s with the pixels made on the device (the product) and - tuning build,
 # HESAFF_DEVICE_JPEG=0 - with the whole decode on the host threads.  One JSON line per case.
@@ -30,7 +30,7 @@ if __name__ == "__main__":
         paths = [ln.strip() for ln in open(sys.argv[2])]
         print(json.dumps(one_case(paths, int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))))
         sys.exit(0)
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 192
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     W = int(sys.argv[2]) if len(sys.argv) > 2 else 3840
     H = int(sys.argv[3]) if len(sys.argv) > 3 else 2160
     from PIL import Image
@@ -39,9 +39,12 @@ if __name__ == "__main__":
     try:
         paths = []
         photos = synth.load_sample_photos()
-        for i in range(n):
+        for i in range(n):   # 32 distinct mosaics, cycled
             q = os.path.join(tmp, "p%04d.jpg" % i)
-            Image.fromarray(synth.photo_mosaic(H, W, i, photos=photos)).save(q, quality=90, subsampling=2)
+            if i < 32:
+                Image.fromarray(synth.photo_mosaic(H, W, i, photos=photos)).save(q, quality=90, subsampling=2)
+            else:
+                shutil.copyfile(paths[i % 32], q)
             paths.append(q)
         lst = os.path.join(tmp, "list.txt")
         open(lst, "w").write("\n".join(paths) + "\n")
