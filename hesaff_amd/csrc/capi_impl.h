@@ -242,7 +242,7 @@ void hesaff_destroy(hesaff_ctx *c)
       if (c->ev_in_free[i]) (void)hipEventDestroy(c->ev_in_free[i]);
       if (c->ev_out_ready[i]) (void)hipEventDestroy(c->ev_out_ready[i]);
       if (c->ev_d2h[i]) (void)hipEventDestroy(c->ev_d2h[i]);
-      for (int q = 0; q < 2; q++) if (c->ev_exp[i][q]) (void)hipEventDestroy(c->ev_exp[i][q]);
+      for (int q = 0; q < 4; q++) if (c->ev_exp[i][q]) (void)hipEventDestroy(c->ev_exp[i][q]);
    }
    for (auto &pb : c->pin_out) pb.release();
    if (c->h2d_stream) (void)hipStreamSynchronize(c->h2d_stream);
@@ -329,8 +329,7 @@ void ensure_copy_streams(hesaff_ctx *c)
       HIP_TRY(hipEventCreateWithFlags(&c->ev_in_free[i], hipEventDisableTiming | hipEventBlockingSync));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_out_ready[i], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_d2h[i], hipEventDisableTiming | hipEventBlockingSync));
-      HIP_TRY(hipEventCreate(&c->ev_exp[i][0]));
-      HIP_TRY(hipEventCreate(&c->ev_exp[i][1]));
+      for (int q = 0; q < 4; q++) HIP_TRY(hipEventCreate(&c->ev_exp[i][q]));
    }
 }
 
@@ -403,8 +402,10 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
    auto deliver = [&](State &s) {
       if (s.total > 0) HIP_TRY(hipEventSynchronize(c->ev_d2h[s.no & 1]));
       if (s.total > 0 && c->profiling && (wants & (WANT_TEXT | WANT_BIN))) {
-         float ms = 0.0f;   // (includes the host's short wait for the byte counts between the length pass and the write pass)
-         if (hipEventElapsedTime(&ms, c->ev_exp[s.no & 1][0], c->ev_exp[s.no & 1][1]) == hipSuccess) { c->export_ms = ms; c->export_rows = s.total; c->tm.export_ms = ms; c->tm.export_rows = s.total; }
+         float ms = 0.0f;   // length pass (with the host's short wait for the byte counts) + write pass
+         float ms2 = 0.0f;
+         if (hipEventElapsedTime(&ms, c->ev_exp[s.no & 1][0], c->ev_exp[s.no & 1][1]) == hipSuccess && hipEventElapsedTime(&ms2, c->ev_exp[s.no & 1][2], c->ev_exp[s.no & 1][3]) == hipSuccess) {
+            ms += ms2; c->export_ms = ms; c->export_rows = s.total; c->tm.export_ms = ms; c->tm.export_rows = s.total; }
          else (void)hipGetLastError();
       }
       ChunkDone d;
@@ -468,6 +469,7 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
             cur->text_at = place((size_t)text_bytes);
          }
          if (wants & WANT_BIN) cur->bin_at = place(n_rows * EX_BIN_ROW);
+         if (time_export) HIP_TRY(hipEventRecord(c->ev_exp[slot][1], c->stream));
          const size_t bytes = at;
          const auto dbg_t3 = std::chrono::steady_clock::now();
          // chunk k-1: its copy out was enqueued before the kernels of chunk k and has long finished
@@ -506,9 +508,10 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
             if (bytes > c->b_outstage[slot].bytes) c->b_outstage[slot].ensure(bytes + bytes / 4);
             char *stg = (char *)c->b_outstage[slot].p;
             if (wants & WANT_KEYS) HIP_TRY(hipMemcpyAsync(stg + keys_at, c->b_out.p, n_rows * sizeof(hesaff_keypoint), hipMemcpyDeviceToDevice, c->stream));
+            if (time_export) HIP_TRY(hipEventRecord(c->ev_exp[slot][2], c->stream));
             if (wants & WANT_TEXT) export_text_write(c, d_keys, (uint32_t)n_rows, stg + cur->text_at);
             if (wants & WANT_BIN) export_bin_rows(c, d_keys, (uint32_t)n_rows, stg + cur->bin_at);
-            if (time_export) HIP_TRY(hipEventRecord(c->ev_exp[slot][1], c->stream));
+            if (time_export) HIP_TRY(hipEventRecord(c->ev_exp[slot][3], c->stream));
             HIP_TRY(hipEventRecord(c->ev_out_ready[slot], c->stream));
             HIP_TRY(hipStreamWaitEvent(c->d2h_stream, c->ev_out_ready[slot], 0));
             HIP_TRY(hipMemcpyAsync(c->pin_out[(size_t)cur->block].p, stg, bytes, hipMemcpyDeviceToHost, c->d2h_stream));

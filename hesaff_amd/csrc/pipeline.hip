@@ -254,7 +254,7 @@ struct hesaff_ctx {
    std::vector<Pinned> pin_out;       // result blocks: one per chunk of the current call (hesaff_detect_batch), or a ring of three
    hesaff_engine::BlockRing ring;     // (hesaff_detect_batch_cb, hesaff_process_files: a block returns to the ring when its consumer is done with it)
    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
-   hipEvent_t ev_exp[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // profiling: brackets of a chunk's export kernels, per staging slot
+   hipEvent_t ev_exp[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // profiling, per staging slot: brackets of a chunk's length pass and of its write pass (the host's waits between them - a free pinned block - are not the export's)
    float export_ms = 0.0f; int32_t export_rows = 0;
    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_in_free[2] = {nullptr, nullptr}, ev_out_ready[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
    std::vector<int32_t> h_starts;

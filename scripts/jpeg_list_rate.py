@@ -8,7 +8,7 @@ sys.path.insert(0, ".")
 def one_case(paths, dt, wt, fmt):
     import hesaff_amd
     p = hesaff_amd.default_params()
-    p.max_batch = 32
+    p.max_batch = int(os.environ.get("JPEG_CHUNK", "32"))   # images per device chunk
     ctx = hesaff_amd.HesaffContext(p, device=0)
     ctx.set_output_format(fmt)
     ctx.process_files(paths[:64], decode_threads=dt, write_threads=wt)   # warm-up: plan, pinned blocks
@@ -21,7 +21,7 @@ def one_case(paths, dt, wt, fmt):
     dt_s = time.perf_counter() - t
     ctx.close()
     assert all(s[0] == 0 for s in st), [s for s in st if s[0] != 0][:3]
-    return {"images": len(paths), "decode_threads": dt, "write_threads": wt, "format": "text" if fmt == 1 else "sidecar",
+    return {"images": len(paths), "chunk_images": p.max_batch, "decode_threads": dt, "write_threads": wt, "format": "text" if fmt == 1 else "sidecar",
             "device_jpeg": os.environ.get("HESAFF_DEVICE_JPEG", "1") != "0", "images_per_s": len(paths) / dt_s,
             "descriptors": int(sum(s[3] for s in st))}
 
