@@ -3,7 +3,7 @@
 # with 2+2, 4+4 and 8+8 host threads: images/s with the pixels made on the device (the product) and - tuning build,
 # HESAFF_DEVICE_JPEG=0 - with the whole decode on the host threads.  One JSON line per case.
 import json, os, shutil, subprocess, sys, tempfile, time
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def one_case(paths, dt, wt, fmt):
     import hesaff_amd

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=64)
     ap.add_argument("--distinct", type=int, default=32)
     ap.add_argument("--format", type=int, default=2, help="1 text, 2 binary sidecar, 3 both")
+    ap.add_argument("--jpeg", action="store_true", help="colour JPEG files (mosaics of the sample photographs, 4:2:0, quality 90) instead of PGM: coefficient blobs, pixels on the device")
     a = ap.parse_args()
     import torch
     import hesaff_amd
@@ -32,14 +33,22 @@ def main():
     try:
         hdr = b"P5\n%d %d\n255\n" % (a.width, a.height)
         src = []
+        ext = "jpg" if a.jpeg else "pgm"
+        if a.jpeg:
+            from PIL import Image
+            from hesaff_amd import synth
+            photos = synth.load_sample_photos()
         for i in range(a.distinct):
-            q = os.path.join(tmp, "src%03d.pgm" % i)
-            with open(q, "wb") as f:
-                f.write(hdr); f.write(imgs[i].tobytes())
+            q = os.path.join(tmp, "src%03d.%s" % (i, ext))
+            if a.jpeg:
+                Image.fromarray(synth.photo_mosaic(a.height, a.width, i, photos=photos)).save(q, quality=90, subsampling=2)
+            else:
+                with open(q, "wb") as f:
+                    f.write(hdr); f.write(imgs[i].tobytes())
             src.append(q)
         paths = []
         for i in range(a.files):
-            q = os.path.join(tmp, "img%05d.pgm" % i)
+            q = os.path.join(tmp, "img%05d.%s" % (i, ext))
             os.link(src[i % a.distinct], q)
             paths.append(q)
         del imgs
@@ -57,7 +66,7 @@ def main():
         ok = sum(1 for s in st if s[0] == 0 and s[1] == 3)
         rows = sum(s[3] for s in st)
         out_bytes = sum(os.path.getsize(q + e) for q in paths for e in ((".hesaff.sift",) if a.format == 1 else (".hesaff.bin",) if a.format == 2 else (".hesaff.sift", ".hesaff.bin")))
-        print({"files": a.files, "size": "%dx%d" % (a.width, a.height), "chunk": a.chunk, "written": ok, "images_per_s": a.files / dt,
+        print({"files": a.files, "input": "colour JPEG" if a.jpeg else "PGM", "size": "%dx%d" % (a.width, a.height), "chunk": a.chunk, "written": ok, "images_per_s": a.files / dt,
                "descriptors_per_s": rows / dt, "seconds": dt, "output_GB": out_bytes / 1e9,
                "peak_rss_GB_before": rss0 / 1e6, "peak_rss_GB_after_warmup_of_%d_files" % (2 * a.chunk): rss1 / 1e6,
                "peak_rss_GB_after_%d_files" % a.files: rss2 / 1e6})
