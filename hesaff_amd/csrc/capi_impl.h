@@ -484,14 +484,15 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
          }
          // device copy / formatting into the staging slot (frees b_out for the next chunk), then D2H beside the next chunk
          if (ring > 0) {
-            // Every block of the ring is sized for a FULL chunk of this density the first time one is needed (the list may start with
-            // small chunks), the other blocks on a helper thread beside the next chunk's kernels: pinning 1.5 GB takes 150 ms, and a
-            // block that is sized - or grown - when its chunk is already waiting leaves the device idle for that long.
-            const size_t full = (bytes * (size_t)std::max(c->par.max_batch, B) + (size_t)B - 1) / (size_t)B;
+            // A list that starts with small chunks (a long one): every block of the ring is sized for a FULL chunk of this density the
+            // first time one is needed, the other blocks on a helper thread beside the next chunk's kernels: pinning 1.5 GB takes
+            // 150 ms, and a block that is sized - or grown - when its chunk is already waiting leaves the device idle for that long.
+            const int follow = std::max(cur->largest, B);   // images of the largest chunk that is known to follow (ChunkIO::largest_chunk)
+            const size_t full = (bytes * (size_t)follow + (size_t)B - 1) / (size_t)B;
             if (presize[(size_t)cur->block].valid()) presize[(size_t)cur->block].get();
             hesaff_ctx::Pinned &pb = c->pin_out[(size_t)cur->block];
             if (bytes > pb.bytes) pb.ensure_grow(std::max<size_t>(full, 16));
-            if (!presized) {
+            if (!presized && follow > B) {   // a list that starts small is a long one: its other blocks will be needed
                presized = true;
                for (int r = 0; r < ring; r++)
                   if (r != cur->block && c->pin_out[(size_t)r].bytes == 0)
