@@ -5,8 +5,9 @@
 // integer function at every block or pixel: the inverse DCT (jidctint.c, JDCT_ISLOW), the chroma up-sampling
 // (jdsample.c "fancy" triangle filters) and the colour conversion (jdcolor.c).  On a host thread the three cost 60 % of
 // the decode time of a 4:2:0 photograph; here they run over all images of a chunk at once:
-//    k_jpeg_idct    one thread per 8 x 8 block of any component of any image: dequantise, two 1-D passes in 32-bit
-//                   integers (wrapping, like libjpeg's INT32), range limit, 8 rows of 8 samples into the component plane
+//    k_jpeg_idct    one thread per 8 x 8 block of any component of any image (coefficients staged through LDS as whole cache
+//                   lines): dequantise, two 1-D passes in 32-bit integers (wrapping, like libjpeg's INT32), range limit, 8 rows of
+//                   8 samples into the component plane
 //    k_jpeg_pixels  one thread per 4 output pixels: up-sample the components that are not at full resolution (edge
 //                   samples replicated), YCbCr -> RGB with jdcolor.c's fixed-point constants, bytes into the chunk's
 //                   input slot in the layout of a raw 1- or 3-channel image - the grey conversion (hesaff.cpp:138-148) and
@@ -16,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "device_common.h"
 
 struct JpegGeom {
    int W, H, nc;
@@ -68,56 +70,83 @@ __device__ __forceinline__ void hs_jpeg_idct8(const int d[8], int out[8], int sh
    out[3] = hs_jpeg_descale(add(tmp13, tmp0), shift); out[4] = hs_jpeg_descale(sub(tmp13, tmp0), shift);
 }
 
-// grid-stride over B * blocks_per_image blocks; block 256
+// Blocks are numbered image by image, component by component, row by row: block t of the chunk lies at
+//    blobs + (t / blocks_per_image) * blob_bytes + HEADER + (t % blocks_per_image) * 128.
+// A wavefront takes 64 consecutive blocks.  Their coefficients (8 KB, contiguous inside an image) are read as whole cache lines - lane l
+// reads 16-byte piece l of every KB - into LDS, from where every lane takes the eight rows of its own block (a lane reading its block
+// straight from memory touches 64 lines per load instruction and the same lines eight times).  Alone on the device: 0.39 ms per 32 UHD
+// 4:2:0 images = 4.6 TB/s of coefficients in and samples out; in the file pipeline it usually runs beside the copy-out of the previous
+// chunk's rows - on this pool a blit kernel on the high-priority copy queue - and then takes 3.0 ms (profiles/r04_notes.md).
+// grid-stride over B * blocks_per_image blocks in steps of 256; block 256
+#define JPEG_LDS_ROW 144   // bytes per block in LDS: 128 + 16, so that the 64 lanes' 16-byte reads spread over the banks
 __global__ __launch_bounds__(256) void k_jpeg_idct(const uint8_t *__restrict__ blobs, uint8_t *__restrict__ planes, JpegGeom g, int B)
 {
+   __shared__ __attribute__((aligned(16))) uint8_t s_cf[4][64 * JPEG_LDS_ROW];
    const unsigned long long total = (unsigned long long)B * g.blocks_per_image;
-   for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (unsigned long long)gridDim.x * blockDim.x) {
-      const unsigned int b = (unsigned int)(t / g.blocks_per_image);
-      unsigned int k = (unsigned int)(t - (unsigned long long)b * g.blocks_per_image);
-      int c = 0;
-      if (k >= g.blocks[0]) { k -= g.blocks[0]; c = 1; if (k >= g.blocks[1]) { k -= g.blocks[1]; c = 2; } }
-      const uint8_t *blob = blobs + (unsigned long long)b * g.blob_bytes;
-      const uint16_t *q = reinterpret_cast<const uint16_t *>(blob) + 64 * c;
-      const int4 *cf = reinterpret_cast<const int4 *>(blob + g.coef_off[c] + (unsigned long long)k * 128);
-      int ws[64];
-      // pass 1: columns, dequantisation inside (|int16 x uint16| < 2^31), results scaled up by PASS1_BITS
-      {
-         int in[64];
-#pragma unroll
-         for (int r = 0; r < 8; r++) {
-            const int4 v = cf[r];   // eight int16 of row r
-            const int4 qq = reinterpret_cast<const int4 *>(q)[r];
-            const int vv[4] = {v.x, v.y, v.z, v.w}, qv[4] = {qq.x, qq.y, qq.z, qq.w};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-               in[8 * r + 2 * j] = (int)(short)(vv[j] & 0xffff) * (int)(qv[j] & 0xffff);
-               in[8 * r + 2 * j + 1] = (int)(short)((unsigned)vv[j] >> 16) * (int)((unsigned)qv[j] >> 16);
-            }
-         }
-#pragma unroll
-         for (int col = 0; col < 8; col++) {
-            const int d[8] = {in[col], in[8 + col], in[16 + col], in[24 + col], in[32 + col], in[40 + col], in[48 + col], in[56 + col]};
-            int o[8];
-            hs_jpeg_idct8(d, o, 13 - 2);
-#pragma unroll
-            for (int r = 0; r < 8; r++) ws[8 * r + col] = o[r];
-         }
-      }
-      // pass 2: rows, descale by CONST_BITS + PASS1_BITS + 3, level shift and range limit
-      const int bx = (int)(k % (unsigned)g.bw[c]), by = (int)(k / (unsigned)g.bw[c]);
-      const int stride = g.bw[c] * 8;
-      uint8_t *dst = planes + (unsigned long long)b * g.plane_bytes + g.plane_off[c] + (unsigned long long)(by * 8) * stride + bx * 8;
+   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+   uint8_t *lds = s_cf[wv];
+   for (unsigned long long t0 = ((unsigned long long)blockIdx.x * 4 + wv) * 64; t0 < total; t0 += (unsigned long long)gridDim.x * 256) {
+      // image and block-in-image of the wavefront's first block (wave-uniform)
+      const unsigned int b0 = (unsigned int)(t0 / g.blocks_per_image);
+      const unsigned int k0 = (unsigned int)(t0 - (unsigned long long)b0 * g.blocks_per_image);
 #pragma unroll
       for (int r = 0; r < 8; r++) {
-         const int d[8] = {ws[8 * r], ws[8 * r + 1], ws[8 * r + 2], ws[8 * r + 3], ws[8 * r + 4], ws[8 * r + 5], ws[8 * r + 6], ws[8 * r + 7]};
-         int o[8];
-         hs_jpeg_idct8(d, o, 13 + 2 + 3);
-         uint2 w;
-         w.x = (unsigned)hs_jpeg_limit(o[0]) | ((unsigned)hs_jpeg_limit(o[1]) << 8) | ((unsigned)hs_jpeg_limit(o[2]) << 16) | ((unsigned)hs_jpeg_limit(o[3]) << 24);
-         w.y = (unsigned)hs_jpeg_limit(o[4]) | ((unsigned)hs_jpeg_limit(o[5]) << 8) | ((unsigned)hs_jpeg_limit(o[6]) << 16) | ((unsigned)hs_jpeg_limit(o[7]) << 24);
-         *reinterpret_cast<uint2 *>(dst + (unsigned long long)r * stride) = w;
+         const unsigned int idx = (unsigned int)(r * 8 + (lane >> 3));   // block of the wavefront this piece belongs to
+         unsigned int bb = b0, kk = k0 + idx;
+         while (kk >= g.blocks_per_image) { kk -= g.blocks_per_image; bb++; }   // at most once unless an image has fewer than 64 blocks
+         int4 v = make_int4(0, 0, 0, 0);
+         if (t0 + idx < total) v = *reinterpret_cast<const int4 *>(blobs + (unsigned long long)bb * g.blob_bytes + HESAFF_JPEG_BLOB_HEADER + (unsigned long long)kk * 128 + (lane & 7) * 16);
+         *reinterpret_cast<int4 *>(lds + idx * JPEG_LDS_ROW + (lane & 7) * 16) = v;
       }
+      HS_WAVE_LDS_SYNC();   // (the stores wait for their loads through the register dependence)
+      const unsigned long long t = t0 + lane;
+      if (t < total) {
+         unsigned int b = b0, k = k0 + (unsigned int)lane;
+         while (k >= g.blocks_per_image) { k -= g.blocks_per_image; b++; }
+         int c = 0;
+         if (k >= g.blocks[0]) { k -= g.blocks[0]; c = 1; if (k >= g.blocks[1]) { k -= g.blocks[1]; c = 2; } }
+         const uint16_t *q = reinterpret_cast<const uint16_t *>(blobs + (unsigned long long)b * g.blob_bytes) + 64 * c;
+         const int4 *cf = reinterpret_cast<const int4 *>(lds + lane * JPEG_LDS_ROW);
+         int ws[64];
+         // pass 1: columns, dequantisation inside (|int16 x uint16| < 2^31), results scaled up by PASS1_BITS
+         {
+            int in[64];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+               const int4 v = cf[r];   // eight int16 of row r
+               const int4 qq = reinterpret_cast<const int4 *>(q)[r];
+               const int vv[4] = {v.x, v.y, v.z, v.w}, qv[4] = {qq.x, qq.y, qq.z, qq.w};
+#pragma unroll
+               for (int j = 0; j < 4; j++) {
+                  in[8 * r + 2 * j] = (int)(short)(vv[j] & 0xffff) * (int)(qv[j] & 0xffff);
+                  in[8 * r + 2 * j + 1] = (int)(short)((unsigned)vv[j] >> 16) * (int)((unsigned)qv[j] >> 16);
+               }
+            }
+#pragma unroll
+            for (int col = 0; col < 8; col++) {
+               const int d[8] = {in[col], in[8 + col], in[16 + col], in[24 + col], in[32 + col], in[40 + col], in[48 + col], in[56 + col]};
+               int o[8];
+               hs_jpeg_idct8(d, o, 13 - 2);
+#pragma unroll
+               for (int r = 0; r < 8; r++) ws[8 * r + col] = o[r];
+            }
+         }
+         // pass 2: rows, descale by CONST_BITS + PASS1_BITS + 3, level shift and range limit
+         const int bx = (int)(k % (unsigned)g.bw[c]), by = (int)(k / (unsigned)g.bw[c]);
+         const int stride = g.bw[c] * 8;
+         uint8_t *dst = planes + (unsigned long long)b * g.plane_bytes + g.plane_off[c] + (unsigned long long)(by * 8) * stride + bx * 8;
+#pragma unroll
+         for (int r = 0; r < 8; r++) {
+            const int d[8] = {ws[8 * r], ws[8 * r + 1], ws[8 * r + 2], ws[8 * r + 3], ws[8 * r + 4], ws[8 * r + 5], ws[8 * r + 6], ws[8 * r + 7]};
+            int o[8];
+            hs_jpeg_idct8(d, o, 13 + 2 + 3);
+            uint2 w;
+            w.x = (unsigned)hs_jpeg_limit(o[0]) | ((unsigned)hs_jpeg_limit(o[1]) << 8) | ((unsigned)hs_jpeg_limit(o[2]) << 16) | ((unsigned)hs_jpeg_limit(o[3]) << 24);
+            w.y = (unsigned)hs_jpeg_limit(o[4]) | ((unsigned)hs_jpeg_limit(o[5]) << 8) | ((unsigned)hs_jpeg_limit(o[6]) << 16) | ((unsigned)hs_jpeg_limit(o[7]) << 24);
+            *reinterpret_cast<uint2 *>(dst + (unsigned long long)r * stride) = w;
+         }
+      }
+      HS_WAVE_LDS_SYNC();   // the next round's pieces overwrite what this round's lanes read
    }
 }
 

@@ -1041,6 +1041,18 @@ def test_device_jpeg_pixels_equal_the_host_reader(ctx, tmp_path):
                 assert got.shape == want.shape and np.array_equal(got, want), (h, w, sub, q, extra)
                 n += 1
     assert n >= 120
+    # luma sampled 4x1 / 1x4 (a 4:2:0 file with the sampling byte patched, tests/test_host_side.py): the replicating 4:1 up-sampling
+    import io
+    buf = io.BytesIO()
+    Image.fromarray(synth(64, 64, True)).save(buf, "JPEG", quality=85, subsampling=2)
+    raw = bytearray(buf.getvalue())
+    sof = raw.find(b"\xff\xc0")
+    for hv in (0x41, 0x14):
+        raw[sof + 11] = hv
+        open(p, "wb").write(raw)
+        lay, blob = hesaff_amd.read_jpeg_coefficients(p)
+        assert max(lay.hx[1], lay.vx[1]) == 4
+        assert np.array_equal(ctx.jpeg_pixels(lay, blob)[0], hesaff_amd.read_image(p)), hex(hv)
     # several images of one layout in one call (what a chunk is), a size that is no multiple of the MCU
     blobs, wants = [], []
     for k in range(5):

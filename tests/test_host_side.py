@@ -430,6 +430,18 @@ def test_read_jpeg_equals_libjpeg_on_many_encodings(tmp_path):
                 assert got.shape == ref.shape and np.array_equal(got, ref), (h, w, sub, q, extra)
                 n += 1
     assert n > 200
+    # 4:1:1 (luma 4x1) and its transpose (1x4): Pillow does not write them, but a 4:2:0 file whose luma sampling byte is patched has
+    # the same six blocks per MCU - the stream decodes, into other positions - and exercises the replicating 4:1 up-sampling
+    buf = io.BytesIO()
+    Image.fromarray(synth(64, 64, True)).save(buf, "JPEG", quality=85, subsampling=2)
+    raw = bytearray(buf.getvalue())
+    sof = raw.find(b"\xff\xc0")
+    assert sof > 0 and raw[sof + 11] == 0x22
+    for hv in (0x41, 0x14):
+        raw[sof + 11] = hv
+        open(p, "wb").write(raw)
+        ref = np.asarray(Image.open(p).convert("RGB"))
+        assert np.array_equal(hesaff_amd.read_image(p), ref), hex(hv)
     # truncated / corrupt files: an error or an image, never a crash
     raw = open(os.path.join(GOLD, "jpeg_420_q85.jpg"), "rb").read()
     for cut in (2, 20, 200, len(raw) // 2, len(raw) - 3):
