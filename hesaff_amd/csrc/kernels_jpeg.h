@@ -200,7 +200,11 @@ __global__ __launch_bounds__(256) void k_jpeg_pixels(const uint8_t *__restrict__
       return;
    }
    const int ycc = *reinterpret_cast<const int *>(blobs + (unsigned long long)b * g.blob_bytes + 384);
-   for (int i = 0; i < n; i++) {
+   const bool words = n == 4 && (g.W & 3) == 0 && (out_img_stride & 3) == 0;   // the thread's 12 bytes are three aligned words
+   unsigned int pk[3] = {0u, 0u, 0u};
+#pragma unroll
+   for (int i = 0; i < 4; i++) {
+      if (i >= n) break;
       int s[3];
 #pragma unroll
       for (int c = 0; c < 3; c++) s[c] = hs_jpeg_sample(pl + g.plane_off[c], g.bw[c] * 8, g.cw[c], g.chgt[c], g.mode[c], g.hx[c], g.vx[c], x0 + i, y);
@@ -211,6 +215,16 @@ __global__ __launch_bounds__(256) void k_jpeg_pixels(const uint8_t *__restrict__
          gg = hs_clamp8(Y + ((-22554 * cb + 32768 + -46802 * cr) >> 16));
          bb = hs_clamp8(Y + ((116130 * cb + 32768) >> 16));
       }
-      o[3 * i] = (uint8_t)r; o[3 * i + 1] = (uint8_t)gg; o[3 * i + 2] = (uint8_t)bb;
+      if (words) {
+         const unsigned int v[3] = {(unsigned)r, (unsigned)gg, (unsigned)bb};
+#pragma unroll
+         for (int k = 0; k < 3; k++) { const int at = 3 * i + k; pk[at >> 2] |= v[k] << (8 * (at & 3)); }
+      } else {
+         o[3 * i] = (uint8_t)r; o[3 * i + 1] = (uint8_t)gg; o[3 * i + 2] = (uint8_t)bb;
+      }
+   }
+   if (words) {
+      unsigned int *ow = reinterpret_cast<unsigned int *>(o);
+      ow[0] = pk[0]; ow[1] = pk[1]; ow[2] = pk[2];
    }
 }
