@@ -1,7 +1,7 @@
 # usage (through gpurun): HESAFF_DEBUG=1 python scripts/dbg_e2e.py <format 1|2> <write threads> [files] [chunk]
 # the file path of bench.py's end_to_end leg with the chunk engine's per-chunk host / device timings on stderr
 import sys, os
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, hesaff_amd, bench
 from hesaff_amd.synth import band_noise_batch_torch
 imgs = band_noise_batch_torch(32, 2160, 3840, seed=1234, device="cuda")
