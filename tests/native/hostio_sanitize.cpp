@@ -1,7 +1,8 @@
 // Sanitizer driver for the host side of the C ABI (test infrastructure; built by tests/test_host_sanitize.py with
 // g++ -fsanitize=address,undefined from hesaff_amd/csrc/hostio.cpp + jpeg_decode.cpp).
 //   hostio_sanitize read <file>...     every file through hesaff_read_image (any return code is fine: the point is
-//                                      that a damaged PNM / PNG / JPEG is refused without touching memory it does not own)
+//                                      that a damaged PNM / PNG / JPEG is refused without touching memory it does not own) and through
+//                                      hesaff_read_jpeg_coefficients (+ _alloc with a dirty recycled blob: same bytes)
 //   hostio_sanitize format <seed> <n>  n keypoints of random bit patterns (NaN, infinities, denormals included) through
 //                                      hesaff_ellipse / hesaff_format_sift / hesaff_format_sift_mt; both texts must agree
 #include <cstdint>
@@ -22,7 +23,7 @@ int main(int argc, char **argv)
 {
    if (argc < 2) return 2;
    if (!strcmp(argv[1], "read")) {
-      int ok = 0, bad = 0;
+      int ok = 0, bad = 0, coef = 0;
       for (int i = 2; i < argc; i++) {
          uint8_t *data = nullptr;
          int w = 0, h = 0, ch = 0;
@@ -38,8 +39,33 @@ int main(int argc, char **argv)
             if (data) return 3;   // an error must not hand out a buffer
             bad++;
          }
+         // the entropy-only half of the JPEG reader (what hesaff_process_files runs): fresh memory, then a recycled blob full of another
+         // image's bytes - the two blobs must be identical, and every byte the layout promises must be readable
+         hesaff_jpeg_layout L1, L2;
+         uint8_t *b1 = nullptr, *b2 = nullptr;
+         size_t n1 = 0, n2 = 0;
+         const int rc1 = hesaff_read_jpeg_coefficients(argv[i], &L1, &b1, &n1);
+         if (rc1 != HESAFF_OK) { if (b1) return 4; continue; }
+         size_t blocks = 0;
+         for (int c = 0; c < L1.channels; c++) blocks += (size_t)L1.bw[c] * L1.bh[c];
+         if (n1 != HESAFF_JPEG_BLOB_HEADER + blocks * 128) return 5;
+         unsigned sum = 0;
+         for (size_t k = 0; k < n1; k++) sum += b1[k];
+         if (sum == 0xffffffffu) puts("");
+         struct Dirty { size_t bytes; } dirty = {n1};
+         auto alloc = [](size_t bytes, int *zeroed, void *user) -> void * {
+            (void)user;
+            void *p = malloc(bytes);
+            if (p) memset(p, 0xA5, bytes);
+            *zeroed = 0;
+            return p;
+         };
+         const int rc2 = hesaff_read_jpeg_coefficients_alloc(argv[i], &L2, &b2, &n2, alloc, &dirty);
+         if (rc2 != HESAFF_OK || n2 != n1 || memcmp(&L1, &L2, sizeof L1) != 0 || memcmp(b1, b2, n1) != 0) return 6;
+         hesaff_free(b1); hesaff_free(b2);
+         coef++;
       }
-      printf("read ok=%d refused=%d\n", ok, bad);
+      printf("read ok=%d refused=%d coefficient blobs=%d\n", ok, bad, coef);
       return 0;
    }
    if (!strcmp(argv[1], "format") && argc >= 4) {
