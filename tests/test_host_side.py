@@ -503,6 +503,82 @@ def test_jpeg_coefficients_for_the_device_pixel_stage(tmp_path):
             pass
 
 
+def _idct_islow_numpy(coef, quant):
+    """jidctint.c (JDCT_ISLOW) on an array of blocks [n, 8, 8] int16 with one quantisation table [8, 8]: int64 arithmetic (a legal
+    stream never leaves 32 bits), the same constants, shifts and range limit as idct_islow / k_jpeg_idct -> uint8 [n, 8, 8]."""
+    F = dict(f0298=2446, f0390=3196, f0541=4433, f0765=6270, f0899=7373, f1175=9633, f1501=12299, f1847=15137, f1961=16069, f2053=16819,
+             f2562=20995, f3072=25172)
+
+    def pass1d(d, shift):   # d: [..., 8] along the transformed axis (last)
+        z2, z3 = d[..., 2], d[..., 6]
+        z1 = (z2 + z3) * F["f0541"]
+        tmp2 = z1 + z3 * -F["f1847"]
+        tmp3 = z1 + z2 * F["f0765"]
+        tmp0 = (d[..., 0] + d[..., 4]) << 13
+        tmp1 = (d[..., 0] - d[..., 4]) << 13
+        tmp10, tmp13, tmp11, tmp12 = tmp0 + tmp3, tmp0 - tmp3, tmp1 + tmp2, tmp1 - tmp2
+        t0, t1, t2, t3 = d[..., 7], d[..., 5], d[..., 3], d[..., 1]
+        z1, z2, z3, z4 = t0 + t3, t1 + t2, t0 + t2, t1 + t3
+        z5 = (z3 + z4) * F["f1175"]
+        t0, t1, t2, t3 = t0 * F["f0298"], t1 * F["f2053"], t2 * F["f3072"], t3 * F["f1501"]
+        z1, z2, z3, z4 = z1 * -F["f0899"], z2 * -F["f2562"], z3 * -F["f1961"] + z5, z4 * -F["f0390"] + z5
+        t0, t1, t2, t3 = t0 + z1 + z3, t1 + z2 + z4, t2 + z2 + z3, t3 + z1 + z4
+        out = np.stack([tmp10 + t3, tmp11 + t2, tmp12 + t1, tmp13 + t0, tmp13 - t0, tmp12 - t1, tmp11 - t2, tmp10 - t3], -1)
+        return (out + (1 << (shift - 1))) >> shift
+    d = coef.astype(np.int64) * quant.astype(np.int64)[None]
+    ws = pass1d(np.swapaxes(d, 1, 2), 13 - 2)          # columns: transform along the row index
+    ws = np.swapaxes(ws, 1, 2)
+    o = pass1d(ws, 13 + 2 + 3)                          # rows
+    v = o & 1023
+    v = np.where(v >= 512, v - 1024, v) + 128
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
+def test_jpeg_coefficient_blob_transforms_to_the_readers_pixels(tmp_path):
+    """CPU-side pin of the host half of the device JPEG path: the coefficient blob of a grey JPEG, put through a numpy restatement of
+    libjpeg's islow inverse DCT (the transform k_jpeg_idct runs), gives exactly the pixels hesaff_read_jpeg decodes - sequential and
+    progressive, restart intervals, a size that is no multiple of the block, the committed grey fixtures."""
+    Image = pytest.importorskip("PIL.Image")
+    import hesaff_amd
+    rng = np.random.default_rng(9)
+    files = [os.path.join(GOLD, "jpeg_gray_q90.jpg"), os.path.join(GOLD, "jpeg_prog_gray_q60.jpg")]
+    yy, xx = np.mgrid[0:67, 0:93]
+    a = np.clip(127 + 90 * np.sin(xx / 6.0) * np.cos(yy / 9.0) + rng.normal(0, 30, (67, 93)), 0, 255).astype(np.uint8)
+    for k, kw in enumerate([dict(quality=92), dict(quality=40, progressive=True), dict(quality=75, restart_marker_blocks=2)]):
+        q = str(tmp_path / ("g%d.jpg" % k))
+        Image.fromarray(a).save(q, "JPEG", **kw)
+        files.append(q)
+    for f in files:
+        lay, blob = hesaff_amd.read_jpeg_coefficients(f)
+        assert lay.channels == 1
+        bw, bh = lay.bw[0], lay.bh[0]
+        quant = blob[:128].view(np.uint16).reshape(8, 8)
+        coef = blob[1024:1024 + bw * bh * 128].view(np.int16).reshape(bw * bh, 8, 8)
+        blocks = _idct_islow_numpy(coef, quant).reshape(bh, bw, 8, 8)
+        plane = blocks.transpose(0, 2, 1, 3).reshape(bh * 8, bw * 8)
+        want = hesaff_amd.read_image(f)
+        assert np.array_equal(plane[:lay.height, :lay.width], want), f
+    # colour without sub-sampling: three planes + jdcolor.c's fixed-point conversion (what k_jpeg_pixels does for mode "none")
+    rgb = np.clip(np.stack([a, a[::-1], a[:, ::-1]], -1).astype(np.int32) + rng.integers(-20, 20, (67, 93, 3)), 0, 255).astype(np.uint8)
+    for k, kw in enumerate([dict(quality=88), dict(quality=60, progressive=True)]):
+        q = str(tmp_path / ("c%d.jpg" % k))
+        Image.fromarray(rgb).save(q, "JPEG", subsampling=0, **kw)
+        lay, blob = hesaff_amd.read_jpeg_coefficients(q)
+        assert lay.channels == 3 and list(lay.hx) == [1, 1, 1] and int(blob[384:388].view(np.int32)[0]) == 1
+        planes, at = [], 1024
+        for c in range(3):
+            bw, bh = lay.bw[c], lay.bh[c]
+            coef = blob[at:at + bw * bh * 128].view(np.int16).reshape(bw * bh, 8, 8)
+            at += bw * bh * 128
+            quant = blob[128 * c:128 * c + 128].view(np.uint16).reshape(8, 8)
+            blocks = _idct_islow_numpy(coef, quant).reshape(bh, bw, 8, 8)
+            planes.append(blocks.transpose(0, 2, 1, 3).reshape(bh * 8, bw * 8)[:lay.height, :lay.width].astype(np.int64))
+        Y, cb, cr = planes[0], planes[1] - 128, planes[2] - 128
+        got = np.stack([np.clip(Y + ((91881 * cr + 32768) >> 16), 0, 255), np.clip(Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16), 0, 255),
+                        np.clip(Y + ((116130 * cb + 32768) >> 16), 0, 255)], -1).astype(np.uint8)
+        assert np.array_equal(got, hesaff_amd.read_image(q)), kw
+
+
 def test_binary_sidecar_holds_the_rows_of_the_text_file(tmp_path):
     """hesaff_write_bin (optional sidecar): the same rows as the text export - x, y, the ellipse (a, b, c)
     and the 128 bytes - unprinted; the text file is the 6-significant-digit print of exactly these floats."""
