@@ -506,8 +506,17 @@ int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *
                               } else if (br.get(1)) blk[0] = (int16_t)(blk[0] | p1);   // DC refinement: one more bit
                            } else if (Ah == 0) {   // AC, first pass (decode_mcu_AC_first)
                               if (eobrun > 0) { eobrun--; continue; }
+                              const Huff &ac = hac[c->ta];
                               for (int k = Ss; k <= Se; k++) {
-                                 const int rs = decode_huff(br, hac[c->ta]);
+                                 const int fa = ac.fast_ac[br.peek(Huff::FAST_BITS)];
+                                 if (fa) {   // run, size and value in one look-up (as in the sequential scan below)
+                                    k += (fa >> 4) & 15;
+                                    br.skip(fa & 15);
+                                    if (k > 63) break;
+                                    blk[kZigZag[k]] = (int16_t)((unsigned)(fa >> 8) << Al);
+                                    continue;
+                                 }
+                                 const int rs = decode_huff(br, ac);
                                  const int r = rs >> 4, sz = rs & 15;
                                  if (sz) {
                                     k += r;

@@ -1,6 +1,6 @@
 # usage (through gpurun): python scripts/jpeg_list_rate.py [files=512] [width=3840] [height=2160]
 # hesaff_process_files on a list of colour JPEG photographs (mosaics of the two sample photographs, 4:2:0, quality 90, on a RAM disk)
-# with 2+2, 4+4 and 8+8 host threads: images/s with the pixels made on the device (the product) and - tuning build,
+# (JPEG_SUBSAMPLING=0|1|2, JPEG_PROGRESSIVE=1 for other encodings) with 2+2, 4+4 and 8+8 host threads: images/s with the pixels made on the device (the product) and - tuning build,
 # HESAFF_DEVICE_JPEG=0 - with the whole decode on the host threads.  One JSON line per case.
 import json, os, shutil, subprocess, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,13 +42,16 @@ if __name__ == "__main__":
         for i in range(n):   # 32 distinct mosaics, cycled
             q = os.path.join(tmp, "p%04d.jpg" % i)
             if i < 32:
-                Image.fromarray(synth.photo_mosaic(H, W, i, photos=photos)).save(q, quality=90, subsampling=2)
+                Image.fromarray(synth.photo_mosaic(H, W, i, photos=photos)).save(q, quality=90, subsampling=int(os.environ.get("JPEG_SUBSAMPLING", "2")),
+                                                                               progressive=os.environ.get("JPEG_PROGRESSIVE", "0") == "1")
             else:
                 shutil.copyfile(paths[i % 32], q)
             paths.append(q)
         lst = os.path.join(tmp, "list.txt")
         open(lst, "w").write("\n".join(paths) + "\n")
-        print(json.dumps({"files": n, "width": W, "height": H, "bytes_per_file": os.path.getsize(paths[0])}))
+        print(json.dumps({"files": n, "width": W, "height": H, "bytes_per_file": os.path.getsize(paths[0]),
+                          "subsampling": {"0": "4:4:4", "1": "4:2:2", "2": "4:2:0"}[os.environ.get("JPEG_SUBSAMPLING", "2")],
+                          "progressive": os.environ.get("JPEG_PROGRESSIVE", "0") == "1"}))
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         tuning = os.path.join(root, "hesaff_amd", "libhesaff_amd_tuning.so")
         for dev in ("1", "0"):
