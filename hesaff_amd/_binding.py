@@ -177,6 +177,7 @@ ABI_SYMBOLS = [
     "hesaff_process_files", "hesaff_write_sift_mt", "hesaff_write_bin", "hesaff_set_output_format",
     "hesaff_write_sift_rows", "hesaff_write_bin_rows", "hesaff_stage_export", "hesaff_stage_fmt_g", "hesaff_set_resume",
     "hesaff_output_is_complete", "hesaff_read_jpeg_coefficients", "hesaff_read_jpeg_coefficients_alloc", "hesaff_stage_jpeg_pixels",
+    "hesaff_read_pnm_alloc", "hesaff_read_image_alloc",
 ]
 
 

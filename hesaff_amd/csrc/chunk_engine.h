@@ -248,8 +248,9 @@ struct FileIO : ChunkIO {
       if (!bin) return o ? std::string(o) : std::string(paths[i]) + ".hesaff.sift";   // hesaff.cpp:170-173
       return o ? (std::string(o) + ((fmt & HESAFF_OUT_TEXT) ? ".bin" : "")) : std::string(paths[i]) + ".hesaff.bin";
    }
-   // coefficient blobs of images that have been copied to pinned memory go to the next decoder instead of back to the allocator
-   // (a UHD 4:4:4 photograph: 50 MB of fresh zero pages per image otherwise - a third of the entropy decoder's time)
+   // pixel buffers and coefficient blobs of images that have been copied to pinned memory go to the next decoder instead of back to the
+   // allocator (a UHD 4:4:4 photograph: 50 MB of fresh zero pages per image otherwise - a third of the entropy decoder's time; a UHD
+   // PGM file: 8 MB, a quarter of the read)
    std::vector<std::pair<uint8_t *, size_t>> blob_pool;   // under mu
    static void *blob_alloc(size_t bytes, int *zeroed, void *user)
    {
@@ -300,7 +301,7 @@ struct FileIO : ChunkIO {
          rc = hesaff_read_jpeg_coefficients_alloc(paths[i], &im.jpeg, &im.data, &im.blob_bytes, blob_alloc, this);
          if (rc == HESAFF_OK) { im.w = im.jpeg.width; im.h = im.jpeg.height; im.ch = im.jpeg.channels; }
       } else if (paths[i]) {
-         rc = hesaff_read_image(paths[i], &im.data, &im.w, &im.h, &im.ch);
+         rc = hesaff_read_image_alloc(paths[i], &im.data, &im.w, &im.h, &im.ch, blob_alloc, this);
       }
       int stage = HESAFF_FILE_UNREADABLE;
       if (rc == HESAFF_OK && (im.w > 65535 || im.h > 65535)) {   // the device plans 16-bit pixel coordinates (plan(), pipeline.hip)
@@ -358,7 +359,8 @@ struct FileIO : ChunkIO {
          std::lock_guard<std::mutex> lk(mu);
          for (int i : q.index) {
             Img &im = imgs[(size_t)i];
-            if (im.blob_bytes && (int)blob_pool.size() < window) blob_pool.emplace_back(im.data, im.blob_bytes);
+            const size_t bytes = im.blob_bytes ? im.blob_bytes : (size_t)im.w * im.h * im.ch;   // (every reader allocates exactly this)
+            if ((int)blob_pool.size() < window) blob_pool.emplace_back(im.data, bytes);
             else hesaff_free(im.data);
             im.data = nullptr;
          }

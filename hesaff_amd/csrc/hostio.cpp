@@ -337,6 +337,11 @@ void hesaff_free(void *p) { big_free(p); }
 //   * bitmaps (P1/P4): bit 0 = white (255), bit 1 = black (0); P4 rows are padded to whole bytes.
 int hesaff_read_pnm(const char *path, uint8_t **data, int *width, int *height, int *channels)
 {
+   return hesaff_read_pnm_alloc(path, data, width, height, channels, nullptr, nullptr);
+}
+
+int hesaff_read_pnm_alloc(const char *path, uint8_t **data, int *width, int *height, int *channels, hesaff_blob_alloc alloc, void *user)
+{
    if (!path || !data || !width || !height || !channels) return HESAFF_ERR_ARG;
    FILE *f = fopen(path, "rb");
    if (!f) return HESAFF_ERR_IO;
@@ -363,7 +368,8 @@ int hesaff_read_pnm(const char *path, uint8_t **data, int *width, int *height, i
                                      : plain ? (kind == 1 ? n : 2 * n - 1) : n * (maxv > 255 ? 2ull : 1ull);
       if (avail < need) { fclose(f); return HESAFF_ERR_IO; }
    }
-   uint8_t *buf = (uint8_t *)malloc(n);
+   int zeroed = 0;
+   uint8_t *buf = alloc ? (uint8_t *)alloc(n, &zeroed, user) : (uint8_t *)malloc(n);   // every byte is written below
    if (!buf) { fclose(f); return HESAFF_ERR_NOMEM; }
    bool ok = true;
    if (kind == 5 || kind == 6) {
@@ -433,12 +439,17 @@ int hesaff_read_png(const char *path, uint8_t **data, int *width, int *height, i
 // the imread of hesaff.cpp:137 for the formats this library decodes itself: PGM/PPM, PNG and baseline JPEG, by magic number
 int hesaff_read_image(const char *path, uint8_t **data, int *width, int *height, int *channels)
 {
+   return hesaff_read_image_alloc(path, data, width, height, channels, nullptr, nullptr);
+}
+
+int hesaff_read_image_alloc(const char *path, uint8_t **data, int *width, int *height, int *channels, hesaff_blob_alloc alloc, void *user)
+{
    if (!path || !data || !width || !height || !channels) return HESAFF_ERR_ARG;
    FILE *f = fopen(path, "rb");
    if (!f) return HESAFF_ERR_IO;
    const int c1 = fgetc(f), c2 = fgetc(f);
    fclose(f);
-   if (c1 == 'P' && c2 >= '1' && c2 <= '6') return hesaff_read_pnm(path, data, width, height, channels);
+   if (c1 == 'P' && c2 >= '1' && c2 <= '6') return hesaff_read_pnm_alloc(path, data, width, height, channels, alloc, user);
    if (c1 == 0x89 && c2 == 'P') return hesaff_read_png(path, data, width, height, channels);
    if (c1 == 0xFF && c2 == 0xD8) return hesaff_read_jpeg(path, data, width, height, channels);
    return HESAFF_ERR_IO;

@@ -244,6 +244,12 @@ int hesaff_read_png(const char *path, uint8_t **data, int *width, int *height, i
 int hesaff_read_jpeg(const char *path, uint8_t **data, int *width, int *height, int *channels);
 /* PGM/PPM, PNG or JPEG by magic number */
 int hesaff_read_image(const char *path, uint8_t **data, int *width, int *height, int *channels);
+/* the same with the pixel buffer from the caller's allocator (only the PNM reader asks it; see hesaff_blob_alloc below):
+ * hesaff_process_files recycles the buffers of images that have been copied to pinned memory - 8 MB of fresh pages per UHD
+ * image otherwise, a quarter of what reading a PGM file costs */
+typedef void *(*hesaff_blob_alloc)(size_t bytes, int *zeroed, void *user);
+int hesaff_read_pnm_alloc(const char *path, uint8_t **data, int *width, int *height, int *channels, hesaff_blob_alloc alloc, void *user);
+int hesaff_read_image_alloc(const char *path, uint8_t **data, int *width, int *height, int *channels, hesaff_blob_alloc alloc, void *user);
 
 /* The host half of cv::imread (hesaff.cpp:137) for a JPEG file when the pixels are made on the device (hesaff_process_files does this
  * for every JPEG of its list): markers and entropy decoding only - Huffman, sequential or progressive - which is the part of a JPEG
@@ -264,7 +270,6 @@ int hesaff_read_jpeg_coefficients(const char *path, hesaff_jpeg_layout *layout, 
 /* the same with the blob's memory from the caller: alloc(bytes, &zeroed, user) returns memory that free() accepts (or NULL) and says
  * whether it is already zero.  hesaff_process_files hands back the blobs of images that have gone to the device - a decoder thread
  * then writes into warm memory instead of 25 MB of fresh zero pages per photograph.  The blob's content does not depend on it. */
-typedef void *(*hesaff_blob_alloc)(size_t bytes, int *zeroed, void *user);
 int hesaff_read_jpeg_coefficients_alloc(const char *path, hesaff_jpeg_layout *layout, uint8_t **blob, size_t *blob_bytes,
                                         hesaff_blob_alloc alloc, void *user);
 
