@@ -103,8 +103,39 @@ __device__ __forceinline__ int hs_div_small(int idx, float inv)   // floor(idx /
 }
 
 // S: blurred window with row pitch `pitch`
-__device__ __forceinline__ void hs_resample_full_tab(const float *S, int pitch, const int *tab_i, const float *tab_f, float *out)
+#ifndef HS_RESAMPLE_COLS
+#define HS_RESAMPLE_COLS 1
+#endif
+template <int PITCH>
+__device__ __forceinline__ void hs_resample_full_tab(const float *S, const int *tab_i, const float *tab_f, float *out)
 {
+#if HS_RESAMPLE_COLS
+   // Thread t < 246 owns column ii = t % 41 of the rows jr, jr + 6, ... (jr = t / 41): the column's table entries and
+   // 1 - wx are registers, a row's entries are one broadcast read, and output index jj * 41 + ii = t + 246 k needs no
+   // division (the flat form below spends a third of its instructions on idx -> (jj, ii) and the four table reads).
+   constexpr int RPP = 256 / HS_PATCH;   // 6 rows per pass
+   const int t = threadIdx.x;
+   const int jr = hs_div_small(t, 1.0f / (float)HS_PATCH), ii = t - jr * HS_PATCH;
+   if (jr < RPP) {
+      const int xi = tab_i[ii];
+      const float wx = tab_f[ii], wx1 = 1.0f - wx;
+#pragma unroll
+      for (int k = 0; k < (HS_PATCH + RPP - 1) / RPP; k++) {
+         const int jj = jr + RPP * k;
+         if (jj < HS_PATCH) {
+            const int yi = tab_i[jj];
+            const float wy = tab_f[jj];
+            const bool in = (xi | yi) >= 0;
+            const float *p = S + (in ? yi * PITCH + xi : 0);
+            const float p00 = p[0], p01 = p[1], p10 = p[PITCH], p11 = p[PITCH + 1];
+            const float v = (1.0f - wy) * (wx1 * p00 + wx * p01) + (wy) * (wx1 * p10 + wx * p11);
+            float *o = out + t + RPP * HS_PATCH * k;
+            if (HS_NT_PATCH) hs_store_nt(o, in ? v : 0.0f); else *o = in ? v : 0.0f;
+         }
+      }
+   }
+#else
+   constexpr int pitch = PITCH;
    for (int idx = threadIdx.x; idx < HS_PATCH_PIX; idx += 256) {
       const int jj = hs_div_small(idx, 1.0f / (float)HS_PATCH), ii = idx - jj * HS_PATCH;
       const int xi = tab_i[ii], yi = tab_i[jj];
@@ -115,6 +146,7 @@ __device__ __forceinline__ void hs_resample_full_tab(const float *S, int pitch, 
       const float v = (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + (wy) * ((1.0f - wx) * p10 + wx * p11);
       if (HS_NT_PATCH) hs_store_nt(out + idx, in ? v : 0.0f); else out[idx] = in ? v : 0.0f;
    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -149,6 +181,9 @@ __device__ __forceinline__ void hs_resample_full_tab(const float *S, int pitch, 
 #endif
 #ifndef HS_MID_SCALAR_TAIL
 #define HS_MID_SCALAR_TAIL 0   // the same form in the one- and two-row variants (tail rows of a window, k_patch_large_rows): measured slower (182.8 vs 179.4, 33.9 vs 32.2 ms)
+#endif
+#ifndef HS_SMALL_WCOLS
+#define HS_SMALL_WCOLS 0   // tuning: the warp of the LDS-window bins with a fixed window column per thread (below); measured slower (profiles/r05_notes.md)
 #endif
 #ifndef HS_SMALL_SCALAR
 #define HS_SMALL_SCALAR 1   // the plain (pair) form of the LDS-window blur with scalar instead of packed operations: -186 register moves, no scratch; bin 0 156.6 -> 153.7 ms per 256 images
@@ -393,6 +428,47 @@ __global__ __launch_bounds__(256, (BIN == 0 ? HS_SMALL_WAVES : 0)) void k_patch_
       // batch issued before the first use.  The batch size is a compile-time constant picked per window (a switch on a
       // block-uniform value): a fixed WNIT would evaluate 1024 taps for a window of 23 x 23 = 529, and a test per slot
       // inside the batch would serialise the gathers (measured: slower than the waste).
+#if HS_SMALL_WCOLS
+      // Thread t owns window column ii = t % P of the rows jr, jr + rpp, ... (jr = t / P, rpp = 256 / P rows per pass; threads
+      // past rpp * P sample the last row again and store nothing): C[ii] and the LDS store address are per-thread constants, R[jj]
+      // is a broadcast read, and no tap needs idx -> (jj, ii) (twice per tap in the flat form: before the gather and at the store).
+      const int rpp = hs_div_small(256, invP);
+      const int jr = hs_div_small(tid, invP), ii0 = tid - jr * P;
+      const v2f cC = s_C[ii0];
+      float *sdst = S + jr * SPITCH + r + ii0;
+      const bool wact = jr < rpp;
+      auto warp_batch = [&](auto nbc, int kb) {
+         constexpr int NB = decltype(nbc)::value;
+         float wv[NB];
+#pragma unroll
+         for (int it = 0; it < NB; it++) {
+            const v2f w = s_R[min(jr + rpp * (kb + it), P - 1)] + cC;
+            wv[it] = hs_tap_inside(pbuf, w.x, w.y);
+         }
+#pragma unroll
+         for (int it = 0; it < NB; it++) HS_KEEP(wv[it]);
+#pragma unroll
+         for (int it = 0; it < NB; it++)
+            if (wact && jr + rpp * (kb + it) < P) sdst[rpp * (kb + it) * SPITCH] = wv[it];
+      };
+      {
+         int kb = 0;
+         for (int rem = hs_div_small(P + rpp - 1, 1.0f / (float)rpp); rem > 0;) {
+            const int nbatch = (rem + WNIT - 1) / WNIT;   // batches left; this one takes an even share of the passes
+            const int nb = (rem + nbatch - 1) / nbatch;
+            switch (nb) {
+               case 1: warp_batch(std::integral_constant<int, 1>{}, kb); break;
+               case 2: warp_batch(std::integral_constant<int, 2>{}, kb); break;
+               case 3: warp_batch(std::integral_constant<int, 3>{}, kb); break;
+               case 4: warp_batch(std::integral_constant<int, 4>{}, kb); break;
+               case 5: if (WNIT >= 5) warp_batch(std::integral_constant<int, (WNIT >= 5 ? 5 : 1)>{}, kb); break;
+               default: if (WNIT >= 6) warp_batch(std::integral_constant<int, (WNIT >= 6 ? 6 : 1)>{}, kb); break;
+            }
+            kb += nb;
+            rem -= nb;
+         }
+      }
+#else
       auto warp_batch = [&](auto nbc, int ib) {
          constexpr int NB = decltype(nbc)::value;
          float wv[NB];
@@ -431,6 +507,7 @@ __global__ __launch_bounds__(256, (BIN == 0 ? HS_SMALL_WAVES : 0)) void k_patch_
             rem -= nb;
          }
       }
+#endif
       __syncthreads();
       // 2. blur, affine.cpp:129 (pinned cv::GaussianBlur order, see the file header)
       switch (K) {
@@ -444,7 +521,7 @@ __global__ __launch_bounds__(256, (BIN == 0 ? HS_SMALL_WAVES : 0)) void k_patch_
          default: hs_small_blur<0, SPITCH, TPITCH, BLK>(S, T, P, s_taps, K); break;
       }
       // 3. resample, affine.cpp:131
-      hs_resample_full_tab(S, SPITCH, s_tab_i, s_tab_f, out);
+      hs_resample_full_tab<SPITCH>(S, s_tab_i, s_tab_f, out);
       __syncthreads();
    }
 }

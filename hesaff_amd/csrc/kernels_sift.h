@@ -266,12 +266,15 @@ __global__ void k_math_sift(int n, const float *__restrict__ gy, const float *__
 // The (mask*grad, o) rows of a step are fetched by the whole wave as consecutive 16-byte items and handed
 // out through LDS (see "Row staging" below), the next step's rows in flight while the current ones are consumed.
 // grid-stride over groups of 4 keypoints, block 64.
+#ifndef HS_HIST_TRIM
+#define HS_HIST_TRIM 1
+#endif
 #ifndef HS_HIST_WAVES
 #define HS_HIST_WAVES 0   // tuning: wavefronts per SIMD to hold the register allocation to (0: the compiler's choice)
 #endif
 __global__ __launch_bounds__(64, HS_HIST_WAVES) void k_sift_hist(SiftIO io, KpTables tb, const float2 *__restrict__ vo)
 {
-   __shared__ float s_acc[8 * 64];
+   __shared__ __attribute__((aligned(2048))) float s_acc[8 * 64];
    __shared__ float s_cw[64];   // [spatial bin][offset 0..15]
    const int tid = threadIdx.x;
    const int kq = tid >> 4, cell = tid & 15, cb_r = cell >> 2, cb_c = cell & 3;
@@ -292,6 +295,9 @@ __global__ __launch_bounds__(64, HS_HIST_WAVES) void k_sift_hist(SiftIO io, KpTa
    for (int j = 0; j < 16; j++) cwc[j] = s_cw[cb_c * 16 + j];
    const uint32_t n = io.h_hi - io.h_lo;
    float *acc = s_acc + tid;
+   // LDS pointers are 32-bit offsets (address space 3 behind the generic pointer): the lane's base with the bin bits clear
+   typedef __attribute__((address_space(3))) float lds_float;
+   const uint32_t acc_base = (uint32_t)(uintptr_t)(lds_float *)acc;
    // Row staging.  At step i the 64 lanes need, of each of the wave's four keypoints, the rows 8 cb_r + i (cb_r = 0..3):
    // 16 rows x 40 pixels x 8 bytes = 5 KB.  Read lane by lane (8 x 16 bytes each, rows 320 bytes and keypoints 12.8 KB
    // apart) every load instruction touches ~32 cache lines (texture addresser 78 % busy).  Instead the wave fetches the
@@ -350,6 +356,22 @@ __global__ __launch_bounds__(64, HS_HIST_WAVES) void k_sift_hist(SiftIO io, KpTa
                const float qy = (j & 1) ? cur[j >> 1].w : cur[j >> 1].y;
                const float wc = cwc[j] * qx;   // w[c] * (mask*grad)
                const float v = wr * wc;
+#if HS_HIST_TRIM
+               // siftdesc.cpp:63-77 in 14 instead of 19 vector instructions.  qy = o lies in [4, 12] (atan2f + 2 pi over 2 pi / 8), so
+               // o - (int)o is v_fract_f32 (exact); v is a product of non-negative finite factors (weights, mask, a gradient of
+               // finite pixels), i.e. +0 or positive: where the reference skips a term (`v > 0` false) v * wo is +0 and adding it
+               // leaves the bin as it is, so the compare and the two selects go; the two bin addresses are bit-field inserts of
+               // (int)o << 8 and ((int)o << 8) + 256 into the lane's base (s_acc is 2 KB-aligned, bits 8..10 select the bin).
+               const float wo1 = __builtin_amdgcn_fractf(qy);
+               const float wo0 = 1.0f - wo1;
+               const uint32_t x8 = (uint32_t)(int)qy << 8;
+               lds_float *p0 = (lds_float *)(uintptr_t)((x8 & 0x700u) | acc_base);
+               lds_float *p1 = (lds_float *)(uintptr_t)(((x8 + 0x100u) & 0x700u) | acc_base);
+               const float t0 = v * wo0, t1 = v * wo1;
+               const float a0 = *p0, a1 = *p1;   // bo0 != bo1: both reads in flight together
+               *p0 = a0 + t0;
+               *p1 = a1 + t1;
+#else
                const int io0 = (int)qy;
                const int bo0 = io0 & 7, bo1 = (io0 + 1) & 7;
                const float wo1 = qy - (float)io0;
@@ -360,6 +382,7 @@ __global__ __launch_bounds__(64, HS_HIST_WAVES) void k_sift_hist(SiftIO io, KpTa
                const float a0 = acc[64 * bo0], a1 = acc[64 * bo1];   // bo0 != bo1: both reads in flight together
                acc[64 * bo0] = a0 + t0;
                acc[64 * bo1] = a1 + t1;
+#endif
             }
          }
       }
