@@ -11,9 +11,12 @@ Prints ONE JSON line (rank 0):
                 records left in HBM (hesaff_detect_batch_device) -- the harness contract for `value`;
   host_path     the same batch through hesaff_detect_batch: host images in -> H2D -> kernels -> D2H -> host
                 records out, chunks pipelined (SURVEY.md 8d: "H2D -> D2H inclusive"), in the same run;
-  end_to_end    hesaff_process_files on EVERY rank at once: PGM files on a RAM disk -> decode threads -> device (rows of the
-                .hesaff.sift files formatted by the GPU) -> writer threads that only write(); each rank with the host-thread
-                budget one device of an 8-GPU node gets (2 + 2 threads); aggregate over the ranks;
+  end_to_end    hesaff_process_files on EVERY rank at once: PGM files on a RAM disk -> pool threads read them into pinned buffers ->
+                device (rows of the .hesaff.sift files formatted by the GPU) -> the pool write()s; 2 + 2 pool threads per rank, not
+                confined to a CPU share; aggregate over the ranks, CPU seconds per image beside the rate;
+  end_to_end_budgeted  the same, every rank's run as a child process pinned - before it loads anything - to one device's share of
+                the host (CPU quota / 8) with the thread counts of the library's rule (hesaff_host_plan_for): the stand-in for the
+                per-device end-to-end rate of an 8-GPU node;
   text_export   the host formatter alone (hesaff_write_sift_batch, the stage API's writer) on a bounded subset;
   photo_density the same device-resident step on mosaics of real photographs (scikit-learn's sample images);
   roofline      the dominant pyramid kernel (k_blur_hess_march: Gaussian + det-of-Hessian), timed live with HIP
@@ -215,11 +218,14 @@ def jpeg_path_leg(hesaff_amd, W, H, n_files, chunk, device, decode_threads, writ
             for q in paths:
                 if os.path.exists(q + ".hesaff.bin"):
                     os.remove(q + ".hesaff.bin")
+            c0 = _cpu_seconds()
             t = time.perf_counter()
             st = ctx.process_files(paths, decode_threads=decode_threads, write_threads=write_threads)
             dt = time.perf_counter() - t
+            cpu_s = _cpu_seconds() - c0
         bad = [s for s in st if s[0] != 0]
         return {"images": n_files, "images_per_s": n_files / dt, "value": sum(s[3] for s in st) / dt, "unit": "keypoints/s", "seconds": dt,
+                "cpu_seconds_per_image": cpu_s / n_files, "cpus_busy": cpu_s / dt,
                 "failed_files": len(bad), "input_bytes_per_file": os.path.getsize(paths[0]), "chunk_images": chunk,
                 "decode_threads": decode_threads, "write_threads": write_threads, "output": "binary sidecar",
                 "what": "hesaff_process_files: %d colour JPEG files (%dx%d mosaics of two photographs, 32 distinct, 4:2:0, quality 90) on a RAM disk -> %d host "
@@ -230,66 +236,166 @@ def jpeg_path_leg(hesaff_amd, W, H, n_files, chunk, device, decode_threads, writ
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def _e2e_files(host_imgs, W, H, n_files, chunk, world):
+    """n PGM files of the bench images on a RAM disk -> (tmp dir, paths, header length), or (None, reason, 0) when it is too small."""
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="hesaff_e2e_", dir=base)
+    # inputs 1 byte per pixel, outputs about 5.3 bytes per pixel at the dense images' 14 k descriptors per Mpx
+    per_image = W * H * 7
+    free = shutil.disk_usage(tmp).free
+    try:   # a RAM disk's pages are host memory: never plan for more than a quarter of what is available, over all ranks
+        avail = [int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable:")][0]
+        free = min(free, avail)
+    except (OSError, IndexError, ValueError):
+        pass
+    n = int(max(0, min(n_files, (free * (0.6 if world == 1 else 0.25) / max(world, 1)) // per_image)))
+    if n < 2 * chunk:
+        shutil.rmtree(tmp, ignore_errors=True)
+        return None, "RAM disk too small: %d bytes free for %d images on %d rank(s)" % (free, n_files, world), 0
+    paths = []
+    hdr = b"P5\n%d %d\n255\n" % (W, H)
+    for i in range(n):
+        q = os.path.join(tmp, "img%04d.pgm" % i)
+        with open(q, "wb") as f:
+            f.write(hdr); f.write(host_imgs[i % len(host_imgs)].tobytes())
+        paths.append(q)
+    return tmp, paths, len(hdr)
+
+
+def _cpu_seconds():
+    """user + system CPU time of this process, all threads (getrusage): what a file leg costs the host."""
+    import resource
+    r = resource.getrusage(resource.RUSAGE_SELF)
+    return r.ru_utime + r.ru_stime
+
+
+def _timed_file_run(hesaff_amd, paths, chunk, device, fmt, decode_threads, write_threads, sync=None):
+    """One warm-up (3 chunks) and one timed hesaff_process_files over `paths`; -> dict with wall seconds, CPU seconds, rows, bytes."""
+    p = hesaff_amd.default_params()
+    p.max_batch = chunk
+    ext = ".hesaff.sift" if fmt == 1 else ".hesaff.bin"
+    with hesaff_amd.HesaffContext(p, device=device) as ctx:
+        ctx.set_output_format(fmt)
+        ctx.set_profiling(1)
+        warm = ctx.process_files(paths[: 3 * chunk], decode_threads=decode_threads, write_threads=write_threads)   # buffers (all three pinned blocks, the readers' pinned buffers), page cache, thread start-up
+        for q in paths[: 3 * chunk]:
+            os.remove(q + ext)
+        if sync:
+            sync()
+        c0 = _cpu_seconds()
+        t0 = time.perf_counter()
+        st = ctx.process_files(paths, decode_threads=decode_threads, write_threads=write_threads)
+        dt = time.perf_counter() - t0
+        cpu = _cpu_seconds() - c0
+        threads = int(ctx.L.hesaff_host_threads())
+        tmx = ctx.timings()
+    bad = [i for i, s_ in enumerate(st) if s_[0] != 0 or s_[1] != 3] + [i for i, s_ in enumerate(warm) if s_[0] != 0]
+    nbytes = sum(os.path.getsize(q + ext) for q in paths)
+    rows = sum(s_[3] for s_ in st)
+    n = len(paths)
+    return {"images": n, "images_per_s": n / dt, "value": rows / dt, "unit": "keypoints/s", "seconds": dt, "chunk_images": chunk,
+            "output": "text (.hesaff.sift, the reference's format)" if fmt == 1 else "binary sidecar (.hesaff.bin, 148 bytes per row)",
+            "failed_files": len(bad), "output_GB_per_s": nbytes / dt / 1e9, "output_GB": nbytes / 1e9,
+            "rows": rows, "output_bytes": nbytes, "cpu_seconds": cpu, "cpu_seconds_per_image": cpu / n, "cpus_busy": cpu / dt,
+            "device_export_ms_last_chunk": tmx.export_ms, "device_export_rows_last_chunk": tmx.export_rows,
+            "decode_threads": decode_threads, "write_threads": write_threads, "host_threads_available": threads}
+
+
 def file_path_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, fmt=1, decode_threads=2, write_threads=2, world=1, sync=None):
     """hesaff_process_files (what `hesaff --batch` runs: decode threads -> chunks through the device, rows formatted there ->
     writer threads that only write) on n_files binary PGM files of the bench images on a RAM disk, every <name>.hesaff.sift
     written there too.  One timed run over the whole list, pipeline fill and drain included.  Every rank runs this at the same
     time (`sync` = barrier before the timed run) with the same host-thread budget."""
-    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
-    tmp = tempfile.mkdtemp(prefix="hesaff_e2e_", dir=base)
+    tmp, paths, hl = _e2e_files(host_imgs, W, H, n_files, chunk, world)
+    if tmp is None:
+        if sync:
+            sync()
+        return {"skipped": paths}
     try:
-        # inputs 1 byte per pixel, outputs about 5.3 bytes per pixel at the dense images' 14 k descriptors per Mpx
-        per_image = W * H * 7
-        free = shutil.disk_usage(tmp).free
-        try:   # a RAM disk's pages are host memory: never plan for more than a quarter of what is available, over all ranks
-            avail = [int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable:")][0]
-            free = min(free, avail)
-        except (OSError, IndexError, ValueError):
-            pass
-        n = int(max(0, min(n_files, (free * (0.6 if world == 1 else 0.25) / max(world, 1)) // per_image)))
-        if n < 2 * chunk:
-            if sync:
-                sync()
-            return {"skipped": "RAM disk too small: %d bytes free for %d images on %d rank(s)" % (free, n_files, world)}
-        paths = []
-        hdr = b"P5\n%d %d\n255\n" % (W, H)
-        for i in range(n):
-            q = os.path.join(tmp, "img%04d.pgm" % i)
-            with open(q, "wb") as f:
-                f.write(hdr); f.write(host_imgs[i % len(host_imgs)].tobytes())
-            paths.append(q)
-        p = hesaff_amd.default_params()
-        p.max_batch = chunk
+        r = _timed_file_run(hesaff_amd, paths, chunk, device, fmt, decode_threads, write_threads, sync)
+        n = len(paths)
         ext = ".hesaff.sift" if fmt == 1 else ".hesaff.bin"
-        with hesaff_amd.HesaffContext(p, device=device) as ctx:
-            ctx.set_output_format(fmt)
-            ctx.set_profiling(1)
-            warm = ctx.process_files(paths[: 3 * chunk], decode_threads=decode_threads, write_threads=write_threads)   # buffers (all three pinned blocks), page cache, thread start-up
-            for q in paths[: 3 * chunk]:
-                os.remove(q + ext)
-            if sync:
-                sync()
-            t0 = time.perf_counter()
-            st = ctx.process_files(paths, decode_threads=decode_threads, write_threads=write_threads)
-            dt = time.perf_counter() - t0
-            threads = int(ctx.L.hesaff_host_threads())
-            tmx = ctx.timings()
-        bad = [i for i, s_ in enumerate(st) if s_[0] != 0 or s_[1] != 3] + [i for i, s_ in enumerate(warm) if s_[0] != 0]
-        nbytes = sum(os.path.getsize(q + ext) for q in paths)
-        rows = sum(s_[3] for s_ in st)
-        return {"images": n, "images_per_s": n / dt, "value": rows / dt, "unit": "keypoints/s", "seconds": dt, "chunk_images": chunk,
-                "output": "text (.hesaff.sift, the reference's format)" if fmt == 1 else "binary sidecar (.hesaff.bin, 148 bytes per row)",
-                "failed_files": len(bad), "output_GB_per_s": nbytes / dt / 1e9, "input_GB": n * (W * H + len(hdr)) / 1e9, "output_GB": nbytes / 1e9,
-                "rows": rows, "output_bytes": nbytes,
-                "device_export_ms_last_chunk": tmx.export_ms, "device_export_rows_last_chunk": tmx.export_rows,
-                "decode_threads": decode_threads, "write_threads": write_threads, "host_threads_available": threads, "target": tmp.rsplit("/", 1)[0],
-                "what": "hesaff_process_files: %d binary PGM files (%dx%d, the bench images) on a RAM disk -> %d decode threads -> chunks of %d "
-                        "images through the device (copy in, kernels, rows of the output files formatted on the device, copy out, all overlapped) "
-                        "-> %d writer threads (write() only) -> %d %s files on the RAM disk; one timed run, pipeline fill and drain included "
-                        "(hesaff.cpp:133-180 for a list of files); the thread budget is what one device of an 8-GPU node gets from this "
-                        "host's CPU quota" % (n, W, H, decode_threads, chunk, write_threads, n, ext)}
+        r.update({"input_GB": n * (W * H + hl) / 1e9, "target": tmp.rsplit("/", 1)[0],
+                  "what": "hesaff_process_files: %d binary PGM files (%dx%d, the bench images) on a RAM disk -> read straight into pinned buffers by the pool's threads "
+                          "-> chunks of %d images through the device (copy in, kernels, rows of the output files formatted on the device, copy out, all overlapped) "
+                          "-> the pool (%d + %d threads) write()s -> %d %s files on the RAM disk; one timed run, pipeline fill and drain included "
+                          "(hesaff.cpp:133-180 for a list of files); threads NOT confined to a CPU share: see end_to_end_budgeted for one device's share of the host"
+                          % (n, W, H, chunk, decode_threads, write_threads, n, ext)})
+        return r
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+BUDGET_SHARE = 8   # devices that share the host in the budgeted leg: one rank of an 8-GPU node (BASELINE.json config 4)
+
+
+def budgeted_child(cfg):
+    """`bench.py --budgeted-child <json>`: the file path of ONE device inside its share of the host.  The CPU mask is set FIRST - before
+    numpy, torch or the library exist in this process - so every thread the run creates (the pool, the staging thread, the HIP
+    runtime's own) is confined to it, and the library's own rule (hesaff_host_plan_for) sees the share as "the host"."""
+    os.sched_setaffinity(0, set(cfg["cpus"]))
+    import hesaff_amd
+    hp = hesaff_amd.host_plan(1)          # == host_plan(BUDGET_SHARE) on the whole quota
+    paths = [os.path.join(cfg["dir"], "img%04d.pgm" % i) for i in range(cfg["n"])]
+
+    def sync():   # all ranks' children start their timed run together (files in a directory every rank knows)
+        d = cfg.get("sync_dir")
+        if not d or cfg["world"] <= 1:
+            return
+        os.makedirs(d, exist_ok=True)
+        open(os.path.join(d, "ready.%d.%d" % (cfg["phase"][0], cfg["rank"])), "w").close()
+        t_end = time.time() + 180
+        while time.time() < t_end and len([q for q in os.listdir(d) if q.startswith("ready.%d." % cfg["phase"][0])]) < cfg["world"]:
+            time.sleep(0.002)
+        cfg["phase"][0] += 1
+
+    cfg["phase"] = [0]
+    out = {"cpus": sorted(os.sched_getaffinity(0)), "plan": hp}
+    for name, fmt in (("text", 1), ("sidecar", 2)):
+        r = _timed_file_run(hesaff_amd, paths, cfg["chunk"], cfg["device"], fmt, hp["decode_threads"], hp["write_threads"], sync)
+        ext = ".hesaff.sift" if fmt == 1 else ".hesaff.bin"
+        if cfg.get("md5"):   # tests: what was written
+            import hashlib
+            r["md5"] = [hashlib.md5(open(q + ext, "rb").read()).hexdigest() for q in paths]
+        for q in paths:
+            if os.path.exists(q + ext):
+                os.remove(q + ext)
+        out[name] = r
+    print(json.dumps(out))
+    return 0
+
+
+def budgeted_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, rank, world, sync):
+    """The file path inside ONE device's share of the host: the CPUs this job may use (affinity mask, capped by the
+    cgroup quota: hesaff_host_threads) divided by BUDGET_SHARE = 8 devices, whatever `world` is; rank r's child process is pinned
+    to the r-th such slice before it loads anything, takes its thread counts from the library's rule and reports CPU seconds
+    (getrusage) beside the rate.  Returns the child's dict or {"skipped": ...}."""
+    import subprocess
+    quota = int(hesaff_amd.load_library().hesaff_host_threads())
+    k = max(1, quota // BUDGET_SHARE)
+    allowed = sorted(os.sched_getaffinity(0))
+    cpus = [allowed[(rank * k + j) % len(allowed)] for j in range(k)]
+    tmp, paths, hl = _e2e_files(host_imgs, W, H, n_files, chunk, world)
+    if sync:
+        sync()
+    if tmp is None:
+        return {"skipped": paths}
+    try:
+        cfg = {"dir": tmp, "n": len(paths), "chunk": chunk, "device": device, "cpus": cpus, "rank": rank, "world": world,
+               "sync_dir": os.path.join(os.path.dirname(tmp), "hesaff_sync_%s" % os.environ.get("MASTER_PORT", "0"))}
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--budgeted-child", json.dumps(cfg)], capture_output=True, text=True, timeout=900)
+        if r.returncode != 0 or not r.stdout.strip():
+            return {"skipped": "the child failed (%d): %s" % (r.returncode, r.stderr[-300:])}
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        d["quota_cpus"] = quota
+        d["share"] = "1/%d of the host: %d CPU(s) of %d" % (BUDGET_SHARE, k, quota)
+        return d
+    except subprocess.TimeoutExpired:
+        return {"skipped": "the child did not finish in 900 s"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+        if rank == 0:
+            shutil.rmtree(os.path.join(os.path.dirname(tmp), "hesaff_sync_%s" % os.environ.get("MASTER_PORT", "0")), ignore_errors=True)
 
 
 def launch_ranks(n):
@@ -314,6 +420,8 @@ def launch_ranks(n):
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--budgeted-child":
+        raise SystemExit(budgeted_child(json.loads(sys.argv[2])))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -328,15 +436,16 @@ def main():
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-inclusive and text-export legs")
     ap.add_argument("--host-chunk", type=int, default=64, help="images per pipelined chunk of the host path (hesaff_params.max_batch)")
     ap.add_argument("--export-images", type=int, default=32, help="images of the batch written as .hesaff.sift text (RAM disk)")
-    ap.add_argument("--cpu-images", type=int, default=4, help="images of the batch timed on the CPU oracle, 1 thread (about 14 s each)")
+    ap.add_argument("--cpu-images", type=int, default=8, help="images of the batch timed on the CPU oracle, 1 thread (about 14 s each; SURVEY.md 8d: at least 8 for 4K)")
     ap.add_argument("--cpu-workers", type=int, default=-1,
                     help="worker processes of the multi-core CPU baseline, one image each (-1: one per physical core, at most the batch; 0: skip)")
     ap.add_argument("--fast-steps", type=int, default=2, help="steps of the fast-mode leg (hesaff_params.fast = 2) of the default run (0: skip)")
     ap.add_argument("--photo-steps", type=int, default=2, help="steps of the extra leg on photographs of the default run (0: skip)")
     ap.add_argument("--e2e-decode-threads", type=int, default=2, help="decoder threads of the end-to-end leg, per rank")
-    ap.add_argument("--e2e-write-threads", type=int, default=2, help="writer threads of the end-to-end leg, per rank (2 + 2 = one device's share of 16 CPUs over 8 GPUs)")
+    ap.add_argument("--e2e-write-threads", type=int, default=2, help="writer threads of the end-to-end leg, per rank (the leg is not confined to a CPU share: end_to_end_budgeted is)")
     ap.add_argument("--e2e-images", type=int, default=512, help="image files of the measured end-to-end file path (0: skip; fewer when the RAM disk is small)")
     ap.add_argument("--jpeg-images", type=int, default=384, help="colour JPEG photographs of the JPEG file-path leg (0: skip)")
+    ap.add_argument("--no-budgeted", dest="budgeted", action="store_false", help="skip the end_to_end_budgeted leg (the file path confined to one device's share of the host's CPUs)")
     ap.add_argument("--e2e-chunk", type=int, default=32, help="images per device chunk of the end-to-end leg (hesaff_params.max_batch)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: every rank owns --batch images per step; strong: --global-images images per step in total, "
@@ -460,6 +569,7 @@ def main():
     # ---- host-inclusive legs, EVERY rank at the same time: hesaff_detect_batch, then the file path ----
     host_path = None
     end_to_end = None
+    end_to_end_budgeted = None
     host_imgs = None
     if not args.no_host_path:
         hp = hesaff_amd.default_params()
@@ -489,12 +599,13 @@ def main():
         hctx.close()
         # the whole file path, measured on every rank at once: image files -> decode -> device -> .hesaff.sift files (hesaff.cpp:133-180)
         if args.e2e_images > 0:
-            def e2e(fmt):
-                r = file_path_leg(hesaff_amd, host_imgs, W, H, args.e2e_images, args.e2e_chunk, local_rank, fmt=fmt,
-                                  decode_threads=args.e2e_decode_threads, write_threads=args.e2e_write_threads, world=world, sync=barrier)
+            quota_cpus = int(hesaff_amd.load_library().hesaff_host_threads())
+
+            def combine(r):
+                """One rank's file-leg dict -> the aggregate over all ranks (rank 0), None elsewhere."""
                 barrier()
                 ok = "images_per_s" in r
-                mine = [r["images"], r["rows"], r["failed_files"], r["output_bytes"], 1] if ok else [0, 0, 0, 0, 0]
+                mine = [r["images"], r["rows"], r["failed_files"], r["output_bytes"], 1, int(r["cpu_seconds"] * 1e6)] if ok else [0, 0, 0, 0, 0, 0]
                 sec = r["seconds"] if ok else 0.0
                 if grouped:
                     t = torch.tensor([sec], device=coll_dev, dtype=torch.float64)
@@ -506,16 +617,42 @@ def main():
                 if int(g[:, 4].sum()) != world or sec <= 0:
                     return r if not ok else {"skipped": "the leg did not run on every rank"}
                 tot = g.sum(axis=0)
-                r.update({"images": int(tot[0]), "images_per_s": float(tot[0]) / sec, "value": float(tot[1]) / sec, "rows": int(tot[1]),
+                cpu_s = float(tot[5]) / 1e6
+                rate = float(tot[0]) / sec
+                r.update({"images": int(tot[0]), "images_per_s": rate, "value": float(tot[1]) / sec, "rows": int(tot[1]),
                           "failed_files": int(tot[2]), "output_bytes": int(tot[3]), "output_GB": float(tot[3]) / 1e9,
                           "output_GB_per_s": float(tot[3]) / sec / 1e9, "seconds": sec, "ranks": world,
                           "per_rank_images": [int(v) for v in g[:, 0]],
-                          "fraction_of_host_path": (float(tot[0]) / sec) / host_path["images_per_s"]})
+                          "cpu_seconds": cpu_s, "cpu_seconds_per_image": cpu_s / max(float(tot[0]), 1.0), "cpus_busy": cpu_s / sec,
+                          # devices that could run at this leg's per-device rate on the CPU seconds the quota provides
+                          "max_devices_at_this_quota": int(quota_cpus / max(cpu_s / max(float(tot[0]), 1.0) * (rate / world), 1e-9)),
+                          "quota_cpus": quota_cpus,
+                          "fraction_of_host_path": rate / host_path["images_per_s"]})
                 return r
+
+            def e2e(fmt):
+                return combine(file_path_leg(hesaff_amd, host_imgs, W, H, args.e2e_images, args.e2e_chunk, local_rank, fmt=fmt,
+                                             decode_threads=args.e2e_decode_threads, write_threads=args.e2e_write_threads, world=world, sync=barrier))
             end_to_end = e2e(1)
             eb = e2e(2)
             if rank == 0 and end_to_end is not None:
                 end_to_end["binary_sidecar"] = eb
+            # the same list inside ONE device's share of the host: a child process per rank, pinned before it loads anything
+            if args.budgeted:
+                bd = budgeted_leg(hesaff_amd, host_imgs, W, H, args.e2e_images, args.e2e_chunk, local_rank, rank, world, barrier)
+                legs = {}
+                for name in ("text", "sidecar"):
+                    legs[name] = combine(dict(bd[name]) if name in bd else {"skipped": bd.get("skipped", "no result")})
+                if rank == 0:
+                    end_to_end_budgeted = {
+                        "what": "hesaff_process_files as in end_to_end, but every rank's run is a child process confined (sched_setaffinity before it "
+                                "loads numpy, torch or the library) to ONE device's share of the host - the CPUs this job may use divided by %d "
+                                "devices, whatever --gpus is - with the thread counts the library's rule gives for that share "
+                                "(hesaff_host_plan_for: include/hesaff_amd.h); cpu_seconds = getrusage of the child around the timed run; "
+                                "max_devices_at_this_quota = quota_cpus / (cpu_seconds_per_image x images_per_s per device). "
+                                "A thread write()s about 6 GB/s of new RAM-disk pages: the text leg (46 MB per dense UHD image) is bound by that, "
+                                "the sidecar (17 MB) is not" % BUDGET_SHARE,
+                        "share": bd.get("share"), "cpus_rank0": bd.get("cpus"), "plan": bd.get("plan"), "text": legs["text"], "binary_sidecar": legs["sidecar"]}
 
     # ---- from here on rank 0 alone (no collective follows: the other ranks are done) ----
     if grouped and rank != 0:
@@ -597,6 +734,7 @@ def main():
             "host_path": host_path,
             "text_export": text_export,
             "end_to_end": end_to_end,
+            "end_to_end_budgeted": end_to_end_budgeted,
             "photo_density": photo,
             "jpeg_path": jpeg_path,
             "fast_modes": fast_modes,

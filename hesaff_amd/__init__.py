@@ -24,6 +24,7 @@ from ._binding import (  # noqa: F401
     ellipse,
     lib_path,
     load_library,
+    host_plan,
     table_gauss_mask,
     table_circ_gauss_mask,
     table_sift_bins,

@@ -55,13 +55,27 @@ _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
-ABI_VERSION = 5   # HESAFF_ABI_VERSION of the include/hesaff_amd.h these ctypes structs mirror
+ABI_VERSION = 6   # HESAFF_ABI_VERSION of the include/hesaff_amd.h these ctypes structs mirror
 
 
 class JpegLayout(C.Structure):
     """hesaff_jpeg_layout: what the JPEG images of one device chunk share."""
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32)] + \
                [(n, C.c_int32 * 3) for n in ("h", "v", "hx", "vx", "bw", "bh", "cw", "chgt")]
+
+
+class HostPlan(C.Structure):
+    """hesaff_host_plan: one device's share of the host (hesaff_host_plan_for)"""
+    _fields_ = [("cpus", C.c_int), ("decode_threads", C.c_int), ("write_threads", C.c_int), ("stage_threads", C.c_int)]
+
+
+def host_plan(devices_sharing_host=1):
+    """The library's one rule for host threads per device: dict(cpus, decode_threads, write_threads, stage_threads)."""
+    hp = HostPlan()
+    rc = load_library().hesaff_host_plan_for(int(devices_sharing_host), C.byref(hp))
+    if rc != 0:
+        raise HesaffError(rc, "hesaff_host_plan_for(%r)" % (devices_sharing_host,))
+    return {k: int(getattr(hp, k)) for k, _ in HostPlan._fields_}
 
 
 class FileStatus(C.Structure):
@@ -130,6 +144,8 @@ def load_library():
     L.hesaff_format_sift_mt.argtypes = [vp, C.c_int, C.c_float, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.hesaff_host_threads.argtypes = []
     L.hesaff_host_threads.restype = C.c_int
+    L.hesaff_host_plan_for.argtypes = [C.c_int, C.POINTER(HostPlan)]
+    L.hesaff_host_plan_for.restype = C.c_int
     L.hesaff_write_sift_batch.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(_Result), C.c_float, C.c_int]
     L.hesaff_test_fmt_g.argtypes = [_f32p, C.c_int]
     L.hesaff_free.argtypes = [vp]; L.hesaff_free.restype = None
@@ -173,7 +189,7 @@ ABI_SYMBOLS = [
     "hesaff_stage_math", "hesaff_stage_math_sift", "hesaff_table_gauss_mask", "hesaff_table_circ_gauss_mask", "hesaff_table_sift_bins",
     "hesaff_table_gauss_kernel", "hesaff_format_sift_mt", "hesaff_write_sift_batch", "hesaff_test_fmt_g",
     "hesaff_read_png", "hesaff_read_image", "hesaff_device_count", "hesaff_shard_range", "hesaff_read_jpeg",
-    "hesaff_host_threads", "hesaff_abi_version", "hesaff_sizeof_params", "hesaff_sizeof_timings", "hesaff_detect_batch_cb",
+    "hesaff_host_threads", "hesaff_host_plan_for", "hesaff_abi_version", "hesaff_sizeof_params", "hesaff_sizeof_timings", "hesaff_detect_batch_cb",
     "hesaff_process_files", "hesaff_write_sift_mt", "hesaff_write_bin", "hesaff_set_output_format",
     "hesaff_write_sift_rows", "hesaff_write_bin_rows", "hesaff_stage_export", "hesaff_stage_fmt_g", "hesaff_set_resume",
     "hesaff_output_is_complete", "hesaff_read_jpeg_coefficients", "hesaff_read_jpeg_coefficients_alloc", "hesaff_stage_jpeg_pixels",

@@ -239,12 +239,14 @@ void hesaff_destroy(hesaff_ctx *c)
    for (int i = 0; i < 2; i++) {
       c->b_in2[i].release(); c->b_outstage[i].release(); c->pin_in[i].release();
       if (c->ev_h2d[i]) (void)hipEventDestroy(c->ev_h2d[i]);
+      if (c->ev_h2d_blk[i]) (void)hipEventDestroy(c->ev_h2d_blk[i]);
       if (c->ev_in_free[i]) (void)hipEventDestroy(c->ev_in_free[i]);
       if (c->ev_out_ready[i]) (void)hipEventDestroy(c->ev_out_ready[i]);
       if (c->ev_d2h[i]) (void)hipEventDestroy(c->ev_d2h[i]);
       for (int q = 0; q < 4; q++) if (c->ev_exp[i][q]) (void)hipEventDestroy(c->ev_exp[i][q]);
    }
    for (auto &pb : c->pin_out) pb.release();
+   c->pin_read.release();
    if (c->h2d_stream) (void)hipStreamSynchronize(c->h2d_stream);
    if (c->d2h_stream) (void)hipStreamSynchronize(c->d2h_stream);
    if (c->pooled_streams) {
@@ -326,6 +328,7 @@ void ensure_copy_streams(hesaff_ctx *c)
    }
    for (int i = 0; i < 2; i++) {
       HIP_TRY(hipEventCreateWithFlags(&c->ev_h2d[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&c->ev_h2d_blk[i], hipEventDisableTiming | hipEventBlockingSync));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_in_free[i], hipEventDisableTiming | hipEventBlockingSync));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_out_ready[i], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_d2h[i], hipEventDisableTiming | hipEventBlockingSync));
@@ -367,9 +370,21 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
       const size_t unit = q.blob_bytes ? q.blob_bytes : img_bytes, total = unit * q.data.size();
       HIP_TRY(hipEventSynchronize(c->ev_in_free[slot]));   // chunk k-2 no longer reads this input buffer (never recorded: returns at once)
       s->largest = std::max<int>((int)q.data.size(), std::min(io.largest_chunk((int)q.data.size()), c->par.max_batch));
-      c->pin_in[slot].ensure(unit * (size_t)s->largest);   // sized once, for the large chunks that follow a small first one
       c->b_in2[slot].ensure(img_bytes * (size_t)s->largest);
       if (q.blob_bytes) c->b_jcoef[slot].ensure(unit * (size_t)s->largest);
+      if (q.pinned) {
+         // the readers filled page-locked buffers of this context (PinHooks): every image goes to the device from where it is, and its
+         // buffer is given back to the readers when the copy engine has read it (this thread sleeps on a blocking event meanwhile)
+         uint8_t *dst = (uint8_t *)(q.blob_bytes ? c->b_jcoef[slot].p : c->b_in2[slot].p);
+         for (size_t b = 0; b < q.data.size(); b++)
+            HIP_TRY(hipMemcpyAsync(dst + unit * b, q.data[b], unit, hipMemcpyHostToDevice, c->h2d_stream));
+         HIP_TRY(hipEventRecord(c->ev_h2d[slot], c->h2d_stream));
+         HIP_TRY(hipEventRecord(c->ev_h2d_blk[slot], c->h2d_stream));
+         HIP_TRY(hipEventSynchronize(c->ev_h2d_blk[slot]));
+         io.staged(q);
+         return s;
+      }
+      c->pin_in[slot].ensure(unit * (size_t)s->largest);   // sized once, for the large chunks that follow a small first one
       // pixels into the pinned buffer: a chunk of 64 UHD images is 0.5 GB - on four threads when it is worth it (the first chunk's
       // copy is the pipeline's fill: nothing runs on the device meanwhile)
       auto copy_images = [&](size_t b0, size_t b1) {
@@ -598,16 +613,25 @@ int hesaff_process_files(hesaff_ctx *c, int n, const char *const *paths, const c
    if (!c || n < 0 || (n > 0 && (!paths || !status))) return HESAFF_ERR_ARG;
    HS_API_BEGIN
    for (int i = 0; i < n; i++) { status[i].rc = HESAFF_ERR_IO; status[i].stage = HESAFF_FILE_PENDING; status[i].count_hessian = 0; status[i].count_desc = 0; }
-   const int host = hesaff_host_threads();
-   const int dt = std::max(1, std::min(decode_threads > 0 ? decode_threads : std::max(2, host / 4), 64));
-   const int wt = std::max(1, std::min(write_threads > 0 ? write_threads : host, 256));
+   hesaff_host_plan hp;
+   (void)hesaff_host_plan_for(1, &hp);   // "0 = auto": this context has the host to itself (callers that share it pass the counts of their own plan)
+   const int dt = std::max(1, std::min(decode_threads > 0 ? decode_threads : hp.decode_threads, 64));
+   const int wt = std::max(1, std::min(write_threads > 0 ? write_threads : hp.write_threads, 256));
    // the rows are formatted on the device (kernels_export.h): the writer threads only write()
    bool device_jpeg = true;
 #ifdef HESAFF_TUNING
    if (const char *dj = getenv("HESAFF_DEVICE_JPEG")) device_jpeg = atoi(dj) != 0;   // A/B: 0 = whole JPEG decode on the host threads (hesaff_read_jpeg)
 #endif
-   FileIO io(&c->ring, c->par.max_batch, c->par.mrSize, c->out_format, n, paths, out_paths, status, dt, wt, true, c->resume, device_jpeg);
-   c->stage_threads = std::max(1, std::min(4, dt));
+   PinHooks pin;   // the readers fill page-locked buffers of this context: no malloc'ed image, no staging copy
+   c->pin_read.device = c->device;
+   pin.alloc = [](size_t bytes, void *user) -> void * { return ((hesaff_ctx *)user)->pin_read.take(bytes); };
+   pin.release = [](void *p, size_t bytes, void *user) { ((hesaff_ctx *)user)->pin_read.give(p, bytes); };
+   pin.user = c;
+#ifdef HESAFF_TUNING
+   if (const char *pr = getenv("HESAFF_PIN_READ")) { if (atoi(pr) == 0) pin = PinHooks(); }   // A/B: 0 = malloc'ed images + staging copy
+#endif
+   FileIO io(&c->ring, c->par.max_batch, c->par.mrSize, c->out_format, n, paths, out_paths, status, dt, wt, true, c->resume, device_jpeg, pin);
+   c->stage_threads = std::max(1, std::min(4, (dt + wt + 1) / 4));   // hesaff_host_plan_for's stage_threads for a pool of dt + wt
    try {
       run_chunks(c, io, 3);
       io.wait_writers();

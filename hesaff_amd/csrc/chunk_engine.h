@@ -11,6 +11,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/hesaff_amd.h"
@@ -58,6 +59,16 @@ struct HostChunk {                // at most max_batch images of one geometry
    // bytes, all images of the chunk have the layout `jpeg`, and the device makes the W x H x ch pixels (kernels_jpeg.h)
    size_t blob_bytes = 0;         // 0: data[b] are pixels
    hesaff_jpeg_layout jpeg = {};
+   bool pinned = false;           // every data[b] is page-locked memory of the context (PinHooks): copied to the device from where it is
+};
+
+// Page-locked host buffers for the images a FileIO reads (the context's hipHostMalloc behind two plain function pointers: nothing here
+// touches HIP).  alloc may return nullptr (no room, or the caller pins nothing): the image then lives in ordinary memory and travels
+// through the context's pinned staging buffer.  release: the buffer goes back to the context, which keeps it pinned for the next list.
+struct PinHooks {
+   void *(*alloc)(size_t bytes, void *user) = nullptr;
+   void (*release)(void *p, size_t bytes, void *user) = nullptr;
+   void *user = nullptr;
 };
 inline bool same_jpeg_layout(const hesaff_jpeg_layout &a, const hesaff_jpeg_layout &b) { return memcmp(&a, &b, sizeof a) == 0; }
 
@@ -188,6 +199,8 @@ struct FileIO : ChunkIO {
    bool device_format;   // rows arrive formatted (ChunkDone::text / bin): the writers only write()
    bool resume;          // hesaff_set_resume: an image whose complete output exists is not read
    bool device_jpeg;     // JPEG files: entropy decoding only on the pool's threads, the pixels are made on the device
+   PinHooks pin;         // where the readers' buffers come from (see blob_alloc)
+   std::unordered_map<void *, size_t> pinned;   // buffers of `pin` that are out (with an image, or in blob_pool); under mu
    struct Img {          // state: 0 pending, 1 decoded, 2 unreadable, 3 handed on
       uint8_t *data = nullptr; int w = 0, h = 0, ch = 0; int state = 0;
       size_t blob_bytes = 0; hesaff_jpeg_layout jpeg = {};   // blob_bytes != 0: data is a coefficient blob
@@ -205,9 +218,9 @@ struct FileIO : ChunkIO {
    std::vector<std::thread> workers;
 
    FileIO(BlockRing *ring_, int max_batch_, float mrSize_, int fmt_, int n_, const char *const *p, const char *const *o, hesaff_file_status *st,
-          int dec_threads, int wr_threads, bool device_format_ = false, bool resume_ = false, bool device_jpeg_ = false)
+          int dec_threads, int wr_threads, bool device_format_ = false, bool resume_ = false, bool device_jpeg_ = false, PinHooks pin_ = PinHooks())
       : ring(ring_), max_batch(max_batch_), n(n_), paths(p), out_paths(o), status(st), mrSize(mrSize_), fmt(fmt_), device_format(device_format_),
-        resume(resume_), device_jpeg(device_jpeg_), imgs((size_t)n_)
+        resume(resume_), device_jpeg(device_jpeg_), pin(pin_), imgs((size_t)n_)
    {
       window = 2 * max_batch + dec_threads;
       try {
@@ -222,10 +235,24 @@ struct FileIO : ChunkIO {
       { std::lock_guard<std::mutex> lk(mu); stop = true; }
       cv_work.notify_all(); cv_img.notify_all(); cv_done.notify_all();
       for (auto &t : workers) if (t.joinable()) t.join();
-      for (Img &im : imgs) if (im.data) { hesaff_free(im.data); im.data = nullptr; }
-      for (auto &b : blob_pool) hesaff_free(b.first);
+      for (Img &im : imgs) if (im.data) { drop_buffer(im.data); im.data = nullptr; }
+      for (auto &b : blob_pool) drop_buffer(b.first);
       blob_pool.clear();
    }
+   // a reader's buffer that is not needed any more: back to the context when it is one of its pinned ones, else to the allocator
+   void drop_buffer(uint8_t *p)
+   {
+      size_t bytes = 0;
+      bool is_pinned = false;
+      {
+         std::lock_guard<std::mutex> lk(mu_pin);
+         auto it = pinned.find(p);
+         if (it != pinned.end()) { is_pinned = true; bytes = it->second; pinned.erase(it); }
+      }
+      if (is_pinned) pin.release(p, bytes, pin.user);
+      else hesaff_free(p);
+   }
+   std::mutex mu_pin;   // guards `pinned` (taken alone or inside mu, never the other way round)
    bool decode_ready() const { return !stop && next_decode < n && next_decode < consumed + window; }   // under mu
    void work_loop()
    {
@@ -248,9 +275,10 @@ struct FileIO : ChunkIO {
       if (!bin) return o ? std::string(o) : std::string(paths[i]) + ".hesaff.sift";   // hesaff.cpp:170-173
       return o ? (std::string(o) + ((fmt & HESAFF_OUT_TEXT) ? ".bin" : "")) : std::string(paths[i]) + ".hesaff.bin";
    }
-   // pixel buffers and coefficient blobs of images that have been copied to pinned memory go to the next decoder instead of back to the
-   // allocator (a UHD 4:4:4 photograph: 50 MB of fresh zero pages per image otherwise - a third of the entropy decoder's time; a UHD
-   // PGM file: 8 MB, a quarter of the read)
+   // Pixel buffers and coefficient blobs come from the context's page-locked memory when it offers some (PinHooks): the reader then
+   // fills the buffer the copy engine reads - no malloc'ed image, no staging copy (8 MB per UHD PGM file, 25-50 MB per UHD JPEG blob:
+   // 1-4 ms of a host thread per image).  Buffers of images that have reached the device go to the next decoder instead of back to
+   // the allocator (fresh zero pages for every image otherwise: a third of the entropy decoder's time, a quarter of a PGM read).
    std::vector<std::pair<uint8_t *, size_t>> blob_pool;   // under mu
    static void *blob_alloc(size_t bytes, int *zeroed, void *user)
    {
@@ -266,8 +294,21 @@ struct FileIO : ChunkIO {
                return p;
             }
       }
+      if (io->pin.alloc) {
+         if (void *p = io->pin.alloc(bytes, io->pin.user)) {
+            std::lock_guard<std::mutex> lk(io->mu_pin);
+            io->pinned[p] = bytes;
+            *zeroed = 0;
+            return p;
+         }
+      }
       *zeroed = 1;
       return calloc(1, bytes);
+   }
+   bool is_pinned(const void *p)
+   {
+      std::lock_guard<std::mutex> lk(mu_pin);
+      return pinned.count(const_cast<void *>(p)) != 0;
    }
    static bool is_jpeg_file(const char *path)   // SOI marker, like hesaff_read_image's choice of reader
    {
@@ -305,9 +346,9 @@ struct FileIO : ChunkIO {
       }
       int stage = HESAFF_FILE_UNREADABLE;
       if (rc == HESAFF_OK && (im.w > 65535 || im.h > 65535)) {   // the device plans 16-bit pixel coordinates (plan(), pipeline.hip)
-         hesaff_free(im.data); im.data = nullptr;
          rc = HESAFF_ERR_ARG; stage = HESAFF_FILE_REJECTED;
       }
+      if (rc != HESAFF_OK && im.data) { drop_buffer(im.data); im.data = nullptr; }   // (a failed reader hands an allocator's buffer back)
       {
          std::lock_guard<std::mutex> lk(mu);
          if (rc == HESAFF_OK) { im.state = 1; imgs[(size_t)i] = im; }
@@ -340,10 +381,11 @@ struct FileIO : ChunkIO {
          if (stop) break;
          Img &im = imgs[(size_t)pos];
          if (im.state == 2) { pos++; consumed = pos; cv_work.notify_all(); continue; }
-         if (out.data.empty()) { out.W = im.w; out.H = im.h; out.ch = im.ch; out.blob_bytes = im.blob_bytes; out.jpeg = im.jpeg; }
+         if (out.data.empty()) { out.W = im.w; out.H = im.h; out.ch = im.ch; out.blob_bytes = im.blob_bytes; out.jpeg = im.jpeg; out.pinned = true; }
          else if (im.w != out.W || im.h != out.H || im.ch != out.ch || im.blob_bytes != out.blob_bytes ||
                   (im.blob_bytes && !same_jpeg_layout(im.jpeg, out.jpeg))) break;
          out.data.push_back(im.data);
+         out.pinned = out.pinned && is_pinned(im.data);
          out.stride.push_back((size_t)im.w * im.ch);
          out.index.push_back(pos);
          im.state = 3;
@@ -360,8 +402,18 @@ struct FileIO : ChunkIO {
          for (int i : q.index) {
             Img &im = imgs[(size_t)i];
             const size_t bytes = im.blob_bytes ? im.blob_bytes : (size_t)im.w * im.h * im.ch;   // (every reader allocates exactly this)
+            // the pool holds at most `window` buffers; on a list of mixed sizes a buffer of a size that is no longer asked for makes
+            // room for the one just used (otherwise the pool would fill with sizes that never match again and stop recycling)
+            if ((int)blob_pool.size() >= window) {
+               for (size_t k = 0; k < blob_pool.size(); k++)
+                  if (blob_pool[k].second != bytes) {
+                     drop_buffer(blob_pool[k].first);
+                     blob_pool.erase(blob_pool.begin() + (long)k);
+                     break;
+                  }
+            }
             if ((int)blob_pool.size() < window) blob_pool.emplace_back(im.data, bytes);
-            else hesaff_free(im.data);
+            else drop_buffer(im.data);
             im.data = nullptr;
          }
          consumed = std::max(consumed, q.index.back() + 1);

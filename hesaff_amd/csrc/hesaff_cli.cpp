@@ -15,6 +15,8 @@
 //       another algorithm for those keypoints); default 0 = parity mode.
 //       --resume                      skip every image whose complete output (of the selected format) already exists; outputs are written
 //       under a temporary name and renamed, so an interrupted run leaves no torn file (checkpoint / resume).
+//       --host-share K                this process may use 1/K of the host's CPUs (default 1): one of K processes on a node, e.g. one per GPU.
+//       Host threads per device context = hesaff_host_plan_for(devices x K): the library's one rule (include/hesaff_amd.h).
 //       --output text | bin | both    what every image gets: <image>.hesaff.sift (default), the binary sidecar
 //       <image>.hesaff.bin (the same rows unprinted, include/hesaff_amd.h: hesaff_write_bin), or both.
 #include <chrono>
@@ -65,7 +67,7 @@ bool parse_devices(const char *spec, std::vector<int> &out)
 
 // hesaff --batch: the list is cut into contiguous shards, one per device context (hesaff_shard_range); every shard runs
 // through hesaff_process_files - decode threads -> device -> writer threads, bounded memory - on its own host thread.
-int run_batch_mode(const char *list_path, const char *devices_spec, int out_format, bool dynamic, int fast, bool resume)
+int run_batch_mode(const char *list_path, const char *devices_spec, int out_format, bool dynamic, int fast, bool resume, int host_share)
 {
    std::ifstream lf(list_path);
    if (!lf) { fprintf(stderr, "hesaff: cannot read list '%s'\n", list_path); return 1; }
@@ -102,8 +104,9 @@ int run_batch_mode(const char *list_path, const char *devices_spec, int out_form
       if (hesaff_create(&ctx, &par, devices[(size_t)rank]) != HESAFF_OK) { errs[(size_t)rank] = hesaff_last_error(nullptr); return; }
       hesaff_set_output_format(ctx, out_format);
       hesaff_set_resume(ctx, resume ? 1 : 0);
-      const int host = hesaff_host_threads();
-      const int wt = std::max(1, host / world), dt = std::max(1, std::min(16, host / (2 * world)));
+      hesaff_host_plan hp;   // this device's share of the host: the library's one rule (include/hesaff_amd.h)
+      hesaff_host_plan_for(world * host_share, &hp);
+      const int wt = hp.write_threads, dt = hp.decode_threads;
       for (;;) {
          if (dynamic) {   // the next block of the list nobody has taken yet
             lo = next_block.fetch_add(1) * kBlock;
@@ -162,13 +165,14 @@ int main(int argc, char **argv)
    for (int i = 1; i < argc; i++) batch = batch || strcmp(argv[i], "--batch") == 0;
    if (batch) {
       const char *devices = nullptr, *list = nullptr;
-      int out_format = HESAFF_OUT_TEXT, fast = 0;
+      int out_format = HESAFF_OUT_TEXT, fast = 0, host_share = 1;
       bool bad = false, dynamic = false, resume = false;
       for (int i = 1; i < argc && !bad; i += 2) {
          if (strcmp(argv[i], "--resume") == 0) { resume = true; i--; continue; }
          if (i + 1 >= argc) bad = true;
          else if (strcmp(argv[i], "--batch") == 0) list = argv[i + 1];
          else if (strcmp(argv[i], "--devices") == 0) devices = argv[i + 1];
+         else if (strcmp(argv[i], "--host-share") == 0) { host_share = atoi(argv[i + 1]); bad = host_share < 1 || host_share > 1024; }
          else if (strcmp(argv[i], "--fast") == 0) {
             if (strcmp(argv[i + 1], "0") == 0 || strcmp(argv[i + 1], "2") == 0) fast = atoi(argv[i + 1]);
             else bad = true;
@@ -182,8 +186,8 @@ int main(int argc, char **argv)
             else bad = true;
          } else bad = true;
       }
-      if (bad || !list) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all] [--output text|bin|both] [--schedule static|dynamic] [--fast 0|2] [--resume]\n"); return 1; }
-      return run_batch_mode(list, devices, out_format, dynamic, fast, resume);
+      if (bad || !list) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all] [--output text|bin|both] [--schedule static|dynamic] [--fast 0|2] [--resume] [--host-share K]\n"); return 1; }
+      return run_batch_mode(list, devices, out_format, dynamic, fast, resume, host_share);
    }
    if (argc > 1) {
       uint8_t *data = nullptr;

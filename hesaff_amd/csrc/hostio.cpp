@@ -19,6 +19,7 @@
 #include <cerrno>
 #include <fcntl.h>
 #include <sched.h>
+#include <sys/uio.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -343,6 +344,9 @@ int hesaff_read_pnm(const char *path, uint8_t **data, int *width, int *height, i
 int hesaff_read_pnm_alloc(const char *path, uint8_t **data, int *width, int *height, int *channels, hesaff_blob_alloc alloc, void *user)
 {
    if (!path || !data || !width || !height || !channels) return HESAFF_ERR_ARG;
+   *data = nullptr;
+   // a buffer from the caller's allocator is the caller's whatever happens: on a failure it is handed back through *data, never free()d
+   auto drop = [&](uint8_t *q) { if (alloc) *data = q; else free(q); };
    FILE *f = fopen(path, "rb");
    if (!f) return HESAFF_ERR_IO;
    const int c1 = fgetc(f), c2 = fgetc(f);
@@ -376,7 +380,7 @@ int hesaff_read_pnm_alloc(const char *path, uint8_t **data, int *width, int *hei
       if (maxv <= 255) ok = fread(buf, 1, n, f) == n;
       else {
          std::vector<uint8_t> row;
-         try { row.resize((size_t)w * ch * 2); } catch (...) { free(buf); fclose(f); return HESAFF_ERR_NOMEM; }
+         try { row.resize((size_t)w * ch * 2); } catch (...) { drop(buf); fclose(f); return HESAFF_ERR_NOMEM; }
          for (int y = 0; y < h && ok; y++) {
             ok = fread(row.data(), 1, row.size(), f) == row.size();
             uint8_t *o = buf + (size_t)y * w * ch;
@@ -386,7 +390,7 @@ int hesaff_read_pnm_alloc(const char *path, uint8_t **data, int *width, int *hei
    } else if (kind == 4) {
       const size_t rb = ((size_t)w + 7) / 8;
       std::vector<uint8_t> row;
-      try { row.resize(rb); } catch (...) { free(buf); fclose(f); return HESAFF_ERR_NOMEM; }
+      try { row.resize(rb); } catch (...) { drop(buf); fclose(f); return HESAFF_ERR_NOMEM; }
       for (int y = 0; y < h && ok; y++) {
          ok = fread(row.data(), 1, rb, f) == rb;
          for (int x = 0; ok && x < w; x++) buf[(size_t)y * w + x] = ((row[(size_t)x >> 3] >> (7 - (x & 7))) & 1) ? 0 : 255;
@@ -412,7 +416,7 @@ int hesaff_read_pnm_alloc(const char *path, uint8_t **data, int *width, int *hei
       }
    }
    fclose(f);
-   if (!ok) { free(buf); return HESAFF_ERR_IO; }
+   if (!ok) { drop(buf); return HESAFF_ERR_IO; }
    *data = buf; *width = w; *height = h; *channels = ch;
    return HESAFF_OK;
 }
@@ -488,6 +492,18 @@ int hesaff_host_threads(void)
    return cached;
 }
 
+int hesaff_host_plan_for(int devices_sharing_host, hesaff_host_plan *out)
+{
+   if (!out || devices_sharing_host < 1) return HESAFF_ERR_ARG;
+   const int cpus = std::max(1, hesaff_host_threads() / devices_sharing_host);
+   out->cpus = cpus;
+   out->stage_threads = std::max(1, std::min(4, cpus / 4));
+   const int pool = std::max(2, cpus - out->stage_threads);
+   out->decode_threads = std::max(1, pool / 4);
+   out->write_threads = pool - out->decode_threads;
+   return HESAFF_OK;
+}
+
 // Rows are formatted by `threads` workers into one buffer.
 int hesaff_format_sift_mt(const hesaff_keypoint *keys, int n, float mrSize, int threads, char **out, size_t *len)
 {
@@ -528,13 +544,52 @@ int hesaff_format_sift_mt(const hesaff_keypoint *keys, int n, float mrSize, int 
    return HESAFF_OK;
 }
 
+// a whole buffer to an open descriptor
+static bool write_all(int fd, const char *q, size_t left)
+{
+   while (left > 0) {
+      const ssize_t w = write(fd, q, left < ((size_t)1 << 30) ? left : ((size_t)1 << 30));
+      if (w < 0) { if (errno == EINTR) continue; return false; }
+      q += w; left -= (size_t)w;
+   }
+   return true;
+}
+
+// header + body with ONE system call when the kernel takes it whole (it does for a regular file with room: a UHD image's 46 MB of rows
+// go out in one writev); what a short write leaves is finished by write_all
+static bool write_head_body(int fd, const char *head, size_t hl, const char *body, size_t len)
+{
+   struct iovec iov[2] = {{(void *)head, hl}, {(void *)body, len < ((size_t)1 << 30) ? len : ((size_t)1 << 30)}};
+   ssize_t w;
+   do { w = writev(fd, iov, len > 0 ? 2 : 1); } while (w < 0 && errno == EINTR);
+   if (w < 0) return false;
+   size_t done = (size_t)w;
+   if (done < hl) { if (!write_all(fd, head + done, hl - done)) return false; done = hl; }
+   return write_all(fd, body + (done - hl), len - (done - hl));
+}
+
+// Every writer of this file puts its output under "<path>.part" and renames it when it is complete and closed: a killed run leaves no
+// torn file under the final name, so a file that exists under its final name is whole (hesaff_set_resume relies on it;
+// hesaff_output_is_complete still checks header, size and the last byte).
+static int open_part(const char *path, std::string &part)
+{
+   part = std::string(path) + ".part";
+   return open(part.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+}
+static int finish_part(int fd, bool ok, const std::string &part, const char *path)
+{
+   if (close(fd) != 0) ok = false;
+   if (ok && rename(part.c_str(), path) != 0) ok = false;
+   if (!ok) unlink(part.c_str());
+   return ok ? HESAFF_OK : HESAFF_ERR_IO;
+}
+
 static int write_file(const char *path, const char *buf, size_t len)
 {
-   FILE *f = fopen(path, "wb");
-   if (!f) return HESAFF_ERR_IO;
-   const size_t w = fwrite(buf, 1, len, f);
-   const int ce = fclose(f);
-   return (w == len && ce == 0) ? HESAFF_OK : HESAFF_ERR_IO;
+   std::string part;
+   const int fd = open_part(path, part);
+   if (fd < 0) return HESAFF_ERR_IO;
+   return finish_part(fd, write_all(fd, buf, len), part, path);
 }
 
 int hesaff_write_sift(const char *path, const hesaff_keypoint *keys, int n, float mrSize)
@@ -562,7 +617,8 @@ int hesaff_write_sift_mt(const char *path, const hesaff_keypoint *keys, int n, f
    static thread_local std::vector<char> tl_buf;
    tl_buf.resize(64 + (size_t)kBlockRows * kRowMax);
    char *buf = tl_buf.data();
-   const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+   std::string part;
+   const int fd = open_part(path, part);
    if (fd < 0) return HESAFF_ERR_IO;
    size_t fill = (size_t)snprintf(buf, 64, "%d\n%d\n", 128, n);
    bool ok = true;
@@ -579,8 +635,7 @@ int hesaff_write_sift_mt(const char *path, const hesaff_keypoint *keys, int n, f
       fill = 0;
       if (i1 >= n) break;
    }
-   if (close(fd) != 0) ok = false;
-   return ok ? HESAFF_OK : HESAFF_ERR_IO;
+   return finish_part(fd, ok, part, path);
    HOSTIO_CATCH
 }
 
@@ -594,7 +649,8 @@ int hesaff_write_bin(const char *path, const hesaff_keypoint *keys, int n, float
    static thread_local std::vector<char> tl_bin;
    tl_bin.resize(16 + kBlock * kRec);
    char *buf = tl_bin.data();
-   const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+   std::string part;
+   const int fd = open_part(path, part);
    if (fd < 0) return HESAFF_ERR_IO;
    memcpy(buf, "HESAFFB1", 8);
    const uint32_t dim = 128, cnt = (uint32_t)n;
@@ -620,49 +676,27 @@ int hesaff_write_bin(const char *path, const hesaff_keypoint *keys, int n, float
       fill = 0;
       if (i1 >= n) break;
    }
-   if (close(fd) != 0) ok = false;
-   return ok ? HESAFF_OK : HESAFF_ERR_IO;
+   return finish_part(fd, ok, part, path);
    HOSTIO_CATCH
-}
-
-// a whole buffer to an open descriptor
-static bool write_all(int fd, const char *q, size_t left)
-{
-   while (left > 0) {
-      const ssize_t w = write(fd, q, left < ((size_t)1 << 30) ? left : ((size_t)1 << 30));
-      if (w < 0) { if (errno == EINTR) continue; return false; }
-      q += w; left -= (size_t)w;
-   }
-   return true;
-}
-
-// The file of hesaff.cpp:109-128 from rows that are already text (formatted on the device, kernels_export.h): the two header
-// lines, then the rows as they are.
-// (written under "<path>.part" and renamed when complete: a killed run leaves no torn file under the final name)
-static int finish_part(int fd, bool ok, const std::string &part, const char *path)
-{
-   if (close(fd) != 0) ok = false;
-   if (ok && rename(part.c_str(), path) != 0) ok = false;
-   if (!ok) unlink(part.c_str());
-   return ok ? HESAFF_OK : HESAFF_ERR_IO;
 }
 
 int hesaff_write_sift_rows(const char *path, const char *rows, size_t len, int n)
 {
    if (!path || n < 0 || (len > 0 && !rows)) return HESAFF_ERR_ARG;
    HOSTIO_TRY
-   const std::string part = std::string(path) + ".part";
-   const int fd = open(part.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+   std::string part;
+   const int fd = open_part(path, part);
    if (fd < 0) return HESAFF_ERR_IO;
    char head[64];
    const int hl = snprintf(head, sizeof head, "%d\n%d\n", 128, n);
-   const bool ok = write_all(fd, head, (size_t)hl) && write_all(fd, rows, len);
-   return finish_part(fd, ok, part, path);
+   return finish_part(fd, write_head_body(fd, head, (size_t)hl, rows, len), part, path);
    HOSTIO_CATCH
 }
 
-// Is `path` the complete output of an earlier run?  text (format HESAFF_OUT_TEXT): "128\n<n>\n", then rows, the last byte a newline
-// (n == 0: nothing after the header); sidecar: magic, dim 128, size == 16 + 148 n.  -> n, or -1
+// Is `path` the complete output of an earlier run?  text (format HESAFF_OUT_TEXT): "128\n<n>\n", then EXACTLY n rows - the newlines of
+// the body are counted, a file cut at a row boundary (a killed writer that does not go through .part + rename, e.g. the reference binary)
+// is not complete - the last byte a newline (n == 0: nothing after the header); sidecar: magic, dim 128, size == 16 + 148 n.  -> n, or -1.
+// What this cannot see: an output made with other parameters (thresholds, fast mode); resume is for re-running the SAME job.
 int hesaff_output_is_complete(const char *path, int format)
 {
    if (!path) return -1;
@@ -683,10 +717,23 @@ int hesaff_output_is_complete(const char *path, int format)
       int i = 4;
       while (i < got && head[i] >= '0' && head[i] <= '9' && n < 100000000) n = n * 10 + (head[i++] - '0');
       if (i > 4 && i < got && head[i] == '\n') {
-         const off_t body = size - (off_t)(i + 1);
+         const off_t body0 = (off_t)(i + 1), body = size - body0;
          char last = 0;
          // a row is at least 5 * 2 + 128 * 2 characters; the text must end with the newline of its last row
-         if (n == 0 ? body == 0 : (body >= (off_t)n * 266 && pread(fd, &last, 1, size - 1) == 1 && last == '\n')) result = (int)n;
+         if (n == 0) { if (body == 0) result = 0; }
+         else if (body >= (off_t)n * 266 && pread(fd, &last, 1, size - 1) == 1 && last == '\n') {
+            long lines = 0;
+            bool ok = true;
+            std::vector<char> buf;
+            try { buf.resize((size_t)1 << 20); } catch (...) { ok = false; }
+            for (off_t at = body0; ok && at < size && lines <= n;) {
+               const ssize_t r = pread(fd, buf.data(), buf.size(), at);
+               if (r <= 0) { if (r < 0 && errno == EINTR) continue; ok = false; break; }
+               for (const char *q = buf.data(), *e = q + r; (q = (const char *)memchr(q, '\n', (size_t)(e - q))) != nullptr; q++) lines++;
+               at += r;
+            }
+            if (ok && lines == n) result = (int)n;
+         }
       }
    }
    close(fd);
@@ -698,15 +745,14 @@ int hesaff_write_bin_rows(const char *path, const char *rows, int n)
 {
    if (!path || n < 0 || (n > 0 && !rows)) return HESAFF_ERR_ARG;
    HOSTIO_TRY
-   const std::string part = std::string(path) + ".part";
-   const int fd = open(part.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+   std::string part;
+   const int fd = open_part(path, part);
    if (fd < 0) return HESAFF_ERR_IO;
    char head[16];
    memcpy(head, "HESAFFB1", 8);
    const uint32_t dim = 128, cnt = (uint32_t)n;
    memcpy(head + 8, &dim, 4); memcpy(head + 12, &cnt, 4);
-   const bool ok = write_all(fd, head, 16) && write_all(fd, rows, (size_t)n * 148);
-   return finish_part(fd, ok, part, path);
+   return finish_part(fd, write_head_body(fd, head, 16, rows, (size_t)n * 148), part, path);
    HOSTIO_CATCH
 }
 

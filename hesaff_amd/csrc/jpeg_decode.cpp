@@ -340,8 +340,12 @@ void upsample_replicate(const uint8_t *in, int w, int h, int stride, int hx, int
 int decode_jpeg(const std::vector<uint8_t> &f, uint8_t **data, int *width, int *height, int *channels, const CoefOut *co = nullptr)
 {
    const bool keep = co != nullptr;   // entropy decoding only: no inverse DCT, no planes, no pixels
-   struct FreeDel { void operator()(uint8_t *p) const { free(p); } };
-   std::unique_ptr<uint8_t, FreeDel> blob;
+   // a blob from the caller's allocator is the caller's whatever happens: on a failure it goes back through *co->blob, never to free()
+   struct FreeDel {
+      const CoefOut *co;
+      void operator()(uint8_t *p) const { if (co && co->alloc) *co->blob = p; else free(p); }
+   };
+   std::unique_ptr<uint8_t, FreeDel> blob(nullptr, FreeDel{co});
    size_t blob_bytes = 0;
    bool blob_dirty = false;   // a recycled blob of a sequential file: blocks that no scan decoded are cleared at the end
    const size_t n = f.size();
@@ -770,6 +774,7 @@ extern "C" int hesaff_read_jpeg_coefficients_alloc(const char *path, hesaff_jpeg
                                                    hesaff_blob_alloc alloc, void *user)
 {
    if (!path || !layout || !blob || !blob_bytes) return HESAFF_ERR_ARG;
+   *blob = nullptr;
    try {
       std::vector<uint8_t> bytes;
       const int rc = read_all(path, bytes);

@@ -251,6 +251,54 @@ struct hesaff_ctx {
       void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
    };
    Pinned pin_in[2];
+   // Page-locked buffers the readers of hesaff_process_files fill directly (chunk_engine.h: PinHooks): handed out by size, taken back
+   // when their image is on the device, kept pinned from one list to the next (pinning costs 0.1 ms per MB), released with the context.
+   // At most kPinReadBytes are out or parked; a request beyond that gets nullptr (the image then takes the staging copy).
+   struct PinReadCache {
+      static constexpr size_t kPinReadBytes = (size_t)4 << 30, kLargest = (size_t)64 << 20;
+      std::mutex mu;
+      std::vector<std::pair<void *, size_t>> parked;
+      size_t bytes_total = 0;   // out + parked
+      int device = 0;
+      void *take(size_t bytes)
+      {
+         if (bytes == 0 || bytes > kLargest) return nullptr;
+         {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t k = 0; k < parked.size(); k++)
+               if (parked[k].second == bytes) { void *q = parked[k].first; parked[k] = parked.back(); parked.pop_back(); return q; }
+            // no room: parked buffers of other sizes (an earlier list's images) make way
+            while (bytes_total + bytes > kPinReadBytes && !parked.empty()) {
+               (void)hipHostFree(parked.back().first);
+               bytes_total -= parked.back().second;
+               parked.pop_back();
+            }
+            if (bytes_total + bytes > kPinReadBytes) return nullptr;
+            bytes_total += bytes;
+         }
+         void *q = nullptr;
+         if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> lk(mu);
+            bytes_total -= bytes;
+            return nullptr;
+         }
+         return q;
+      }
+      void give(void *q, size_t bytes)
+      {
+         std::lock_guard<std::mutex> lk(mu);
+         parked.emplace_back(q, bytes);
+      }
+      void release()
+      {
+         std::lock_guard<std::mutex> lk(mu);
+         for (auto &b : parked) (void)hipHostFree(b.first);
+         parked.clear();
+         bytes_total = 0;
+      }
+   } pin_read;
+   hipEvent_t ev_h2d_blk[2] = {nullptr, nullptr};   // blocking-sync: the staging thread sleeps until a chunk's direct copies have left the readers' buffers
    std::vector<Pinned> pin_out;       // result blocks: one per chunk of the current call (hesaff_detect_batch), or a ring of three
    hesaff_engine::BlockRing ring;     // (hesaff_detect_batch_cb, hesaff_process_files: a block returns to the ring when its consumer is done with it)
    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
@@ -553,8 +601,11 @@ void plan_buffers(hesaff_ctx *c, int B, int H, int W)
    c->b_R.ensure(pplane0 * 4 * 5);
    {
       const void *before = c->b_map.p;
+      const size_t before_bytes = c->b_map.bytes;
       c->b_map.ensure(std::max<size_t>((size_t)B * PH * PW * 4, 16));
-      if (c->b_map.p != before) c->map_clean = false;   // a new block: filled once before its first use (run_detection)
+      // a new block is filled once before its first use (run_detection).  Pointer AND size: ensure()'s out-of-memory path frees the old
+      // block first, and the larger one may come back at the same address with a tail that was never filled
+      if (c->b_map.p != before || c->b_map.bytes != before_bytes) c->map_clean = false;
    }
    const long long total_words = (long long)B * words;
    c->b_bitmask.ensure(std::max<size_t>((size_t)total_words * 8, 16));
@@ -572,7 +623,9 @@ void plan_buffers(hesaff_ctx *c, int B, int H, int W)
       // candidate slots: the keypoint capacity + what the wavefronts of k_extrema_march may leave unused of their blocks of 64
       // (octave 0 has the most wavefronts: one per 248-column strip and 32-row band at least)
       const unsigned long long waves0 = (unsigned long long)((PW + EXM_STRIP - 1) / EXM_STRIP) * (unsigned long long)(PH / 32 + 1) * (unsigned long long)B;
-      const unsigned long long cc = (unsigned long long)cap + HS_CAND_BLOCK * waves0;
+      // + cap / 8: a wavefront also abandons the rest of its block whenever a ballot group does not fit (holes grow with the number of
+      // blocks, not only with the number of wavefronts).  96 bytes per slot: 11 GB per 256 UHD images at the default max_kpts_per_mpx
+      const unsigned long long cc = (unsigned long long)cap + (unsigned long long)cap / 8 + HS_CAND_BLOCK * waves0;
       if (cc > 0xfffffff0ull) throw HsError(HESAFF_ERR_ARG, "batch too large for 32-bit candidate indices");
       c->cand_cap = (uint32_t)cc;
       c->b_cand.ensure((size_t)cc * sizeof(CandRec));

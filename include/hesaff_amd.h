@@ -33,7 +33,7 @@ extern "C" {
  * struct and bump this number.   1: round 1;  2: + upscaleInputImage, fast, pack_ms (inserted mid-struct);  3: + extrema_*;
  * 4: hesaff_params.fast = 1 withdrawn, HESAFF_FILE_REJECTED, rows formatted on the device;
  * 5: this header (+ hesaff_jpeg_layout, hesaff_read_jpeg_coefficients, hesaff_stage_jpeg_pixels: JPEG pixels made on the device). */
-#define HESAFF_ABI_VERSION 5
+#define HESAFF_ABI_VERSION 6
 int hesaff_abi_version(void);
 size_t hesaff_sizeof_params(void);
 size_t hesaff_sizeof_timings(void);
@@ -147,7 +147,7 @@ int hesaff_detect_batch_cb(hesaff_ctx *ctx, int n, const uint8_t *const *images,
  * size through the device (copy in / kernels / copy out overlapped) -> writer threads.  Host memory stays bounded
  * (about 2 max_batch decoded images and three result blocks).  out_paths may be NULL (or hold NULLs): the reference's
  * name.  status[i].rc = HESAFF_OK, or why file i was skipped (unreadable input, unwritable output); one bad file does
- * not stop the others.  decode_threads / write_threads: 0 = auto (hesaff_host_threads); the two counts add up to ONE pool of
+ * not stop the others.  decode_threads / write_threads: 0 = auto (hesaff_host_plan_for(1): this context has the host to itself); the two counts add up to ONE pool of
  * host threads that decode when the look-ahead window has room and write otherwise.  The rows of the output files are formatted
  * on the device (hesaff.cpp:124-128 as a kernel): a writer only write()s what the copy engine delivered. */
 #define HESAFF_FILE_PENDING 0   /* never reached (the run stopped on a device error before this file) */
@@ -224,6 +224,21 @@ int hesaff_write_sift_batch(int n_images, const char *const *paths, const hesaff
  * container's CPU-time limit (cgroup v2 cpu.max) when there is one, at most 64, at least 1.
  * (No counterpart in the reference, which is single-threaded: hesaff.cpp:133-180.) */
 int hesaff_host_threads(void);
+/* The ONE rule for "host threads per device" (the CLI's --batch, hesaff_process_files' "0 = auto", bench.py and tools/ all use it).
+ * devices_sharing_host: how many devices are fed from the CPUs hesaff_host_threads() counts - 8 for one rank of an 8-GPU node,
+ * 1 for a process that has the host to itself.
+ *   cpus           = max(1, hesaff_host_threads() / devices_sharing_host)      the CPU share of one device, everything included:
+ *                                                                                the caller's thread (kernel launches; it sleeps on events),
+ *                                                                                the staging threads and the decode / write pool
+ *   stage_threads  = clamp(cpus / 4, 1, 4)                                       threads that copy a chunk into pinned memory
+ *   pool           = max(2, cpus - stage_threads)                                decode_threads + write_threads (ONE pool, see
+ *   decode_threads = max(1, pool / 4) ; write_threads = pool - decode_threads    hesaff_process_files)
+ * With 2 CPUs the pool is 2 and time-slices with the caller's and the staging thread, which are idle most of the time.
+ * (No counterpart in the reference, which is single-threaded: hesaff.cpp:133-180.) */
+typedef struct hesaff_host_plan {
+   int cpus, decode_threads, write_threads, stage_threads;
+} hesaff_host_plan;
+int hesaff_host_plan_for(int devices_sharing_host, hesaff_host_plan *out);
 /* test hook: number of inputs on which the fast "%g" formatter and snprintf disagree (must be 0) */
 int hesaff_test_fmt_g(const float *v, int n);
 void hesaff_free(void *p);
@@ -245,8 +260,9 @@ int hesaff_read_jpeg(const char *path, uint8_t **data, int *width, int *height, 
 /* PGM/PPM, PNG or JPEG by magic number */
 int hesaff_read_image(const char *path, uint8_t **data, int *width, int *height, int *channels);
 /* the same with the pixel buffer from the caller's allocator (only the PNM reader asks it; see hesaff_blob_alloc below):
- * hesaff_process_files recycles the buffers of images that have been copied to pinned memory - 8 MB of fresh pages per UHD
- * image otherwise, a quarter of what reading a PGM file costs */
+ * hesaff_process_files reads straight into pinned host memory this way (no malloc'ed buffer, no staging copy) and recycles the
+ * buffers.  A buffer the allocator handed out belongs to the caller whatever happens: when the call fails after the allocator was
+ * asked, the buffer comes back through *data (NULL otherwise) and is never passed to free(). */
 typedef void *(*hesaff_blob_alloc)(size_t bytes, int *zeroed, void *user);
 int hesaff_read_pnm_alloc(const char *path, uint8_t **data, int *width, int *height, int *channels, hesaff_blob_alloc alloc, void *user);
 int hesaff_read_image_alloc(const char *path, uint8_t **data, int *width, int *height, int *channels, hesaff_blob_alloc alloc, void *user);

@@ -110,6 +110,7 @@ int main(int argc, char **argv)
    if (argc < 6) return 2;
    const int max_batch = atoi(argv[1]), dt = atoi(argv[2]), wt = atoi(argv[3]), fmt = atoi(argv[4]) & 3;
    const bool device_format = (atoi(argv[4]) & 4) != 0, device_jpeg = (atoi(argv[4]) & 8) != 0;
+   const bool mock_pin = (atoi(argv[4]) & 16) != 0;   // the context's page-locked read buffers (PinHooks), here plain malloc with a small budget
    const int n = argc - 5;
    std::vector<const char *> paths((size_t)n);
    for (int i = 0; i < n; i++) paths[(size_t)i] = argv[5 + i];
@@ -121,11 +122,47 @@ int main(int argc, char **argv)
    std::vector<std::vector<char>> text_blocks(3), bin_blocks(3);
    long long rows = 0;
    std::string chunk_sizes;
+   // mock of hesaff_ctx::PinReadCache: a budget of a few buffers, so that lists mix chunks of "pinned" and ordinary images; every buffer must
+   // come back (release) before the run ends, and a chunk may only call itself pinned when all its images are
+   struct MockPin {
+      std::mutex mu;
+      std::unordered_map<void *, size_t> out;
+      size_t budget = 40000, given = 0, returned = 0;
+   } mp;
+   PinHooks pin;
+   if (mock_pin) {
+      pin.user = &mp;
+      pin.alloc = [](size_t bytes, void *user) -> void * {
+         MockPin *m = (MockPin *)user;
+         std::lock_guard<std::mutex> lk(m->mu);
+         size_t live = 0;
+         for (auto &e : m->out) live += e.second;
+         if (live + bytes > m->budget) return nullptr;
+         void *q = malloc(bytes);
+         if (q) { m->out[q] = bytes; m->given++; }
+         return q;
+      };
+      pin.release = [](void *q, size_t bytes, void *user) {
+         MockPin *m = (MockPin *)user;
+         std::lock_guard<std::mutex> lk(m->mu);
+         auto it = m->out.find(q);
+         if (it == m->out.end() || it->second != bytes) { fprintf(stderr, "release of a buffer that is not out\n"); abort(); }
+         m->out.erase(it); m->returned++;
+         free(q);
+      };
+   }
+   int pinned_chunks = 0;
    {
-      FileIO io(&ring, max_batch, 5.196152f, fmt, n, paths.data(), nullptr, status.data(), dt, wt, device_format, false, device_jpeg);
+      FileIO io(&ring, max_batch, 5.196152f, fmt, n, paths.data(), nullptr, status.data(), dt, wt, device_format, false, device_jpeg, pin);
       auto stage = [&]() -> std::unique_ptr<State> {
          std::unique_ptr<State> s(new State());
          if (!io.next(s->q)) return nullptr;
+         if (s->q.pinned) {
+            if (!mock_pin) { fprintf(stderr, "pinned chunk without hooks\n"); abort(); }
+            std::lock_guard<std::mutex> lk(mp.mu);
+            for (const uint8_t *d : s->q.data) if (!mp.out.count((void *)d)) { fprintf(stderr, "pinned chunk holds an ordinary buffer\n"); abort(); }
+            pinned_chunks++;
+         }
          // "copy to pinned memory": read every pixel of every image of the chunk
          for (size_t b = 0; b < s->q.data.size(); b++) {
             uint32_t acc = 0;
@@ -209,6 +246,11 @@ int main(int argc, char **argv)
       if (status[(size_t)i].stage == HESAFF_FILE_WRITTEN && status[(size_t)i].rc == HESAFF_OK) written++;
       else if (status[(size_t)i].stage == HESAFF_FILE_UNREADABLE) unreadable++;
       else other++;
+   }
+   if (mock_pin) {
+      std::lock_guard<std::mutex> lk(mp.mu);
+      printf("pinned_chunks=%d given=%zu returned=%zu out=%zu\n", pinned_chunks, mp.given, mp.returned, mp.out.size());
+      if (!mp.out.empty() || mp.given != mp.returned || mp.given == 0) return 5;
    }
    printf("chunks=%s\n", chunk_sizes.c_str());
    printf("files=%d written=%d unreadable=%d other=%d rows=%lld\n", n, written, unreadable, other, rows);

@@ -221,7 +221,7 @@ def test_file_pipeline_threads_under_sanitizers(san, tmp_path):
     names.insert(7, str(bad)); names.append(str(bad))
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1")
     # fmt + 4: the mock device hands the writers finished rows (ChunkDone::text / bin) like the GPU formatter does
-    for max_batch, dt, wt, fmt in ((1, 1, 1, 1), (4, 3, 3, 3), (64, 8, 2, 2), (3, 2, 8, 1), (4, 2, 3, 7), (2, 1, 2, 5), (8, 2, 2, 6)):
+    for max_batch, dt, wt, fmt in ((1, 1, 1, 1), (4, 3, 3, 3), (64, 8, 2, 2), (3, 2, 8, 1), (4, 2, 3, 7), (2, 1, 2, 5), (8, 2, 2, 6), (4, 3, 2, 16 + 7), (2, 2, 2, 16 + 2)):
         for n_ in names:
             for ext in (".hesaff.sift", ".hesaff.bin"):
                 if os.path.exists(n_ + ext):
@@ -230,6 +230,8 @@ def test_file_pipeline_threads_under_sanitizers(san, tmp_path):
         assert r.returncode == 0, (max_batch, dt, wt, fmt, r.stdout[-500:], r.stderr[-4000:])
         assert "files=47 written=45 unreadable=2 other=0" in r.stdout, r.stdout
         rows = int(r.stdout.strip().rsplit("rows=", 1)[1])
+        if fmt & 16:   # readers fill the (mock) context's page-locked buffers: some chunks travel without a staging copy, every buffer comes back
+            assert "pinned_chunks=" in r.stdout and "out=0" in r.stdout and "pinned_chunks=0 " not in r.stdout, r.stdout
         fmt &= 3
         got = 0
         for n_ in names:

@@ -608,3 +608,68 @@ def test_binary_sidecar_holds_the_rows_of_the_text_file(tmp_path):
     with pytest.raises(hesaff_amd.HesaffError):
         (tmp_path / "junk.bin").write_bytes(b"not a sidecar")
         hesaff_amd.read_bin(str(tmp_path / "junk.bin"))
+
+
+def test_output_is_complete_counts_rows_and_writers_leave_no_torn_file(tmp_path):
+    """hesaff_set_resume's test of an existing output: a text file cut at a ROW BOUNDARY - what a killed writer that
+    does not go through <name>.part + rename leaves, e.g. the reference binary - is not complete; every writer of the library
+    (single- and multi-threaded text, sidecar, batch, the *_rows forms) goes through .part + rename and leaves no .part behind."""
+    import hesaff_amd
+    L = hesaff_amd.load_library()
+    rng = np.random.default_rng(5)
+    n = 9000
+    keys = np.zeros(n, hesaff_amd.KEYPOINT_DTYPE)
+    keys["x"] = rng.uniform(0, 3840, n); keys["y"] = rng.uniform(0, 2160, n); keys["s"] = rng.uniform(1, 30, n)
+    keys["a11"] = rng.uniform(0.5, 2, n); keys["a21"] = rng.uniform(-1, 1, n); keys["a22"] = 1.0 / keys["a11"]
+    keys["desc"] = rng.integers(0, 256, (n, 128), dtype=np.uint8)
+    mr = hesaff_amd.default_params().mrSize
+    text = hesaff_amd.format_sift(keys, mr)
+    q = str(tmp_path / "a.pgm.hesaff.sift")
+    for threads in (1, 4):     # hesaff_write_sift_mt: the block-wise single-thread form and the one-buffer form
+        assert L.hesaff_write_sift_mt(os.fsencode(q), keys.ctypes.data_as(C.c_void_p), n, mr, threads) == 0
+        assert open(q, "rb").read() == text and not os.path.exists(q + ".part")
+        assert L.hesaff_output_is_complete(os.fsencode(q), 1) == n
+    b = str(tmp_path / "a.pgm.hesaff.bin")
+    hesaff_amd.write_bin(b, keys, mr)
+    assert L.hesaff_output_is_complete(os.fsencode(b), 2) == n and not os.path.exists(b + ".part")
+    # the *_rows writers (rows formatted elsewhere - on the device): header + rows in one writev, the same file
+    body = text.split(b"\n", 2)[2]
+    r = str(tmp_path / "rows.hesaff.sift")
+    assert L.hesaff_write_sift_rows(os.fsencode(r), body, len(body), n) == 0
+    assert open(r, "rb").read() == text and not os.path.exists(r + ".part")
+    binrows = open(b, "rb").read()[16:]
+    r2 = str(tmp_path / "rows.hesaff.bin")
+    assert L.hesaff_write_bin_rows(os.fsencode(r2), binrows, n) == 0 and open(r2, "rb").read() == open(b, "rb").read()
+    # truncated at a row boundary after 75 % of the rows: header intact, last byte a newline, longer than 266 bytes per row on average
+    lines = text.split(b"\n")
+    cut = b"\n".join(lines[: 2 + (3 * n) // 4]) + b"\n"
+    t = str(tmp_path / "torn.hesaff.sift")
+    open(t, "wb").write(cut)
+    assert L.hesaff_output_is_complete(os.fsencode(t), 1) == -1
+    open(t, "wb").write(text + lines[5] + b"\n")       # one row too many
+    assert L.hesaff_output_is_complete(os.fsencode(t), 1) == -1
+    open(t, "wb").write(text[:-1])                     # no final newline
+    assert L.hesaff_output_is_complete(os.fsencode(t), 1) == -1
+    open(t, "wb").write(b"128\n0\n")
+    assert L.hesaff_output_is_complete(os.fsencode(t), 1) == 0
+    open(t, "wb").write(open(b, "rb").read()[:-148])   # sidecar with a row missing
+    assert L.hesaff_output_is_complete(os.fsencode(t), 2) == -1
+    # an unwritable target reports an error and leaves nothing behind
+    bad = str(tmp_path / "no_such_dir" / "x.hesaff.sift")
+    assert L.hesaff_write_sift_rows(os.fsencode(bad), body, len(body), n) != 0
+
+
+def test_host_plan_is_one_rule():
+    """hesaff_host_plan_for: threads per device = f(CPUs this process may use, devices that share them) - the rule the
+    CLI, hesaff_process_files' "auto", bench.py and tools/batch_ranks.py all use."""
+    import hesaff_amd
+    host = int(hesaff_amd.load_library().hesaff_host_threads())
+    assert 1 <= host <= 64
+    for dev in (1, 2, 8, 64):
+        hp = hesaff_amd.host_plan(dev)
+        cpus = max(1, host // dev)
+        stage = max(1, min(4, cpus // 4))
+        pool = max(2, cpus - stage)
+        assert hp == {"cpus": cpus, "decode_threads": max(1, pool // 4), "write_threads": pool - max(1, pool // 4), "stage_threads": stage}
+    with pytest.raises(hesaff_amd.HesaffError):
+        hesaff_amd.host_plan(0)

@@ -40,25 +40,30 @@ def main():
     ctx = hesaff_amd.HesaffContext(p, device=0 if args.one_device else local)
     # the rank's shard through hesaff_process_files (what `hesaff --batch` runs per device): decode ahead, device, rows formatted
     # on the device, write behind - with this rank's share of the host threads
-    threads = max(1, int(ctx.L.hesaff_host_threads()) // max(world, 1))
-    st = ctx.process_files(names[lo:hi], decode_threads=max(1, threads // 2), write_threads=max(1, threads - threads // 2))
+    hp = hesaff_amd.host_plan(max(world, 1))   # the library's one rule (hesaff_host_plan_for): this rank's share of the host
+    st = ctx.process_files(names[lo:hi], decode_threads=hp["decode_threads"], write_threads=hp["write_threads"])
     bad = [names[lo + i] for i, s_ in enumerate(st) if s_[0] != 0]
     if bad:
         print("rank %d: %d file(s) failed, first: %s" % (rank, len(bad), bad[0]), file=sys.stderr)
-    nh = sum(s_[2] for s_ in st if s_[0] == 0); nd = sum(s_[3] for s_ in st if s_[0] == 0)
+    # totals over the files that were written in THIS run (stage 3); a skipped file (resume) carries count_hessian = -1
+    nh = sum(max(0, s_[2]) for s_ in st if s_[0] == 0 and s_[1] == 3); nd = sum(max(0, s_[3]) for s_ in st if s_[0] == 0 and s_[1] == 3)
     device = None
     if world > 1 and backend == "nccl":
         import torch
         device = torch.device("cuda", 0 if args.one_device else local)
-    tot = gather_counts([nh, nd, hi - lo], device=device)
+    tot = gather_counts([nh, nd, hi - lo, len(bad)], device=device)
+    failed = int(tot[:, 3].sum())
     if rank == 0:
         print(json.dumps({"world": world, "images": int(tot[:, 2].sum()), "hessian_keypoints": int(tot[:, 0].sum()),
-                          "descriptors": int(tot[:, 1].sum()), "per_rank_images": [int(x) for x in tot[:, 2]]}))
+                          "descriptors": int(tot[:, 1].sum()), "per_rank_images": [int(x) for x in tot[:, 2]], "failed_files": failed,
+                          "host_plan_per_rank": hp}))
     ctx.close()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    # every rank leaves with the same status, after the collective: a job with unreadable or rejected images is not a success
+    return 1 if failed else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
