@@ -269,31 +269,57 @@ def _cpu_seconds():
     return r.ru_utime + r.ru_stime
 
 
-def _timed_file_run(hesaff_amd, paths, chunk, device, fmt, decode_threads, write_threads, sync=None):
+def _thread_cpu():
+    """{tid: (name, CPU seconds, allowed CPUs)} of this process's threads, from /proc (threads that have exited are not listed)."""
+    out = {}
+    try:
+        hz = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                st = open("/proc/self/task/%s/stat" % tid).read()
+                name = st[st.index("(") + 1: st.rindex(")")]
+                f = st[st.rindex(")") + 2:].split()
+                allowed = [ln.split(":", 1)[1].strip() for ln in open("/proc/self/task/%s/status" % tid) if ln.startswith("Cpus_allowed_list")]
+                out[tid] = (name, (int(f[11]) + int(f[12])) / hz, allowed[0] if allowed else "?")
+            except (OSError, ValueError, IndexError):
+                pass
+    except OSError:
+        pass
+    return out
+
+
+def _timed_file_run(hesaff_amd, paths, chunk, device, fmt, decode_threads, write_threads, sync=None, threads_table=False, profiling=1):
     """One warm-up (3 chunks) and one timed hesaff_process_files over `paths`; -> dict with wall seconds, CPU seconds, rows, bytes."""
     p = hesaff_amd.default_params()
     p.max_batch = chunk
     ext = ".hesaff.sift" if fmt == 1 else ".hesaff.bin"
     with hesaff_amd.HesaffContext(p, device=device) as ctx:
         ctx.set_output_format(fmt)
-        ctx.set_profiling(1)
+        ctx.set_profiling(profiling)   # 1: per-stage HIP events (device_export_ms); 0: what the CLI runs
         warm = ctx.process_files(paths[: 3 * chunk], decode_threads=decode_threads, write_threads=write_threads)   # buffers (all three pinned blocks, the readers' pinned buffers), page cache, thread start-up
         for q in paths[: 3 * chunk]:
             os.remove(q + ext)
         if sync:
             sync()
+        th0 = _thread_cpu() if threads_table else None
         c0 = _cpu_seconds()
         t0 = time.perf_counter()
         st = ctx.process_files(paths, decode_threads=decode_threads, write_threads=write_threads)
         dt = time.perf_counter() - t0
         cpu = _cpu_seconds() - c0
+        th1 = _thread_cpu() if threads_table else None
         threads = int(ctx.L.hesaff_host_threads())
         tmx = ctx.timings()
     bad = [i for i, s_ in enumerate(st) if s_[0] != 0 or s_[1] != 3] + [i for i, s_ in enumerate(warm) if s_[0] != 0]
     nbytes = sum(os.path.getsize(q + ext) for q in paths)
     rows = sum(s_[3] for s_ in st)
     n = len(paths)
-    return {"images": n, "images_per_s": n / dt, "value": rows / dt, "unit": "keypoints/s", "seconds": dt, "chunk_images": chunk,
+    extra = {}
+    if threads_table:   # CPU seconds per thread that still exists after the run (pool and staging threads have exited: their time is the remainder)
+        rows_t = sorted(((th1[t][1] - th0.get(t, (0, 0.0, 0))[1], th1[t][0], th1[t][2]) for t in th1), reverse=True)
+        extra["threads_cpu_seconds"] = [{"name": nm, "cpu_seconds": round(s_, 3), "allowed": al} for s_, nm, al in rows_t if s_ >= 0.02]
+        extra["threads_exited_cpu_seconds"] = round(cpu - sum(s_ for s_, _, _ in rows_t), 3)
+    return {**extra, "images": n, "images_per_s": n / dt, "value": rows / dt, "unit": "keypoints/s", "seconds": dt, "chunk_images": chunk,
             "output": "text (.hesaff.sift, the reference's format)" if fmt == 1 else "binary sidecar (.hesaff.bin, 148 bytes per row)",
             "failed_files": len(bad), "output_GB_per_s": nbytes / dt / 1e9, "output_GB": nbytes / 1e9,
             "rows": rows, "output_bytes": nbytes, "cpu_seconds": cpu, "cpu_seconds_per_image": cpu / n, "cpus_busy": cpu / dt,
@@ -352,7 +378,7 @@ def budgeted_child(cfg):
     cfg["phase"] = [0]
     out = {"cpus": sorted(os.sched_getaffinity(0)), "plan": hp}
     for name, fmt in (("text", 1), ("sidecar", 2)):
-        r = _timed_file_run(hesaff_amd, paths, cfg["chunk"], cfg["device"], fmt, hp["decode_threads"], hp["write_threads"], sync)
+        r = _timed_file_run(hesaff_amd, paths, cfg["chunk"], cfg["device"], fmt, hp["decode_threads"], hp["write_threads"], sync, threads_table=True, profiling=0)
         ext = ".hesaff.sift" if fmt == 1 else ".hesaff.bin"
         if cfg.get("md5"):   # tests: what was written
             import hashlib

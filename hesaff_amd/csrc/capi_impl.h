@@ -247,6 +247,7 @@ void hesaff_destroy(hesaff_ctx *c)
    }
    for (auto &pb : c->pin_out) pb.release();
    c->pin_read.release();
+   c->h_small_end.release(); c->h_small_mid.release(); c->h_small_exp.release();
    if (c->h2d_stream) (void)hipStreamSynchronize(c->h2d_stream);
    if (c->d2h_stream) (void)hipStreamSynchronize(c->d2h_stream);
    if (c->pooled_streams) {
@@ -360,6 +361,7 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
 
    // stage(k): chunk k -> pinned buffer -> device input buffer (k & 1) on the H2D stream; runs while chunk k-1 computes
    auto stage = [&](int k) -> std::unique_ptr<State> {
+      (void)pthread_setname_np(pthread_self(), "hs-stage");
       HIP_TRY(hipSetDevice(c->device));
       std::unique_ptr<State> s(new State());
       if (!io.next(s->q)) return nullptr;
@@ -368,7 +370,7 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
       const size_t row_bytes = (size_t)q.W * q.ch, img_bytes = row_bytes * q.H;
       // what travels per image: its pixels, or - a JPEG file - its coefficient blob (the pixels are then made in b_in2 by the device)
       const size_t unit = q.blob_bytes ? q.blob_bytes : img_bytes, total = unit * q.data.size();
-      HIP_TRY(hipEventSynchronize(c->ev_in_free[slot]));   // chunk k-2 no longer reads this input buffer (never recorded: returns at once)
+      hs_wait_event(c->ev_in_free[slot]);   // chunk k-2 no longer reads this input buffer (never recorded: returns at once)
       s->largest = std::max<int>((int)q.data.size(), std::min(io.largest_chunk((int)q.data.size()), c->par.max_batch));
       c->b_in2[slot].ensure(img_bytes * (size_t)s->largest);
       if (q.blob_bytes) c->b_jcoef[slot].ensure(unit * (size_t)s->largest);
@@ -380,7 +382,7 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
             HIP_TRY(hipMemcpyAsync(dst + unit * b, q.data[b], unit, hipMemcpyHostToDevice, c->h2d_stream));
          HIP_TRY(hipEventRecord(c->ev_h2d[slot], c->h2d_stream));
          HIP_TRY(hipEventRecord(c->ev_h2d_blk[slot], c->h2d_stream));
-         HIP_TRY(hipEventSynchronize(c->ev_h2d_blk[slot]));
+         hs_wait_event(c->ev_h2d_blk[slot]);
          io.staged(q);
          return s;
       }
@@ -415,7 +417,7 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
       return s;
    };
    auto deliver = [&](State &s) {
-      if (s.total > 0) HIP_TRY(hipEventSynchronize(c->ev_d2h[s.no & 1]));
+      if (s.total > 0) hs_wait_event(c->ev_d2h[s.no & 1]);
       if (s.total > 0 && c->profiling && (wants & (WANT_TEXT | WANT_BIN))) {
          float ms = 0.0f;   // length pass (with the host's short wait for the byte counts) + write pass
          float ms2 = 0.0f;
@@ -437,9 +439,11 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
    try {
       for (int k = 0;; k++) {
          const auto dbg_t0 = std::chrono::steady_clock::now();
+         const double dbg_c0 = c->debug ? thread_cpu_ms() : 0.0;
          std::unique_ptr<State> cur = staged.get();           // H2D of chunk k is enqueued
          if (!cur) break;
          const auto dbg_t1 = std::chrono::steady_clock::now();
+         const double dbg_c1 = c->debug ? thread_cpu_ms() : 0.0;
          cur->no = k;
          staged = std::async(std::launch::async, stage, k + 1);
          const HostChunk &q = cur->q;
@@ -462,6 +466,7 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
          }
          HIP_TRY(hipEventRecord(c->ev_in_free[slot], c->stream));
          const auto dbg_t2 = std::chrono::steady_clock::now();
+         const double dbg_c2 = c->debug ? thread_cpu_ms() : 0.0;
          const int32_t *hs = c->h_starts.data(), *ds = c->h_starts.data() + (B + 1);
          cur->total = ds[B];
          cur->nh.resize((size_t)B); cur->nd.resize((size_t)B); cur->off.resize((size_t)B);
@@ -536,6 +541,7 @@ void run_chunks(hesaff_ctx *c, ChunkIO &io, int ring)
          if (c->debug) {
             auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
             const auto dbg_t5 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[hesaff] chunk %d: caller's CPU: wait staged %.1f run_batch %.1f rest %.1f ms\n", k, dbg_c1 - dbg_c0, dbg_c2 - dbg_c1, thread_cpu_ms() - dbg_c2);
             fprintf(stderr, "[hesaff] chunk %d: wait staged %.1f  run_batch %.1f  export prepare %.1f  deliver prev %.1f  acquire+enqueue %.1f ms | device: pyramid %.1f detect %.1f affine %.1f patch %.1f sift %.1f pack %.1f total %.1f\n", k, ms(dbg_t0, dbg_t1),
                     ms(dbg_t1, dbg_t2), ms(dbg_t2, dbg_t3), ms(dbg_t3, dbg_t4), ms(dbg_t4, dbg_t5), c->tm.pyramid_ms, c->tm.detect_ms, c->tm.affine_ms, c->tm.patch_ms, c->tm.sift_ms, c->tm.pack_ms, c->tm.total_ms);
          }

@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <deque>
 #include <mutex>
+#include <pthread.h>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -256,13 +257,20 @@ struct FileIO : ChunkIO {
    bool decode_ready() const { return !stop && next_decode < n && next_decode < consumed + window; }   // under mu
    void work_loop()
    {
+      (void)pthread_setname_np(pthread_self(), "hs-pool");   // (shows in /proc/<pid>/task/*/comm: bench.py's per-thread CPU table)
       for (;;) {
          int i = -1;
          Task t{};
          {
             std::unique_lock<std::mutex> lk(mu);
             cv_work.wait(lk, [&] { return stop || decode_ready() || !tasks.empty(); });
-            if (decode_ready()) i = next_decode++;
+            // Decode first while the device could run dry (less than one chunk decoded ahead), otherwise write first: finished rows hold
+            // one of the three pinned result blocks until their files are written, and a small pool that fills the whole look-ahead
+            // window (two chunks) before it writes lets the device wait for a free block (2 threads: 268 -> see profiles/r05_notes.md)
+            const bool can_decode = decode_ready();
+            const bool fed = next_decode - consumed >= max_batch || next_decode >= n;   // a full next chunk is decoded or being decoded
+            if (!tasks.empty() && (!can_decode || fed)) { t = tasks.front(); tasks.pop_front(); }
+            else if (can_decode) i = next_decode++;
             else if (!tasks.empty()) { t = tasks.front(); tasks.pop_front(); }
             else return;   // stop, nothing left to write
          }

@@ -118,14 +118,25 @@ __device__ __forceinline__ float hs_bilinear(const float *__restrict__ im, int p
    return in ? v : 0.0f;
 }
 
+#ifndef HS_TAP_FRACT
+#define HS_TAP_FRACT 1
+#endif
 // The tap of a window that lies inside the plane (all four corners tested: hs_window_outside): no bounds test, no selects,
 // a 32-bit element offset.  Same arithmetic as the inside case of hs_bilinear.
 __device__ __forceinline__ float hs_tap_inside_ptr(const float *__restrict__ im, int pitch, float wx, float wy)
 {
+#if HS_TAP_FRACT
+   // inside the plane w >= 0: (int)floorf(w) == (int)w (conversion truncates) and w - floorf(w) is v_fract_f32's exact value;
+   // two instructions per axis instead of three (helpers.cpp:227-232)
+   const uint32_t off = (uint32_t)(int)wy * (uint32_t)pitch + (uint32_t)(int)wx;
+   wx = __builtin_amdgcn_fractf(wx);
+   wy = __builtin_amdgcn_fractf(wy);
+#else
    const float fx = floorf(wx), fy = floorf(wy);
    wx -= fx;
    wy -= fy;
    const uint32_t off = (uint32_t)(int)fy * (uint32_t)pitch + (uint32_t)(int)fx;
+#endif
    const float *p = im + off;
    const float p00 = p[0], p01 = p[1], p10 = p[pitch], p11 = p[pitch + 1];
    return (1.0f - wy) * ((1.0f - wx) * p00 + wx * p01) + (wy) * ((1.0f - wx) * p10 + wx * p11);

@@ -51,10 +51,16 @@ struct PatchIO {
 // resource still bounds every load to the plane.)
 __device__ __forceinline__ float hs_tap_inside(const HsPlaneBuf &im, float wx, float wy)
 {
+#if HS_TAP_FRACT
+   const uint32_t off = ((uint32_t)(int)wy * im.pitch + (uint32_t)(int)wx) * 4u;   // w >= 0: truncation is floor (see hs_tap_inside_ptr)
+   wx = __builtin_amdgcn_fractf(wx);
+   wy = __builtin_amdgcn_fractf(wy);
+#else
    const float fx = floorf(wx), fy = floorf(wy);
    wx -= fx;
    wy -= fy;
    const uint32_t off = ((uint32_t)(int)fy * im.pitch + (uint32_t)(int)fx) * 4u;
+#endif
    const hs_v2u r0 = __builtin_amdgcn_raw_buffer_load_b64(im.rsrc, (int)off, 0, 0);
    const hs_v2u r1 = __builtin_amdgcn_raw_buffer_load_b64(im.rsrc, (int)off, (int)im.pitch_bytes, 0);
    const float p00 = __uint_as_float(r0.x), p01 = __uint_as_float(r0.y), p10 = __uint_as_float(r1.x), p11 = __uint_as_float(r1.y);

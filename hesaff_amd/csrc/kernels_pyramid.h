@@ -855,7 +855,13 @@ struct FivePlanes { DPlane R[5]; };
 // grid (ceil(cols/248), ceil(rows/band), B), block 64.
 // ---------------------------------------------------------------------------------------
 #define EXM_STRIP 248
-#define EXM_RS 5
+#ifndef EXM_RS
+#define EXM_RS 5      // ring rows: 3 under test + EXM_RS - 3 in flight (tuning; profiles/r05_notes.md)
+#endif
+#define EXM_AHEAD (EXM_RS - 3)
+#ifndef EXM_WAVES
+#define EXM_WAVES 0   // tuning: wavefronts per SIMD the register allocation is held to (0: the compiler's choice, 3)
+#endif
 
 __device__ __forceinline__ float hs_max3(float a, float b, float c)
 {
@@ -870,7 +876,7 @@ __device__ __forceinline__ float hs_min3(float a, float b, float c)
    return r;
 }
 
-__global__ __launch_bounds__(64) void k_extrema_march(FivePlanes fp, float posThr, float negThr, CandList cl, int band)
+__global__ __launch_bounds__(64, EXM_WAVES) void k_extrema_march(FivePlanes fp, float posThr, float negThr, CandList cl, int band)
 {
    const int lane = threadIdx.x, b = blockIdx.z;
    const int rows = fp.R[0].rows, cols = fp.R[0].cols, pitch = fp.R[0].pitch;
@@ -894,9 +900,9 @@ __global__ __launch_bounds__(64) void k_extrema_march(FivePlanes fp, float posTh
 
    float4 ring[5][EXM_RS];
    const int nsteps = yb - ya + 2;   // step k brings row ya - 1 + k; rows ya .. yb-1 are tested at steps 2 .. nsteps-1
-   // prologue: rows of steps 0 and 1
+   // prologue: rows of steps 0 .. EXM_AHEAD - 1
 #pragma unroll
-   for (int k = 0; k < 2; k++) {
+   for (int k = 0; k < EXM_AHEAD; k++) {
       const long long off = (long long)min(ya - 1 + k, rows - 1) * pitch;
 #pragma unroll
       for (int p = 0; p < 5; p++) ring[p][k] = HS_NT_EXT ? hs_load_nt4(reinterpret_cast<const float4 *>(base[p] + off)) : *reinterpret_cast<const float4 *>(base[p] + off);
@@ -906,10 +912,10 @@ __global__ __launch_bounds__(64) void k_extrema_march(FivePlanes fp, float posTh
       for (int u = 0; u < EXM_RS; u++) {
          const int k = k0 + u;
          {
-            // two rows ahead, into the slot whose row (k - 3) is no longer needed
-            const long long off = (long long)min(ya - 1 + k + 2, rows - 1) * pitch;
+            // EXM_AHEAD rows ahead, into the slot whose row (k - 3) is no longer needed
+            const long long off = (long long)min(ya - 1 + k + EXM_AHEAD, rows - 1) * pitch;
 #pragma unroll
-            for (int p = 0; p < 5; p++) ring[p][(u + 2) % EXM_RS] = HS_NT_EXT ? hs_load_nt4(reinterpret_cast<const float4 *>(base[p] + off)) : *reinterpret_cast<const float4 *>(base[p] + off);
+            for (int p = 0; p < 5; p++) ring[p][(u + EXM_AHEAD) % EXM_RS] = HS_NT_EXT ? hs_load_nt4(reinterpret_cast<const float4 *>(base[p] + off)) : *reinterpret_cast<const float4 *>(base[p] + off);
          }
          const int y = ya - 2 + k;        // row under test: slots (u-2, u-1, u) = rows y-1, y, y+1
          const int s0 = (u + EXM_RS - 2) % EXM_RS, s1 = (u + EXM_RS - 1) % EXM_RS, s2 = u;

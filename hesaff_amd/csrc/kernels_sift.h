@@ -33,6 +33,14 @@ struct SiftIO {
 
 #define HS_VO_DIM 40                          // rows/columns of the patch that carry weight in samplePatch
 #define HS_VO_PITCH (HS_VO_DIM * HS_VO_DIM)   // float2 per keypoint in the gradient-pair buffer (rows 16-byte aligned)
+// Row order of the gradient pairs in HBM.  At step i k_sift_hist needs the rows i, 8 + i, 16 + i, 24 + i of a keypoint (one per row of
+// cells).  HS_VO_PERM: row r is stored at position (r & 7) * 5 + (r >> 3), so that those four rows are 1280 CONSECUTIVE bytes (10-11 cache
+// lines per keypoint and step instead of four pieces of 320 bytes that touch 3-4 lines each); k_sift_grad writes the keypoint's 12.8 KB
+// as one contiguous block either way (its LDS tile is indexed through the host-built table KpTables::sgrad_om).
+#ifndef HS_VO_PERM
+#define HS_VO_PERM 1
+#endif
+#define HS_VO_ROW(r) (HS_VO_PERM ? (((r) & 7) * 5 + ((r) >> 3)) : (r))
 #define HS_SIFT_MSK_IT 5   // ceil(1245 / 256): pixels inside the circular mask per thread of a 256-thread block
 #define SM_TILE 64
 
@@ -307,8 +315,8 @@ __global__ __launch_bounds__(64, HS_HIST_WAVES) void k_sift_hist(SiftIO io, KpTa
    int st_off[5];      // float4 offset of staged item e = tid + 64 u inside the group's gradient pairs (without the step term)
 #pragma unroll
    for (int u = 0; u < 5; u++) {
-      const int e = tid + 64 * u, row16 = e / (HS_VO_DIM / 2), f = e - row16 * (HS_VO_DIM / 2);
-      st_off[u] = (row16 >> 2) * (HS_VO_PITCH / 2) + 8 * (row16 & 3) * (HS_VO_DIM / 2) + f;
+      const int e = tid + 64 * u, row16 = e / (HS_VO_DIM / 2), f = e - row16 * (HS_VO_DIM / 2);   // row16 = 4 * keypoint + row of cells
+      st_off[u] = (row16 >> 2) * (HS_VO_PITCH / 2) + HS_VO_ROW(8 * (row16 & 3)) * (HS_VO_DIM / 2) + f;
    }
    const float4 *my_rows = s_rows + (4 * kq + cb_r) * (HS_VO_DIM / 2) + 4 * cb_c;
    for (uint32_t g = blockIdx.x; 4 * g < n; g += gridDim.x) {
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(64, HS_HIST_WAVES) void k_sift_hist(SiftIO io, KpTa
          // step i + 1's items are requested now and parked at the top of the next round (unconditionally: the last round
          // re-reads its own rows)
          {
-            const float4 *gi = g4 + min(i + 1, 15) * (HS_VO_DIM / 2);
+            const float4 *gi = g4 + HS_VO_ROW(min(i + 1, 15)) * (HS_VO_DIM / 2);   // HS_VO_ROW(8 cb + i) = cb + HS_VO_ROW(i)
             st0 = HS_VO_LD(gi + st_src[0]); st1 = HS_VO_LD(gi + st_src[1]); st2 = HS_VO_LD(gi + st_src[2]); st3 = HS_VO_LD(gi + st_src[3]);
             st4 = HS_VO_LD(gi + st_src[4]);
          }

@@ -86,6 +86,36 @@ struct HsError {
    HsError(int c, const std::string &m) : code(c), msg(m) {}
 };
 
+// Host wait for a HIP event WITHOUT a spinning core.  hipEventSynchronize spins in this runtime even on events created with
+// hipEventBlockingSync (measured in round 5 with CLOCK_THREAD_CPUTIME_ID around the call: 96 ms of CPU for a 96 ms wait, one busy core per
+// context while a chunk's kernels run - half the CPU quota of an 8-GPU node).  Poll hipEventQuery instead: a few immediate queries for
+// waits of microseconds, then sleeps of 20 .. 200 us.
+static void hs_wait_event(hipEvent_t ev)
+{
+   timespec t0;
+   clock_gettime(CLOCK_MONOTONIC, &t0);
+   for (int tries = 0;; tries++) {
+      const hipError_t e = hipEventQuery(ev);
+      if (e == hipSuccess) return;
+      if (e != hipErrorNotReady) throw HsError(HESAFF_ERR_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(e));
+      (void)hipGetLastError();   // hipErrorNotReady is not an error
+      if (tries < 16) continue;
+      // sleep an eighth of what has been waited so far, 20 .. 200 us: the wake-up is late by at most ~6 % of a short wait, 0.2 ms of a long one
+      timespec now;
+      clock_gettime(CLOCK_MONOTONIC, &now);
+      const long long waited = (long long)(now.tv_sec - t0.tv_sec) * 1000000000ll + (now.tv_nsec - t0.tv_nsec);
+      const timespec nap = {0, (long)std::min<long long>(std::max<long long>(waited / 8, 20000), 200000)};
+      nanosleep(&nap, nullptr);
+   }
+}
+
+static double thread_cpu_ms()   // CPU time of the calling thread (debug lines: does the caller sleep while the device works?)
+{
+   timespec ts;
+   clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+   return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+
 // A device buffer that only grows.  ensure() never leaves a dangling pointer behind: the new block
 // is allocated before the old one is released (when the device cannot hold both, the old block
 // is released first and the allocation retried); on failure the buffer is empty (p == nullptr,
@@ -305,7 +335,29 @@ struct hesaff_ctx {
    hipEvent_t ev_exp[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // profiling, per staging slot: brackets of a chunk's length pass and of its write pass (the host's waits between them - a free pinned block - are not the export's)
    float export_ms = 0.0f; int32_t export_rows = 0;
    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_in_free[2] = {nullptr, nullptr}, ev_out_ready[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
-   std::vector<int32_t> h_starts;
+   // Small results the host reads every batch (per-image counts, counters, byte offsets of the text rows) arrive in PAGE-LOCKED memory:
+   // a hipMemcpyAsync into pageable memory is not asynchronous - the calling thread waits inside the runtime, spinning, until everything
+   // before it in the stream has run (a whole batch of kernels: one busy core per context, measured in round 5) - whereas a copy into
+   // pinned memory is enqueued and the host sleeps on a blocking-sync event.
+   struct HostSmall {
+      void *p = nullptr; size_t bytes = 0;
+      void *ensure(size_t need)
+      {
+         if (need > bytes) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr; bytes = 0;
+            const size_t cap = std::max<size_t>(need * 2, 4096);
+            if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { p = nullptr; throw HsError(HESAFF_ERR_NOMEM, "hipHostMalloc failed (small result block)"); }
+            bytes = cap;
+         }
+         return p;
+      }
+      void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+   } h_small_end, h_small_mid, h_small_exp;
+   struct HStarts {   // view of h_small_end with std::vector's two members in use
+      int32_t *q = nullptr;
+      int32_t *data() const { return q; }
+   } h_starts;
    DevBuf t_mask_idx, t_sgrad_nb, t_sgrad_om, b_rowprefix, b_trows, b_trows2, b_trows3;
    DevBuf b_jcoef[2], b_jplane;   // JPEG chunks: the images' coefficient blobs per input slot, the component planes after the inverse DCT (kernels_jpeg.h)
    DevBuf b_ex_len, b_ex_sums, b_ex_off, b_ex_imgoff, b_ex_starts;   // device export (kernels_export.h): row lengths, sums / offsets per 64 rows, offsets per image
@@ -392,7 +444,7 @@ void build_tables(hesaff_ctx *c)
             nb[4 * s + 2] = 4 * (r == 0 ? i : i - HS_PATCH);
             nb[4 * s + 3] = 4 * (i + HS_PATCH);
          }
-         om[2 * s + 0] = valid ? r * (HS_PATCH - 1) + cc : -1;
+         om[2 * s + 0] = valid ? HS_VO_ROW(r) * (HS_PATCH - 1) + cc : -1;   // slot in the keypoint's block of gradient pairs (kernels_sift.h: HS_VO_ROW)
          memcpy(&om[2 * s + 1], &sm[i], 4);
       }
       upload(c->t_sgrad_nb, nb); upload(c->t_sgrad_om, om);
@@ -1079,10 +1131,13 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       // The one host round trip of a batch: per-image Hessian counts + large-window row bounds.  The bin kernels
       // only extract the 41x41 patches (to HBM); the descriptor runs as four kernels with the parallel axis each
       // part wants (kernels_sift.h).  Images are processed in groups so that the patch buffers stay bounded.
-      std::vector<int32_t> hs(3 * (B + 1) + 1);
+      int32_t *hs_p = (int32_t *)c->h_small_mid.ensure(((size_t)3 * (B + 1) + 1) * 4);   // pinned: see hesaff_ctx::HostSmall
+      struct { int32_t *q; int32_t *data() const { return q; } int32_t &operator[](size_t i) const { return q[i]; } } hs{hs_p};
       HIP_TRY(hipMemcpyAsync(hs.data(), c->b_starts.p, ((size_t)3 * (B + 1) + 1) * 4, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipEventRecord(c->ev_detect_done, st));
-      HIP_TRY(hipEventSynchronize(c->ev_detect_done));   // blocking-sync event: no core spins while the detection stage runs
+      const double dbg_ca = c->debug ? thread_cpu_ms() : 0.0;
+      hs_wait_event(c->ev_detect_done);   // sleeps: no core spins while the detection stage runs
+      if (c->debug) fprintf(stderr, "[hesaff] run_batch: caller's CPU inside the wait for the detection stage %.2f ms\n", thread_cpu_ms() - dbg_ca);
       if ((uint32_t)hs[B] > c->cap) throw HsError(HESAFF_ERR_CAPACITY, "keypoint capacity exceeded; raise hesaff_params.max_kpts_per_mpx");
       const uint32_t *lrows = (const uint32_t *)hs.data() + 2 * (B + 1);
       c->batch_max_p = (int)lrows[B + 1];   // largest huge window of the batch (0: none)
@@ -1178,11 +1233,13 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
                       c->b_starts.as<int32_t>() + (B + 1));
    tm.end(t);
    tm.end(tt);
-   c->h_starts.resize(2 * (B + 1) + 8);
+   c->h_starts.q = (int32_t *)c->h_small_end.ensure(((size_t)2 * (B + 1) + 8) * 4);
    HIP_TRY(hipMemcpyAsync(c->h_starts.data(), c->b_starts.p, (size_t)2 * (B + 1) * 4, hipMemcpyDeviceToHost, st));
    HIP_TRY(hipMemcpyAsync(c->h_starts.data() + 2 * (B + 1), cnt, 8 * 4, hipMemcpyDeviceToHost, st));
    HIP_TRY(hipEventRecord(c->ev_batch_done, st));
-   HIP_TRY(hipEventSynchronize(c->ev_batch_done));
+   const double dbg_cb = c->debug ? thread_cpu_ms() : 0.0;
+   hs_wait_event(c->ev_batch_done);
+   if (c->debug) fprintf(stderr, "[hesaff] run_batch: caller's CPU inside the wait for the end of the batch %.2f ms\n", thread_cpu_ms() - dbg_cb);
    HIP_TRY(hipGetLastError());
    if (c->profiling) collect_timings(c, tm, B);
    const int32_t *cn = c->h_starts.data() + 2 * (B + 1);
@@ -1209,9 +1266,13 @@ unsigned long long export_text_prepare(hesaff_ctx *c, const KeyRec *keys, uint32
    hipLaunchKernelGGL(k_text_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)c->b_ex_sums.p, nblk, c->b_ex_off.as<unsigned long long>());
    hipLaunchKernelGGL(k_text_imgoff, dim3((B + 1 + 63) / 64), dim3(64), 0, st, d_starts, B, (const uint16_t *)c->b_ex_len.p,
                       (const unsigned long long *)c->b_ex_off.p, c->b_ex_imgoff.as<unsigned long long>());
-   HIP_TRY(hipMemcpyAsync(img_off.data(), c->b_ex_imgoff.p, ((size_t)B + 1) * 8, hipMemcpyDeviceToHost, st));
-   HIP_TRY(hipStreamSynchronize(st));
+   // into pinned memory, then a sleep on the blocking-sync event (a copy into the pageable vector would spin in the runtime)
+   unsigned long long *ho = (unsigned long long *)c->h_small_exp.ensure(((size_t)B + 1) * 8);
+   HIP_TRY(hipMemcpyAsync(ho, c->b_ex_imgoff.p, ((size_t)B + 1) * 8, hipMemcpyDeviceToHost, st));
+   HIP_TRY(hipEventRecord(c->ev_batch_done, st));      // (run_batch has returned: the event is free)
+   hs_wait_event(c->ev_batch_done);
    HIP_TRY(hipGetLastError());
+   memcpy(img_off.data(), ho, ((size_t)B + 1) * 8);
    return img_off[(size_t)B];
 }
 

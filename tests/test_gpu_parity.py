@@ -1324,3 +1324,94 @@ def test_process_files_resume_skips_complete_outputs(tmp_path, oracle):
         ctx.set_resume(False)
         st = ctx.process_files(paths[1:2])
         assert st[0][1] == 3
+
+
+@pytest.mark.gpu
+def test_budgeted_file_path_writes_the_same_bytes(tmp_path, oracle):
+    """the file path confined to one device's share of the host - bench.py's `--budgeted-child` (CPU mask set before
+    anything is loaded, thread counts from hesaff_host_plan_for) and `hesaff --batch ... --host-share 8` under the same mask - writes
+    the bytes the unconfined run writes (which are the oracle's): neither the thread counts nor the pinned read buffers change a file."""
+    import hashlib
+    import json
+    import sys
+    import hesaff_amd
+    from tests import _oracle
+    n, W, H = 20, 320, 240
+    d = tmp_path / "files"; d.mkdir()
+    paths = []
+    for i in range(n):
+        img = band_noise_image(H, W, 900 + i, SMALL_BANDS)
+        q = d / ("img%04d.pgm" % i)
+        q.write_bytes(b"P5\n%d %d\n255\n" % (W, H) + img.tobytes())
+        paths.append(str(q))
+    want0 = _oracle.OracleRun(_oracle.gray_from_u8(band_noise_image(H, W, 900, SMALL_BANDS))).export_text()
+    p = hesaff_amd.default_params(); p.max_batch = 4
+    with hesaff_amd.HesaffContext(p, device=0) as ctx:
+        ctx.set_output_format(3)
+        st = ctx.process_files(paths)          # the library's "auto" plan, twice: the second run reads into the recycled pinned buffers
+        st = ctx.process_files(paths)
+    assert all((rc, stage) == (0, 3) for rc, stage, _, _ in st)
+    text = [open(q + ".hesaff.sift", "rb").read() for q in paths]
+    side = [open(q + ".hesaff.bin", "rb").read() for q in paths]
+    assert text[0] == want0
+    for q in paths:
+        os.remove(q + ".hesaff.sift"); os.remove(q + ".hesaff.bin")
+    cpus = sorted(os.sched_getaffinity(0))[:2]
+    cfg = {"dir": str(d), "n": n, "chunk": 4, "device": 0, "cpus": cpus, "rank": 0, "world": 1, "md5": True}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--budgeted-child", json.dumps(cfg)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["cpus"] == cpus and out["plan"]["cpus"] <= 2 and out["plan"]["decode_threads"] + out["plan"]["write_threads"] == 2
+    assert out["text"]["md5"] == [hashlib.md5(t).hexdigest() for t in text] and out["text"]["failed_files"] == 0
+    assert out["sidecar"]["md5"] == [hashlib.md5(t).hexdigest() for t in side]
+    assert out["text"]["cpu_seconds_per_image"] > 0
+    # the CLI with the same share
+    exe = os.path.join(ROOT, "hesaff_amd", "bin", "hesaff")
+    lst = tmp_path / "list.txt"; lst.write_text("\n".join(paths) + "\n")
+    r = subprocess.run([exe, "--batch", str(lst), "--output", "both", "--host-share", "8"], capture_output=True, text=True,
+                       preexec_fn=lambda: os.sched_setaffinity(0, set(cpus)))
+    assert r.returncode == 0, r.stderr
+    assert [open(q + ".hesaff.sift", "rb").read() for q in paths] == text and [open(q + ".hesaff.bin", "rb").read() for q in paths] == side
+    assert subprocess.run([exe, "--batch", str(lst), "--host-share", "0"], capture_output=True, text=True).returncode == 1
+
+
+@pytest.mark.gpu
+def test_graf_layout_directory_in_one_command(tmp_path, oracle):
+    """BASELINE.json config 5: `tools/repeatability.py --graf DIR` on a directory in the layout of the Oxford sequences -
+    img1..img4.ppm (the format graf ships in) and H1to2p..H1to4p - runs `hesaff --batch` over it and prints the table.  Every output equals
+    the oracle's for the file's pixels; the table equals what evaluate() gives on those files; --devices is passed through."""
+    import json
+    import sys
+    import hesaff_amd
+    from tests import _oracle
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import repeatability as rp
+    seq = tmp_path / "jpg"
+    angles = (15, 30, 45)
+    paths, Hs = rp.write_sequence_files(str(seq), 480, 400, angles)
+    d = tmp_path / "graf"; d.mkdir()
+    for k, q in enumerate(paths):      # the same pixels as binary PPM, named like the Oxford sets
+        pix = hesaff_amd.read_image(q)
+        (d / ("img%d.ppm" % (k + 1))).write_bytes(b"P6\n%d %d\n255\n" % (pix.shape[1], pix.shape[0]) + pix.tobytes())
+        if k > 0:
+            np.savetxt(str(d / ("H1to%dp" % (k + 1))), Hs[k])
+    (d / "readme.txt").write_text("not an image")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "repeatability.py"), "--graf", str(d), "--devices", "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout)
+    assert [e["pair"] for e in res["pairs"]] == ["img1 -> img2", "img1 -> img3", "img1 -> img4"] and "--devices 0" in res["command"]
+    assert "repeatability" in r.stderr and "img1 -> img4" in r.stderr        # the table
+    for k in range(4):
+        q = str(d / ("img%d.ppm" % (k + 1)))
+        o = _oracle.OracleRun(_oracle.gray_from_u8(hesaff_amd.read_image(q)))
+        assert open(q + ".hesaff.sift", "rb").read() == o.export_text() and o.n_keys > 500
+    r1, d1 = rp.read_sift(str(d / "img1.ppm.hesaff.sift"))
+    for k, e in enumerate(res["pairs"]):
+        r2, d2 = rp.read_sift(str(d / ("img%d.ppm.hesaff.sift" % (k + 2))))
+        want = rp.evaluate(r1, d1, r2, d2, Hs[k + 1], (480, 400), (480, 400))
+        assert all(e[key] == want[key] for key in want), (e, want)
+    assert res["pairs"][0]["repeatability"] > res["pairs"][2]["repeatability"] > 0.2
+    # a directory without homographies / without img1 is refused with a message, not a traceback of the CLI
+    os.remove(str(d / "H1to3p"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "repeatability.py"), "--graf", str(d)], capture_output=True, text=True)
+    assert r.returncode != 0 and "H1to3p" in r.stderr

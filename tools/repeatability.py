@@ -8,6 +8,8 @@ M = [[a, b], [b, c]]  (README:27-44 of the reference).
   python tools/repeatability.py A.hesaff.sift B.hesaff.sift --H H.txt --size1 W H --size2 W H
   python tools/repeatability.py --synthetic            # needs the GPU: detects on a synthetic
                                                        # image and on homography-warped copies
+  python tools/repeatability.py --graf DIR [--devices 0-7]   # a directory in the layout of the Oxford sequences (img1..6.ppm,
+                                                       # H1to2p..H1to6p): hesaff --batch over it, then the table (BASELINE config 5)
 
 The Oxford sequences are not available offline; --synthetic substitutes a band-noise image
 warped by a viewpoint-like family of homographies (stated in the output).
@@ -272,6 +274,64 @@ def sequence_through_cli(out_dir, width=800, height=640, angles=(10, 20, 30, 40,
             "pairs": evaluate_sequence_files(paths, Hs, (width, height), list(angles))}
 
 
+def image_size(path):
+    """(width, height) of an image file through the library's own reader (the cv::imread of hesaff.cpp:137)."""
+    import hesaff_amd
+    img = hesaff_amd.read_image(path)
+    return int(img.shape[1]), int(img.shape[0])
+
+
+def graf_directory(d, devices=None, fast=0, table=True):
+    """BASELINE.json config 5 in ONE command for a directory in the layout of the Oxford affine-covariant-regions sequences
+    (graf, wall, boat, ...; the format README:27-44 of the reference is written for): img1..imgN.{ppm,pgm,png,jpg} and the
+    homographies H1to2p..H1toNp (3 x 3, text).  Every image goes through `hesaff --batch` (one list, sharded over `devices`
+    like any other list), then image 1 is evaluated against every other image under its homography."""
+    import re
+    import subprocess
+    imgs = {}
+    for f in sorted(os.listdir(d)):
+        m = re.fullmatch(r"img(\d+)\.(ppm|pgm|pbm|pnm|png|jpg|jpeg)", f, re.IGNORECASE)
+        if m and int(m.group(1)) not in imgs:
+            imgs[int(m.group(1))] = os.path.join(d, f)
+    if 1 not in imgs or len(imgs) < 2:
+        raise RuntimeError("%s: no img1.* plus at least one more imgK.* (ppm, pgm, png or jpg)" % d)
+    ks = [k for k in sorted(imgs) if k != 1]
+    Hs = {}
+    for k in ks:
+        for name in ("H1to%dp" % k, "H1to%d" % k, "H1to%dp.txt" % k):
+            q = os.path.join(d, name)
+            if os.path.exists(q):
+                Hs[k] = np.loadtxt(q).reshape(3, 3)
+                break
+        else:
+            raise RuntimeError("%s: no homography H1to%dp for %s" % (d, k, os.path.basename(imgs[k])))
+    paths = [imgs[1]] + [imgs[k] for k in ks]
+    lst = os.path.join(d, "hesaff_list.txt")
+    with open(lst, "w") as f:
+        f.write("\n".join(paths) + "\n")
+    exe = os.path.join(ROOT, "hesaff_amd", "bin", "hesaff")
+    cmd = [exe, "--batch", lst] + (["--devices", devices] if devices else []) + (["--fast", str(fast)] if fast else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hesaff --batch failed: " + (r.stderr or r.stdout)[-2000:])
+    size1 = image_size(imgs[1])
+    r1, d1 = read_sift(imgs[1] + ".hesaff.sift")
+    pairs = []
+    for k in ks:
+        r2, d2 = read_sift(imgs[k] + ".hesaff.sift")
+        ev = evaluate(r1, d1, r2, d2, Hs[k], size1, image_size(imgs[k]))
+        ev["pair"] = "img1 -> img%d" % k
+        pairs.append(ev)
+    out = {"data": "%s: %d images in the layout of the Oxford affine-covariant-regions sequences (img1..N, H1toKp)" % (os.path.abspath(d), len(paths)),
+           "command": " ".join(cmd), "fast": fast, "cli_stdout_tail": r.stdout.strip().splitlines()[-1], "pairs": pairs}
+    if table:
+        keys = [k for k in ("n1", "n2", "correspondences", "repeatability", "matches", "matching_score") if pairs and k in pairs[0]]
+        print("%-14s" % "pair" + "".join("%16s" % k for k in keys), file=sys.stderr)
+        for ev in pairs:
+            print("%-14s" % ev["pair"] + "".join(("%16.4f" % ev[k]) if isinstance(ev[k], float) else ("%16d" % ev[k]) for k in keys), file=sys.stderr)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("files", nargs="*")
@@ -282,7 +342,13 @@ def main():
     ap.add_argument("--synthetic-files", metavar="DIR", help="write the synthetic sequence as JPEG files into DIR, run `hesaff --batch` on it, evaluate")
     ap.add_argument("--fast", type=int, default=0, help="with --synthetic-files: hesaff_params.fast (0 = parity mode through the CLI)")
     ap.add_argument("--photo", type=int, default=None, help="with --synthetic-files: warp this sample photograph (0: china.jpg, 1: flower.jpg) instead of band noise")
+    ap.add_argument("--graf", metavar="DIR", help="a directory in the layout of the Oxford sequences (img1..N.ppm|pgm|png|jpg, H1to2p..H1toNp): "
+                                                  "`hesaff --batch` over its images, then image 1 against every other image; table on stderr, JSON on stdout")
+    ap.add_argument("--devices", help="with --graf: passed to `hesaff --batch --devices` (0-7, 0,2, all)")
     args = ap.parse_args()
+    if args.graf:
+        print(json.dumps(graf_directory(args.graf, devices=args.devices, fast=args.fast), indent=1))
+        return
     if args.synthetic_files:
         print(json.dumps(sequence_through_cli(args.synthetic_files, fast=args.fast, photo=args.photo), indent=1))
         return
