@@ -213,7 +213,7 @@ void hesaff_destroy(hesaff_ctx *c)
                      &c->t_patch_off, &c->t_patch_k, &c->b_gray, &c->b_up, &c->b_L, &c->b_L3, &c->b_R, &c->b_map, &c->b_bitmask, &c->b_prefix,
                      &c->b_blocksums, &c->b_generic, &c->b_counters, &c->b_cand, &c->b_rec_f, &c->b_rec_i, &c->b_rec_w, &c->b_hess_f, &c->b_hess_i,
                      &c->b_aff, &c->b_pw, &c->b_bins, &c->b_rank, &c->b_desc, &c->b_out, &c->b_starts, &c->b_patches,
-                     &c->b_stage, &c->b_input, &c->t_mask_idx, &c->t_sgrad_nb, &c->t_sgrad_om, &c->b_rowprefix, &c->b_trows, &c->b_trows2, &c->b_trows3,
+                     &c->b_stage, &c->b_input, &c->t_mask_idx, &c->t_sgrad_nb, &c->t_sgrad_om, &c->t_vo_rows, &c->t_vo_src, &c->b_rowprefix, &c->b_trows, &c->b_trows2, &c->b_trows3,
                      &c->b_ex_len, &c->b_ex_sums, &c->b_ex_off, &c->b_ex_imgoff, &c->b_ex_starts, &c->b_jcoef[0], &c->b_jcoef[1], &c->b_jplane};
    for (DevBuf *b : bufs) b->release();
    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

@@ -10,6 +10,9 @@
 #include <deque>
 #include <mutex>
 #include <pthread.h>
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -258,6 +261,10 @@ struct FileIO : ChunkIO {
    void work_loop()
    {
       (void)pthread_setname_np(pthread_self(), "hs-pool");   // (shows in /proc/<pid>/task/*/comm: bench.py's per-thread CPU table)
+      // The pool's threads read and write() flat out; the caller's thread needs the CPU for microseconds at a time, to launch the next kernels
+      // the moment an event fires.  On a share of two CPUs it must not queue behind them: the pool runs at a lower priority (nice is per
+      // thread on Linux; lowering it needs no privilege).
+      (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 10);
       for (;;) {
          int i = -1;
          Task t{};

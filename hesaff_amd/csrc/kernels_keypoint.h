@@ -26,6 +26,11 @@ struct KpTables {   // device tables built on the host once per context
    // patch, and {output slot r * 40 + c (or -1: row / column 40, no weight), mask value bits}
    const int4 *sgrad_nb;
    const int2 *sgrad_om;
+   // layout of a keypoint's gradient pairs in HBM (kernels_sift.h: HS_VO_COMPACT): per patch row r < 40 {first item of the row in the
+   // keypoint's block minus f_lo, f_lo, f_hi, 0} in 16-byte items (an empty row: f_lo > f_hi), and per item of the block the item of
+   // k_sift_grad's 40 x 20 LDS tile it is a copy of (padding items: tile item 0, which holds no masked pixel)
+   const int4 *vo_rows;
+   const uint16_t *vo_src;
    const int32_t *bin0, *bin1;   // precomputeBinsAndWeights siftdesc.cpp:18 (already x8)
    const float *w0, *w1;
    const float *patch_taps;      // Gaussian taps of every odd P0, concatenated

@@ -32,15 +32,17 @@ struct SiftIO {
 };
 
 #define HS_VO_DIM 40                          // rows/columns of the patch that carry weight in samplePatch
-#define HS_VO_PITCH (HS_VO_DIM * HS_VO_DIM)   // float2 per keypoint in the gradient-pair buffer (rows 16-byte aligned)
-// Row order of the gradient pairs in HBM.  At step i k_sift_hist needs the rows i, 8 + i, 16 + i, 24 + i of a keypoint (one per row of
-// cells).  HS_VO_PERM: row r is stored at position (r & 7) * 5 + (r >> 3), so that those four rows are 1280 CONSECUTIVE bytes (10-11 cache
-// lines per keypoint and step instead of four pieces of 320 bytes that touch 3-4 lines each); k_sift_grad writes the keypoint's 12.8 KB
-// as one contiguous block either way (its LDS tile is indexed through the host-built table KpTables::sgrad_om).
-#ifndef HS_VO_PERM
-#define HS_VO_PERM 1
+#define HS_VO_TILE (HS_VO_DIM * HS_VO_DIM)    // float2 of k_sift_grad's LDS tile (row-major 40 x 40)
+// The gradient pairs of a keypoint in HBM (written once by k_sift_grad, read by k_sift_hist: the largest stream of the descriptor stage, and
+// what both kernels are bound by - profiles/r05_notes.md).  HS_VO_COMPACT: only the 16-byte items (2 pixels) of every row's span inside the
+// circular mask are stored, row after row (row r: items f_lo(r) .. f_hi(r) of its 20) - 642 items + 6 zero items instead of 800: 10.4 KB
+// instead of 12.8 KB per keypoint.  KpTables::vo_rows / vo_src (host-built from the mask itself) describe the layout to both kernels.
+#ifndef HS_VO_COMPACT
+#define HS_VO_COMPACT 1
 #endif
-#define HS_VO_ROW(r) (HS_VO_PERM ? (((r) & 7) * 5 + ((r) >> 3)) : (r))
+#define HS_VO_ITEMS (HS_VO_COMPACT ? 648 : 800)   // 16-byte items per keypoint; the items from HS_VO_ZERO on are zero
+#define HS_VO_ZERO (HS_VO_COMPACT ? 642 : 0)      // an item that is (0, 0, 0, 0) in every keypoint's block (plain layout: row 0 holds no masked pixel)
+#define HS_VO_PITCH (2 * HS_VO_ITEMS)             // float2 per keypoint in the gradient-pair buffer
 #define HS_SIFT_MSK_IT 5   // ceil(1245 / 256): pixels inside the circular mask per thread of a 256-thread block
 #define SM_TILE 64
 
@@ -134,16 +136,21 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
    __shared__ float s_p[HS_PATCH_PIX];
    __shared__ float s_at[HM_ATAN_TAB_FLOATS];
 #if HS_SGRAD_TILE
-   // The keypoint's 40 x 40 pairs are collected here and leave as whole 16-byte items of consecutive addresses (zeros for
-   // the pixels outside the circular mask, which no thread ever writes): 100 full cache lines per keypoint instead of
-   // 8-byte pieces that start and end in the middle of lines.  The kernel is bound by this write stream (without the
+   // The keypoint's 40 x 40 pairs are collected here and leave as whole 16-byte items of consecutive addresses (the items of the rows'
+   // masked spans; zeros for the pixels of an item outside the mask, which no thread ever writes): 81 full cache lines per keypoint
+   // instead of 8-byte pieces that start and end in the middle of lines.  The kernel is bound by this write stream (without the
    // stores it runs in half the time).
-   __shared__ __attribute__((aligned(16))) float2 s_vo[HS_VO_PITCH];
+   __shared__ __attribute__((aligned(16))) float2 s_vo[HS_VO_TILE];
 #endif
    const int tid = threadIdx.x;
    const uint32_t n = io.h_hi - io.h_lo;
 #if HS_SGRAD_TILE
-   for (int i = tid; i < HS_VO_PITCH; i += 256) s_vo[i] = make_float2(0.0f, 0.0f);
+   for (int i = tid; i < HS_VO_TILE; i += 256) s_vo[i] = make_float2(0.0f, 0.0f);
+   // this thread's items of the keypoint's block in HBM: which tile item each of them is (KpTables::vo_src)
+   constexpr int VO_NI = (HS_VO_ITEMS + 255) / 256;
+   int vsrc[VO_NI];
+#pragma unroll
+   for (int i = 0; i < VO_NI; i++) vsrc[i] = tb.vo_src[min(tid + 256 * i, HS_VO_ITEMS - 1)];
 #endif
    {
       const float at_init[HM_ATAN_TAB_FLOATS] = HM_ATAN_TAB_INIT;
@@ -232,10 +239,10 @@ __global__ __launch_bounds__(256, HS_SGRAD_WAVES) void k_sift_grad(SiftIO io, Kp
          float4 *o4 = reinterpret_cast<float4 *>(vo + (size_t)k * HS_VO_PITCH);
          const float4 *t4 = reinterpret_cast<const float4 *>(s_vo);
 #pragma unroll
-         for (int i = 0; i < (HS_VO_PITCH / 2 + 255) / 256; i++) {
+         for (int i = 0; i < VO_NI; i++) {
             const int e = tid + 256 * i;
-            if (e < HS_VO_PITCH / 2) {
-               const float4 v = t4[e];
+            if (e < HS_VO_ITEMS) {
+               const float4 v = t4[vsrc[i]];
                hs_store_nt4(reinterpret_cast<float *>(o4 + e), v.x, v.y, v.z, v.w);
             }
          }
@@ -277,6 +284,7 @@ __global__ void k_math_sift(int n, const float *__restrict__ gy, const float *__
 #ifndef HS_HIST_TRIM
 #define HS_HIST_TRIM 1
 #endif
+#define HS_HIST_AHEAD 1   // steps the row items are requested ahead (2, with a second set of five registers, measured the same: profiles/r05_notes.md)
 #ifndef HS_HIST_WAVES
 #define HS_HIST_WAVES 0   // tuning: wavefronts per SIMD to hold the register allocation to (0: the compiler's choice)
 #endif
@@ -312,11 +320,23 @@ __global__ __launch_bounds__(64, HS_HIST_WAVES) void k_sift_hist(SiftIO io, KpTa
    // 16 rows as 320 consecutive 16-byte items (5 per lane, 3 rows per instruction), parks them in LDS and every lane
    // takes its 8 items from there; the next step's items are in flight meanwhile (20 registers instead of 32).
    __shared__ __attribute__((aligned(16))) float4 s_rows[16 * (HS_VO_DIM / 2)];
-   int st_off[5];      // float4 offset of staged item e = tid + 64 u inside the group's gradient pairs (without the step term)
+   // staged item e = tid + 64 u is item f of row 8 cb + i of keypoint kq_e (e = (4 kq_e + cb) * 20 + f).  s_vtab[row * 20 + f] = its place
+   // in the keypoint's block in HBM: vo_rows[row].x + f inside the row's span, HS_VO_ZERO (a zero item) outside; the lane walks its five
+   // table entries down the rows (40 bytes per step) - one 16-bit LDS read and one add per item and step
+   __shared__ uint16_t s_vtab[HS_VO_DIM * (HS_VO_DIM / 2)];
+   for (int q = tid; q < HS_VO_DIM * (HS_VO_DIM / 2); q += 64) {
+      const int r = q / (HS_VO_DIM / 2), f = q - r * (HS_VO_DIM / 2);
+      const int4 rw = tb.vo_rows[r];
+      s_vtab[q] = (uint16_t)((f >= rw.y && f <= rw.z) ? rw.x + f : HS_VO_ZERO);
+   }
+   __syncthreads();
+   int st_kq[5];
+   const uint16_t *st_tab[5];   // &s_vtab[(8 cb) * 20 + f] of item u
 #pragma unroll
    for (int u = 0; u < 5; u++) {
-      const int e = tid + 64 * u, row16 = e / (HS_VO_DIM / 2), f = e - row16 * (HS_VO_DIM / 2);   // row16 = 4 * keypoint + row of cells
-      st_off[u] = (row16 >> 2) * (HS_VO_PITCH / 2) + HS_VO_ROW(8 * (row16 & 3)) * (HS_VO_DIM / 2) + f;
+      const int e = tid + 64 * u, row16 = e / (HS_VO_DIM / 2);   // row16 = 4 * keypoint + row of cells
+      st_kq[u] = row16 >> 2;
+      st_tab[u] = s_vtab + 8 * (row16 & 3) * (HS_VO_DIM / 2) + (e - row16 * (HS_VO_DIM / 2));
    }
    const float4 *my_rows = s_rows + (4 * kq + cb_r) * (HS_VO_DIM / 2) + 4 * cb_c;
    for (uint32_t g = blockIdx.x; 4 * g < n; g += gridDim.x) {
@@ -327,31 +347,27 @@ __global__ __launch_bounds__(64, HS_HIST_WAVES) void k_sift_hist(SiftIO io, KpTa
       // the group's pairs; a group that runs past the list re-reads its last keypoint (values unused)
       const float4 *g4 = reinterpret_cast<const float4 *>(vo + (size_t)(4 * g) * HS_VO_PITCH);
       const int kmax = (int)min(3u, n - 1 - 4 * g);   // last keypoint of the group that exists
-      int st_src[5];
+      int st_src[5];   // the item's keypoint block inside the group (a keypoint past the list: the last one that exists)
 #pragma unroll
-      for (int u = 0; u < 5; u++) {
-         const int kq_e = (tid + 64 * u) / (4 * (HS_VO_DIM / 2));
-         st_src[u] = st_off[u] - (kq_e > kmax ? (kq_e - kmax) * (HS_VO_PITCH / 2) : 0);
-      }
+      for (int u = 0; u < 5; u++) st_src[u] = min(st_kq[u], kmax) * HS_VO_ITEMS;
       // five named registers, not an array: carried around the loop an array ends up in scratch memory
 #if HS_NT_VO_LD
 #define HS_VO_LD(p) hs_load_nt4(p)
 #else
 #define HS_VO_LD(p) (*(p))
 #endif
-      float4 st0 = HS_VO_LD(g4 + st_src[0]), st1 = HS_VO_LD(g4 + st_src[1]), st2 = HS_VO_LD(g4 + st_src[2]), st3 = HS_VO_LD(g4 + st_src[3]),
-             st4 = HS_VO_LD(g4 + st_src[4]);
-#pragma unroll 1
-      for (int i = 0; i < 16; i++) {
-         HS_WAVE_LDS_SYNC();   // every lane has taken step i - 1's items
-         s_rows[tid] = st0; s_rows[tid + 64] = st1; s_rows[tid + 128] = st2; s_rows[tid + 192] = st3; s_rows[tid + 256] = st4;
+      auto item_at = [&](int u, int i) { return st_src[u] + (int)st_tab[u][i * (HS_VO_DIM / 2)]; };   // float4 offset of staged item u at step i
+      float4 st0 = HS_VO_LD(g4 + item_at(0, 0)), st1 = HS_VO_LD(g4 + item_at(1, 0)), st2 = HS_VO_LD(g4 + item_at(2, 0)), st3 = HS_VO_LD(g4 + item_at(3, 0)),
+             st4 = HS_VO_LD(g4 + item_at(4, 0));
+      // One step: park the step's items, request the items of step i + HS_HIST_AHEAD into the registers they came from, consume.
+      auto step = [&](int i, float4 &a0, float4 &a1, float4 &a2, float4 &a3, float4 &a4) {
+         HS_WAVE_LDS_SYNC();   // every lane has taken the previous step's items
+         s_rows[tid] = a0; s_rows[tid + 64] = a1; s_rows[tid + 128] = a2; s_rows[tid + 192] = a3; s_rows[tid + 256] = a4;
          HS_WAVE_LDS_SYNC();
-         // step i + 1's items are requested now and parked at the top of the next round (unconditionally: the last round
-         // re-reads its own rows)
          {
-            const float4 *gi = g4 + HS_VO_ROW(min(i + 1, 15)) * (HS_VO_DIM / 2);   // HS_VO_ROW(8 cb + i) = cb + HS_VO_ROW(i)
-            st0 = HS_VO_LD(gi + st_src[0]); st1 = HS_VO_LD(gi + st_src[1]); st2 = HS_VO_LD(gi + st_src[2]); st3 = HS_VO_LD(gi + st_src[3]);
-            st4 = HS_VO_LD(gi + st_src[4]);
+            const int in = min(i + HS_HIST_AHEAD, 15);   // (unconditionally: the last rounds re-read row 15's items)
+            a0 = HS_VO_LD(g4 + item_at(0, in)); a1 = HS_VO_LD(g4 + item_at(1, in)); a2 = HS_VO_LD(g4 + item_at(2, in)); a3 = HS_VO_LD(g4 + item_at(3, in));
+            a4 = HS_VO_LD(g4 + item_at(4, in));
          }
          if (valid) {
             float4 cur[8];
@@ -393,7 +409,9 @@ __global__ __launch_bounds__(64, HS_HIST_WAVES) void k_sift_hist(SiftIO io, KpTa
 #endif
             }
          }
-      }
+      };
+#pragma unroll 1
+      for (int i = 0; i < 16; i++) step(i, st0, st1, st2, st3, st4);
       if (k < n) {
          float4 *dst = reinterpret_cast<float4 *>(io.vec + (size_t)k * 128 + cell * 8);
          dst[0] = make_float4(acc[0], acc[64], acc[128], acc[192]);

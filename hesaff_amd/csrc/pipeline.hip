@@ -358,7 +358,7 @@ struct hesaff_ctx {
       int32_t *q = nullptr;
       int32_t *data() const { return q; }
    } h_starts;
-   DevBuf t_mask_idx, t_sgrad_nb, t_sgrad_om, b_rowprefix, b_trows, b_trows2, b_trows3;
+   DevBuf t_mask_idx, t_sgrad_nb, t_sgrad_om, t_vo_rows, t_vo_src, b_rowprefix, b_trows, b_trows2, b_trows3;
    DevBuf b_jcoef[2], b_jplane;   // JPEG chunks: the images' coefficient blobs per input slot, the component planes after the inverse DCT (kernels_jpeg.h)
    DevBuf b_ex_len, b_ex_sums, b_ex_off, b_ex_imgoff, b_ex_starts;   // device export (kernels_export.h): row lengths, sums / offsets per 64 rows, offsets per image
    size_t rows_lds_set = 0;            // dynamic LDS opt-in of k_patch_large_rows on THIS device
@@ -444,10 +444,28 @@ void build_tables(hesaff_ctx *c)
             nb[4 * s + 2] = 4 * (r == 0 ? i : i - HS_PATCH);
             nb[4 * s + 3] = 4 * (i + HS_PATCH);
          }
-         om[2 * s + 0] = valid ? HS_VO_ROW(r) * (HS_PATCH - 1) + cc : -1;   // slot in the keypoint's block of gradient pairs (kernels_sift.h: HS_VO_ROW)
+         om[2 * s + 0] = valid ? r * (HS_PATCH - 1) + cc : -1;
          memcpy(&om[2 * s + 1], &sm[i], 4);
       }
       upload(c->t_sgrad_nb, nb); upload(c->t_sgrad_om, om);
+      // layout of the gradient pairs in HBM (kernels_sift.h: HS_VO_COMPACT), from the mask itself: per row the span of 16-byte items
+      // (two pixels) that hold a pixel with weight, rows back to back; the plain layout is "every row whole"
+      std::vector<int32_t> vrow(4 * HS_VO_DIM, 0);
+      std::vector<uint16_t> vsrc(HS_VO_ITEMS, 0);
+      int at = 0;
+      for (int r = 0; r < HS_VO_DIM; r++) {
+         int flo = 1, fhi = 0;
+         if (HS_VO_COMPACT) {
+            for (int cc = 0; cc < HS_VO_DIM; cc++)
+               if (sm[r * HS_PATCH + cc] > 0) { if (fhi < flo) flo = cc / 2; fhi = cc / 2; }
+         } else { flo = 0; fhi = HS_VO_DIM / 2 - 1; }
+         vrow[4 * r + 0] = at - flo; vrow[4 * r + 1] = flo; vrow[4 * r + 2] = fhi;
+         for (int f = flo; f <= fhi; f++, at++)
+            if (at < HS_VO_ITEMS) vsrc[(size_t)at] = (uint16_t)(r * (HS_VO_DIM / 2) + f);
+      }
+      // the layout constants of kernels_sift.h are those of THIS mask (helpers.cpp:131-147 at patchSize 41)
+      if (at != (HS_VO_COMPACT ? HS_VO_ZERO : HS_VO_ITEMS) || sm[0] > 0) throw HsError(HESAFF_ERR_ARG, "internal: gradient-pair layout does not match the circular mask");
+      upload(c->t_vo_rows, vrow); upload(c->t_vo_src, vsrc);
    }
    upload(c->t_smm, smm); upload(c->t_sift, sm); upload(c->t_bin0, b0); upload(c->t_bin1, b1); upload(c->t_w0, w0); upload(c->t_w1, w1);
    c->up = c->par.upscaleInputImage > 0 ? 1 : 0;
@@ -512,6 +530,7 @@ void refresh_tables_struct(hesaff_ctx *c)
    t.max_p0 = c->max_p0;
    t.mask_idx = c->t_mask_idx.as<int32_t>();
    t.sgrad_nb = c->t_sgrad_nb.as<int4>(); t.sgrad_om = c->t_sgrad_om.as<int2>();
+   t.vo_rows = c->t_vo_rows.as<int4>(); t.vo_src = c->t_vo_src.as<uint16_t>();
    t.n_masked = c->n_masked;
 }
 

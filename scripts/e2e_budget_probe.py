@@ -27,6 +27,8 @@ try:
         if r.returncode != 0:
             print("child failed", r.stderr[-1000:])
             continue
+        if os.environ.get("HESAFF_DEBUG"):   # tuning build: the chunk engine's per-chunk log of the sidecar run (the last 14 chunks)
+            print("\n".join([ln for ln in r.stderr.splitlines() if "] chunk" in ln and "caller" not in ln][-14:]))
         d = json.loads(r.stdout.strip().splitlines()[-1])
         for name in ("text", "sidecar"):
             q = d[name]
