@@ -15,6 +15,7 @@ cp $G/${T}_kernels_serial_photo.txt profiles/${R}_kernels_serial_photographs.txt
 cp $G/${T}_fast_mode.json profiles/${R}_fast_mode.json
 cp $G/${T}_fast_mode_photo.json profiles/${R}_fast_mode_photographs.json
 grep -v '^{"metric' $G/${T}_e2e_thread_sweep.txt > profiles/${R}_e2e_thread_sweep.txt
+grep -v amdgpu.ids $G/${T}_e2e_budget_probe.txt > profiles/${R}_e2e_budget_probe.txt
 tail -4 $G/${T}_tests.log > profiles/${R}_gpu_tests.log
 grep -v amdgpu.ids $G/${T}_jpeg_list_rate.txt > profiles/${R}_jpeg_list_rate.txt
 python3 - $T $R <<'PY'

@@ -1,12 +1,12 @@
 # usage (through gpurun): bash scripts/gpu_final.sh <tag>
 # round-end evidence, ONE pass: GPU test suite, default bench line, rocprofv3 stats + HBM traffic of the bench command, per-kernel PMC tables,
 # per-kernel serial times (parity, fast = 2, photographs), fast-mode reports, config-5 sequence tables (band noise and photograph, fast 0 / 2),
-# end-to-end thread sweep, JPEG lists (UHD and 1024x768; pixels on the device / on the host)
+# the file path inside 2 / 4 / 8 CPUs with per-thread CPU seconds, end-to-end thread sweep, JPEG lists (UHD and 1024x768; pixels on the device / on the host)
 cd $GRAFT_REPO_ROOT
 TAG=$1
 mkdir -p gpurun_out
 timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_tests.log 2>&1; tail -4 gpurun_out/${TAG}_tests.log
-(time timeout 1200 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err); tail -4 gpurun_out/${TAG}_bench.err
+T0=$(date +%s); timeout 1200 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench.py wall seconds: $(( $(date +%s) - T0 ))" | tee -a gpurun_out/${TAG}_bench.err
 bash scripts/gpu_profile_round.sh ${TAG}_prof > gpurun_out/${TAG}_prof.log 2>&1; tail -20 gpurun_out/${TAG}_prof.log | cut -c1-400
 bash scripts/gpu_pmc2.sh ${TAG} 8 > gpurun_out/${TAG}_pmc.md 2>&1; cat gpurun_out/${TAG}_pmc.md
 bash scripts/gpu_pmc_lds.sh ${TAG} 8 > gpurun_out/${TAG}_pmc_lds.md 2>&1; cat gpurun_out/${TAG}_pmc_lds.md
@@ -29,5 +29,6 @@ for q in sorted(glob.glob("gpurun_out/${TAG}_repeatability_*.json")):
     except Exception as e:
         print(q, "unreadable", e)
 PY
+timeout 900 python scripts/e2e_budget_probe.py 512 2 4 8 > gpurun_out/${TAG}_e2e_budget_probe.txt 2>&1; grep -v "amdgpu.ids" gpurun_out/${TAG}_e2e_budget_probe.txt | cut -c1-200
 timeout 900 python scripts/e2e_thread_sweep.py 384 > gpurun_out/${TAG}_e2e_thread_sweep.txt 2>&1; tail -12 gpurun_out/${TAG}_e2e_thread_sweep.txt | cut -c1-300
 timeout 600 python scripts/jpeg_list_rate.py 512 > gpurun_out/${TAG}_jpeg_list_rate.txt 2>&1; timeout 600 python scripts/jpeg_list_rate.py 2048 1024 768 >> gpurun_out/${TAG}_jpeg_list_rate.txt 2>&1; cut -c1-220 gpurun_out/${TAG}_jpeg_list_rate.txt
