@@ -362,6 +362,8 @@ def budgeted_child(cfg):
     os.sched_setaffinity(0, set(cfg["cpus"]))
     import hesaff_amd
     hp = hesaff_amd.host_plan(1)          # == host_plan(BUDGET_SHARE) on the whole quota
+    if cfg.get("pool"):                   # experiments: another split of the pool inside the same CPU mask
+        hp = dict(hp, decode_threads=int(cfg["pool"][0]), write_threads=int(cfg["pool"][1]))
     paths = [os.path.join(cfg["dir"], "img%04d.pgm" % i) for i in range(cfg["n"])]
 
     def sync():   # all ranks' children start their timed run together (files in a directory every rank knows)
