@@ -408,6 +408,8 @@ def budgeted_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, rank, worl
         sync()
     if tmp is None:
         return {"skipped": paths}
+    if rank == 0:   # what an interrupted earlier run may have left behind (the other ranks' children need seconds before they write here)
+        shutil.rmtree(os.path.join(os.path.dirname(tmp), "hesaff_sync_%s" % os.environ.get("MASTER_PORT", "0")), ignore_errors=True)
     try:
         cfg = {"dir": tmp, "n": len(paths), "chunk": chunk, "device": device, "cpus": cpus, "rank": rank, "world": world,
                "sync_dir": os.path.join(os.path.dirname(tmp), "hesaff_sync_%s" % os.environ.get("MASTER_PORT", "0"))}

@@ -445,32 +445,55 @@ struct KeyRec {   // == hesaff_keypoint (include/hesaff_amd.h), 164 bytes
    uint8_t desc[128];
 };
 
+// A block takes 64 consecutive Hessian keypoints: their head fields come in as coalesced runs of the nine arrays, their descriptors as one
+// 8 KB run, the records are assembled in LDS in rank order - the ranks of a run's survivors are consecutive (stable compaction) - and leave as
+// ONE contiguous run of dwords.  (Round 4's form - 32 lanes per keypoint, lane 0 fetching nine fields from nine lines and storing nine
+// dwords - ran at 2.2 TB/s: 4.6 ms per 256 UHD images; profiles/r05_notes.md.)
+#define HS_PACK_KP 64
+#define HS_PACK_DW 41   // dwords per record
 __global__ __launch_bounds__(256) void k_pack(HessList hl, const uint32_t *__restrict__ n_ptr, PatchWork pw,
                                               const uint32_t *__restrict__ rank, const uint8_t *__restrict__ desc, KeyRec *__restrict__ out)
 {
+   static_assert(sizeof(KeyRec) == 4 * HS_PACK_DW, "record layout");
+   __shared__ uint32_t s_rec[HS_PACK_KP * HS_PACK_DW];
+   __shared__ int s_lr[HS_PACK_KP];   // rank inside the block's run of records, -1: not described
    const uint32_t n = min(*n_ptr, hl.cap);
-   // 32 threads per keypoint: lane 0 writes the 36-byte head, all write 4 descriptor bytes
-   const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, lane = threadIdx.x & 31;
-   const uint32_t stride = (gridDim.x * blockDim.x) >> 5;
-   for (uint32_t h = g; h < n; h += stride) {
-      if (!pw.alive[h]) continue;
-      KeyRec *o = out + rank[h];
-      if (lane == 0) {
-         o->x = hl.x[h]; o->y = hl.y[h]; o->s = hl.s[h];
-         o->a11 = pw.A[4 * h]; o->a12 = pw.A[4 * h + 1]; o->a21 = pw.A[4 * h + 2]; o->a22 = pw.A[4 * h + 3];
-         o->response = hl.response[h];
-         o->type = hl.meta[h] & 3;
+   const int tid = threadIdx.x;
+   const uint32_t *desc32 = reinterpret_cast<const uint32_t *>(desc);
+   uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+   for (uint32_t h0 = blockIdx.x * HS_PACK_KP; h0 < n; h0 += gridDim.x * HS_PACK_KP) {
+      const uint32_t base = rank[h0];   // exclusive scan of `alive`: records of earlier keypoints
+      if (tid < HS_PACK_KP) {
+         const uint32_t h = h0 + tid;
+         const bool live = h < n && pw.alive[h];
+         const int lr = live ? (int)(rank[h] - base) : -1;
+         s_lr[tid] = lr;
+         if (live) {
+            uint32_t *r = s_rec + lr * HS_PACK_DW;
+            const float4 A = *reinterpret_cast<const float4 *>(pw.A + 4 * (size_t)h);
+            r[0] = __float_as_uint(hl.x[h]); r[1] = __float_as_uint(hl.y[h]); r[2] = __float_as_uint(hl.s[h]);
+            r[3] = __float_as_uint(A.x); r[4] = __float_as_uint(A.y); r[5] = __float_as_uint(A.z); r[6] = __float_as_uint(A.w);
+            r[7] = __float_as_uint(hl.response[h]);
+            r[8] = (uint32_t)(hl.meta[h] & 3);
+         }
       }
-      const uint32_t v = *(const uint32_t *)(desc + (size_t)h * 128 + 4 * lane);
-      *(uint32_t *)(o->desc + 4 * lane) = v;
+      __syncthreads();
+      int n_live = 0;
+#pragma unroll
+      for (int q = 0; q < HS_PACK_KP * 32 / 256; q++) {
+         const int idx = tid + 256 * q, j = idx >> 5, d = idx & 31;
+         const int lr = s_lr[j];
+         if (lr >= 0) s_rec[lr * HS_PACK_DW + 9 + d] = desc32[(size_t)(h0 + j) * 32 + d];
+      }
+      // the run's length: the last described keypoint's rank + 1 (s_lr is non-decreasing over the described ones)
+      for (int j = HS_PACK_KP - 1; j >= 0; j--)
+         if (s_lr[j] >= 0) { n_live = s_lr[j] + 1; break; }
+      __syncthreads();
+      const uint32_t total = (uint32_t)n_live * HS_PACK_DW;
+      uint32_t *o = out32 + (size_t)base * HS_PACK_DW;
+      for (uint32_t i = tid; i < total; i += 256) o[i] = s_rec[i];
+      __syncthreads();
    }
-}
-
-// zero flags[i] for i in [*n_ptr, cap): slots the current batch did not touch
-__global__ __launch_bounds__(256) void k_clear_tail(int32_t *__restrict__ flags, const uint32_t *__restrict__ n_ptr, uint32_t cap)
-{
-   const uint32_t n = min(*n_ptr, cap);
-   for (uint32_t i = n + blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) flags[i] = 0;
 }
 
 // device check of hmath.h against the host (stage API)

@@ -1144,6 +1144,7 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
    int t;
    PlaneTab pt;
    memset(&pt, 0, sizeof pt);
+   uint32_t n_hess_host = 0;   // Hessian keypoints of the batch (known after the host round trip below)
    for (size_t o = 0; o < c->oct.size(); o++)
       for (int l = 0; l < 3; l++) pt.L[o][l] = c->L[o * 3 + l];
    {
@@ -1158,6 +1159,7 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
       hs_wait_event(c->ev_detect_done);   // sleeps: no core spins while the detection stage runs
       if (c->debug) fprintf(stderr, "[hesaff] run_batch: caller's CPU inside the wait for the detection stage %.2f ms\n", thread_cpu_ms() - dbg_ca);
       if ((uint32_t)hs[B] > c->cap) throw HsError(HESAFF_ERR_CAPACITY, "keypoint capacity exceeded; raise hesaff_params.max_kpts_per_mpx");
+      n_hess_host = (uint32_t)hs[B];
       const uint32_t *lrows = (const uint32_t *)hs.data() + 2 * (B + 1);
       c->batch_max_p = (int)lrows[B + 1];   // largest huge window of the batch (0: none)
       // image groups [h_lo, h_hi) of at most group_kpts keypoints: about 16 groups per batch keep the
@@ -1240,11 +1242,11 @@ void run_batch(hesaff_ctx *c, const uint8_t *d_src, int channels, long long src_
          if (slot_used[sl]) HIP_TRY(hipStreamWaitEvent(st, c->ev_sift_done[sl], 0));
    }
    t = tm.begin(T_PACK);
-   // final stable compaction (hesaff.cpp:87: keys.push_back in detection order): exclusive scan of the alive
-   // flags over the whole capacity; alive[] is rewritten for h < n_hess each batch, the tail is cleared here
+   // final stable compaction (hesaff.cpp:87: keys.push_back in detection order): exclusive scan of the alive flags of the batch's
+   // Hessian keypoints (alive[] is rewritten for h < n_hess each batch; the host knows n_hess since the round trip after detection -
+   // the scan used to run over the whole capacity, 85 M flags for 31 M keypoints, behind a kernel that cleared the tail)
    LoadFlagI32 lf; lf.p = s.pw.alive;
-   hipLaunchKernelGGL(k_clear_tail, dim3(1024), dim3(256), 0, st, s.pw.alive, (const uint32_t *)(cnt + 3), c->cap);
-   exclusive_scan(c, lf, (long long)c->cap, c->b_rank.as<uint32_t>(), cnt + 4);
+   exclusive_scan(c, lf, (long long)n_hess_host, c->b_rank.as<uint32_t>(), cnt + 4);
    hipLaunchKernelGGL(k_pack, dim3(HS_GRID_PACK), dim3(256), 0, st, s.hl, (const uint32_t *)(cnt + 3), s.pw, (const uint32_t *)c->b_rank.p,
                       (const uint8_t *)c->b_desc.p, c->b_out.as<KeyRec>());
    hipLaunchKernelGGL(k_desc_starts, dim3((B + 1 + 63) / 64), dim3(64), 0, st, (const int32_t *)c->b_starts.p, B,
