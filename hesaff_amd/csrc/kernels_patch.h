@@ -185,6 +185,9 @@ __device__ __forceinline__ void hs_resample_full_tab(const float *S, const int *
 #define HS_MID_SCALAR 1     // the row pass of the row-streamed windows as scalar sliding-window chains: every sample is read from LDS once (the pair form reads
                             // it twice) and no register pairs are assembled; k_patch_mid<512> 195.5 -> 178.1, <128> 149.5 -> 144.0 ms per 256 images
 #endif
+#ifndef HS_ABL_MIDCONF
+#define HS_ABL_MIDCONF 0
+#endif
 #ifndef HS_MID_SCALAR_TAIL
 #define HS_MID_SCALAR_TAIL 0   // the same form in the one- and two-row variants (tail rows of a window, k_patch_large_rows): measured slower (182.8 vs 179.4, 33.9 vs 32.2 ms)
 #endif
@@ -860,7 +863,11 @@ __device__ __forceinline__ void hs_row_stream3(const HsPlaneBuf &img, float x, f
       const int colA = tA - HS_PATCH * rowA, colB = tB - HS_PATCH * rowB;
       const float c0 = (float)half;
       const float wA = c0 + (float)(colA - 20) * scale, wB = c0 + (float)(colB - 20) * scale;
+#if HS_ABL_MIDCONF   // ablation only (results invalid): every lane starts at its own column, i.e. consecutive LDS words - what the row pass costs WITHOUT its bank conflicts
+      const int xA = min(colA, pm - 1), xB = min(colB, pm - 1);
+#else
       const int xA = min(max((int)floorf(wA), 0), pm - 1), xB = min(max((int)floorf(wB), 0), pm - 1);
+#endif
       const float *sA = srow + rowA * sstride + xA, *sB = srow + rowB * sstride + xB;
       auto GA = [&](int jt) { v2f g; g.x = sA[jt]; g.y = sA[jt + 1]; return g; };
       auto GB = [&](int jt) { v2f g; g.x = sB[jt]; g.y = sB[jt + 1]; return g; };

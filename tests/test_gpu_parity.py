@@ -1415,3 +1415,22 @@ def test_graf_layout_directory_in_one_command(tmp_path, oracle):
     os.remove(str(d / "H1to3p"))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "repeatability.py"), "--graf", str(d)], capture_output=True, text=True)
     assert r.returncode != 0 and "H1to3p" in r.stderr
+
+
+@pytest.mark.gpu
+def test_the_caller_sleeps_while_the_device_works():
+    """Round 5: hipEventSynchronize spins in this runtime even on hipEventBlockingSync events - one busy core per context while a batch's kernels
+    run.  The library waits with hipEventQuery + nanosleep (hs_wait_event, pipeline.hip): the calling thread's own CPU time
+    (CLOCK_THREAD_CPUTIME_ID) inside a batch call must be a small part of the call's wall time."""
+    import time
+    import hesaff_amd
+    imgs = [band_noise_image(1080, 1920, 4000 + i) for i in range(12)]
+    p = hesaff_amd.default_params(); p.max_batch = len(imgs)
+    with hesaff_amd.HesaffContext(p, device=0) as ctx:
+        ctx.detect_batch_raw(imgs)                      # plan, buffers, pinned blocks
+        c0, t0 = time.thread_time(), time.perf_counter()
+        for _ in range(3):
+            res = ctx.detect_batch_raw(imgs)
+        cpu, wall = time.thread_time() - c0, time.perf_counter() - t0
+    assert sum(r.count_desc for r in res) > 100000
+    assert wall > 0.05 and cpu < 0.5 * wall, (cpu, wall)    # a spinning wait measures cpu ~= wall (was 0.96-1.0 before the change)
