@@ -184,6 +184,7 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       if (const char *sd = getenv("HESAFF_SIDE")) c->side_mask = atoi(sd);
       if (const char *gk = getenv("HESAFF_GROUP")) c->sift_group_kpts = (uint32_t)std::max(1000, atoi(gk));
       if (const char *wv = getenv("HESAFF_BANDS")) c->force_bands = std::max(0, atoi(wv));
+      if (const char *eb = getenv("HESAFF_EXBAND")) c->force_exband = std::max(0, atoi(eb));
       c->debug = getenv("HESAFF_DEBUG") != nullptr;
       if (const char *sg = getenv("HESAFF_SGRAD_GRID")) c->sgrad_grid = (uint32_t)std::max(0, atoi(sg));
       if (const char *gm = getenv("HESAFF_GRID_MULT")) {   // the persistent grids of the LDS-window patch kernels and of k_sift_hist x this

@@ -392,6 +392,7 @@ struct hesaff_ctx {
                                    // make the step 3.5 % slower (453 vs 438 ms at B = 128): the queued blocks take every slot that frees up
    int side_mask = 15;             // HESAFF_SIDE: bit i = window-size bin i runs on its own side stream
    int force_bands = 0;            // HESAFF_BANDS: force the band count of k_blur_hess_march
+   int force_exband = 0;           // HESAFF_EXBAND: rows per band of k_extrema_march (tuning)
    bool debug = false;             // HESAFF_DEBUG=1: launch geometry on stderr
    uint32_t sgrad_grid = 0;        // persistent grid of k_sift_grad (set with the device: 32 blocks per CU; HESAFF_SGRAD_GRID; 0: one block per keypoint)
 
@@ -1030,9 +1031,11 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
       if (g.rows > 2 * HS_BORDER && g.cols > 2 * HS_BORDER) {
          FivePlanes fp;
          for (int l = 0; l < 5; l++) fp.R[l] = Ro[l];
-         // bands of 64 rows; 32 when that would leave the chip short of wavefronts
+         // bands of 128 rows (a band re-reads 4 rows of halo and starts with two row loads nothing overlaps: 32 / 64 / 128 / 256 rows measured
+         // 25.0 / 23.4 / 22.2 / 23.5 ms for the detection stage of 256 UHD images); shorter bands when that would leave the chip short of wavefronts
          const int strips = (g.cols + EXM_STRIP - 1) / EXM_STRIP;
-         const int band = ((long long)strips * ((g.rows + 63) / 64) * B >= 4096) ? 64 : 32;
+         auto waves_at = [&](int rows_per_band) { return (long long)strips * ((g.rows + rows_per_band - 1) / rows_per_band) * B; };
+         const int band = c->force_exband > 0 ? c->force_exband : (waves_at(128) >= 4096 ? 128 : (waves_at(64) >= 4096 ? 64 : 32));
          const dim3 grid(strips, (g.rows + band - 1) / band, B);
          const int te = tm.begin(T_EXTREMA, 20.0 * (double)B * g.rows * g.cols);
          hipLaunchKernelGGL(k_extrema_march, grid, dim3(64), 0, st, fp, c->consts.positiveThreshold, c->consts.negativeThreshold, s.cl, band);

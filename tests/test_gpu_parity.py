@@ -1429,8 +1429,8 @@ def test_the_caller_sleeps_while_the_device_works():
     with hesaff_amd.HesaffContext(p, device=0) as ctx:
         ctx.detect_batch_raw(imgs)                      # plan, buffers, pinned blocks
         c0, t0 = time.thread_time(), time.perf_counter()
-        for _ in range(3):
+        for _ in range(10):
             res = ctx.detect_batch_raw(imgs)
         cpu, wall = time.thread_time() - c0, time.perf_counter() - t0
     assert sum(r.count_desc for r in res) > 100000
-    assert wall > 0.05 and cpu < 0.5 * wall, (cpu, wall)    # a spinning wait measures cpu ~= wall (was 0.96-1.0 before the change)
+    assert wall > 0.02 and cpu < 0.5 * wall, (cpu, wall)    # a spinning wait measures cpu ~= wall (0.96-1.0 before the change; 0.06 after)
