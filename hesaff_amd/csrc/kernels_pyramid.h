@@ -245,7 +245,12 @@ struct OctaveCtx {
    float sigma[HS_NSCALES + 2];   // curSigma of each level (sigma[1..3] used as curScale)
    float pixelDistance;
    int octave;
-   uint32_t *map;                 // [B][rows][cols] order keys, 0xFFFFFFFF = free
+   uint32_t *map;                 // [B][rows][cols] order keys of the CURRENT epoch, anything larger = free
+   // Every pass over an octave bids with keys of its own epoch in the bits above the key, and epochs count DOWN: whatever earlier passes (other
+   // octaves, earlier batches) left in a cell is larger than any bid of this pass and loses the atomicMin - nothing has to be reset between
+   // passes (rounds 1-3 filled the whole map per octave, round 4 had every record give its cell back: 1.1 ms per 256 UHD images).  The host
+   // refills the map with 0xFFFFFFFF when the epochs run out (127 passes for UHD: key < 3 x 8.3 M needs 25 bits).
+   uint32_t map_epoch;            // epoch << key bits
    long long word_base;           // first bitmask word of this octave inside one image
    long long words_per_image;     // bitmask words of a whole image (all octaves)
    int words_per_row;
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(256) void k_localize(OctaveCtx oc, CandList cl, Rec
             rl.key[slot] = o_key;
             rl.word[slot] = o_word;
             rl.bit[slot] = o_bit;
-            atomicMin(oc.map + (long long)o_map * rows * cols + o_cell, o_key);
+            atomicMin(oc.map + (long long)o_map * rows * cols + o_cell, o_key | oc.map_epoch);   // (the epoch: OctaveCtx)
          }
       }
    }
@@ -395,20 +400,11 @@ __global__ __launch_bounds__(256) void k_dedupe(OctaveCtx oc, RecList rl, const 
    const long long N = (long long)oc.R[0].rows * oc.R[0].cols;
    for (uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
       const int b = rl.meta[i] >> 8;
-      if (oc.map[(long long)b * N + rl.cell[i]] == rl.key[i]) atomicOr(bitmask + rl.word[i], 1ull << rl.bit[i]);
+      if (oc.map[(long long)b * N + rl.cell[i]] == (rl.key[i] | oc.map_epoch)) atomicOr(bitmask + rl.word[i], 1ull << rl.bit[i]);
       else rl.word[i] = -1;   // lost the octaveMap race
    }
 }
 
-// the octave's records give their map cells back (all records: the losers of a cell reset it as well as its winner)
-__global__ __launch_bounds__(256) void k_map_reset(OctaveCtx oc, RecList rl, const uint32_t *__restrict__ start_ptr)
-{
-   const uint32_t start = *start_ptr;
-   const uint32_t n = min(*rl.count, rl.cap);
-   const long long N = (long long)oc.R[0].rows * oc.R[0].cols;
-   for (uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-      oc.map[(long long)(rl.meta[i] >> 8) * N + rl.cell[i]] = 0xffffffffu;
-}
 
 // ---------------------------------------------------------------------------------------
 // Exclusive scan of 32-bit counts (three phases, 4096 items per block).  LOAD turns the
@@ -523,8 +519,12 @@ struct HessList {   // ordered Hessian keypoints of the batch = onHessianKeypoin
    uint32_t cap;
 };
 
+// Two launches: the record goes to its rank as ONE 32-byte item (the six fields side by side) and a second, streaming kernel deals the items out to
+// the six arrays of the Hessian list.  Scattering the six fields themselves (rounds 1-4) was six partial-line stores per record, 33 M records per
+// 256 UHD images: 2.7 ms; a 32-byte store is one whole sector, and the second pass is coalesced on both sides.
+struct __attribute__((aligned(32))) HessItem { float x, y, s, response; int32_t meta, r0c0; uint32_t pad0, pad1; };
 __global__ __launch_bounds__(256) void k_scatter_ordered(RecList rl, const unsigned long long *__restrict__ bitmask,
-                                                         const uint32_t *__restrict__ prefix, HessList hl)
+                                                         const uint32_t *__restrict__ prefix, HessItem *__restrict__ items, uint32_t cap)
 {
    const uint32_t n = min(*rl.count, rl.cap);
    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -533,14 +533,20 @@ __global__ __launch_bounds__(256) void k_scatter_ordered(RecList rl, const unsig
       const uint32_t bit = rl.bit[i];
       const unsigned long long below = bitmask[w] & ((1ull << bit) - 1ull);
       const uint32_t rank = prefix[w] + (uint32_t)__popcll(below);
-      if (rank >= hl.cap) continue;
-      hl.x[rank] = rl.x[i];
-      hl.y[rank] = rl.y[i];
-      hl.s[rank] = rl.s[i];
-      hl.response[rank] = rl.response[i];
-      hl.meta[rank] = rl.meta[i];
-      // recover r0,c0 from the key is not needed on the batch path; kept for the stage API
-      hl.r0c0[rank] = (int32_t)rl.key[i];
+      if (rank >= cap) continue;
+      float4 *o = reinterpret_cast<float4 *>(items + rank);
+      o[0] = make_float4(rl.x[i], rl.y[i], rl.s[i], rl.response[i]);
+      // (r0, c0 is recovered from the key by the stage API; the batch path does not read it)
+      o[1] = make_float4(__int_as_float(rl.meta[i]), __int_as_float((int32_t)rl.key[i]), 0.0f, 0.0f);
+   }
+}
+__global__ __launch_bounds__(256) void k_hess_deal(const HessItem *__restrict__ items, const uint32_t *__restrict__ n_ptr, HessList hl)
+{
+   const uint32_t n = min(*n_ptr, hl.cap);
+   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+      const float4 a = reinterpret_cast<const float4 *>(items + r)[0], b = reinterpret_cast<const float4 *>(items + r)[1];
+      hl.x[r] = a.x; hl.y[r] = a.y; hl.s[r] = a.z; hl.response[r] = a.w;
+      hl.meta[r] = __float_as_int(b.x); hl.r0c0[r] = __float_as_int(b.y);
    }
 }
 

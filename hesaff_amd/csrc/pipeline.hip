@@ -245,7 +245,9 @@ struct hesaff_ctx {
    long long words_per_image = 0;
    uint32_t cap = 0;      // keypoint capacity of a batch
    uint32_t cand_cap = 0; // candidate slots of one octave (k_extrema_march -> k_localize)
-   bool map_clean = false;   // every cell of b_map is 0xFFFFFFFF (free): k_map_reset puts back what an octave's records touched
+   bool map_clean = false;   // b_map holds nothing but 0xFFFFFFFF and bids of epochs above map_epoch (OctaveCtx::map_epoch, kernels_pyramid.h)
+   int map_kbits = 32;       // bits of an order key (3 x pixels of the first pyramid level)
+   uint32_t map_epoch = 0;   // the last epoch handed out; 0: the next pass refills the map first
 
    // planes
    DevBuf b_gray, b_up, b_L, b_L3, b_R, b_map, b_bitmask, b_prefix, b_blocksums, b_generic;
@@ -678,6 +680,9 @@ void plan_buffers(hesaff_ctx *c, int B, int H, int W)
       // a new block is filled once before its first use (run_detection).  Pointer AND size: ensure()'s out-of-memory path frees the old
       // block first, and the larger one may come back at the same address with a tail that was never filled
       if (c->b_map.p != before || c->b_map.bytes != before_bytes) c->map_clean = false;
+      int kb = 1;
+      while (kb < 32 && (3ull * (unsigned long long)PH * PW) > (1ull << kb)) kb++;
+      if (kb != c->map_kbits) { c->map_kbits = kb; c->map_clean = false; }   // (another key width: epochs of the old one mean nothing)
    }
    const long long total_words = (long long)B * words;
    c->b_bitmask.ensure(std::max<size_t>((size_t)total_words * 8, 16));
@@ -929,10 +934,9 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
    const float *ptaps = c->t_pyr_taps.as<float>();
    HIP_TRY(hipMemsetAsync(cnt, 0, 64 * 4, st));
    HIP_TRY(hipMemsetAsync(c->b_bitmask.p, 0, std::max<size_t>((size_t)B * c->words_per_image * 8, 8), st));
-   // octaveMap (pyramid.cpp:226: zeroed per octave): the order-key map is filled with "free" once; after an octave's dedupe the
-   // cells its records touched are set back (k_map_reset) - 0.1 GB of scattered stores per 256 UHD images instead of an 11 GB fill
-   if (!c->map_clean) HIP_TRY(hipMemsetAsync(c->b_map.p, 0xFF, c->b_map.bytes, st));
-   c->map_clean = false;
+   // octaveMap (pyramid.cpp:226: zeroed per octave): the order-key map is filled with "free" when it is new; every pass over an octave then bids
+   // with keys of a fresh, smaller epoch (OctaveCtx::map_epoch), so what earlier passes left behind never wins - no fill and no reset per octave
+   if (!c->map_clean) { HIP_TRY(hipMemsetAsync(c->b_map.p, 0xFF, c->b_map.bytes, st)); c->map_epoch = c->map_kbits < 32 ? (0xffffffffu >> c->map_kbits) : 0u; c->map_clean = true; }
 
    int t = tm.begin(T_PYR);
    DPlane none = make_plane(nullptr, 0, 0, 0);
@@ -1025,6 +1029,10 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
       oc.pixelDistance = c->consts.pd0 * (float)(1 << o);   // pyramid.cpp:288: doubles per octave
       oc.octave = (int)o;
       oc.map = c->b_map.as<uint32_t>();
+      // a fresh epoch for this pass (counting down; the all-ones epoch is the fill value): refill when they have run out
+      if (c->map_epoch == 0) { HIP_TRY(hipMemsetAsync(c->b_map.p, 0xFF, c->b_map.bytes, st)); c->map_epoch = c->map_kbits < 32 ? (0xffffffffu >> c->map_kbits) : 0u; }
+      if (c->map_epoch > 0) c->map_epoch--;
+      oc.map_epoch = c->map_kbits < 32 ? (c->map_epoch << c->map_kbits) : 0u;
       oc.word_base = g.word_base;
       oc.words_per_image = c->words_per_image;
       oc.words_per_row = g.words_per_row;
@@ -1043,7 +1051,6 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
          hipLaunchKernelGGL(k_localize, dim3(HS_GRID_LOC), dim3(256), 0, st, oc, s.cl, s.rl, c->consts);
          hipLaunchKernelGGL(k_dedupe, dim3(HS_GRID_DED), dim3(256), 0, st, oc, s.rl, (const uint32_t *)(cnt + 32 + o),
                             c->b_bitmask.as<unsigned long long>());
-         hipLaunchKernelGGL(k_map_reset, dim3(HS_GRID_DED), dim3(256), 0, st, oc, s.rl, (const uint32_t *)(cnt + 32 + o));
       }
       tm.end(t);
    }
@@ -1052,8 +1059,12 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
    const long long total_words = (long long)B * c->words_per_image;
    LoadPopc lp; lp.p = c->b_bitmask.as<unsigned long long>();
    exclusive_scan(c, lp, total_words, c->b_prefix.as<uint32_t>(), cnt + 3);
+   // the records at their ranks as 32-byte items (in the candidate buffer: its last reader, the last octave's k_localize, is done), then dealt out
+   HessItem *items = reinterpret_cast<HessItem *>(c->b_cand.p);
+   static_assert(sizeof(HessItem) == 32 && sizeof(CandRec) >= sizeof(HessItem), "the items fit the candidate slots (cand_cap >= cap)");
    hipLaunchKernelGGL(k_scatter_ordered, dim3(HS_GRID_SCAT), dim3(256), 0, st, s.rl, (const unsigned long long *)c->b_bitmask.p,
-                      (const uint32_t *)c->b_prefix.p, s.hl);
+                      (const uint32_t *)c->b_prefix.p, items, s.hl.cap);
+   hipLaunchKernelGGL(k_hess_deal, dim3(HS_GRID_SCAT), dim3(256), 0, st, (const HessItem *)items, (const uint32_t *)(cnt + 3), s.hl);
    hipLaunchKernelGGL(k_image_counts, dim3((B + 1 + 63) / 64), dim3(64), 0, st, (const uint32_t *)c->b_prefix.p,
                       c->words_per_image, B, (const uint32_t *)(cnt + 3), c->b_starts.as<int32_t>());
    // per image: upper bound of the T' rows its huge windows (P > 512) need, known from the scales alone
@@ -1061,7 +1072,6 @@ void run_detection(hesaff_ctx *c, const uint8_t *d_src, int channels, long long 
    hipLaunchKernelGGL(k_image_large_rows, dim3(512), dim3(256), 0, st, s.hl, (const uint32_t *)(cnt + 3), c->consts.mrSize,
                       c->b_starts.as<uint32_t>() + 2 * (B + 1), B);
    tm.end(t);
-   c->map_clean = true;   // (in stream order; a HIP error on the way leaves the flag false)
 }
 
 __global__ void k_desc_starts(const int32_t *__restrict__ hess_starts, int nimg, const uint32_t *__restrict__ rank,

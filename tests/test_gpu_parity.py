@@ -1434,3 +1434,26 @@ def test_the_caller_sleeps_while_the_device_works():
         cpu, wall = time.thread_time() - c0, time.perf_counter() - t0
     assert sum(r.count_desc for r in res) > 100000
     assert wall > 0.02 and cpu < 0.5 * wall, (cpu, wall)    # a spinning wait measures cpu ~= wall (0.96-1.0 before the change; 0.06 after)
+
+
+@pytest.mark.gpu
+def test_octave_map_epochs_wrap_around(oracle):
+    """The order-key map (octaveMap, pyramid.cpp:189-193,226) is never reset between octaves or batches: every pass bids with keys of a fresh,
+    smaller epoch, and the map is refilled when the epochs run out - after 127 passes for a 3840 x 2160 image (25 key bits), i.e. in the 16th batch
+    of 8 octaves.  Forty batches through one context cross that point twice: every batch must return the first one's bytes (which are the oracle's)."""
+    import hesaff_amd
+    from tests import _oracle
+    img = band_noise_image(2160, 3840, 77)
+    p = hesaff_amd.default_params(); p.max_batch = 1
+    with hesaff_amd.HesaffContext(p, device=0) as ctx:
+        nh0, first = ctx.detect_batch([img])[0]
+        for it in range(40):
+            nh, again = ctx.detect_batch([img])[0]
+            assert nh == nh0 and len(again) == len(first) and again.tobytes() == first.tobytes(), it
+        small = band_noise_image(480, 640, 78, SMALL_BANDS)      # another geometry: another key width, the map starts over
+        nh_s, got = ctx.detect_batch([small])[0]
+        nh_b, back = ctx.detect_batch([img])[0]
+        assert nh_b == nh0 and back.tobytes() == first.tobytes()
+    o = _oracle.OracleRun(_oracle.gray_from_u8(small))
+    assert nh_s == o.n_hessian and len(got) == o.n_keys and hesaff_amd.format_sift(got, p.mrSize) == o.export_text()
+    assert len(first) > 100000
