@@ -413,17 +413,36 @@ __global__ __launch_bounds__(256) void k_dedupe(OctaveCtx oc, RecList rl, const 
 #define SCAN_ITEMS 16
 #define SCAN_BLOCK (256 * SCAN_ITEMS)
 
+// load16: a thread's SCAN_ITEMS consecutive items (base a multiple of 16, all inside the array) as 16-byte loads
 struct LoadPopc {
    const unsigned long long *p;
    __device__ uint32_t operator()(long long i) const { return (uint32_t)__popcll(p[i]); }
+   __device__ void load16(long long base, uint32_t *v) const
+   {
+      const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(p + base);
+#pragma unroll
+      for (int i = 0; i < 8; i++) { const ulonglong2 w = q[i]; v[2 * i] = (uint32_t)__popcll(w.x); v[2 * i + 1] = (uint32_t)__popcll(w.y); }
+   }
 };
 struct LoadU32 {
    const uint32_t *p;
    __device__ uint32_t operator()(long long i) const { return p[i]; }
+   __device__ void load16(long long base, uint32_t *v) const
+   {
+      const uint4 *q = reinterpret_cast<const uint4 *>(p + base);
+#pragma unroll
+      for (int i = 0; i < 4; i++) { const uint4 w = q[i]; v[4 * i] = w.x; v[4 * i + 1] = w.y; v[4 * i + 2] = w.z; v[4 * i + 3] = w.w; }
+   }
 };
 struct LoadFlagI32 {
    const int32_t *p;
    __device__ uint32_t operator()(long long i) const { return p[i] != 0 ? 1u : 0u; }
+   __device__ void load16(long long base, uint32_t *v) const
+   {
+      const int4 *q = reinterpret_cast<const int4 *>(p + base);
+#pragma unroll
+      for (int i = 0; i < 4; i++) { const int4 w = q[i]; v[4 * i] = w.x != 0; v[4 * i + 1] = w.y != 0; v[4 * i + 2] = w.z != 0; v[4 * i + 3] = w.w != 0; }
+   }
 };
 
 __device__ __forceinline__ uint32_t hs_block_exclusive_scan(uint32_t v, uint32_t *s_wave /*4*/, uint32_t &block_total)
@@ -489,21 +508,35 @@ __global__ __launch_bounds__(256) void k_scan_down(LOAD load, long long n, const
    __shared__ uint32_t s_wave[4];
    // thread owns SCAN_ITEMS consecutive items so that the scan is in index order
    const long long base = (long long)blockIdx.x * SCAN_BLOCK + (long long)threadIdx.x * SCAN_ITEMS;
+   static_assert(SCAN_ITEMS == 16, "load16 / the 16-byte stores below");
    uint32_t vals[SCAN_ITEMS];
    uint32_t sum = 0;
+   // (base is a multiple of 16 items; the source may start anywhere - the alive flags sit behind another array - so its alignment is tested)
+   const bool whole = base + SCAN_ITEMS <= n && (reinterpret_cast<uintptr_t>(load.p + base) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out + base) & 15u) == 0;
+   if (whole) load.load16(base, vals);          // 128 (64) consecutive bytes per thread as 16-byte loads; item by item it was 16 loads of 8 (4) bytes, every one a line of its own
 #pragma unroll
    for (int i = 0; i < SCAN_ITEMS; i++) {
       const long long idx = base + i;
-      vals[i] = (idx < n) ? load(idx) : 0u;
+      if (!whole) vals[i] = (idx < n) ? load(idx) : 0u;
       sum += vals[i];
    }
    uint32_t tot;
    uint32_t ex = hs_block_exclusive_scan(sum, s_wave, tot) + block_sums[blockIdx.x];
+   if (whole) {
+      uint4 *o = reinterpret_cast<uint4 *>(out + base);
 #pragma unroll
-   for (int i = 0; i < SCAN_ITEMS; i++) {
-      const long long idx = base + i;
-      if (idx < n) out[idx] = ex;
-      ex += vals[i];
+      for (int i = 0; i < SCAN_ITEMS; i += 4) {
+         uint4 w;
+         w.x = ex; ex += vals[i]; w.y = ex; ex += vals[i + 1]; w.z = ex; ex += vals[i + 2]; w.w = ex; ex += vals[i + 3];
+         o[i >> 2] = w;
+      }
+   } else {
+#pragma unroll
+      for (int i = 0; i < SCAN_ITEMS; i++) {
+         const long long idx = base + i;
+         if (idx < n) out[idx] = ex;
+         ex += vals[i];
+      }
    }
 }
 

@@ -183,7 +183,7 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 #define HS_GRID_SCAT 1024
 #endif
 #ifndef HS_GRID_PACK
-#define HS_GRID_PACK 2048
+#define HS_GRID_PACK 3584   // 14 blocks per CU: what k_pack's 10.7 KB of LDS per block lets a CU hold
 #endif
 #ifndef HS_MID_CAP
 #define HS_MID_CAP 6   // blocks per CU of the two row-streamed bins (at most; the occupancy query may say fewer)
@@ -691,7 +691,7 @@ void plan_buffers(hesaff_ctx *c, int B, int H, int W)
    double capd = mpx * (double)c->par.max_kpts_per_mpx;
    if (capd < 4096) capd = 4096;
    if (capd > 2.0e9) throw HsError(HESAFF_ERR_ARG, "batch too large for 32-bit keypoint indices");
-   c->cap = (uint32_t)capd;
+   c->cap = ((uint32_t)capd + 63u) & ~63u;   // a multiple of 64: the arrays carved out of one buffer (cap entries each) stay 16-byte aligned
    const size_t cap = c->cap;
    const long long scan_items = std::max<long long>(total_words, (long long)cap);
    c->b_blocksums.ensure((size_t)((scan_items + SCAN_BLOCK - 1) / SCAN_BLOCK + 1) * 4);
