@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64, HS_HIST_WAVES) void k_sift_hist(SiftIO io, KpTa
    typedef __attribute__((address_space(3))) float lds_float;
    const uint32_t acc_base = (uint32_t)(uintptr_t)(lds_float *)acc;
    // Row staging.  At step i the 64 lanes need, of each of the wave's four keypoints, the rows 8 cb_r + i (cb_r = 0..3):
-   // 16 rows x 40 pixels x 8 bytes = 5 KB.  Read lane by lane (8 x 16 bytes each, rows 320 bytes and keypoints 12.8 KB
+   // 16 rows x 40 pixels x 8 bytes = 5 KB.  Read lane by lane (8 x 16 bytes each, rows up to 320 bytes and keypoints 10.4 KB
    // apart) every load instruction touches ~32 cache lines (texture addresser 78 % busy).  Instead the wave fetches the
    // 16 rows as 320 consecutive 16-byte items (5 per lane, 3 rows per instruction), parks them in LDS and every lane
    // takes its 8 items from there; the next step's items are in flight meanwhile (20 registers instead of 32).

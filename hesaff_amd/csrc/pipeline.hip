@@ -1124,7 +1124,7 @@ void launch_sift(hesaff_ctx *c, hipStream_t ss, const SiftIO &so, uint32_t n, fl
 void ensure_group_buffers(hesaff_ctx *c, uint32_t n)
 {
    // The patch buffers rotate over HS_NSLOT slots (the patch stage fills one while the descriptor stage reads the others).  The
-   // descriptor stage's own intermediates - gradient pairs (12.8 KB per keypoint), histograms, mean / variance - live and die on its
+   // descriptor stage's own intermediates - gradient pairs (10.4 KB per keypoint), histograms, mean / variance - live and die on its
    // stream: when both descriptor streams are one HIP stream (the product), one copy of them serves every group.
    const int dslots = (c->sift_stream == c->sift_stream2 && !c->no_overlap) ? 1 : HS_NSLOT;
    for (int slot = 0; slot < HS_NSLOT; slot++) {
