@@ -280,7 +280,7 @@ def _thread_cpu():
                 name = st[st.index("(") + 1: st.rindex(")")]
                 f = st[st.rindex(")") + 2:].split()
                 allowed = [ln.split(":", 1)[1].strip() for ln in open("/proc/self/task/%s/status" % tid) if ln.startswith("Cpus_allowed_list")]
-                out[tid] = (name, (int(f[11]) + int(f[12])) / hz, allowed[0] if allowed else "?")
+                out[tid] = (name, (int(f[11]) + int(f[12])) / hz, allowed[0] if allowed else "?", int(f[12]) / hz)
             except (OSError, ValueError, IndexError):
                 pass
     except OSError:
@@ -316,9 +316,9 @@ def _timed_file_run(hesaff_amd, paths, chunk, device, fmt, decode_threads, write
     n = len(paths)
     extra = {}
     if threads_table:   # CPU seconds per thread that still exists after the run (pool and staging threads have exited: their time is the remainder)
-        rows_t = sorted(((th1[t][1] - th0.get(t, (0, 0.0, 0))[1], th1[t][0], th1[t][2]) for t in th1), reverse=True)
-        extra["threads_cpu_seconds"] = [{"name": nm, "cpu_seconds": round(s_, 3), "allowed": al} for s_, nm, al in rows_t if s_ >= 0.02]
-        extra["threads_exited_cpu_seconds"] = round(cpu - sum(s_ for s_, _, _ in rows_t), 3)
+        rows_t = sorted(((th1[t][1] - th0.get(t, (0, 0.0, 0, 0.0))[1], th1[t][0], th1[t][2], th1[t][3] - th0.get(t, (0, 0.0, 0, 0.0))[3]) for t in th1), reverse=True)
+        extra["threads_cpu_seconds"] = [{"name": nm, "cpu_seconds": round(s_, 3), "in_kernel_seconds": round(k_, 3), "allowed": al} for s_, nm, al, k_ in rows_t if s_ >= 0.02]
+        extra["threads_exited_cpu_seconds"] = round(cpu - sum(r_[0] for r_ in rows_t), 3)
     return {**extra, "images": n, "images_per_s": n / dt, "value": rows / dt, "unit": "keypoints/s", "seconds": dt, "chunk_images": chunk,
             "output": "text (.hesaff.sift, the reference's format)" if fmt == 1 else "binary sidecar (.hesaff.bin, 148 bytes per row)",
             "failed_files": len(bad), "output_GB_per_s": nbytes / dt / 1e9, "output_GB": nbytes / 1e9,

@@ -178,24 +178,34 @@ __device__ __forceinline__ float hs_bilinear_buf(const HsPlaneBuf &im, int width
 
 // ---- helpers.cpp:46-88 solveLinear3x3 (value swaps, partial pivoting) ----
 __device__ __forceinline__ void hs_swap(float &a, float &b) { const float t = a; a = b; b = t; }
-__device__ inline void hs_solve3x3(float *A, float *b)
+__device__ __forceinline__ void hs_solve3x3(float *A, float *b)
 {
-   int i = 0;
-   float vp = fabsf(A[0]);
-   const float tmp = fabsf(A[3]);
-   if (tmp > vp) { i = 1; vp = tmp; }
-   if (fabsf(A[6]) > vp) { i = 2; }
-   if (i == 1) { hs_swap(A[3], A[0]); hs_swap(A[4], A[1]); hs_swap(A[5], A[2]); hs_swap(b[1], b[0]); }
-   if (i == 2) { hs_swap(A[6], A[0]); hs_swap(A[7], A[1]); hs_swap(A[8], A[2]); hs_swap(b[2], b[0]); }
-   vp = A[3] / A[0]; A[4] -= vp * A[1]; A[5] -= vp * A[2]; b[1] -= vp * b[0];
-   vp = A[6] / A[0]; A[7] -= vp * A[1]; A[8] -= vp * A[2]; b[2] -= vp * b[0];
-   if (fabsf(A[4]) < fabsf(A[7])) { hs_swap(A[7], A[4]); hs_swap(A[8], A[5]); hs_swap(b[2], b[1]); }
-   vp = A[7] / A[4];
-   A[8] -= vp * A[5];
-   b[2] -= vp * b[1];
-   b[2] = (b[2]) / A[8];
-   b[1] = (b[1] - A[5] * b[2]) / A[4];
-   b[0] = (b[0] - A[2] * b[2] - A[1] * b[1]) / A[0];
+   // Scalars and selects, not the arrays: the compiler turns "if (i == 1) swap(A[3], A[0]) ... if (i == 2) swap(A[6], A[0])" into ONE swap
+   // at the dynamic index 3 * i, which sends A and b to scratch memory (48 bytes per lane in k_localize) - and a kernel that uses scratch
+   // costs the host a runtime thread that is busy for as long as the device works (profiles/r05_notes.md).  The row exchanges move values
+   // only, so the arithmetic and its order are the reference's.
+   float a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5], a6 = A[6], a7 = A[7], a8 = A[8], b0 = b[0], b1 = b[1], b2 = b[2];
+   float vp = fabsf(a0);
+   const float tmp = fabsf(a3);
+   bool p1 = false, p2 = false;   // pivot row: 1, 2 (else 0)
+   if (tmp > vp) { p1 = true; vp = tmp; }
+   if (fabsf(a6) > vp) { p1 = false; p2 = true; }
+   {  // row 0 <-> pivot row
+      const float r0 = p1 ? a3 : (p2 ? a6 : a0), r1 = p1 ? a4 : (p2 ? a7 : a1), r2 = p1 ? a5 : (p2 ? a8 : a2), rb = p1 ? b1 : (p2 ? b2 : b0);
+      a3 = p1 ? a0 : a3; a4 = p1 ? a1 : a4; a5 = p1 ? a2 : a5; b1 = p1 ? b0 : b1;
+      a6 = p2 ? a0 : a6; a7 = p2 ? a1 : a7; a8 = p2 ? a2 : a8; b2 = p2 ? b0 : b2;
+      a0 = r0; a1 = r1; a2 = r2; b0 = rb;
+   }
+   vp = a3 / a0; a4 -= vp * a1; a5 -= vp * a2; b1 -= vp * b0;
+   vp = a6 / a0; a7 -= vp * a1; a8 -= vp * a2; b2 -= vp * b0;
+   if (fabsf(a4) < fabsf(a7)) { hs_swap(a7, a4); hs_swap(a8, a5); hs_swap(b2, b1); }
+   vp = a7 / a4;
+   a8 -= vp * a5;
+   b2 -= vp * b1;
+   b2 = (b2) / a8;
+   b1 = (b1 - a5 * b2) / a4;
+   b0 = (b0 - a2 * b2 - a1 * b1) / a0;
+   b[0] = b0; b[1] = b1; b[2] = b2;
 }
 
 // ---- helpers.cpp:149-175 invSqrt (double inside) ----

@@ -115,13 +115,14 @@ HM_HD void hx_big_sub(HxBig &a, const HxBig &b)   // a -= b, a >= b
 }
 
 // digits d (100000 <= d <= 999999) and decimal exponent X of |v| = mant * 2^e, any mant < 2^24, mant != 0
-// (not inlined on the device: five prints per row would carry five copies of a path no real row takes)
+// (not inlined on the device: five prints per row would carry five copies of a path no real row takes; the result comes back in
+//  registers - digits | exponent << 32 - because reference parameters would live in scratch memory, see hs_solve3x3)
 #if defined(__HIPCC__)
 __host__ __device__ __attribute__((noinline))
 #else
 inline
 #endif
-void hx_digits_big(uint32_t mant, int e, unsigned &d_out, int &X_out)
+unsigned long long hx_digits_big(uint32_t mant, int e)
 {
    const int msb = 31 - __builtin_clz(mant);
    int X = ((msb + e) * 1233) >> 12;   // floor(log10 |v|) or one off: floor((msb + e) * log10(2)), 1233 / 4096 = 0.30103
@@ -151,8 +152,7 @@ void hx_digits_big(uint32_t mant, int e, unsigned &d_out, int &X_out)
       if (d == 1000000u) { d = 100000u; X++; }
       break;
    }
-   d_out = d;
-   X_out = X;
+   return (unsigned long long)d | ((unsigned long long)(uint32_t)X << 32);
 }
 
 template <class Sink> HM_HD void hx_fmt_g(Sink &out, float vf)
@@ -192,7 +192,7 @@ template <class Sink> HM_HD void hx_fmt_g(Sink &out, float vf)
          if (d == 1000000u) { d = 100000u; X++; }
       }
    }
-   if (!fast) hx_digits_big(mant, e, d, X);
+   if (!fast) { const unsigned long long dx = hx_digits_big(mant, e); d = (unsigned)dx; X = (int)(uint32_t)(dx >> 32); }
    // six digits, most significant first
    char dig[6];
    for (int i = 5; i >= 0; i--) { dig[i] = (char)('0' + d % 10u); d /= 10u; }

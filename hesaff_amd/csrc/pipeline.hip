@@ -104,7 +104,12 @@ static void hs_wait_event(hipEvent_t ev)
       timespec now;
       clock_gettime(CLOCK_MONOTONIC, &now);
       const long long waited = (long long)(now.tv_sec - t0.tv_sec) * 1000000000ll + (now.tv_nsec - t0.tv_nsec);
-      const timespec nap = {0, (long)std::min<long long>(std::max<long long>(waited / 8, 20000), 200000)};
+#ifdef HESAFF_TUNING
+      static const long long nap_cap = getenv("HESAFF_NAP_US") ? atoll(getenv("HESAFF_NAP_US")) * 1000ll : 200000ll;
+#else
+      const long long nap_cap = 200000ll;
+#endif
+      const timespec nap = {0, (long)std::min<long long>(std::max<long long>(waited / 8, 20000), nap_cap)};
       nanosleep(&nap, nullptr);
    }
 }

@@ -37,7 +37,7 @@ try:
             print("cpus %d plan %s %-7s %6.1f images/s  cpu %.2f ms/image  busy %.2f  exited threads (pool + staging) %.2f s of %.2f s" %
                   (k, d["plan"], name, q["images_per_s"], 1e3 * q["cpu_seconds_per_image"], q["cpus_busy"], q["threads_exited_cpu_seconds"], q["cpu_seconds"]))
             for t in q["threads_cpu_seconds"][:8]:
-                print("      %-16s %6.2f s  allowed %s" % (t["name"], t["cpu_seconds"], t["allowed"]))
+                print("      %-16s %6.2f s (%.2f in the kernel)  allowed %s" % (t["name"], t["cpu_seconds"], t.get("in_kernel_seconds", 0.0), t["allowed"]))
 finally:
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
