@@ -96,3 +96,25 @@ with hesaff_amd.HesaffContext(p, device=0) as ctx:
             y.add_(1.0)
     torch.cuda.synchronize()
     table("(e) 2000 + 2000 launches on two streams, an event record + wait per pair", th0, bench._thread_cpu(), time.perf_counter() - t0)
+    # (f): the same 4000 launches replayed from a captured graph (40 replays of 100 kernel nodes)
+    g = torch.cuda.CUDAGraph()
+    cs = torch.cuda.Stream()
+    with torch.cuda.stream(cs):
+        x.add_(1.0)
+        cs.synchronize()
+        with torch.cuda.graph(g, stream=cs):
+            for _ in range(100):
+                x.add_(1.0)
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    th0, t0 = bench._thread_cpu(), time.perf_counter()
+    for _ in range(40):
+        g.replay()
+    torch.cuda.synchronize()
+    table("(f) 40 replays of a graph of 100 such launches", th0, bench._thread_cpu(), time.perf_counter() - t0)
+    th0, t0 = bench._thread_cpu(), time.perf_counter()
+    for _ in range(400):
+        g.replay()
+    torch.cuda.synchronize()
+    table("(g) 400 replays", th0, bench._thread_cpu(), time.perf_counter() - t0)
