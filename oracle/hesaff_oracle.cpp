@@ -994,7 +994,7 @@ long ho_export(void *h, char *buf, long cap)
 {
    const Oracle *o = (Oracle *)h;
    std::string s;
-   char line[64];
+   char line[96];   // five %g of a float: at most 5 x 13 characters + 4 blanks
    snprintf(line, sizeof line, "%d\n%zu\n", 128, o->keys.size());
    s += line;
    for (size_t n = 0; n < o->keys.size(); n++) {
