@@ -122,6 +122,7 @@ def hbm_probe(torch, dev):
     t(lambda: b.copy_(a), 8.0 * n, "copy_1r1w_GBs")
     t(lambda: b.fill_(1.0), 4.0 * n, "fill_1w_GBs")
     t(lambda: torch.add(a, b, out=c), 12.0 * n, "add_2r1w_GBs")
+    t(lambda: torch.sum(a), 4.0 * n, "sum_1r_GBs")   # read-only: the yardstick of a kernel that only reads (k_extrema_march)
     del a, b, c
     torch.cuda.empty_cache()
     return out
@@ -360,6 +361,10 @@ def budgeted_child(cfg):
     numpy, torch or the library exist in this process - so every thread the run creates (the pool, the staging thread, the HIP
     runtime's own) is confined to it, and the library's own rule (hesaff_host_plan_for) sees the share as "the host"."""
     os.sched_setaffinity(0, set(cfg["cpus"]))
+    if cfg.get("confine_runtime", True):
+        # ROCr gives its helper threads (the asynchronous-event thread: one busy core per process while the device works) the whole machine's
+        # CPU mask unless told not to; with this they inherit the share's mask like every other thread of the child
+        os.environ["HSA_OVERRIDE_CPU_AFFINITY_DEBUG"] = "0"
     import hesaff_amd
     hp = hesaff_amd.host_plan(1)          # == host_plan(BUDGET_SHARE) on the whole quota
     if cfg.get("pool"):                   # experiments: another split of the pool inside the same CPU mask
@@ -393,7 +398,7 @@ def budgeted_child(cfg):
     return 0
 
 
-def budgeted_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, rank, world, sync):
+def budgeted_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, rank, world, sync, confine_runtime=True):
     """The file path inside ONE device's share of the host: the CPUs this job may use (affinity mask, capped by the
     cgroup quota: hesaff_host_threads) divided by BUDGET_SHARE = 8 devices, whatever `world` is; rank r's child process is pinned
     to the r-th such slice before it loads anything, takes its thread counts from the library's rule and reports CPU seconds
@@ -411,7 +416,7 @@ def budgeted_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, rank, worl
     if rank == 0:   # what an interrupted earlier run may have left behind (the other ranks' children need seconds before they write here)
         shutil.rmtree(os.path.join(os.path.dirname(tmp), "hesaff_sync_%s" % os.environ.get("MASTER_PORT", "0")), ignore_errors=True)
     try:
-        cfg = {"dir": tmp, "n": len(paths), "chunk": chunk, "device": device, "cpus": cpus, "rank": rank, "world": world,
+        cfg = {"dir": tmp, "n": len(paths), "chunk": chunk, "device": device, "cpus": cpus, "rank": rank, "world": world, "confine_runtime": confine_runtime,
                "sync_dir": os.path.join(os.path.dirname(tmp), "hesaff_sync_%s" % os.environ.get("MASTER_PORT", "0"))}
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--budgeted-child", json.dumps(cfg)], capture_output=True, text=True, timeout=900)
         if r.returncode != 0 or not r.stdout.strip():
@@ -426,6 +431,56 @@ def budgeted_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, rank, worl
         shutil.rmtree(tmp, ignore_errors=True)
         if rank == 0:
             shutil.rmtree(os.path.join(os.path.dirname(tmp), "hesaff_sync_%s" % os.environ.get("MASTER_PORT", "0")), ignore_errors=True)
+
+
+def contexts_leg(host_imgs, W, H, n_files, chunk, device, k=2):
+    """What INTEGRATION.md recommends for several devices on one host - ONE process with a context per device (`hesaff --batch --devices a,b,..`) -
+    against one process per device, measured on this one device: k contexts on it in one process, then k processes with one context
+    each (`--host-share k`), the same list to binary sidecars; images/s and the children's CPU seconds per image (getrusage).
+    The runtime's event thread is one per PROCESS: k processes carry k of them."""
+    import resource
+    import subprocess
+    exe = os.path.join(ROOT, "hesaff_amd", "bin", "hesaff")
+    tmp, paths, _ = _e2e_files(host_imgs, W, H, n_files, chunk, 1)
+    if tmp is None:
+        return {"skipped": paths}
+
+    def cpu_children():
+        r = resource.getrusage(resource.RUSAGE_CHILDREN)
+        return r.ru_utime + r.ru_stime
+
+    def clean():
+        for q in paths:
+            if os.path.exists(q + ".hesaff.bin"):
+                os.remove(q + ".hesaff.bin")
+    try:
+        lists = []
+        for r in range(k + 1):   # lists[0..k-1]: the k shards; lists[k]: the whole list
+            lo, hi = (len(paths) * r // k, len(paths) * (r + 1) // k) if r < k else (0, len(paths))
+            q = os.path.join(tmp, "list_%d.txt" % r)
+            open(q, "w").write("\n".join(paths[lo:hi]) + "\n")
+            lists.append(q)
+        dev = str(device)
+        subprocess.run([exe, "--batch", lists[0], "--devices", dev, "--output", "bin"], capture_output=True, timeout=600)   # warm-up: page cache, the box
+        out = {"what": "%d UHD PGM files -> sidecars on device %s through the CLI: ONE process with %d contexts (--devices %s) against %d processes "
+                       "with one context each (--host-share %d); CPU = the children's user + system seconds (getrusage)" % (len(paths), dev, k, ",".join([dev] * k), k, k),
+               "images": len(paths), "contexts": k}
+        clean()
+        c0, t0 = cpu_children(), time.perf_counter()
+        r = subprocess.run([exe, "--batch", lists[k], "--devices", ",".join([dev] * k), "--output", "bin"], capture_output=True, text=True, timeout=900)
+        dt, cpu = time.perf_counter() - t0, cpu_children() - c0
+        out["one_process"] = {"images_per_s": len(paths) / dt, "seconds": dt, "cpu_seconds_per_image": cpu / len(paths), "rc": r.returncode}
+        clean()
+        c0, t0 = cpu_children(), time.perf_counter()
+        ps = [subprocess.Popen([exe, "--batch", q, "--devices", dev, "--output", "bin", "--host-share", str(k)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for q in lists[:k]]
+        rcs = [p_.wait(timeout=900) for p_ in ps]
+        dt, cpu = time.perf_counter() - t0, cpu_children() - c0
+        out["one_process_per_context"] = {"images_per_s": len(paths) / dt, "seconds": dt, "cpu_seconds_per_image": cpu / len(paths), "rc": max(abs(x) for x in rcs)}
+        return out
+    except (OSError, subprocess.TimeoutExpired) as e:
+        return {"skipped": "the CLI runs failed: %s" % e}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def launch_ranks(n):
@@ -669,20 +724,29 @@ def main():
                 end_to_end["binary_sidecar"] = eb
             # the same list inside ONE device's share of the host: a child process per rank, pinned before it loads anything
             if args.budgeted:
-                bd = budgeted_leg(hesaff_amd, host_imgs, W, H, args.e2e_images, args.e2e_chunk, local_rank, rank, world, barrier)
-                legs = {}
-                for name in ("text", "sidecar"):
-                    legs[name] = combine(dict(bd[name]) if name in bd else {"skipped": bd.get("skipped", "no result")})
+                def budgeted(confine_runtime):
+                    bd = budgeted_leg(hesaff_amd, host_imgs, W, H, args.e2e_images, args.e2e_chunk, local_rank, rank, world, barrier, confine_runtime)
+                    legs = {}
+                    for name in ("text", "sidecar"):
+                        legs[name] = combine(dict(bd[name]) if name in bd else {"skipped": bd.get("skipped", "no result")})
+                    return bd, legs
+                bd, legs = budgeted(True)
+                bd_u, legs_u = budgeted(False)
                 if rank == 0:
                     end_to_end_budgeted = {
                         "what": "hesaff_process_files as in end_to_end, but every rank's run is a child process confined (sched_setaffinity before it "
-                                "loads numpy, torch or the library) to ONE device's share of the host - the CPUs this job may use divided by %d "
+                                "loads numpy, torch or the library; HSA_OVERRIDE_CPU_AFFINITY_DEBUG=0 so that the HIP runtime's helper threads stay inside "
+                                "the mask too) to ONE device's share of the host - the CPUs this job may use divided by %d "
                                 "devices, whatever --gpus is - with the thread counts the library's rule gives for that share "
                                 "(hesaff_host_plan_for: include/hesaff_amd.h); cpu_seconds = getrusage of the child around the timed run; "
                                 "max_devices_at_this_quota = quota_cpus / (cpu_seconds_per_image x images_per_s per device). "
                                 "A thread write()s about 6 GB/s of new RAM-disk pages: the text leg (46 MB per dense UHD image) is bound by that, "
-                                "the sidecar (17 MB) is not" % BUDGET_SHARE,
-                        "share": bd.get("share"), "cpus_rank0": bd.get("cpus"), "plan": bd.get("plan"), "text": legs["text"], "binary_sidecar": legs["sidecar"]}
+                                "the sidecar (17 MB) is not.  runtime_threads_unconfined: the same without the environment variable (the runtime's "
+                                "event thread then runs on CPUs outside the share: the confinement leaks by that thread)" % BUDGET_SHARE,
+                        "share": bd.get("share"), "cpus_rank0": bd.get("cpus"), "plan": bd.get("plan"), "text": legs["text"], "binary_sidecar": legs["sidecar"],
+                        "runtime_threads_unconfined": {"text": legs_u["text"], "binary_sidecar": legs_u["sidecar"]}}
+                if world == 1:
+                    end_to_end_budgeted["contexts_in_one_process"] = contexts_leg(host_imgs, W, H, args.e2e_images, args.e2e_chunk, local_rank)
 
     # ---- from here on rank 0 alone (no collective follows: the other ranks are done) ----
     if grouped and rank != 0:
@@ -772,6 +836,7 @@ def main():
             "roofline_detect": {"bound": "hbm", "kernel": "k_extrema_march (the three 3x3x3 extrema scans of an octave in one launch; SURVEY.md 8d: "
                                                           "B_ext = 20 bytes per pixel and octave, five response planes read once)",
                                 "achieved": ex_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ex_achieved / HBM_PEAK_GBS,
+                                "frac_of_read_probe": ex_achieved / probe["sum_1r_GBs"] if probe.get("sum_1r_GBs") else None,
                                 "launches": bh["ex_launches"], "avg_launch_ms": bh["ex_ms"] / max(bh["ex_launches"], 1),
                                 "stage": {"what": "whole detection stage (map clear, extrema, localisation, dedupe, ordering scans) against B_ext",
                                           "achieved": (bh["ex_bytes"] / args.steps / 1e9) / (st["detect_ms"] / 1e3) if st["detect_ms"] > 0 else 0.0}},

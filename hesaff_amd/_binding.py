@@ -55,7 +55,7 @@ _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
-ABI_VERSION = 6   # HESAFF_ABI_VERSION of the include/hesaff_amd.h these ctypes structs mirror
+ABI_VERSION = 7   # HESAFF_ABI_VERSION of the include/hesaff_amd.h these ctypes structs mirror
 
 
 class JpegLayout(C.Structure):
@@ -134,6 +134,9 @@ def load_library():
     L.hesaff_set_output_format.argtypes = [vp, C.c_int]
     L.hesaff_set_resume.argtypes = [vp, C.c_int]
     L.hesaff_output_is_complete.argtypes = [C.c_char_p, C.c_int]
+    L.hesaff_set_pinned_read_budget.argtypes = [vp, C.c_size_t, C.c_size_t]
+    L.hesaff_set_pool_priority.argtypes = [vp, C.c_int]
+    L.hesaff_stage_threads_for_pool.argtypes = [C.c_int]
     L.hesaff_detect_batch_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, _i32p, _i32p, C.POINTER(vp), C.POINTER(C.c_int64)]
     L.hesaff_set_profiling.argtypes = [vp, C.c_int]
     L.hesaff_get_timings.argtypes = [vp, C.POINTER(Timings)]
@@ -193,7 +196,8 @@ ABI_SYMBOLS = [
     "hesaff_process_files", "hesaff_write_sift_mt", "hesaff_write_bin", "hesaff_set_output_format",
     "hesaff_write_sift_rows", "hesaff_write_bin_rows", "hesaff_stage_export", "hesaff_stage_fmt_g", "hesaff_set_resume",
     "hesaff_output_is_complete", "hesaff_read_jpeg_coefficients", "hesaff_read_jpeg_coefficients_alloc", "hesaff_stage_jpeg_pixels",
-    "hesaff_read_pnm_alloc", "hesaff_read_image_alloc",
+    "hesaff_read_pnm_alloc", "hesaff_read_image_alloc", "hesaff_set_pinned_read_budget", "hesaff_set_pool_priority",
+    "hesaff_stage_threads_for_pool",
 ]
 
 
@@ -443,9 +447,17 @@ class HesaffContext:
         """1 = text (.hesaff.sift, default), 2 = binary sidecar (.hesaff.bin), 3 = both."""
         self._check(self.L.hesaff_set_output_format(self.h, fmt))
 
-    def set_resume(self, on=True):
-        """hesaff_process_files skips images whose complete output exists."""
-        self._check(self.L.hesaff_set_resume(self.h, 1 if on else 0))
+    def set_resume(self, on=True, strict=False):
+        """hesaff_process_files skips images whose complete output exists (strict: the rows of an existing text file are counted too)."""
+        self._check(self.L.hesaff_set_resume(self.h, (2 if strict else 1) if on else 0))
+
+    def set_pinned_read_budget(self, max_bytes, keep_bytes):
+        """page-locked read buffers of process_files: at most max_bytes at any time, keep_bytes kept from call to call"""
+        self._check(self.L.hesaff_set_pinned_read_budget(self.h, max_bytes, keep_bytes))
+
+    def set_pool_priority(self, mode):
+        """-1: the pool of process_files steps down (nice 10) when the host plan is CPU-starved (default); 0 never; 1 always"""
+        self._check(self.L.hesaff_set_pool_priority(self.h, mode))
 
     def process_files(self, paths, out_paths=None, decode_threads=0, write_threads=0):
         """hesaff_process_files: image files -> <name>.hesaff.sift through the decode / device / write pipeline.

@@ -193,6 +193,8 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       }
       if (const char *s2 = getenv("HESAFF_SIFT2")) c->sift2 = atoi(s2) != 0;
       if (const char *tp = getenv("HESAFF_TAPER")) c->taper_groups = atoi(tp) != 0;
+      if (const char *sl = getenv("HESAFF_SIFT_SLICE")) c->sift_slice = (uint32_t)std::max(0, atoi(sl));
+      if (const char *sr = getenv("HESAFF_SLICE_RING")) c->sift_slice_ring = atoi(sr) != 0;
 #endif
    } catch (const HsError &e) {
       hesaff_destroy(c);
@@ -237,6 +239,7 @@ void hesaff_destroy(hesaff_ctx *c)
       if (c->ev_sift_done[i]) (void)hipEventDestroy(c->ev_sift_done[i]);
       c->b_patches2[i].release(); c->b_siftvec2[i].release(); c->b_meanvar2[i].release(); c->b_siftvo2[i].release();
    }
+   if (c->h2d_stream) (void)hipStreamSynchronize(c->h2d_stream);   // (pin_in is the copy-in stream's source)
    for (int i = 0; i < 2; i++) {
       c->b_in2[i].release(); c->b_outstage[i].release(); c->pin_in[i].release();
       if (c->ev_h2d[i]) (void)hipEventDestroy(c->ev_h2d[i]);
@@ -246,11 +249,12 @@ void hesaff_destroy(hesaff_ctx *c)
       if (c->ev_d2h[i]) (void)hipEventDestroy(c->ev_d2h[i]);
       for (int q = 0; q < 4; q++) if (c->ev_exp[i][q]) (void)hipEventDestroy(c->ev_exp[i][q]);
    }
+   // the copy streams are idle before any page-locked block they may still read or write goes back
+   if (c->h2d_stream) (void)hipStreamSynchronize(c->h2d_stream);
+   if (c->d2h_stream) (void)hipStreamSynchronize(c->d2h_stream);
    for (auto &pb : c->pin_out) pb.release();
    c->pin_read.release();
    c->h_small_end.release(); c->h_small_mid.release(); c->h_small_exp.release();
-   if (c->h2d_stream) (void)hipStreamSynchronize(c->h2d_stream);
-   if (c->d2h_stream) (void)hipStreamSynchronize(c->d2h_stream);
    if (c->pooled_streams) {
       c->sset.h2d = c->h2d_stream; c->sset.d2h = c->d2h_stream;
       give_stream_set(c->device, c->sset);   // idle now; the next context of this device runs on them
@@ -609,8 +613,27 @@ int hesaff_set_output_format(hesaff_ctx *c, int format)
 
 int hesaff_set_resume(hesaff_ctx *c, int on)
 {
+   if (!c || on < 0 || on > 2) return HESAFF_ERR_ARG;
+   c->resume = on;
+   return HESAFF_OK;
+}
+
+int hesaff_set_pinned_read_budget(hesaff_ctx *c, size_t max_bytes, size_t keep_bytes)
+{
    if (!c) return HESAFF_ERR_ARG;
-   c->resume = on != 0;
+   {
+      std::lock_guard<std::mutex> lk(c->pin_read.mu);
+      c->pin_read.max_bytes = max_bytes;
+      c->pin_read.keep_bytes = std::min(keep_bytes, max_bytes);
+   }
+   c->pin_read.trim(c->pin_read.keep_bytes);
+   return HESAFF_OK;
+}
+
+int hesaff_set_pool_priority(hesaff_ctx *c, int mode)
+{
+   if (!c || mode < -1 || mode > 1) return HESAFF_ERR_ARG;
+   c->pool_priority = mode;
    return HESAFF_OK;
 }
 
@@ -637,16 +660,20 @@ int hesaff_process_files(hesaff_ctx *c, int n, const char *const *paths, const c
 #ifdef HESAFF_TUNING
    if (const char *pr = getenv("HESAFF_PIN_READ")) { if (atoi(pr) == 0) pin = PinHooks(); }   // A/B: 0 = malloc'ed images + staging copy
 #endif
-   FileIO io(&c->ring, c->par.max_batch, c->par.mrSize, c->out_format, n, paths, out_paths, status, dt, wt, true, c->resume, device_jpeg, pin);
-   c->stage_threads = std::max(1, std::min(4, (dt + wt + 1) / 4));   // hesaff_host_plan_for's stage_threads for a pool of dt + wt
+   // the pool's threads step down (nice 10) only where they would otherwise crowd out the caller's thread: a CPU-starved plan
+   const bool nice_pool = c->pool_priority == 1 || (c->pool_priority < 0 && hesaff_host_threads() <= dt + wt + 1);
+   FileIO io(&c->ring, c->par.max_batch, c->par.mrSize, c->out_format, n, paths, out_paths, status, dt, wt, true, c->resume, device_jpeg, pin, nice_pool);
+   c->stage_threads = hesaff_stage_threads_for_pool(dt + wt);
    try {
       run_chunks(c, io, 3);
       io.wait_writers();
    } catch (...) {
       io.shutdown();
+      c->pin_read.trim(c->pin_read.keep_bytes);
       throw;
    }
    io.shutdown();
+   c->pin_read.trim(c->pin_read.keep_bytes);   // a long-lived context does not keep the peak of its largest list pinned
    HS_API_END(c)
 }
 

@@ -201,7 +201,8 @@ struct FileIO : ChunkIO {
    float mrSize;
    int fmt;
    bool device_format;   // rows arrive formatted (ChunkDone::text / bin): the writers only write()
-   bool resume;          // hesaff_set_resume: an image whose complete output exists is not read
+   int resume;           // hesaff_set_resume: an image whose complete output exists is not read (2: the rows of a text output are counted)
+   bool nice_pool;       // the pool's threads run at nice 10 (hesaff_set_pool_priority: a CPU-starved plan)
    bool device_jpeg;     // JPEG files: entropy decoding only on the pool's threads, the pixels are made on the device
    PinHooks pin;         // where the readers' buffers come from (see blob_alloc)
    std::unordered_map<void *, size_t> pinned;   // buffers of `pin` that are out (with an image, or in blob_pool); under mu
@@ -222,9 +223,10 @@ struct FileIO : ChunkIO {
    std::vector<std::thread> workers;
 
    FileIO(BlockRing *ring_, int max_batch_, float mrSize_, int fmt_, int n_, const char *const *p, const char *const *o, hesaff_file_status *st,
-          int dec_threads, int wr_threads, bool device_format_ = false, bool resume_ = false, bool device_jpeg_ = false, PinHooks pin_ = PinHooks())
+          int dec_threads, int wr_threads, bool device_format_ = false, int resume_ = 0, bool device_jpeg_ = false, PinHooks pin_ = PinHooks(),
+          bool nice_pool_ = false)
       : ring(ring_), max_batch(max_batch_), n(n_), paths(p), out_paths(o), status(st), mrSize(mrSize_), fmt(fmt_), device_format(device_format_),
-        resume(resume_), device_jpeg(device_jpeg_), pin(pin_), imgs((size_t)n_)
+        resume(resume_), nice_pool(nice_pool_), device_jpeg(device_jpeg_), pin(pin_), imgs((size_t)n_)
    {
       window = 2 * max_batch + dec_threads;
       try {
@@ -262,9 +264,10 @@ struct FileIO : ChunkIO {
    {
       (void)pthread_setname_np(pthread_self(), "hs-pool");   // (shows in /proc/<pid>/task/*/comm: bench.py's per-thread CPU table)
       // The pool's threads read and write() flat out; the caller's thread needs the CPU for microseconds at a time, to launch the next kernels
-      // the moment an event fires.  On a share of two CPUs it must not queue behind them: the pool runs at a lower priority (nice is per
-      // thread on Linux; lowering it needs no privilege).
-      (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 10);
+      // the moment an event fires.  On a share of two CPUs it must not queue behind them: the pool then runs at a lower priority (nice is
+      // per thread on Linux; lowering it needs no privilege; a refusal changes nothing but the latency of the next launch).  On a host
+      // with CPUs to spare the pool keeps the priority it was started with: it is what feeds the device.
+      if (nice_pool) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 10);
       for (;;) {
          int i = -1;
          Task t{};
@@ -338,7 +341,7 @@ struct FileIO : ChunkIO {
    {
       if (resume && paths[i]) {
          int n_text = 0, n_bin = 0;
-         if (fmt & HESAFF_OUT_TEXT) n_text = hesaff_output_is_complete(out_name(i, false).c_str(), HESAFF_OUT_TEXT);
+         if (fmt & HESAFF_OUT_TEXT) n_text = hesaff_output_is_complete(out_name(i, false).c_str(), HESAFF_OUT_TEXT | (resume == 2 ? HESAFF_OUT_STRICT : 0));
          if (fmt & HESAFF_OUT_BIN) n_bin = hesaff_output_is_complete(out_name(i, true).c_str(), HESAFF_OUT_BIN);
          if (n_text >= 0 && n_bin >= 0 && (fmt != (HESAFF_OUT_TEXT | HESAFF_OUT_BIN) || n_text == n_bin)) {
             {

@@ -13,7 +13,8 @@
 //       keypoint density varies strongly along the list; the output files are the same either way.
 //       --fast 2                      hesaff_params.fast: windows larger than the patch sampled from the scale space (NOT bit-exact,
 //       another algorithm for those keypoints); default 0 = parity mode.
-//       --resume                      skip every image whose complete output (of the selected format) already exists; outputs are written
+//       --resume | --resume=strict    skip every image whose complete output (of the selected format) already exists (strict: the rows of an
+//                                     existing text file are counted too - for outputs a non-renaming writer may have left torn); outputs are written
 //       under a temporary name and renamed, so an interrupted run leaves no torn file (checkpoint / resume).
 //       --host-share K                this process may use 1/K of the host's CPUs (default 1): one of K processes on a node, e.g. one per GPU.
 //       Host threads per device context = hesaff_host_plan_for(devices x K): the library's one rule (include/hesaff_amd.h).
@@ -67,7 +68,7 @@ bool parse_devices(const char *spec, std::vector<int> &out)
 
 // hesaff --batch: the list is cut into contiguous shards, one per device context (hesaff_shard_range); every shard runs
 // through hesaff_process_files - decode threads -> device -> writer threads, bounded memory - on its own host thread.
-int run_batch_mode(const char *list_path, const char *devices_spec, int out_format, bool dynamic, int fast, bool resume, int host_share)
+int run_batch_mode(const char *list_path, const char *devices_spec, int out_format, bool dynamic, int fast, int resume, int host_share)
 {
    std::ifstream lf(list_path);
    if (!lf) { fprintf(stderr, "hesaff: cannot read list '%s'\n", list_path); return 1; }
@@ -103,7 +104,7 @@ int run_batch_mode(const char *list_path, const char *devices_spec, int out_form
       hesaff_ctx *ctx = nullptr;
       if (hesaff_create(&ctx, &par, devices[(size_t)rank]) != HESAFF_OK) { errs[(size_t)rank] = hesaff_last_error(nullptr); return; }
       hesaff_set_output_format(ctx, out_format);
-      hesaff_set_resume(ctx, resume ? 1 : 0);
+      hesaff_set_resume(ctx, resume);
       hesaff_host_plan hp;   // this device's share of the host: the library's one rule (include/hesaff_amd.h)
       hesaff_host_plan_for(world * host_share, &hp);
       const int wt = hp.write_threads, dt = hp.decode_threads;
@@ -166,9 +167,11 @@ int main(int argc, char **argv)
    if (batch) {
       const char *devices = nullptr, *list = nullptr;
       int out_format = HESAFF_OUT_TEXT, fast = 0, host_share = 1;
-      bool bad = false, dynamic = false, resume = false;
+      bool bad = false, dynamic = false;
+      int resume = 0;
       for (int i = 1; i < argc && !bad; i += 2) {
-         if (strcmp(argv[i], "--resume") == 0) { resume = true; i--; continue; }
+         if (strcmp(argv[i], "--resume") == 0) { resume = 1; i--; continue; }
+         if (strcmp(argv[i], "--resume=strict") == 0) { resume = 2; i--; continue; }   // also count the rows of existing text outputs
          if (i + 1 >= argc) bad = true;
          else if (strcmp(argv[i], "--batch") == 0) list = argv[i + 1];
          else if (strcmp(argv[i], "--devices") == 0) devices = argv[i + 1];
@@ -186,7 +189,7 @@ int main(int argc, char **argv)
             else bad = true;
          } else bad = true;
       }
-      if (bad || !list) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all] [--output text|bin|both] [--schedule static|dynamic] [--fast 0|2] [--resume] [--host-share K]\n"); return 1; }
+      if (bad || !list) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all] [--output text|bin|both] [--schedule static|dynamic] [--fast 0|2] [--resume|--resume=strict] [--host-share K]\n"); return 1; }
       return run_batch_mode(list, devices, out_format, dynamic, fast, resume, host_share);
    }
    if (argc > 1) {

@@ -19,6 +19,8 @@
 #include <cerrno>
 #include <fcntl.h>
 #include <sched.h>
+#include <sys/stat.h>
+#include <sys/syscall.h>
 #include <sys/uio.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -492,6 +494,17 @@ int hesaff_host_threads(void)
    return cached;
 }
 
+// hesaff_host_plan_for's stage_threads for a pool of decode_threads + write_threads (callers of hesaff_process_files pass the two counts
+// of their plan, not the plan): the largest s in 1..4 with clamp((pool + s) / 4, 1, 4) == s.  (The rule is not one-to-one - 7 and 8
+// CPUs both give a pool of 6 - and the larger count is taken: cpus = 8 -> 2, 16 -> 4, as hesaff_host_plan_for says.)
+int hesaff_stage_threads_for_pool(int pool)
+{
+   int best = 1;
+   for (int s = 1; s <= 4; s++)
+      if (std::max(1, std::min(4, (pool + s) / 4)) == s) best = s;
+   return best;
+}
+
 int hesaff_host_plan_for(int devices_sharing_host, hesaff_host_plan *out)
 {
    if (!out || devices_sharing_host < 1) return HESAFF_ERR_ARG;
@@ -568,17 +581,27 @@ static bool write_head_body(int fd, const char *head, size_t hl, const char *bod
    return write_all(fd, body + (done - hl), len - (done - hl));
 }
 
-// Every writer of this file puts its output under "<path>.part" and renames it when it is complete and closed: a killed run leaves no
-// torn file under the final name, so a file that exists under its final name is whole (hesaff_set_resume relies on it;
-// hesaff_output_is_complete still checks header, size and the last byte).
+// Every writer of this file puts its output under a temporary name next to `path` ("<path>.part.<pid>.<tid>": two writers of one
+// path - a caller's mistake - never share it) and renames it when it is complete and closed: a killed run leaves no torn file under the
+// final name, so a regular file that exists under its final name is whole (hesaff_set_resume relies on it).  Where that cannot work the
+// writer falls back to writing `path` itself: a target that exists and is not a regular file (/dev/stdout, a FIFO, a device), or a
+// directory in which no new file can be created (an existing writable file in a read-only directory).
 static int open_part(const char *path, std::string &part)
 {
-   part = std::string(path) + ".part";
-   return open(part.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+   struct stat sb;
+   if (stat(path, &sb) == 0 && !S_ISREG(sb.st_mode)) { part.clear(); return open(path, O_WRONLY | O_CLOEXEC); }
+   char suffix[64];
+   snprintf(suffix, sizeof suffix, ".part.%ld.%ld", (long)getpid(), (long)syscall(SYS_gettid));
+   part = std::string(path) + suffix;
+   const int fd = open(part.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+   if (fd >= 0) return fd;
+   part.clear();
+   return open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
 }
 static int finish_part(int fd, bool ok, const std::string &part, const char *path)
 {
    if (close(fd) != 0) ok = false;
+   if (part.empty()) return ok ? HESAFF_OK : HESAFF_ERR_IO;   // written in place
    if (ok && rename(part.c_str(), path) != 0) ok = false;
    if (!ok) unlink(part.c_str());
    return ok ? HESAFF_OK : HESAFF_ERR_IO;
@@ -693,13 +716,17 @@ int hesaff_write_sift_rows(const char *path, const char *rows, size_t len, int n
    HOSTIO_CATCH
 }
 
-// Is `path` the complete output of an earlier run?  text (format HESAFF_OUT_TEXT): "128\n<n>\n", then EXACTLY n rows - the newlines of
-// the body are counted, a file cut at a row boundary (a killed writer that does not go through .part + rename, e.g. the reference binary)
-// is not complete - the last byte a newline (n == 0: nothing after the header); sidecar: magic, dim 128, size == 16 + 148 n.  -> n, or -1.
+// Is `path` the complete output of an earlier run?  text (format HESAFF_OUT_TEXT): "128\n<n>\n", a body of at least n minimal rows, the
+// last byte a newline (n == 0: nothing after the header) - three small reads, whatever the size of the file: every writer of this library
+// renames its output into place when it is whole, so for its own files the test is exact.  With HESAFF_OUT_STRICT or-ed into `format` the
+// newlines of the body are counted too (the whole file is read: about 46 MB per dense 3840 x 2160 image): a text cut at a row boundary by a
+// writer that does not rename - the reference binary - is then not complete.  sidecar: magic, dim 128, size == 16 + 148 n.  -> n, or -1.
 // What this cannot see: an output made with other parameters (thresholds, fast mode); resume is for re-running the SAME job.
 int hesaff_output_is_complete(const char *path, int format)
 {
    if (!path) return -1;
+   const bool strict = (format & HESAFF_OUT_STRICT) != 0;
+   format &= ~HESAFF_OUT_STRICT;
    const int fd = open(path, O_RDONLY | O_CLOEXEC);
    if (fd < 0) return -1;
    int result = -1;
@@ -721,7 +748,8 @@ int hesaff_output_is_complete(const char *path, int format)
          char last = 0;
          // a row is at least 5 * 2 + 128 * 2 characters; the text must end with the newline of its last row
          if (n == 0) { if (body == 0) result = 0; }
-         else if (body >= (off_t)n * 266 && pread(fd, &last, 1, size - 1) == 1 && last == '\n') {
+         else if (body >= (off_t)n * 266 && pread(fd, &last, 1, size - 1) == 1 && last == '\n' && !strict) result = (int)n;
+         else if (body >= (off_t)n * 266 && last == '\n') {
             long lines = 0;
             bool ok = true;
             std::vector<char> buf;

@@ -1032,7 +1032,8 @@ __global__ __launch_bounds__(256, HS_MID_WAVES) void k_patch_mid(HessList hl, Pa
 // ---------------------------------------------------------------------------------------
 #define HS_LARGE_CHUNK 16   // consecutive window rows per wavefront task
 
-// dynamic LDS: per wave  srow_stride floats (window row + borders)  +  tap_stride floats (taps)
+// dynamic LDS: per wave  srow_stride floats (window row + borders)  +  tap_stride floats (taps); blocks of 4, 2 or 1 wavefronts
+// (the host picks the largest count whose rows fit the CU's 160 KB: windows up to about 6 900 / 13 900 / 27 900 pixels a side)
 __global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork pw, PatchIO io, KpTables tb, int srow_stride, int tap_stride)
 {
    extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1049,7 +1050,8 @@ __global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork
    }
    const int imPitch = io.image.pitch;
    const uint32_t ntasks = (row_hi + HS_LARGE_CHUNK - 1) / HS_LARGE_CHUNK;
-   for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+   const uint32_t nw = blockDim.x >> 6;   // wavefronts per block: 4, or fewer when a window row of the batch's largest window needs more than a quarter of the LDS
+   for (uint32_t task = blockIdx.x * nw + wave; task < ntasks; task += gridDim.x * nw) {
       uint32_t row = task * HS_LARGE_CHUNK;
       const uint32_t row_end = min(row + HS_LARGE_CHUNK, row_hi);
       // item of the first row: largest kk in [0, n_items) with pre[kk] <= row (one search per task)

@@ -292,27 +292,34 @@ struct hesaff_ctx {
    // when their image is on the device, kept pinned from one list to the next (pinning costs 0.1 ms per MB), released with the context.
    // At most kPinReadBytes are out or parked; a request beyond that gets nullptr (the image then takes the staging copy).
    struct PinReadCache {
-      static constexpr size_t kPinReadBytes = (size_t)4 << 30, kLargest = (size_t)64 << 20;
+      static constexpr size_t kLargest = (size_t)64 << 20;
+      size_t max_bytes = (size_t)4 << 30;    // out + parked never exceed this (hesaff_set_pinned_read_budget)
+      size_t keep_bytes = (size_t)1 << 30;   // parked buffers kept from one hesaff_process_files call to the next
       std::mutex mu;
       std::vector<std::pair<void *, size_t>> parked;
       size_t bytes_total = 0;   // out + parked
       int device = 0;
+      // (hipHostFree / hipHostMalloc are device-synchronising and slow: never under `mu`, which FileIO reaches with its own lock held)
       void *take(size_t bytes)
       {
          if (bytes == 0 || bytes > kLargest) return nullptr;
+         std::vector<std::pair<void *, size_t>> evicted;
+         bool room = false;
          {
             std::lock_guard<std::mutex> lk(mu);
             for (size_t k = 0; k < parked.size(); k++)
                if (parked[k].second == bytes) { void *q = parked[k].first; parked[k] = parked.back(); parked.pop_back(); return q; }
             // no room: parked buffers of other sizes (an earlier list's images) make way
-            while (bytes_total + bytes > kPinReadBytes && !parked.empty()) {
-               (void)hipHostFree(parked.back().first);
+            while (bytes_total + bytes > max_bytes && !parked.empty()) {
+               evicted.push_back(parked.back());
                bytes_total -= parked.back().second;
                parked.pop_back();
             }
-            if (bytes_total + bytes > kPinReadBytes) return nullptr;
-            bytes_total += bytes;
+            room = bytes_total + bytes <= max_bytes;
+            if (room) bytes_total += bytes;
          }
+         for (auto &b : evicted) (void)hipHostFree(b.first);
+         if (!room) return nullptr;
          void *q = nullptr;
          if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
@@ -327,11 +334,26 @@ struct hesaff_ctx {
          std::lock_guard<std::mutex> lk(mu);
          parked.emplace_back(q, bytes);
       }
+      // the end of a hesaff_process_files call: what is parked beyond `keep` goes back to the system
+      void trim(size_t keep)
+      {
+         std::vector<std::pair<void *, size_t>> out;
+         {
+            std::lock_guard<std::mutex> lk(mu);
+            size_t held = 0;
+            for (auto &b : parked) held += b.second;
+            while (held > keep && !parked.empty()) {
+               out.push_back(parked.back());
+               held -= parked.back().second; bytes_total -= parked.back().second;
+               parked.pop_back();
+            }
+         }
+         for (auto &b : out) (void)hipHostFree(b.first);
+      }
       void release()
       {
+         trim(0);
          std::lock_guard<std::mutex> lk(mu);
-         for (auto &b : parked) (void)hipHostFree(b.first);
-         parked.clear();
          bytes_total = 0;
       }
    } pin_read;
@@ -378,7 +400,8 @@ struct hesaff_ctx {
    hesaff_timings tm;
    int profiling = 0;
    int out_format = HESAFF_OUT_TEXT;   // hesaff_set_output_format
-   bool resume = false;                // hesaff_set_resume
+   int resume = 0;                     // hesaff_set_resume: 0 off, 1 skip complete outputs (O(1) test), 2 strict (rows counted)
+   int pool_priority = -1;             // hesaff_set_pool_priority: -1 lower the pool's priority when the plan is CPU-starved, 0 never, 1 always
    int stage_threads = 4;              // host threads that copy a chunk's pixels into pinned memory (hesaff_process_files: within its thread budget)
    hipStream_t side_streams[HS_NSIDE] = {nullptr, nullptr, nullptr, nullptr};
    hipStream_t sift_stream = nullptr, sift_stream2 = nullptr;   // descriptor kernels of even / odd groups (sift2: HESAFF_SIFT2)
@@ -402,6 +425,8 @@ struct hesaff_ctx {
    int force_exband = 0;           // HESAFF_EXBAND: rows per band of k_extrema_march (tuning)
    bool debug = false;             // HESAFF_DEBUG=1: launch geometry on stderr
    uint32_t sgrad_grid = 0;        // persistent grid of k_sift_grad (set with the device: 32 blocks per CU; HESAFF_SGRAD_GRID; 0: one block per keypoint)
+   uint32_t sift_slice = 0;        // HESAFF_SIFT_SLICE: keypoints per slice of the descriptor stage (launch_sift); 0 = a group's kernels each over the whole group
+   bool sift_slice_ring = true;    // HESAFF_SLICE_RING: the slices of a group reuse one slice-sized piece of the intermediates (0: every slice its own piece)
 
    std::vector<hipEvent_t> ev_pool;
    size_t ev_used = 0;
@@ -559,7 +584,8 @@ size_t mid_lds_bytes() { return (size_t)MidGeom<HS_MID_PMAX>::FLOATS * 4; }
 size_t big_lds_bytes() { return (size_t)MidGeom<HS_BIN3_PMAX>::FLOATS * 4; }
 
 // geometry of the large-window row kernel for windows up to pmax: LDS per wave = window row + replicated borders + taps
-struct LargeGeom { int srow_stride, tap_stride; size_t lds; };
+constexpr size_t HS_LDS_PER_CU = 160 * 1024;
+struct LargeGeom { int srow_stride, tap_stride; size_t lds; };   // lds: bytes for a block of FOUR wavefronts
 LargeGeom large_geom(int pmax)
 {
    LargeGeom g;
@@ -732,11 +758,15 @@ void plan_buffers(hesaff_ctx *c, int B, int H, int W)
    c->b_trows2.ensure((size_t)HS_MID_BLOCKS * (HS_MID_PMAX + 2 * HS_MID_RPAD) * HS_NEED * 4);
    c->b_trows3.ensure((size_t)HS_BIG_BLOCKS * (HS_BIN3_PMAX + 2 * HS_BIG_RPAD) * HS_NEED * 4);
    {
+      // k_patch_large_rows keeps one window row (+ borders, + taps) per wavefront in LDS: blocks of four wavefronts while four rows of the
+      // batch's largest window fit the CU's 160 KB, of two or one beyond that (run_patch_stage); a row that does not fit alone - a window
+      // above ~27 900 pixels a side, i.e. an image of more than 780 Mpx - is refused here
       const LargeGeom lg = large_geom(c->max_p0 + 2);
-      if (lg.lds > 160 * 1024) throw HsError(HESAFF_ERR_ARG, "image too large for the large-window row kernel");
-      if (lg.lds > c->rows_lds_set) {
-         set_dyn_lds(k_patch_large_rows, lg.lds);
-         c->rows_lds_set = lg.lds;
+      if (lg.lds / 4 > HS_LDS_PER_CU) throw HsError(HESAFF_ERR_ARG, "image too large for the large-window row kernel (sqrt(width x height) above about 27900)");
+      const size_t want = std::min<size_t>(lg.lds, HS_LDS_PER_CU);
+      if (want > c->rows_lds_set) {
+         set_dyn_lds(k_patch_large_rows, want);
+         c->rows_lds_set = want;
       }
    }
    c->B = B; c->H = H; c->W = W;
@@ -919,9 +949,12 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
       io.row_prefix = c->b_rowprefix.as<uint32_t>();
       io.trows_cap = rows_cap;
       io.overflow = s.counters + 6;
-      const uint32_t gblocks = std::min<uint32_t>((large_rows_bound + 4 * HS_LARGE_CHUNK - 1) / (4 * HS_LARGE_CHUNK), 256 * 16);
+      // wavefronts per block: four while their rows fit the CU's LDS (plan_buffers made sure one fits)
+      uint32_t nw = 4;
+      while (nw > 1 && lg.lds / 4 * nw > HS_LDS_PER_CU) nw >>= 1;
+      const uint32_t gblocks = std::min<uint32_t>((large_rows_bound + nw * HS_LARGE_CHUNK - 1) / (nw * HS_LARGE_CHUNK), 256 * 16 * (4 / nw));
       hipLaunchKernelGGL(k_large_prefix, dim3(1), dim3(256), 0, st, s.pw, c->b_rowprefix.as<uint32_t>());
-      hipLaunchKernelGGL(k_patch_large_rows, dim3(gblocks), dim3(256), lg.lds, st, s.hl, s.pw, io, c->tables, lg.srow_stride, lg.tap_stride);
+      hipLaunchKernelGGL(k_patch_large_rows, dim3(gblocks), dim3(64 * nw), lg.lds / 4 * nw, st, s.hl, s.pw, io, c->tables, lg.srow_stride, lg.tap_stride);
       hipLaunchKernelGGL(k_patch_large_finish, dim3(c->g_lfin), dim3(256), 0, st, s.pw, io, c->tables);
    }
    if (forked)
@@ -1116,13 +1149,34 @@ void collect_timings(hesaff_ctx *c, StageTimer &tm, int B)
 }
 
 // The descriptor kernels (kernels_sift.h) over n patches in HBM.
-void launch_sift(hesaff_ctx *c, hipStream_t ss, const SiftIO &so, uint32_t n, float2 *vo)
+// sift_slice > 0: the group's keypoints in slices of that many, the four kernels back to back per slice, so that what a kernel
+// writes (mean / variance, gradient pairs, histograms) and the patches the slice's first kernel fetched are still in the device's
+// 256 MB memory-side cache when the next kernel of the slice reads them (sweep in profiles/r06_notes.md).
+void launch_sift_range(hesaff_ctx *c, hipStream_t ss, const SiftIO &so, uint32_t n, float2 *vo)
 {
    const uint32_t nb64 = (n + 63) / 64;
    hipLaunchKernelGGL(k_sift_meanvar, dim3((n + SM_KP - 1) / SM_KP), dim3(64), 0, ss, so, c->tables);
    hipLaunchKernelGGL(k_sift_grad, dim3(c->sgrad_grid ? std::min(n, c->sgrad_grid) : n), dim3(256), 0, ss, so, c->tables, vo);
    hipLaunchKernelGGL(k_sift_hist, dim3(std::min<uint32_t>((n + 3) / 4, c->g_shist)), dim3(64), 0, ss, so, c->tables, (const float2 *)vo);
    hipLaunchKernelGGL(k_sift_quantize, dim3(nb64), dim3(64), 0, ss, so, c->consts);
+}
+
+void launch_sift(hesaff_ctx *c, hipStream_t ss, const SiftIO &so, uint32_t n, float2 *vo)
+{
+   const uint32_t slice = c->sift_slice;
+   if (slice == 0 || slice >= n) { launch_sift_range(c, ss, so, n, vo); return; }
+   for (uint32_t lo = 0; lo < n; lo += slice) {
+      const uint32_t m = std::min(slice, n - lo);
+      SiftIO s = so;
+      s.patches = so.patches + (size_t)lo * HS_PATCH_PIX;
+      s.h_lo = so.h_lo + lo; s.h_hi = s.h_lo + m;
+      // the intermediates are indexed relative to h_lo: in ring mode every slice uses the group buffers' first slice-sized piece
+      // (the kernels of one stream run one after the other; a keypoint's zero items of the pair block are never written)
+      const size_t at = c->sift_slice_ring ? 0 : lo;
+      s.meanvar = so.meanvar + 2 * at;
+      s.vec = so.vec + 128 * at;
+      launch_sift_range(c, ss, s, m, vo + at * HS_VO_PITCH);
+   }
 }
 
 // per-group patch / descriptor buffers (two slots): sized once per batch for the largest group

@@ -33,7 +33,7 @@ extern "C" {
  * struct and bump this number.   1: round 1;  2: + upscaleInputImage, fast, pack_ms (inserted mid-struct);  3: + extrema_*;
  * 4: hesaff_params.fast = 1 withdrawn, HESAFF_FILE_REJECTED, rows formatted on the device;
  * 5: this header (+ hesaff_jpeg_layout, hesaff_read_jpeg_coefficients, hesaff_stage_jpeg_pixels: JPEG pixels made on the device). */
-#define HESAFF_ABI_VERSION 6
+#define HESAFF_ABI_VERSION 7
 int hesaff_abi_version(void);
 size_t hesaff_sizeof_params(void);
 size_t hesaff_sizeof_timings(void);
@@ -172,12 +172,17 @@ int hesaff_process_files(hesaff_ctx *ctx, int n, const char *const *paths, const
  * given, the binary file is out_paths[i] + ".bin" when both are written, out_paths[i] itself when only the binary one is. */
 #define HESAFF_OUT_TEXT 1
 #define HESAFF_OUT_BIN 2
+#define HESAFF_OUT_STRICT 0x100   /* hesaff_output_is_complete only: also count the rows of a text file (reads the whole file) */
 int hesaff_set_output_format(hesaff_ctx *ctx, int format);
 /* Resume a list that was interrupted (checkpoint / resume; no counterpart in the reference, which handles one
  * image per process): with on != 0 hesaff_process_files skips every image whose output file(s) of the selected format exist and
- * are complete - a .hesaff.sift with its two header lines and a final newline, a .hesaff.bin whose size matches its row count.
- * hesaff_process_files writes every output under a temporary name and renames it when it is complete, so a run that is killed
- * never leaves a torn file under the final name. */
+ * are complete - a .hesaff.sift with its two header lines, a plausible size and a final newline, a .hesaff.bin whose size matches its
+ * row count (three small reads per file).  on = 2 (strict): the rows of an existing text file are counted as well - the whole file is
+ * read, about 46 MB per dense 3840 x 2160 image, on the decode threads - for directories that a writer which does not rename its
+ * outputs into place (the reference binary) may have left torn at a row boundary.  Every writer of this library puts its output under
+ * a temporary name ("<name>.part.<pid>.<tid>") and renames it when it is complete, so a run that is killed never leaves a torn file
+ * under the final name; a target that is not a regular file (/dev/stdout, a FIFO) or whose directory takes no new file is written in
+ * place. */
 int hesaff_set_resume(hesaff_ctx *ctx, int on);
 
 /* Same path with inputs already resident in device memory (bench / pipelines that decode
@@ -208,8 +213,8 @@ int hesaff_write_bin(const char *path, const hesaff_keypoint *keys, int n, float
  * n rows of 148 bytes; the header lines (hesaff.cpp:109-110) / the 16-byte sidecar header are added here. */
 int hesaff_write_sift_rows(const char *path, const char *rows, size_t len, int n);
 int hesaff_write_bin_rows(const char *path, const char *rows, int n);
-/* the row count of `path` when it is the complete output (format HESAFF_OUT_TEXT or HESAFF_OUT_BIN) of an earlier run, -1
- * otherwise: what hesaff_set_resume goes by */
+/* the row count of `path` when it is the complete output (format HESAFF_OUT_TEXT or HESAFF_OUT_BIN, optionally | HESAFF_OUT_STRICT)
+ * of an earlier run, -1 otherwise: what hesaff_set_resume goes by (on = 1: as given; on = 2: with HESAFF_OUT_STRICT) */
 int hesaff_output_is_complete(const char *path, int format);
 /* formats into a malloc'ed buffer (*out, *len); caller frees with hesaff_free */
 int hesaff_format_sift(const hesaff_keypoint *keys, int n, float mrSize, char **out, size_t *len);
@@ -239,6 +244,17 @@ typedef struct hesaff_host_plan {
    int cpus, decode_threads, write_threads, stage_threads;
 } hesaff_host_plan;
 int hesaff_host_plan_for(int devices_sharing_host, hesaff_host_plan *out);
+/* the plan's stage_threads for a pool of decode_threads + write_threads (what hesaff_process_files derives from the two counts it is given) */
+int hesaff_stage_threads_for_pool(int pool);
+/* Page-locked read buffers of hesaff_process_files (the readers fill pinned memory of the context, the copy engine takes the image
+ * from where it was read): at most max_bytes are out or parked at any time (default 4 GiB; a request beyond it takes the staging
+ * copy), and at most keep_bytes stay pinned when hesaff_process_files returns (default 1 GiB: the next list of a long-lived
+ * context starts with warm buffers; 0 releases everything).  No counterpart in the reference. */
+int hesaff_set_pinned_read_budget(hesaff_ctx *ctx, size_t max_bytes, size_t keep_bytes);
+/* The decode / write pool of hesaff_process_files lowers its threads' priority (nice 10) only when the host plan is CPU-starved
+ * (CPUs of this process <= pool threads + 1), so that the caller's thread - which launches the next kernels when an event fires -
+ * never queues behind threads that write() flat out.  mode: 0 = never, 1 = always, -1 = that rule (default). */
+int hesaff_set_pool_priority(hesaff_ctx *ctx, int mode);
 /* test hook: number of inputs on which the fast "%g" formatter and snprintf disagree (must be 0) */
 int hesaff_test_fmt_g(const float *v, int n);
 void hesaff_free(void *p);

@@ -20,6 +20,7 @@
 // which has no FMA).
 //
 // Build: see oracle/Makefile  ->  oracle/libhesaff_oracle.so
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -93,6 +94,9 @@ void gaussKernel(int n, float sigmaf, float *cf)
 inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // helpers.cpp:283-295 -> cv::GaussianBlur(..., BORDER_REPLICATE), float32 single channel
+// (target_clones: the same loops compiled for wider vectors where the CPU has them, chosen at load time; element-wise IEEE multiplies and adds,
+//  no fused multiply-add - "avx2" does not include FMA and contraction is off - so every clone computes the same bits)
+__attribute__((target_clones("avx512f", "avx2", "default")))
 void gaussianBlur(const Plane &in, float sigma, Plane &out)
 {
    const int n = gaussKsize(sigma);
@@ -103,6 +107,7 @@ void gaussianBlur(const Plane &in, float sigma, Plane &out)
    gaussKernel(n, sigma, k.data());
    const int r = n / 2;
    Plane tmp(rows, cols);
+   std::vector<float> pad;
    // row pass
    for (int y = 0; y < rows; y++) {
       const float *S = in.row(y);
@@ -121,24 +126,44 @@ void gaussianBlur(const Plane &in, float sigma, Plane &out)
             T[x] = v;
          }
       } else {
-         // RowFilter: ascending sequential accumulation
-         for (int x = 0; x < cols; x++) {
-            float t = k[0] * S[clampi(x - r, 0, cols - 1)];
-            for (int j = 1; j < n; j++) t += k[j] * S[clampi(x - r + j, 0, cols - 1)];
-            T[x] = t;
+         // RowFilter: ascending sequential accumulation, t = k[0] * S[x - r]; t += k[j] * S[x - r + j] (j = 1 .. n-1), columns clamped
+         // (BORDER_REPLICATE).  Loop order only: the row is padded once (pad[i] = S[clamp(i - r)]) and the taps run in the OUTER loop
+         // over a chunk of pixels, so that the compiler can vectorise across pixels; every pixel's own chain of operations - the
+         // only thing the result depends on - is the one above, in the same order.
+         pad.resize((size_t)cols + 2 * r);
+         for (int i = 0; i < cols + 2 * r; i++) pad[i] = S[clampi(i - r, 0, cols - 1)];
+         const int CH = 1024;
+         for (int x0 = 0; x0 < cols; x0 += CH) {
+            const int m = std::min(CH, cols - x0);
+            const float *P0 = pad.data() + x0;
+            float *Tx = T + x0;
+            const float k0 = k[0];
+            for (int x = 0; x < m; x++) Tx[x] = k0 * P0[x];
+            for (int j = 1; j < n; j++) {
+               const float kj = k[j];
+               const float *Pj = P0 + j;
+               for (int x = 0; x < m; x++) Tx[x] += kj * Pj[x];
+            }
          }
       }
    }
-   // column pass: SymmColumnFilter
-   for (int y = 0; y < rows; y++) {
-      float *D = res.row(y);
-      const float *T0 = tmp.row(y);
-      for (int x = 0; x < cols; x++) D[x] = k[r] * T0[x];
-      for (int j = 1; j <= r; j++) {
-         const float *Tp = tmp.row(clampi(y + j, 0, rows - 1));
-         const float *Tm = tmp.row(clampi(y - j, 0, rows - 1));
-         const float kj = k[r + j];
-         for (int x = 0; x < cols; x++) D[x] += kj * (Tp[x] + Tm[x]);
+   // column pass: SymmColumnFilter  d = k[r] * T[y]; d += k[r + j] * (T[y + j] + T[y - j]) (j = 1 .. r), rows clamped.  Loop order only: tiles of
+   // columns, so that the 2 r + 1 rows an output row reads stay in the cache for the huge windows of normalizeAffine (K up to ~1600);
+   // per output element the operations and their order are unchanged.
+   const int CW = 256;
+   for (int x0 = 0; x0 < cols; x0 += CW) {
+      const int m = std::min(CW, cols - x0);
+      for (int y = 0; y < rows; y++) {
+         float *D = res.row(y) + x0;
+         const float *T0 = tmp.row(y) + x0;
+         const float kr = k[r];
+         for (int x = 0; x < m; x++) D[x] = kr * T0[x];
+         for (int j = 1; j <= r; j++) {
+            const float *Tp = tmp.row(clampi(y + j, 0, rows - 1)) + x0;
+            const float *Tm = tmp.row(clampi(y - j, 0, rows - 1)) + x0;
+            const float kj = k[r + j];
+            for (int x = 0; x < m; x++) D[x] += kj * (Tp[x] + Tm[x]);
+         }
       }
    }
    out = res;

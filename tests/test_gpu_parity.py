@@ -1457,3 +1457,39 @@ def test_octave_map_epochs_wrap_around(oracle):
     o = _oracle.OracleRun(_oracle.gray_from_u8(small))
     assert nh_s == o.n_hessian and len(got) == o.n_keys and hesaff_amd.format_sift(got, p.mrSize) == o.export_text()
     assert len(first) > 100000
+    # ... and the 3840 x 2160 bytes every batch returned ARE the oracle's (one oracle run, about 15 s)
+    ob = _oracle.OracleRun(_oracle.gray_from_u8(img))
+    g, t, d = ob.keys()
+    assert nh0 == ob.n_hessian and len(first) == ob.n_keys
+    assert np.array_equal(first["desc"], d) and np.array_equal(first["type"], t)
+    for j, name in enumerate(["x", "y", "s", "a11", "a12", "a21", "a22", "response"]):
+        assert_bit_equal(first[name], g[:, j], name)
+
+
+@pytest.mark.gpu
+def test_image_and_window_beyond_the_old_size_ceiling(oracle):
+    """the reference has no bound on the window normalizeAffine warps (affine.cpp:120-124 resizes its workspace per call);
+    the library refused every image with sqrt(W H) above ~7000 at plan time (LDS of the large-window row kernel sized for the largest window
+    the image could hold).  A 12000 x 8000 image (sqrt = 9798) with one blob whose window is 7359 pixels a side - above the 6912 that four
+    wavefronts' rows fit in a CU's LDS, so k_patch_large_rows runs with two per block - plus windows in the other size bins: every
+    field and descriptor equal to the oracle's."""
+    import hesaff_amd
+    H, W = 8000, 12000
+    yy = np.arange(H, dtype=np.float32)[:, None]; xx = np.arange(W, dtype=np.float32)[None, :]
+    acc = np.full((H, W), 40.0, np.float32)
+    for cy, cx, sy, sx, amp in ((H * 0.5, W * 0.5, 700.0, 700.0, 180.0), (H * 0.2, W * 0.15, 150.0, 150.0, 120.0), (H * 0.8, W * 0.85, 60.0, 90.0, 100.0),
+                                (H * 0.25, W * 0.8, 20.0, 20.0, 150.0)):
+        acc += np.float32(amp) * np.exp(-0.5 * ((yy - np.float32(cy)) / np.float32(sy)) ** 2) * np.exp(-0.5 * ((xx - np.float32(cx)) / np.float32(sx)) ** 2)
+    img = np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+    del acc
+    p = hesaff_amd.default_params(); p.max_batch = 1
+    with hesaff_amd.HesaffContext(p, device=0) as ctx:
+        (nh, keys), = ctx.detect_batch([img])
+    o = oracle.OracleRun(oracle.gray_from_u8(img))
+    g, t, d = o.keys()
+    assert nh == o.n_hessian and len(keys) == o.n_keys and o.n_keys >= 4
+    P0 = 2 * np.ceil(g[:, 2] * np.float32(p.mrSize)).astype(int) + 1
+    assert P0.max() + 2 > 6912 and (P0 > 512).sum() >= 2, P0
+    assert np.array_equal(keys["desc"], d) and np.array_equal(keys["type"], t)
+    for j, name in enumerate(["x", "y", "s", "a11", "a12", "a21", "a22", "response"]):
+        assert_bit_equal(keys[name], g[:, j], name)

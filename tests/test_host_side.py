@@ -610,10 +610,15 @@ def test_binary_sidecar_holds_the_rows_of_the_text_file(tmp_path):
         hesaff_amd.read_bin(str(tmp_path / "junk.bin"))
 
 
+STRICT = 0x100   # HESAFF_OUT_STRICT
+
+
 def test_output_is_complete_counts_rows_and_writers_leave_no_torn_file(tmp_path):
     """hesaff_set_resume's test of an existing output: a text file cut at a ROW BOUNDARY - what a killed writer that
     does not go through <name>.part + rename leaves, e.g. the reference binary - is not complete; every writer of the library
-    (single- and multi-threaded text, sidecar, batch, the *_rows forms) goes through .part + rename and leaves no .part behind."""
+    (single- and multi-threaded text, sidecar, batch, the *_rows forms) goes through a temporary name + rename and leaves nothing behind.
+    ADVICE r05: the row count reads the whole file, so it is the STRICT form (HESAFF_OUT_STRICT, hesaff_set_resume(ctx, 2)); the default
+    test is three small reads and exact for files the library's renaming writers made."""
     import hesaff_amd
     L = hesaff_amd.load_library()
     rng = np.random.default_rng(5)
@@ -627,16 +632,16 @@ def test_output_is_complete_counts_rows_and_writers_leave_no_torn_file(tmp_path)
     q = str(tmp_path / "a.pgm.hesaff.sift")
     for threads in (1, 4):     # hesaff_write_sift_mt: the block-wise single-thread form and the one-buffer form
         assert L.hesaff_write_sift_mt(os.fsencode(q), keys.ctypes.data_as(C.c_void_p), n, mr, threads) == 0
-        assert open(q, "rb").read() == text and not os.path.exists(q + ".part")
-        assert L.hesaff_output_is_complete(os.fsencode(q), 1) == n
+        assert open(q, "rb").read() == text and os.listdir(tmp_path) == [os.path.basename(q)]
+        assert L.hesaff_output_is_complete(os.fsencode(q), 1) == n and L.hesaff_output_is_complete(os.fsencode(q), 1 | STRICT) == n
     b = str(tmp_path / "a.pgm.hesaff.bin")
     hesaff_amd.write_bin(b, keys, mr)
-    assert L.hesaff_output_is_complete(os.fsencode(b), 2) == n and not os.path.exists(b + ".part")
+    assert L.hesaff_output_is_complete(os.fsencode(b), 2) == n and not [f for f in os.listdir(tmp_path) if ".part" in f]
     # the *_rows writers (rows formatted elsewhere - on the device): header + rows in one writev, the same file
     body = text.split(b"\n", 2)[2]
     r = str(tmp_path / "rows.hesaff.sift")
     assert L.hesaff_write_sift_rows(os.fsencode(r), body, len(body), n) == 0
-    assert open(r, "rb").read() == text and not os.path.exists(r + ".part")
+    assert open(r, "rb").read() == text and not [f for f in os.listdir(tmp_path) if ".part" in f]
     binrows = open(b, "rb").read()[16:]
     r2 = str(tmp_path / "rows.hesaff.bin")
     assert L.hesaff_write_bin_rows(os.fsencode(r2), binrows, n) == 0 and open(r2, "rb").read() == open(b, "rb").read()
@@ -645,10 +650,13 @@ def test_output_is_complete_counts_rows_and_writers_leave_no_torn_file(tmp_path)
     cut = b"\n".join(lines[: 2 + (3 * n) // 4]) + b"\n"
     t = str(tmp_path / "torn.hesaff.sift")
     open(t, "wb").write(cut)
-    assert L.hesaff_output_is_complete(os.fsencode(t), 1) == -1
+    assert L.hesaff_output_is_complete(os.fsencode(t), 1 | STRICT) == -1
+    assert L.hesaff_output_is_complete(os.fsencode(t), 1) == n    # (the O(1) form cannot see it: the stated limit of the default)
     open(t, "wb").write(text + lines[5] + b"\n")       # one row too many
-    assert L.hesaff_output_is_complete(os.fsencode(t), 1) == -1
+    assert L.hesaff_output_is_complete(os.fsencode(t), 1 | STRICT) == -1
     open(t, "wb").write(text[:-1])                     # no final newline
+    assert L.hesaff_output_is_complete(os.fsencode(t), 1) == -1 and L.hesaff_output_is_complete(os.fsencode(t), 1 | STRICT) == -1
+    open(t, "wb").write(text[: len(text) // 3])        # cut far too short for its row count: the O(1) form sees that
     assert L.hesaff_output_is_complete(os.fsencode(t), 1) == -1
     open(t, "wb").write(b"128\n0\n")
     assert L.hesaff_output_is_complete(os.fsencode(t), 1) == 0
@@ -657,6 +665,25 @@ def test_output_is_complete_counts_rows_and_writers_leave_no_torn_file(tmp_path)
     # an unwritable target reports an error and leaves nothing behind
     bad = str(tmp_path / "no_such_dir" / "x.hesaff.sift")
     assert L.hesaff_write_sift_rows(os.fsencode(bad), body, len(body), n) != 0
+    # a target that is not a regular file is written in place (/dev/stdout, a FIFO): here a FIFO with a reader thread
+    import threading
+    fifo = str(tmp_path / "pipe.hesaff.sift")
+    os.mkfifo(fifo)
+    got = []
+    th = threading.Thread(target=lambda: got.append(open(fifo, "rb").read()))
+    th.start()
+    assert L.hesaff_write_sift_rows(os.fsencode(fifo), body, len(body), n) == 0
+    th.join(30)
+    assert got and got[0] == text and not [f for f in os.listdir(tmp_path) if ".part" in f]
+    # an existing writable file in a directory that takes no new file: written in place as well
+    if os.geteuid() != 0:    # (root creates files anywhere)
+        ro = tmp_path / "ro"; ro.mkdir()
+        target = str(ro / "y.hesaff.sift"); open(target, "wb").write(b"old")
+        os.chmod(ro, 0o555)
+        try:
+            assert L.hesaff_write_sift_rows(os.fsencode(target), body, len(body), n) == 0 and open(target, "rb").read() == text
+        finally:
+            os.chmod(ro, 0o755)
 
 
 def test_host_plan_is_one_rule():
@@ -673,3 +700,13 @@ def test_host_plan_is_one_rule():
         assert hp == {"cpus": cpus, "decode_threads": max(1, pool // 4), "write_threads": pool - max(1, pool // 4), "stage_threads": stage}
     with pytest.raises(hesaff_amd.HesaffError):
         hesaff_amd.host_plan(0)
+    # hesaff_process_files gets the plan's two pool counts, not the plan: the staging threads it derives from them are the plan's
+    # (8 CPUs -> pool 6, stage 2; 16 CPUs -> pool 12, stage 4)
+    L = hesaff_amd.load_library()
+    by_pool = {}
+    for cpus in range(1, 257):
+        stage = max(1, min(4, cpus // 4))
+        by_pool.setdefault(max(2, cpus - stage), set()).add(stage)
+    for pool, stages in by_pool.items():      # the rule is not one-to-one (7 and 8 CPUs share a pool of 6): the larger count is taken
+        assert L.hesaff_stage_threads_for_pool(pool) == max(stages), (pool, stages)
+    assert L.hesaff_stage_threads_for_pool(6) == 2 and L.hesaff_stage_threads_for_pool(12) == 4 and L.hesaff_stage_threads_for_pool(2) == 1
