@@ -193,6 +193,10 @@ int hesaff_create(hesaff_ctx **out, const hesaff_params *p, int device)
       }
       if (const char *s2 = getenv("HESAFF_SIFT2")) c->sift2 = atoi(s2) != 0;
       if (const char *tp = getenv("HESAFF_TAPER")) c->taper_groups = atoi(tp) != 0;
+      if (const char *lst = getenv("HESAFF_LARGE_STREAM")) c->large_stream = atoi(lst) == 1 ? 1 : 0;
+      if (const char *lw = getenv("HESAFF_LARGE_NW")) c->large_nw = std::max(0, std::min(4, atoi(lw)));
+      if (const char *ln = getenv("HESAFF_LARGE_NROW")) c->large_nrow = atoi(ln) == 3 ? 3 : 1;
+      if (const char *ls = getenv("HESAFF_LARGE_SPLIT")) c->large_split = std::max(0, atoi(ls));
       if (const char *sl = getenv("HESAFF_SIFT_SLICE")) c->sift_slice = (uint32_t)std::max(0, atoi(sl));
       if (const char *sr = getenv("HESAFF_SLICE_RING")) c->sift_slice_ring = atoi(sr) != 0;
 #endif

@@ -181,6 +181,24 @@ __device__ __forceinline__ void hs_resample_full_tab(const float *S, const int *
 #ifndef HS_MID_WAVES
 #define HS_MID_WAVES 0
 #endif
+// HS_TAPS_SCALAR: the row pass of the row-streamed windows takes its taps as SCALAR operands.  Everything that selects a window is the same
+// for all lanes of a wavefront (the wavefront's task, its keypoint, P, K, the tap table's offset), but the compiler cannot know that of a value
+// derived from threadIdx.x or read from LDS; with the wave index / the claimed item passed through v_readfirstlane the whole chain of per-item
+// parameters lives in scalar registers, and taps[jt] is an s_load from the tap table in global memory (2.4 KB at most, scalar-cache resident)
+// instead of a broadcast ds_read from a staged copy: a third of the row pass's LDS instructions gone, on kernels whose LDS pipe is 45-60 % busy.
+// (The table is read through a pointer to the constant address space: what tells the compiler that the memory does not change during the
+// kernel, without which a uniform load still goes through the vector memory path.)
+#ifndef HS_TAPS_SCALAR
+#define HS_TAPS_SCALAR 1
+#endif
+typedef __attribute__((address_space(4))) const float hs_cfloat;
+#if HS_TAPS_SCALAR
+typedef hs_cfloat *hs_row_taps;
+#define HS_ROW_TAPS(global_table, lds_copy) (reinterpret_cast<hs_cfloat *>(reinterpret_cast<uintptr_t>(global_table)))
+#else
+typedef const float *hs_row_taps;
+#define HS_ROW_TAPS(global_table, lds_copy) (lds_copy)
+#endif
 #ifndef HS_MID_SCALAR
 #define HS_MID_SCALAR 1     // the row pass of the row-streamed windows as scalar sliding-window chains: every sample is read from LDS once (the pair form reads
                             // it twice) and no register pairs are assembled; k_patch_mid<512> 195.5 -> 178.1, <128> 149.5 -> 144.0 ms per 256 images
@@ -542,8 +560,8 @@ __global__ __launch_bounds__(256, (BIN == 0 ? HS_SMALL_WAVES : 0)) void k_patch_
 // the plane is read through L2 / HBM, where a load per tap step followed by its use is a full round trip per step -
 // and the two columns of a row ride in one packed operation.  CLAMP = false: T points at window row 0 of a plane
 // stored with r replicated rows above and below (k_patch_mid's HBM slot), no index clamps.
-template <int JC, bool CLAMP>
-__device__ __forceinline__ void hs_colpass4_rows(const float *__restrict__ T, int y0, int q, int pm, const float *__restrict__ taps, int r,
+template <int JC, bool CLAMP, class TAPS = const float *>
+__device__ __forceinline__ void hs_colpass4_rows(const float *__restrict__ T, int y0, int q, int pm, TAPS taps, int r,
                                                  v2f &pa, v2f &pb)
 {
    // row y of the window -> pair at T[row][q]; CLAMP: BORDER_REPLICATE by index clamp (unpadded plane)
@@ -583,8 +601,8 @@ __device__ __forceinline__ void hs_colpass4_rows(const float *__restrict__ T, in
 
 // resample of affine.cpp:131 from the row-pass plane at the 82 needed columns (PADDED: T points at
 // window row 0 of a plane with r replicated rows above and below; otherwise rows are clamped)
-template <bool PADDED>
-__device__ __forceinline__ void hs_resample_reduced_batched(const float *__restrict__ T, int P, float scale, const float *__restrict__ taps, int r,
+template <bool PADDED, class TAPS = const float *>
+__device__ __forceinline__ void hs_resample_reduced_batched(const float *__restrict__ T, int P, float scale, TAPS taps, int r,
                                                             float *s_patch)
 {
    const float c0 = (float)(P >> 1);
@@ -597,7 +615,7 @@ __device__ __forceinline__ void hs_resample_reduced_batched(const float *__restr
       wx -= fx; wy -= fy;
       const int y0 = min(max((int)fy, 0), P - 2);   // always inside: |j * scale| < P0 / 2
       v2f pa, pb;   // (p00, p01), (p10, p11)
-      hs_colpass4_rows<8, !PADDED>(T, y0, 2 * ii, P - 1, taps, r, pa, pb);
+      hs_colpass4_rows<8, !PADDED, TAPS>(T, y0, 2 * ii, P - 1, taps, r, pa, pb);
       s_patch[idx] = (1.0f - wy) * ((1.0f - wx) * pa.x + wx * pa.y) + (wy) * ((1.0f - wx) * pb.x + wx * pb.y);
    }
 }
@@ -608,7 +626,8 @@ __device__ __forceinline__ void hs_resample_reduced_batched(const float *__restr
 // output, 21 round trips per wavefront and keypoint - 46 % of k_patch_mid<128>, 29 % of <512> in the ablation.  Here as
 // many consecutive output rows as fit are taken per round: their rows of T' come in with one coalesced sweep, and the
 // column pass reads LDS.  Same sums, same order.  T: window row 0 of the padded plane; chunk_rows >= K + 2.
-__device__ __forceinline__ void hs_resample_chunked(const float *__restrict__ T, int P, float scale, const float *__restrict__ taps, int r,
+template <class TAPS = const float *>
+__device__ __forceinline__ void hs_resample_chunked(const float *__restrict__ T, int P, float scale, TAPS taps, int r,
                                                     float *__restrict__ s_chunk, int chunk_rows, float *s_patch)
 {
    const int tid = threadIdx.x;
@@ -719,9 +738,9 @@ __device__ __forceinline__ void hs_gather_rows(const HsPlaneBuf &img, const v2f 
 // LDS (`taps`, broadcast reads).  ctab: the window's column table C[ii] = (i*a11, i*a21) in LDS, or nullptr
 // (huge windows: computed per tap).
 // Lane i < 41 owns the output pair (2i, 2i + 1); the two accumulation chains run as one packed chain.
-template <int NIT>
+template <int NIT, class TAPS = const float *>
 __device__ __forceinline__ void hs_row_stream(const HsPlaneBuf &img, float x, float y, float a11, float a12, float a21, float a22, int P, int yy,
-                                              float scale, const v2f *__restrict__ ctab, const float *__restrict__ taps, int K,
+                                              float scale, const v2f *__restrict__ ctab, TAPS taps, int K,
                                               float *__restrict__ srow, float *__restrict__ out82, int pad_r = 0)
 {
    const int lane = threadIdx.x & 63, half = P >> 1, pm = P - 1, r = K >> 1;
@@ -774,14 +793,15 @@ __device__ __forceinline__ void hs_row_stream(const HsPlaneBuf &img, float x, fl
 // Two window rows at once (rows yyA and yyB of the same window, one LDS row each): the gathers of both rows are in
 // flight together and the two row-pass chains interleave, so that neither the memory round trip nor the dependent
 // accumulation of one row leaves the wavefront without work.  Same operations per row as hs_row_stream.
-template <int NIT>
+template <int NIT, class TAPS = const float *>
 __device__ __forceinline__ void hs_row_stream2(const HsPlaneBuf &img, float x, float y, float a12, float a22, int P, int yyA, int yyB,
-                                               float scale, const v2f *__restrict__ ctab, const float *__restrict__ taps, int K,
-                                               float *__restrict__ srowA, float *__restrict__ srowB, float *__restrict__ outA, float *__restrict__ outB, int pad_r)
+                                               float scale, const v2f *__restrict__ ctab, TAPS taps, int K,
+                                               float *__restrict__ srowA, float *__restrict__ srowB, float *__restrict__ outA, float *__restrict__ outB, int pad_r,
+                                               float a11 = 0.0f, float a21 = 0.0f)   // a11, a21: only read when ctab == nullptr
 {
    const int lane = threadIdx.x & 63, half = P >> 1, pm = P - 1, r = K >> 1;
    const v2f rc[2] = {hs_row_coord(x, y, a12, a22, yyA - half), hs_row_coord(x, y, a12, a22, yyB - half)};
-   hs_gather_rows<2, NIT>(img, rc, ctab, 0.0f, 0.0f, half, P, r, srowA, (int)(srowB - srowA));
+   hs_gather_rows<2, NIT>(img, rc, ctab, a11, a21, half, P, r, srowA, (int)(srowB - srowA));
    HS_WAVE_LDS_SYNC();
    {
       const float fA = srowA[r], lA = srowA[r + pm], fB = srowB[r], lB = srowB[r + pm];
@@ -835,17 +855,17 @@ __device__ __forceinline__ void hs_row_stream2(const HsPlaneBuf &img, float x, f
 // (s = 0, 1) is pair t % 41 of row t / 41.  Every task is the same RowFilter chain as before (one lane, ascending taps);
 // only the assignment of chains to lanes changes.  srow: three LDS rows `sstride` floats apart; out[i]: T' row of window
 // row yy[i].
-template <int NIT>
+template <int NIT, class TAPS = const float *>
 __device__ __forceinline__ void hs_row_stream3(const HsPlaneBuf &img, float x, float y, float a12, float a22, int P, int yy0, int yy1, int yy2,
-                                               float scale, const v2f *__restrict__ ctab, const float *__restrict__ taps, int K,
+                                               float scale, const v2f *__restrict__ ctab, TAPS taps, int K,
                                                float *__restrict__ srow, int sstride, float *__restrict__ out0, float *__restrict__ out1,
-                                               float *__restrict__ out2, int pad_r)
+                                               float *__restrict__ out2, int pad_r, float a11 = 0.0f, float a21 = 0.0f)   // a11, a21: only read when ctab == nullptr
 {
    const int lane = threadIdx.x & 63, half = P >> 1, pm = P - 1, r = K >> 1;
    const v2f rc[3] = {hs_row_coord(x, y, a12, a22, yy0 - half), hs_row_coord(x, y, a12, a22, yy1 - half),
                       hs_row_coord(x, y, a12, a22, yy2 - half)};
    float *srow1 = srow + sstride, *srow2 = srow + 2 * sstride;
-   hs_gather_rows<3, NIT>(img, rc, ctab, 0.0f, 0.0f, half, P, r, srow, sstride);
+   hs_gather_rows<3, NIT>(img, rc, ctab, a11, a21, half, P, r, srow, sstride);
    HS_WAVE_LDS_SYNC();
    {
       const float f0 = srow[r], l0 = srow[r + pm], f1 = srow1[r], l1 = srow1[r + pm], f2 = srow2[r], l2 = srow2[r + pm];
@@ -976,7 +996,7 @@ __global__ __launch_bounds__(256, HS_MID_WAVES) void k_patch_mid(HessList hl, Pa
    for (;;) {
       if (tid == 0) s_item = atomicAdd(pw.bin_work + BIN, 1u);
       __syncthreads();
-      const uint32_t wi = s_item;
+      const uint32_t wi = HS_TAPS_SCALAR ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item) : s_item;
       if (wi >= cnt) break;
       const uint32_t h = pw.bin_items[(size_t)BIN * pw.cap + wi];
       const int b = hl.meta[h] >> 8;
@@ -987,7 +1007,8 @@ __global__ __launch_bounds__(256, HS_MID_WAVES) void k_patch_mid(HessList hl, Pa
       const float scale = (float)P0 / (float)HS_PATCH;
       const int K = tb.patch_tap_k[(P0 - 1) >> 1];
       const float *taps_g = tb.patch_taps + tb.patch_tap_off[(P0 - 1) >> 1];
-      if (tid < K) s_taps[tid] = taps_g[tid];
+      const hs_row_taps ktap = HS_ROW_TAPS(taps_g, s_taps);   // the row pass's taps: scalar loads from the table, or the LDS copy
+      if (!HS_TAPS_SCALAR && tid < K) s_taps[tid] = taps_g[tid];
       for (int m = tid; m < P; m += 256) s_C[m] = hs_col_coord(a11, a21, m - half);
       __syncthreads();
       float *srowA = s_srow + wave * 3 * GM::SROW, *srowB = srowA + GM::SROW;
@@ -996,22 +1017,22 @@ __global__ __launch_bounds__(256, HS_MID_WAVES) void k_patch_mid(HessList hl, Pa
          // rows yy, yy + 4 and yy + 8 of this wavefront together; the last one or two rows in the narrower forms
          const int rr = K >> 1;
          if (yy + 8 < P)
-            hs_row_stream3<NIT3>(ib, x, y, a12, a22, P, yy, yy + 4, yy + 8, scale, s_C, s_taps, K, srowA, GM::SROW,
+            hs_row_stream3<NIT3, hs_row_taps>(ib, x, y, a12, a22, P, yy, yy + 4, yy + 8, scale, s_C, ktap, K, srowA, GM::SROW,
                                  Tp + (size_t)(yy + rr) * HS_NEED, Tp + (size_t)(yy + 4 + rr) * HS_NEED, Tp + (size_t)(yy + 8 + rr) * HS_NEED, rr);
          else if (yy + 4 < P)
-            hs_row_stream2<NIT>(ib, x, y, a12, a22, P, yy, yy + 4, scale, s_C, s_taps, K, srowA, srowB,
+            hs_row_stream2<NIT, hs_row_taps>(ib, x, y, a12, a22, P, yy, yy + 4, scale, s_C, ktap, K, srowA, srowB,
                                 Tp + (size_t)(yy + (K >> 1)) * HS_NEED, Tp + (size_t)(yy + 4 + (K >> 1)) * HS_NEED, K >> 1);
          else
-            hs_row_stream<NIT>(ib, x, y, a11, a12, a21, a22, P, yy, scale, s_C, s_taps, K, srowA,
+            hs_row_stream<NIT, hs_row_taps>(ib, x, y, a11, a12, a21, a22, P, yy, scale, s_C, ktap, K, srowA,
                                Tp + (size_t)(yy + (K >> 1)) * HS_NEED, K >> 1);
       }
       __syncthreads();   // workgroup-scope release/acquire: the T' rows of all four waves are visible
       // staged column pass when a round holds at least HS_CHUNK_MIN_ROWS output rows (a round of one or two rows leaves
       // most of the block's threads idle: 41 outputs per row); otherwise straight from the slot
       if ((float)(K + 1) + (float)(HS_CHUNK_MIN_ROWS - 1) * scale <= (float)GM::CHUNK_ROWS)
-         hs_resample_chunked(Tp + (K >> 1) * HS_NEED, P, scale, s_taps, K >> 1, s_srow, GM::CHUNK_ROWS, s_patch);
+         hs_resample_chunked<hs_row_taps>(Tp + (K >> 1) * HS_NEED, P, scale, ktap, K >> 1, s_srow, GM::CHUNK_ROWS, s_patch);
       else
-         hs_resample_reduced_batched<true>(Tp + (K >> 1) * HS_NEED, P, scale, s_taps, K >> 1, s_patch);
+         hs_resample_reduced_batched<true, hs_row_taps>(Tp + (K >> 1) * HS_NEED, P, scale, ktap, K >> 1, s_patch);
       __syncthreads();
       for (int i = tid; i < HS_PATCH_PIX; i += 256) {
          float *po = io.patches + (size_t)(h - io.h_base) * HS_PATCH_PIX + i;
@@ -1030,16 +1051,26 @@ __global__ __launch_bounds__(256, HS_MID_WAVES) void k_patch_mid(HessList hl, Pa
 // The item count and the prefix stay on the device; the host only supplies an upper bound of the rows
 // (k_image_large_rows) to size the T' buffer.
 // ---------------------------------------------------------------------------------------
-#define HS_LARGE_CHUNK 16   // consecutive window rows per wavefront task
+#ifndef HS_LARGE_CHUNK
+#define HS_LARGE_CHUNK 18   // consecutive window rows per wavefront task (a multiple of three: the three-row form below)
+#endif
+#ifndef HS_LARGE_NIT3
+#define HS_LARGE_NIT3 2     // gathers in flight per row of the three-row form
+#endif
 
-// dynamic LDS: per wave  srow_stride floats (window row + borders)  +  tap_stride floats (taps); blocks of 4, 2 or 1 wavefronts
-// (the host picks the largest count whose rows fit the CU's 160 KB: windows up to about 6 900 / 13 900 / 27 900 pixels a side)
-__global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork pw, PatchIO io, KpTables tb, int srow_stride, int tap_stride)
+// dynamic LDS: per wave  nrow x srow_stride floats (window rows + borders)  +  tap_stride floats (taps); blocks of 4, 2 or 1 wavefronts
+// (the host picks the largest count whose rows fit the CU's 160 KB).
+// nrow = 3: three consecutive window rows per step (hs_row_stream3: one tap broadcast and one column coordinate serve three rows, 123 pair
+// chains on 64 lanes instead of 41 - a third fewer vector and two thirds fewer LDS instructions per row than the one-row form); nrow = 1: the
+// one-row form, for windows whose three rows do not fit.  Items with P outside (p_lo, p_hi] are skipped: a batch whose largest window is far
+// above the common ones runs as two launches, so that the 513..1024 windows do not live with the LDS (= occupancy) of one 2800-pixel outlier.
+__global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork pw, PatchIO io, KpTables tb, int srow_stride, int tap_stride, int nrow,
+                                                          int p_lo, int p_hi)
 {
    extern __shared__ __attribute__((aligned(16))) float smem[];
-   const int wave = threadIdx.x >> 6;
-   float *srow = smem + (size_t)wave * (srow_stride + tap_stride);
-   float *stap = srow + srow_stride;
+   const int wave = HS_TAPS_SCALAR ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
+   float *srow = smem + (size_t)wave * (nrow * srow_stride + tap_stride);
+   float *stap = srow + nrow * srow_stride;
    const uint32_t *pre = io.row_prefix;
    const uint32_t n_items = min(pw.bin_count[HS_NBINS - 1], pw.cap);
    if (n_items == 0) return;
@@ -1050,7 +1081,7 @@ __global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork
    }
    const int imPitch = io.image.pitch;
    const uint32_t ntasks = (row_hi + HS_LARGE_CHUNK - 1) / HS_LARGE_CHUNK;
-   const uint32_t nw = blockDim.x >> 6;   // wavefronts per block: 4, or fewer when a window row of the batch's largest window needs more than a quarter of the LDS
+   const uint32_t nw = blockDim.x >> 6;   // wavefronts per block: 4, or fewer when the rows of the launch's largest window need more than a quarter of the LDS
    for (uint32_t task = blockIdx.x * nw + wave; task < ntasks; task += gridDim.x * nw) {
       uint32_t row = task * HS_LARGE_CHUNK;
       const uint32_t row_end = min(row + HS_LARGE_CHUNK, row_hi);
@@ -1064,8 +1095,9 @@ __global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork
       while (row < row_end) {
          const uint32_t it_rows_end = min(pre[it + 1], row_end);
          const uint32_t h = pw.bin_items[(size_t)(HS_NBINS - 1) * pw.cap + it];
-         const int b = hl.meta[h] >> 8;
          const int P0 = pw.P0[h], P = P0 + 2;
+         if (P <= p_lo || P > p_hi) { row = it_rows_end; it++; continue; }   // another launch's window (wave-uniform)
+         const int b = hl.meta[h] >> 8;
          const float scale = (float)P0 / (float)HS_PATCH;
          const int K = tb.patch_tap_k[(P0 - 1) >> 1];
          const float *taps = tb.patch_taps + tb.patch_tap_off[(P0 - 1) >> 1];
@@ -1073,12 +1105,30 @@ __global__ __launch_bounds__(256) void k_patch_large_rows(HessList hl, PatchWork
          const float kx = hl.x[h], ky = hl.y[h];
          const float a11 = pw.A[4 * h], a12 = pw.A[4 * h + 1], a21 = pw.A[4 * h + 2], a22 = pw.A[4 * h + 3];
          const uint32_t first = pre[it];
-         // this item's taps -> the wave's LDS tap buffer (broadcast reads in the tap loop)
-         for (int i = threadIdx.x & 63; i < K; i += 64) stap[i] = taps[i];
-         HS_WAVE_LDS_SYNC();
-         for (; row < it_rows_end; row++)
-            hs_row_stream<8>(ib, kx, ky, a11, a12, a21, a22, P, (int)(row - first), scale, nullptr, stap, K, srow,
-                             io.trows + (size_t)row * HS_NEED);
+         // this item's taps -> the wave's LDS tap buffer (broadcast reads in the tap loop); with HS_TAPS_SCALAR they are read from the table itself
+         if (!HS_TAPS_SCALAR) {
+            for (int i = threadIdx.x & 63; i < K; i += 64) stap[i] = taps[i];
+            HS_WAVE_LDS_SYNC();
+         }
+         const hs_row_taps ktap = HS_ROW_TAPS(taps, stap);
+         float *const out0 = io.trows + (size_t)row * HS_NEED;
+         const int yy0 = (int)(row - first), nr = (int)(it_rows_end - row);
+         int d = 0;
+         if (nrow == 3) {
+#pragma unroll 1
+            for (; d + 3 <= nr; d += 3)
+               hs_row_stream3<HS_LARGE_NIT3, hs_row_taps>(ib, kx, ky, a12, a22, P, yy0 + d, yy0 + d + 1, yy0 + d + 2, scale, nullptr, ktap, K, srow, srow_stride,
+                                             out0 + (size_t)d * HS_NEED, out0 + (size_t)(d + 1) * HS_NEED, out0 + (size_t)(d + 2) * HS_NEED, 0, a11, a21);
+            if (d + 2 <= nr) {
+               hs_row_stream2<HS_LARGE_NIT3, hs_row_taps>(ib, kx, ky, a12, a22, P, yy0 + d, yy0 + d + 1, scale, nullptr, ktap, K, srow, srow + srow_stride,
+                                             out0 + (size_t)d * HS_NEED, out0 + (size_t)(d + 1) * HS_NEED, 0, a11, a21);
+               d += 2;
+            }
+         }
+#pragma unroll 1
+         for (; d < nr; d++)
+            hs_row_stream<8, hs_row_taps>(ib, kx, ky, a11, a12, a21, a22, P, yy0 + d, scale, nullptr, ktap, K, srow, out0 + (size_t)d * HS_NEED);
+         row = it_rows_end;
          it++;
       }
    }
@@ -1096,7 +1146,7 @@ __global__ __launch_bounds__(256) void k_patch_large_finish(PatchWork pw, PatchI
       const float scale = (float)P0 / (float)HS_PATCH;
       const int K = tb.patch_tap_k[(P0 - 1) >> 1];
       const float *taps = tb.patch_taps + tb.patch_tap_off[(P0 - 1) >> 1];
-      hs_resample_reduced_batched<false>(io.trows + (size_t)pre[it] * HS_NEED, P, scale, taps, K >> 1, s_patch);
+      hs_resample_reduced_batched<false, hs_row_taps>(io.trows + (size_t)pre[it] * HS_NEED, P, scale, HS_ROW_TAPS(taps, taps), K >> 1, s_patch);
       __syncthreads();
       for (int i = threadIdx.x; i < HS_PATCH_PIX; i += 256) {
          float *po = io.patches + (size_t)(h - io.h_base) * HS_PATCH_PIX + i;

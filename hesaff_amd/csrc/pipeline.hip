@@ -425,6 +425,10 @@ struct hesaff_ctx {
    int force_exband = 0;           // HESAFF_EXBAND: rows per band of k_extrema_march (tuning)
    bool debug = false;             // HESAFF_DEBUG=1: launch geometry on stderr
    uint32_t sgrad_grid = 0;        // persistent grid of k_sift_grad (set with the device: 32 blocks per CU; HESAFF_SGRAD_GRID; 0: one block per keypoint)
+   int large_stream = 0;           // HESAFF_LARGE_STREAM: 1 = the large-window kernels behind bins 0 and 1 on their stream, 0 = on the main stream (behind bin 3)
+   int large_nw = 2;               // HESAFF_LARGE_NW: wavefronts per block of the three-row form at most (0: as many as fit, up to four).  Two: blocks of 40 KB find room beside the other stages' kernels where blocks of 80 KB wait (dense step 786 -> 773 ms, photographs 393 -> 383)
+   int large_nrow = 3;             // HESAFF_LARGE_NROW: window rows per wavefront step of k_patch_large_rows (3, or 1: the round-5 form)
+   int large_split = 1280;         // HESAFF_LARGE_SPLIT: windows up to this side in a launch of their own when the batch holds larger ones (0: one launch)
    uint32_t sift_slice = 0;        // HESAFF_SIFT_SLICE: keypoints per slice of the descriptor stage (launch_sift); 0 = a group's kernels each over the whole group
    bool sift_slice_ring = true;    // HESAFF_SLICE_RING: the slices of a group reuse one slice-sized piece of the intermediates (0: every slice its own piece)
 
@@ -763,7 +767,8 @@ void plan_buffers(hesaff_ctx *c, int B, int H, int W)
       // above ~27 900 pixels a side, i.e. an image of more than 780 Mpx - is refused here
       const LargeGeom lg = large_geom(c->max_p0 + 2);
       if (lg.lds / 4 > HS_LDS_PER_CU) throw HsError(HESAFF_ERR_ARG, "image too large for the large-window row kernel (sqrt(width x height) above about 27900)");
-      const size_t want = std::min<size_t>(lg.lds, HS_LDS_PER_CU);
+      // (three rows per wavefront where they fit: the launches ask for up to the whole LDS of a CU)
+      const size_t want = std::min<size_t>(lg.lds + (size_t)8 * lg.srow_stride * 4, HS_LDS_PER_CU);
       if (want > c->rows_lds_set) {
          set_dyn_lds(k_patch_large_rows, want);
          c->rows_lds_set = want;
@@ -934,31 +939,51 @@ void run_patch_stage(hesaff_ctx *c, const Lists &s, const DPlane &image, float *
       hipLaunchKernelGGL(k_patch_mid<HS_MID_PMAX>, dim3(c->g_mid), dim3(256), mid_lds_bytes(), s2, s.hl, s.pw, io2, c->tables);
       hipLaunchKernelGGL(k_patch_mid<HS_BIN3_PMAX>, dim3(c->g_big), dim3(256), big_lds_bytes(), s3, s.hl, s.pw, io3, c->tables);
    }
-   if (forked)
-      for (int i = 0; i < HS_NSIDE; i++) HIP_TRY(hipEventRecord(c->ev_join[i], c->side_streams[i]));
-   // the rare huge windows (P > 512): row tasks over all of them, then one block per keypoint
+   // the rare huge windows (P > 512): row tasks over all of them, then one block per keypoint.  The main stream shares its HIP stream
+   // (= hardware queue) with bin 3, whose kernel is the longest of the bins on photographs: behind it the large-window kernels made that
+   // queue the stage's critical path (8.1 + 8.8 + 1.9 ms per 32 photograph mosaics against 5.3 for the queue of bins 0 and 1).  They go
+   // behind bins 0 and 1 instead (large_stream = 1); k_prepare_patch and the fork event order them after the bin counts either way.
+   hipStream_t sl = (forked && c->large_stream == 1) ? s1 : st;
    if (large_rows_bound > 0) {
       const uint32_t rows_cap = std::max(large_rows_bound, c->trows_rows);
       c->b_trows.ensure((size_t)rows_cap * HS_NEED * 4);
       c->b_rowprefix.ensure(((size_t)c->cap + 1) * 4);
       // LDS per wavefront for the largest window that exists in this batch (rounded up so that few distinct launch shapes occur),
-      // not for the largest the image could hold: 2 -> 5 resident blocks per CU on UHD images
+      // not for the largest the image could hold.  Three window rows per wavefront step where they fit (k_patch_large_rows); a batch whose
+      // largest window is above 1024 runs as two launches - windows up to 1024 with the LDS, i.e. the occupancy, of a 1024 window, the
+      // rest with that of the batch's largest.
       const int pmax = std::min(c->max_p0 + 2, std::max(HS_BIN3_PMAX + 1, (c->batch_max_p > 0 ? c->batch_max_p : c->max_p0 + 2)));
-      const LargeGeom lg = large_geom(std::min(c->max_p0 + 2, (pmax + 255) / 256 * 256));
       io.trows = c->b_trows.as<float>();
       io.row_prefix = c->b_rowprefix.as<uint32_t>();
       io.trows_cap = rows_cap;
       io.overflow = s.counters + 6;
-      // wavefronts per block: four while their rows fit the CU's LDS (plan_buffers made sure one fits)
-      uint32_t nw = 4;
-      while (nw > 1 && lg.lds / 4 * nw > HS_LDS_PER_CU) nw >>= 1;
-      const uint32_t gblocks = std::min<uint32_t>((large_rows_bound + nw * HS_LARGE_CHUNK - 1) / (nw * HS_LARGE_CHUNK), 256 * 16 * (4 / nw));
-      hipLaunchKernelGGL(k_large_prefix, dim3(1), dim3(256), 0, st, s.pw, c->b_rowprefix.as<uint32_t>());
-      hipLaunchKernelGGL(k_patch_large_rows, dim3(gblocks), dim3(64 * nw), lg.lds / 4 * nw, st, s.hl, s.pw, io, c->tables, lg.srow_stride, lg.tap_stride);
-      hipLaunchKernelGGL(k_patch_large_finish, dim3(c->g_lfin), dim3(256), 0, st, s.pw, io, c->tables);
+      hipLaunchKernelGGL(k_large_prefix, dim3(1), dim3(256), 0, sl, s.pw, c->b_rowprefix.as<uint32_t>());
+      auto launch_rows = [&](int p_lo, int p_hi) {
+         const LargeGeom lg = large_geom(std::min(c->max_p0 + 2, (p_hi + 255) / 256 * 256));
+         const size_t wave1 = lg.lds / 4;                                        // one row + taps
+         const size_t wave3 = wave1 + (size_t)2 * lg.srow_stride * 4;            // three rows + taps
+         // the three-row form only where six wavefronts of it fit a CU (windows up to about 1700): below that occupancy the kernel
+         // is all exposed gather latency (measured: 3.5x slower at two wavefronts per CU, profiles/r06_notes.md)
+         const int nrow = (c->large_nrow == 3 && wave3 * 6 <= HS_LDS_PER_CU) ? 3 : 1;
+         const size_t per_wave = nrow == 3 ? wave3 : wave1;
+         // wavefronts per block: four while their rows fit the CU's LDS (plan_buffers made sure one row fits); blocks of two where two
+         // such blocks pack the CU's LDS more tightly than one block of four
+         uint32_t nw = 4;
+         while (nw > 1 && per_wave * nw > HS_LDS_PER_CU) nw >>= 1;
+         if (nw == 4 && (HS_LDS_PER_CU / (per_wave * 2)) * 2 > (HS_LDS_PER_CU / (per_wave * 4)) * 4) nw = 2;
+         if (nrow == 3 && c->large_nw > 0) nw = std::min<uint32_t>(nw, (uint32_t)c->large_nw);
+         const uint32_t gblocks = std::min<uint32_t>((large_rows_bound + nw * HS_LARGE_CHUNK - 1) / (nw * HS_LARGE_CHUNK), 256 * 16 * (4 / nw));
+         hipLaunchKernelGGL(k_patch_large_rows, dim3(gblocks), dim3(64 * nw), per_wave * nw, sl, s.hl, s.pw, io, c->tables, lg.srow_stride, lg.tap_stride, nrow,
+                            p_lo, std::min(p_hi, 0x7ffffff0));
+      };
+      if (c->large_split > 0 && pmax > c->large_split) { launch_rows(0, c->large_split); launch_rows(c->large_split, pmax); }
+      else launch_rows(0, pmax);
+      hipLaunchKernelGGL(k_patch_large_finish, dim3(c->g_lfin), dim3(256), 0, sl, s.pw, io, c->tables);
    }
-   if (forked)
+   if (forked) {
+      for (int i = 0; i < HS_NSIDE; i++) HIP_TRY(hipEventRecord(c->ev_join[i], c->side_streams[i]));
       for (int i = 0; i < HS_NSIDE; i++) HIP_TRY(hipStreamWaitEvent(st, c->ev_join[i], 0));
+   }
 }
 
 // The scale-space + detection part for the current plan; fills the ordered Hessian list.

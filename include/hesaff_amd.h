@@ -32,7 +32,12 @@ extern "C" {
  * before the first hesaff_create - hesaff.hpp and the Python binding do.  New fields are appended at the END of a
  * struct and bump this number.   1: round 1;  2: + upscaleInputImage, fast, pack_ms (inserted mid-struct);  3: + extrema_*;
  * 4: hesaff_params.fast = 1 withdrawn, HESAFF_FILE_REJECTED, rows formatted on the device;
- * 5: this header (+ hesaff_jpeg_layout, hesaff_read_jpeg_coefficients, hesaff_stage_jpeg_pixels: JPEG pixels made on the device). */
+ * 5: + hesaff_jpeg_layout, hesaff_read_jpeg_coefficients, hesaff_stage_jpeg_pixels (JPEG pixels made on the device);
+ * 6: + hesaff_host_plan_for, allocator-owned read buffers (hesaff_read_*_alloc);
+ * 7: this header (+ hesaff_set_pinned_read_budget, hesaff_set_pool_priority, hesaff_stage_threads_for_pool, HESAFF_OUT_STRICT; hesaff_set_resume
+ *    takes 0 / 1 / 2; no struct changed).
+ * Image sizes: a side of at most 65535 pixels at the first pyramid level, and sqrt(width x height) of at most about 27900 (the largest window
+ * normalizeAffine could ask for, affine.cpp:114-124, must fit a compute unit's LDS as one row): HESAFF_ERR_ARG beyond. */
 #define HESAFF_ABI_VERSION 7
 int hesaff_abi_version(void);
 size_t hesaff_sizeof_params(void);

@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc2_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export HESAFF_AMD_LIB=$LIB HESAFF_OVERLAP=0
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --batch $BATCH --no-cpu-baseline --no-host-path > $OUT/bench.json 2> $OUT/log.txt
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --batch $BATCH --no-cpu-baseline --no-host-path $BENCH_EXTRA > $OUT/bench.json 2> $OUT/log.txt
 cd $GRAFT_REPO_ROOT
 python3 - $OUT <<'PY'
 import csv, sys, glob, collections

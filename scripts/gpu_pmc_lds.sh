@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcl_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export HESAFF_AMD_LIB=$LIB HESAFF_OVERLAP=0
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --batch $BATCH --no-cpu-baseline --no-host-path > $OUT/bench.json 2> $OUT/log.txt
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --batch $BATCH --no-cpu-baseline --no-host-path $BENCH_EXTRA > $OUT/bench.json 2> $OUT/log.txt
 cd $GRAFT_REPO_ROOT
 python3 - $OUT <<'PY'
 import csv, sys, glob, collections

@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export HESAFF_AMD_LIB=$LIB HESAFF_OVERLAP=0
 # two TA and two TCP counters fit one pass (more: "exceeds the capabilities of the hardware", and the aborted profiler hangs)
-timeout -k 5 240 rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --batch $BATCH --no-cpu-baseline --no-host-path > $OUT/bench.json 2> $OUT/log.txt
+timeout -k 5 240 rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --batch $BATCH --no-cpu-baseline --no-host-path $BENCH_EXTRA > $OUT/bench.json 2> $OUT/log.txt
 cd $GRAFT_REPO_ROOT
 python3 - $OUT <<'PY'
 import csv, sys, glob, collections
