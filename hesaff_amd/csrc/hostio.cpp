@@ -442,7 +442,136 @@ int hesaff_read_png(const char *path, uint8_t **data, int *width, int *height, i
    HOSTIO_CATCH
 }
 
-// the imread of hesaff.cpp:137 for the formats this library decodes itself: PGM/PPM, PNG and baseline JPEG, by magic number
+
+// cv::imread (hesaff.cpp:137) for Windows bitmaps, the way OpenCV's BMP decoder (grfmt_bmp.cpp) delivers them at imread's default flag:
+// 1 / 4 / 8 bits per pixel through the palette (BI_RGB, BI_RLE4, BI_RLE8), 16 bits as 5-5-5 or - BI_BITFIELDS with a green mask of 0x7e0 -
+// 5-6-5 with the low bits left zero (5-5-5: b = v << 3, g = (v >> 2) & ~7, r = (v >> 7) & ~7; 5-6-5: g = (v >> 3) & ~3, r = (v >> 8) & ~7), 24 bits, 32 bits
+// with the fourth byte dropped; bottom-up or top-down rows, OS/2 core headers (12 bytes, 3-byte palette entries) as well.  Pixels a
+// run-length stream skips (delta escapes, short lines) keep palette entry 0.  -> R, G, B order, 3 channels (1 when every palette entry the
+// file can address is grey: (g + g + g) / 3.0f is g exactly, so the grey conversion of hesaff.cpp:145 sees the same image either way).
+static int read_bmp_bytes(const std::vector<uint8_t> &b, uint8_t **data, int *width, int *height, int *channels)
+{
+   auto u16 = [&](size_t o) { return (uint32_t)b[o] | ((uint32_t)b[o + 1] << 8); };
+   auto u32 = [&](size_t o) { return u16(o) | (u16(o + 2) << 16); };
+   if (b.size() < 26 || b[0] != 'B' || b[1] != 'M') return HESAFF_ERR_IO;
+   const size_t off_bits = u32(10), hsize = u32(14);
+   long long w = 0, h = 0;
+   uint32_t bpp = 0, comp = 0, clr_used = 0;
+   bool core = false;
+   if (hsize == 12) { core = true; w = u16(18); h = u16(20); bpp = u16(24); }
+   else if (hsize >= 40 && b.size() >= 14 + 40) {
+      w = (int32_t)u32(18); h = (int32_t)u32(22); bpp = u16(28); comp = u32(30); clr_used = u32(46);
+   } else return HESAFF_ERR_IO;
+   const bool top_down = h < 0;
+   if (top_down) h = -h;
+   if (w < 1 || h < 1 || w > (1 << 30) / h || u16(core ? 22 : 26) != 1) return HESAFF_ERR_IO;
+   if (!(bpp == 1 || bpp == 4 || bpp == 8 || bpp == 16 || bpp == 24 || bpp == 32)) return HESAFF_ERR_IO;
+   if (!(comp == 0 || (comp == 1 && bpp == 8) || (comp == 2 && bpp == 4) || (comp == 3 && (bpp == 16 || bpp == 32)))) return HESAFF_ERR_IO;
+   if (top_down && (comp == 1 || comp == 2)) return HESAFF_ERR_IO;
+   bool is565 = false;
+   if (comp == 3) {
+      const size_t mo = 14 + 40;   // the three masks follow a 40-byte header, or are its fields 40.. in the V4 / V5 headers: the same offset
+      if (b.size() < mo + 12) return HESAFF_ERR_IO;
+      const uint32_t rm = u32(mo), gm = u32(mo + 4), bm = u32(mo + 8);
+      if (bpp == 16) {
+         if (rm == 0xf800 && gm == 0x7e0 && bm == 0x1f) is565 = true;
+         else if (!(rm == 0x7c00 && gm == 0x3e0 && bm == 0x1f)) return HESAFF_ERR_IO;
+      } else if (!(rm == 0xff0000 && gm == 0xff00 && bm == 0xff)) return HESAFF_ERR_IO;
+   }
+   uint8_t pal[256][3];   // R, G, B
+   memset(pal, 0, sizeof pal);
+   bool grey_pal = false;
+   if (bpp <= 8) {
+      const size_t po = 14 + hsize, esz = core ? 3 : 4;
+      size_t n = clr_used ? clr_used : ((size_t)1 << bpp);
+      if (n > ((size_t)1 << bpp)) n = (size_t)1 << bpp;
+      if (po + n * esz > b.size()) return HESAFF_ERR_IO;
+      grey_pal = true;
+      for (size_t i = 0; i < n; i++) {
+         pal[i][2] = b[po + i * esz]; pal[i][1] = b[po + i * esz + 1]; pal[i][0] = b[po + i * esz + 2];
+         if (pal[i][0] != pal[i][1] || pal[i][1] != pal[i][2]) grey_pal = false;
+      }
+   }
+   const int ch = grey_pal ? 1 : 3;
+   const size_t npix = (size_t)w * (size_t)h;
+   uint8_t *out = (uint8_t *)malloc(npix * ch);
+   if (!out) return HESAFF_ERR_NOMEM;
+   auto put = [&](long long x, long long yfile, const uint8_t *rgb) {   // yfile: row in file order
+      const long long y = top_down ? yfile : h - 1 - yfile;
+      uint8_t *o = out + ((size_t)y * w + x) * ch;
+      if (ch == 1) o[0] = rgb[0]; else { o[0] = rgb[0]; o[1] = rgb[1]; o[2] = rgb[2]; }
+   };
+   bool ok = off_bits <= b.size();
+   if (ok && comp != 1 && comp != 2) {
+      const size_t stride = (((size_t)w * bpp + 31) / 32) * 4;
+      if (stride * (size_t)h > b.size() - off_bits) ok = false;   // (w h <= 2^30: no overflow)
+      for (long long yf = 0; ok && yf < h; yf++) {
+         const uint8_t *row = b.data() + off_bits + (size_t)yf * stride;
+         for (long long x = 0; x < w; x++) {
+            uint8_t rgb[3];
+            if (bpp <= 8) {
+               const uint32_t idx = bpp == 8 ? row[x] : bpp == 4 ? ((row[x >> 1] >> ((x & 1) ? 0 : 4)) & 15) : ((row[x >> 3] >> (7 - (x & 7))) & 1);
+               rgb[0] = pal[idx][0]; rgb[1] = pal[idx][1]; rgb[2] = pal[idx][2];
+            } else if (bpp == 16) {
+               const uint32_t v = (uint32_t)row[2 * x] | ((uint32_t)row[2 * x + 1] << 8);
+               rgb[2] = (uint8_t)(v << 3);
+               rgb[1] = is565 ? (uint8_t)((v >> 3) & ~3u) : (uint8_t)((v >> 2) & ~7u);
+               rgb[0] = is565 ? (uint8_t)((v >> 8) & ~7u) : (uint8_t)((v >> 7) & ~7u);
+            } else {
+               const uint8_t *q = row + x * (bpp / 8);
+               rgb[0] = q[2]; rgb[1] = q[1]; rgb[2] = q[0];
+            }
+            put(x, yf, rgb);
+         }
+      }
+   } else if (ok) {
+      // BI_RLE8 / BI_RLE4: (count, value) runs; 0,0 end of line; 0,1 end of bitmap; 0,2,dx,dy move; 0,n >= 3: n literal pixels, padded to 16 bits
+      for (size_t i = 0; i < npix; i++) { if (ch == 1) out[i] = pal[0][0]; else { out[3 * i] = pal[0][0]; out[3 * i + 1] = pal[0][1]; out[3 * i + 2] = pal[0][2]; } }
+      size_t p = off_bits;
+      long long x = 0, yf = 0;
+      auto pix = [&](uint32_t idx) { if (x < w && yf < h) put(x, yf, pal[idx]); x++; };
+      bool done = false;
+      while (!done && p + 1 < b.size()) {
+         const uint32_t n = b[p], v = b[p + 1];
+         p += 2;
+         if (n > 0) {
+            for (uint32_t k = 0; k < n; k++) pix(bpp == 8 ? v : ((k & 1) ? (v & 15) : (v >> 4)));
+         } else if (v == 0) { x = 0; yf++; }
+         else if (v == 1) done = true;
+         else if (v == 2) { if (p + 1 >= b.size()) { ok = false; break; } x += b[p]; yf += b[p + 1]; p += 2; }
+         else {
+            const size_t nbytes = bpp == 8 ? v : (v + 1) / 2;
+            if (p + nbytes > b.size()) { ok = false; break; }
+            for (uint32_t k = 0; k < v; k++) pix(bpp == 8 ? b[p + k] : ((k & 1) ? (b[p + k / 2] & 15) : (b[p + k / 2] >> 4)));
+            p += (nbytes + 1) & ~(size_t)1;
+         }
+      }
+   }
+   if (!ok) { free(out); return HESAFF_ERR_IO; }
+   *data = out; *width = (int)w; *height = (int)h; *channels = ch;
+   return HESAFF_OK;
+}
+
+int hesaff_read_bmp(const char *path, uint8_t **data, int *width, int *height, int *channels)
+{
+   if (!path || !data || !width || !height || !channels) return HESAFF_ERR_ARG;
+   FILE *f = fopen(path, "rb");
+   if (!f) return HESAFF_ERR_IO;
+   HOSTIO_TRY
+   std::vector<uint8_t> bytes;
+   try {
+      uint8_t chunk[1 << 16];
+      for (size_t n; (n = fread(chunk, 1, sizeof chunk, f)) > 0;) bytes.insert(bytes.end(), chunk, chunk + n);
+   } catch (...) {
+      fclose(f);
+      throw;
+   }
+   fclose(f);
+   return read_bmp_bytes(bytes, data, width, height, channels);
+   HOSTIO_CATCH
+}
+
+// the imread of hesaff.cpp:137 for the formats this library decodes itself: PBM/PGM/PPM, PNG, JPEG and BMP, by magic number
 int hesaff_read_image(const char *path, uint8_t **data, int *width, int *height, int *channels)
 {
    return hesaff_read_image_alloc(path, data, width, height, channels, nullptr, nullptr);
@@ -458,6 +587,7 @@ int hesaff_read_image_alloc(const char *path, uint8_t **data, int *width, int *h
    if (c1 == 'P' && c2 >= '1' && c2 <= '6') return hesaff_read_pnm_alloc(path, data, width, height, channels, alloc, user);
    if (c1 == 0x89 && c2 == 'P') return hesaff_read_png(path, data, width, height, channels);
    if (c1 == 0xFF && c2 == 0xD8) return hesaff_read_jpeg(path, data, width, height, channels);
+   if (c1 == 'B' && c2 == 'M') return hesaff_read_bmp(path, data, width, height, channels);
    return HESAFF_ERR_IO;
 }
 

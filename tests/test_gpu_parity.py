@@ -869,18 +869,18 @@ def test_process_files_pipeline(tmp_path, oracle):
 
 
 def test_process_files_mixed_formats_against_the_oracle(tmp_path, oracle):
-    """One list with PGM, colour PPM, PNG, sequential and progressive JPEG files of several sizes through hesaff_process_files:
+    """One list with PGM, colour PPM, PNG, sequential and progressive JPEG and BMP files of several sizes through hesaff_process_files:
     every output equals the oracle's text for the pixels the in-tree readers deliver (pixels == Pillow's, i.e. libjpeg / zlib)."""
     import hesaff_amd
     from PIL import Image
     from tests import _oracle
     rng = np.random.default_rng(17)
     paths = []
-    for i, (h, w) in enumerate(((150, 200), (150, 200), (131, 177), (200, 260), (150, 200), (96, 128))):
+    for i, (h, w) in enumerate(((150, 200), (150, 200), (131, 177), (200, 260), (150, 200), (96, 128), (150, 200), (131, 177))):
         g = band_noise_image(h, w, 300 + i, SMALL_BANDS)
         rgb = np.stack([g, np.roll(g, 3, 1), np.roll(g, 5, 0)], 2)
-        kind = ("pgm", "ppm", "png", "jpg", "pjpg", "gpng")[i]
-        q = str(tmp_path / ("m%d.%s" % (i, {"pjpg": "jpg", "gpng": "png"}.get(kind, kind))))
+        kind = ("pgm", "ppm", "png", "jpg", "pjpg", "gpng", "bmp", "gbmp")[i]
+        q = str(tmp_path / ("m%d.%s" % (i, {"pjpg": "jpg", "gpng": "png", "gbmp": "bmp"}.get(kind, kind))))
         if kind == "pgm":
             open(q, "wb").write(b"P5\n%d %d\n255\n" % (w, h) + g.tobytes())
         elif kind == "ppm":
@@ -889,6 +889,10 @@ def test_process_files_mixed_formats_against_the_oracle(tmp_path, oracle):
             Image.fromarray(rgb, "RGB").save(q, "PNG")
         elif kind == "gpng":
             Image.fromarray(g, "L").save(q, "PNG")
+        elif kind == "bmp":
+            Image.fromarray(rgb, "RGB").save(q, "BMP")
+        elif kind == "gbmp":
+            Image.fromarray(g, "L").save(q, "BMP")
         elif kind == "jpg":
             Image.fromarray(rgb, "RGB").save(q, "JPEG", quality=88, subsampling=1)
         else:
@@ -1493,3 +1497,37 @@ def test_image_and_window_beyond_the_old_size_ceiling(oracle):
     assert np.array_equal(keys["desc"], d) and np.array_equal(keys["type"], t)
     for j, name in enumerate(["x", "y", "s", "a11", "a12", "a21", "a22", "response"]):
         assert_bit_equal(keys[name], g[:, j], name)
+
+
+@pytest.mark.gpu
+def test_large_window_forms_in_one_batch(oracle):
+    """k_patch_large_rows runs the windows of a batch in two forms (round 6): up to 1280 pixels a side three window rows per wavefront
+    step, larger ones one row per step in a launch of their own, both sized from the batch's largest window (affine.cpp:114-135 for P > 512).
+    Two 3840 x 2160 images of elongated Gaussian blobs: windows of 579 .. 1205 pixels in the first, 1519 and 1861 in the second - as one
+    batch (split launches), then the first image alone (one launch): every field and descriptor equals the oracle's."""
+    import hesaff_amd
+    H, W = 2160, 3840
+    yy = np.arange(H, dtype=np.float32)[:, None]; xx = np.arange(W, dtype=np.float32)[None, :]
+
+    def blobs(spec):
+        acc = np.full((H, W), 30.0, np.float32)
+        for sg, cy, cx in spec:
+            acc += np.float32(150) * np.exp(-0.5 * ((yy - cy) / np.float32(sg)) ** 2) * np.exp(-0.5 * ((xx - cx) / np.float32(sg * 1.15)) ** 2)
+        return np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+    a = blobs(zip((52, 60, 70, 85, 100, 112, 122, 135, 150, 175),
+                  *zip((400, 450), (400, 1300), (400, 2200), (450, 3200), (1150, 700), (1150, 1900), (1200, 3100), (1750, 600), (1700, 1800), (1650, 3000))))
+    b = blobs([(165, 1080, 1000), (135, 1080, 2900), (60, 300, 400), (75, 300, 1900), (90, 1850, 1900), (50, 1900, 3500)])
+    p = hesaff_amd.default_params(); p.max_batch = 2
+    with hesaff_amd.HesaffContext(p, device=0) as ctx:
+        both = ctx.detect_batch([a, b])
+        alone = ctx.detect_batch([a])
+    sizes = []
+    for img, (nh, keys) in ((a, both[0]), (b, both[1]), (a, alone[0])):
+        o = oracle.OracleRun(oracle.gray_from_u8(img))
+        g, t, d = o.keys()
+        assert nh == o.n_hessian and len(keys) == o.n_keys and o.n_keys >= 2
+        assert np.array_equal(keys["desc"], d) and np.array_equal(keys["type"], t)
+        for j, name in enumerate(["x", "y", "s", "a11", "a12", "a21", "a22", "response"]):
+            assert_bit_equal(keys[name], g[:, j], name)
+        sizes.append(2 * np.ceil(g[:, 2] * np.float32(p.mrSize)).astype(int) + 3)
+    assert (sizes[0] > 512).sum() >= 10 and sizes[0].max() <= 1280 and sizes[1].min() > 1280, sizes

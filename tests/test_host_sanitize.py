@@ -166,6 +166,18 @@ def test_readers_refuse_damaged_files_without_memory_errors(driver, tmp_path):
               ("p5_16.pgm", b"P5 11 7 65535\n" + nrng.integers(0, 65536, 77, dtype=np.uint16).astype(">u2").tobytes()),
               ("p4.pbm", b"P4 13 6\n" + nrng.integers(0, 256, 12, dtype=np.uint8).tobytes()),
               ("p1.pbm", b"P1 7 5\n" + b"".join(b"%d" % v for v in nrng.integers(0, 2, 35)))]
+    # round 6: Windows bitmaps (24-bit, 4-bit palette, 16-bit with bit fields, RLE8 with escapes)
+    import struct
+
+    def bmp(w, h, bpp, body, comp=0, palette=b"", masks=b""):
+        off = 14 + 40 + len(masks) + len(palette)
+        hdr = struct.pack("<IiiHHIIiiII", 40, w, h, 1, bpp, comp, len(body), 2835, 2835, len(palette) // 4, 0)
+        return b"BM" + struct.pack("<IHHI", off + len(body), 0, 0, off) + hdr + masks + palette + body
+    blobs += [("c24.bmp", bmp(13, 9, 24, nrng.integers(0, 256, 40 * 9, dtype=np.uint8).tobytes())),
+              ("p4.bmp", bmp(13, 9, 4, nrng.integers(0, 256, 8 * 9, dtype=np.uint8).tobytes(), palette=nrng.integers(0, 256, 64, dtype=np.uint8).tobytes())),
+              ("b565.bmp", bmp(13, 9, 16, nrng.integers(0, 256, 28 * 9, dtype=np.uint8).tobytes(), comp=3, masks=struct.pack("<III", 0xF800, 0x7E0, 0x1F))),
+              ("rle8.bmp", bmp(8, 4, 8, bytes([5, 7, 0, 3, 1, 2, 3, 0, 0, 0, 2, 9, 0, 2, 3, 1, 2, 4, 0, 0, 8, 200, 0, 1]), comp=1,
+                               palette=nrng.integers(0, 256, 1024, dtype=np.uint8).tobytes()))]
     paths = []
     for f, data in blobs:
         p0 = str(tmp_path / ("intact_" + f)); open(p0, "wb").write(data); paths.append(p0)   # the intact file too

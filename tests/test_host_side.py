@@ -710,3 +710,90 @@ def test_host_plan_is_one_rule():
     for pool, stages in by_pool.items():      # the rule is not one-to-one (7 and 8 CPUs share a pool of 6): the larger count is taken
         assert L.hesaff_stage_threads_for_pool(pool) == max(stages), (pool, stages)
     assert L.hesaff_stage_threads_for_pool(6) == 2 and L.hesaff_stage_threads_for_pool(12) == 4 and L.hesaff_stage_threads_for_pool(2) == 1
+
+
+def test_read_bmp_matches_imread_semantics(tmp_path):
+    """hesaff_read_bmp (cv::imread hesaff.cpp:137 for Windows bitmaps, OpenCV's grfmt_bmp conventions): files written by Pillow (1-, 8-bit
+    palette, 24-, 32-bit) against Pillow's own decoder, and hand-made files for what Pillow does not write: 4-bit palette, top-down rows,
+    16-bit 5-5-5 / 5-6-5, RLE8 with every escape, an OS/2 core header; damaged files are refused, never read past."""
+    import struct
+    import hesaff_amd
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    for H, W in ((37, 53), (8, 8), (1, 1), (5, 1024)):
+        rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        q = str(tmp_path / "c.bmp"); Image.fromarray(rgb).save(q)
+        assert np.array_equal(hesaff_amd.read_image(q), rgb)
+        rgba = np.dstack([rgb, rng.integers(0, 256, (H, W, 1), dtype=np.uint8)])
+        q = str(tmp_path / "a.bmp"); Image.fromarray(rgba, "RGBA").save(q)
+        assert np.array_equal(hesaff_amd.read_image(q), rgb)              # fourth byte dropped
+        g = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        q = str(tmp_path / "g.bmp"); Image.fromarray(g).save(q)           # 8-bit, grey palette -> one channel
+        assert np.array_equal(hesaff_amd.read_image(q), g)
+        p = Image.fromarray(g).convert("P"); p.putpalette(list(rng.integers(0, 256, 768)))
+        q = str(tmp_path / "p.bmp"); p.save(q)
+        assert np.array_equal(hesaff_amd.read_image(q), np.asarray(Image.open(q).convert("RGB")))
+        bits = rng.integers(0, 2, (H, W), dtype=np.uint8)
+        q = str(tmp_path / "b.bmp"); Image.fromarray(bits * 255).convert("1").save(q)
+        assert np.array_equal(hesaff_amd.read_image(q), bits * 255)
+
+    def bmp(w, h, bpp, body, comp=0, palette=b"", masks=b"", top_down=False):
+        off = 14 + 40 + len(masks) + len(palette)
+        hdr = struct.pack("<IiiHHIIiiII", 40, w, -h if top_down else h, 1, bpp, comp, len(body), 2835, 2835, len(palette) // 4, 0)
+        return b"BM" + struct.pack("<IHHI", off + len(body), 0, 0, off) + hdr + masks + palette + body
+
+    H, W = 9, 13
+    # 4-bit palette, bottom-up and top-down
+    pal = rng.integers(0, 256, (16, 4), dtype=np.uint8); pal[:, 3] = 0
+    idx = rng.integers(0, 16, (H, W), dtype=np.uint8)
+    stride = ((W * 4 + 31) // 32) * 4
+    rows = []
+    for y in range(H):
+        r = bytearray(stride)
+        for x in range(W):
+            r[x >> 1] |= int(idx[y, x]) << (0 if x & 1 else 4)
+        rows.append(bytes(r))
+    want = pal[idx][:, :, [2, 1, 0]]
+    for td in (False, True):
+        q = str(tmp_path / "n4.bmp"); open(q, "wb").write(bmp(W, H, 4, b"".join(rows if td else rows[::-1]), palette=pal.tobytes(), top_down=td))
+        assert np.array_equal(hesaff_amd.read_image(q), want), td
+        assert np.array_equal(np.asarray(Image.open(q).convert("RGB")), want), td
+    # 16 bits: 5-5-5 (BI_RGB) and 5-6-5 (BI_BITFIELDS); low bits stay zero (icvCvt_BGR5552BGR / 5652BGR)
+    v = rng.integers(0, 65536, (H, W)).astype(np.uint16)
+    stride = ((W * 16 + 31) // 32) * 4
+    body = b"".join(v[y].astype("<u2").tobytes().ljust(stride, b"\0") for y in range(H - 1, -1, -1))
+    q = str(tmp_path / "n555.bmp"); open(q, "wb").write(bmp(W, H, 16, body))
+    want = np.dstack([(v >> 7) & 0xF8, (v >> 2) & 0xF8, (v << 3) & 0xFF]).astype(np.uint8)
+    assert np.array_equal(hesaff_amd.read_image(q), want)
+    q = str(tmp_path / "n565.bmp"); open(q, "wb").write(bmp(W, H, 16, body, comp=3, masks=struct.pack("<III", 0xF800, 0x7E0, 0x1F)))
+    want = np.dstack([(v >> 8) & 0xF8, (v >> 3) & 0xFC, (v << 3) & 0xFF]).astype(np.uint8)
+    assert np.array_equal(hesaff_amd.read_image(q), want)
+    # RLE8: runs, literal runs (odd length: padded), end of line, a delta, end of bitmap; skipped pixels keep palette entry 0
+    pal = rng.integers(0, 256, (256, 4), dtype=np.uint8); pal[:, 3] = 0
+    exp = np.zeros((4, 8), np.uint8)          # indices, FILE row order (bottom row first)
+    s = bytes([5, 7]) + bytes([0, 3, 1, 2, 3, 0]) + bytes([0, 0])                 # row 0: five 7s, literal 1 2 3 (+ pad), end of line
+    exp[0, :5] = 7; exp[0, 5:8] = (1, 2, 3)
+    s += bytes([2, 9]) + bytes([0, 2, 3, 1]) + bytes([2, 4]) + bytes([0, 0])      # row 1: two 9s, move +3,+1 -> row 2 column 5: two 4s, end of line
+    exp[1, :2] = 9; exp[2, 5:7] = 4
+    s += bytes([8, 200]) + bytes([0, 1])                                          # row 3: eight 200s, end of bitmap
+    exp[3, :] = 200
+    q = str(tmp_path / "rle8.bmp"); open(q, "wb").write(bmp(8, 4, 8, s, comp=1, palette=pal.tobytes()))
+    want = pal[exp[::-1]][:, :, [2, 1, 0]]
+    assert np.array_equal(hesaff_amd.read_image(q), want)
+    assert np.array_equal(np.asarray(Image.open(q).convert("RGB")), want)
+    # OS/2 core header (12 bytes, 3-byte palette entries), 8 bits
+    idx = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    pal3 = rng.integers(0, 256, (256, 3), dtype=np.uint8)
+    stride = (W + 3) & ~3
+    body = b"".join(idx[y].tobytes().ljust(stride, b"\0") for y in range(H - 1, -1, -1))
+    off = 14 + 12 + 768
+    core = b"BM" + struct.pack("<IHHI", off + len(body), 0, 0, off) + struct.pack("<IHHHH", 12, W, H, 1, 8) + pal3.tobytes() + body
+    q = str(tmp_path / "core.bmp"); open(q, "wb").write(core)
+    assert np.array_equal(hesaff_amd.read_image(q), pal3[idx][:, :, [2, 1, 0]])
+    # damaged: truncated pixel data, absurd sizes, an unknown compression, a palette that runs past the file
+    good = open(str(tmp_path / "c.bmp"), "rb").read()
+    for bad in (good[: len(good) - 7], good[:30], bmp(W, H, 24, b"\0" * 10), bmp(1 << 20, 1 << 20, 24, b""), bmp(W, H, 8, b"\0" * 400, comp=7),
+                bmp(W, H, 8, b"", palette=b"")[:54], b"BM" + b"\0" * 10):
+        q = str(tmp_path / "bad.bmp"); open(q, "wb").write(bad)
+        with pytest.raises(hesaff_amd.HesaffError):
+            hesaff_amd.read_image(q)
