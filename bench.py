@@ -877,8 +877,9 @@ def main():
             cdt = time.perf_counter() - t1
             out["cpu_baseline"] = {"value": nk / cdt, "unit": "keypoints/s", "cores": 1, "kind": "port",
                                    "images_per_s": len(host) / cdt,
-                                   "sample": "%d of the %d batch images (%dx%d), oracle/libhesaff_oracle.so, 1 thread, %.1f s"
-                                             % (len(host), B, W, H, cdt),
+                                   "sample": "%d of the %d batch images (%dx%d), oracle/libhesaff_oracle.so, 1 thread, %.1f s (a port: the reference's loops, "
+                                             "with the Gaussian blur - cv::GaussianBlur, SIMD code in OpenCV too - vectorised across pixels in the reference's "
+                                             "order of operations, AVX2 / AVX-512 where the CPU has them)" % (len(host), B, W, H, cdt),
                                    "cpu": cpu}
             # the same oracle, one worker process per physical core, one image each (>= 8 images)
             phys = cpu.get("physical_cores") or max(1, (cpu.get("logical_cpus") or 4) // 2)

@@ -156,6 +156,7 @@ def load_library():
     L.hesaff_read_png.argtypes = L.hesaff_read_pnm.argtypes
     L.hesaff_read_image.argtypes = L.hesaff_read_pnm.argtypes
     L.hesaff_read_bmp.argtypes = L.hesaff_read_pnm.argtypes
+    L.hesaff_read_tiff.argtypes = L.hesaff_read_pnm.argtypes
     L.hesaff_read_jpeg.argtypes = L.hesaff_read_pnm.argtypes
     L.hesaff_stage_gaussian_blur.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_float, _f32p]
     L.hesaff_stage_hessian_response.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_float, _f32p]
@@ -198,7 +199,7 @@ ABI_SYMBOLS = [
     "hesaff_write_sift_rows", "hesaff_write_bin_rows", "hesaff_stage_export", "hesaff_stage_fmt_g", "hesaff_set_resume",
     "hesaff_output_is_complete", "hesaff_read_jpeg_coefficients", "hesaff_read_jpeg_coefficients_alloc", "hesaff_stage_jpeg_pixels",
     "hesaff_read_pnm_alloc", "hesaff_read_image_alloc", "hesaff_set_pinned_read_budget", "hesaff_set_pool_priority",
-    "hesaff_stage_threads_for_pool", "hesaff_read_bmp",
+    "hesaff_stage_threads_for_pool", "hesaff_read_bmp", "hesaff_read_tiff",
 ]
 
 

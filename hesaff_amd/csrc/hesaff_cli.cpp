@@ -142,7 +142,7 @@ int run_batch_mode(const char *list_path, const char *devices_spec, int out_form
          rc = 1;
          if (st.stage == HESAFF_FILE_DETECTED) fprintf(stderr, "hesaff: cannot write the output of '%s'\n", names[(size_t)i].c_str());
          else if (st.stage == HESAFF_FILE_UNREADABLE)
-            fprintf(stderr, "hesaff: cannot read '%s' (binary PGM/PPM with maxval 255, PNG or JPEG expected): skipped\n", names[(size_t)i].c_str());
+            fprintf(stderr, "hesaff: cannot read '%s' (PBM / PGM / PPM, PNG, JPEG, BMP or baseline TIFF expected): skipped\n", names[(size_t)i].c_str());
       }
    }
    std::cout << "Detected " << tot_h << " keypoints and " << tot_d << " affine shapes in " << n_ok << " images in " << dt << " sec.";
@@ -196,7 +196,7 @@ int main(int argc, char **argv)
       uint8_t *data = nullptr;
       int w = 0, h = 0, ch = 0;
       if (hesaff_read_image(argv[1], &data, &w, &h, &ch) != HESAFF_OK) {
-         fprintf(stderr, "hesaff: cannot read '%s' (binary PGM/PPM with maxval 255, PNG or JPEG expected)\n", argv[1]);
+         fprintf(stderr, "hesaff: cannot read '%s' (PBM / PGM / PPM, PNG, JPEG, BMP or baseline TIFF expected)\n", argv[1]);
          return 1;
       }
       try {

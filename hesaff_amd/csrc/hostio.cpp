@@ -571,7 +571,232 @@ int hesaff_read_bmp(const char *path, uint8_t **data, int *width, int *height, i
    HOSTIO_CATCH
 }
 
-// the imread of hesaff.cpp:137 for the formats this library decodes itself: PBM/PGM/PPM, PNG, JPEG and BMP, by magic number
+// cv::imread (hesaff.cpp:137) for TIFF files.  OpenCV hands 8-bit TIFFs to libtiff's RGBA interface (TIFFReadRGBAStrip / Tile) and drops the
+// alpha byte; this reader restates that interface for the baseline forms - what scanners, cameras' converters and image tools write:
+//   * bilevel / 2 / 4 / 8-bit grey (MinIsBlack, MinIsWhite: v * 255 / (2^bits - 1), inverted for MinIsWhite), 8-bit palette (the 16-bit colour map
+//     reduced with >> 8, or taken as it is when no entry exceeds 255: libtiff's checkcmap), 8-bit RGB, RGB + one extra sample (unassociated
+//     alpha is multiplied in the way libtiff does, (v * a + 127) / 255; associated alpha and unspecified extra samples are dropped);
+//   * strips or tiles, chunky or planar, little- or big-endian, the first directory of the file;
+//   * no compression, PackBits, LZW (both bit orders of the code stream libtiff accepts: the post-6.0 MSB-first form only), Deflate (8 / 32946),
+//     horizontal differencing (predictor 2) for 8-bit samples.
+// Everything else - 16-bit and floating-point samples, YCbCr / CMYK / Lab, JPEG- and fax-compressed data, BigTIFF - returns HESAFF_ERR_IO.
+// -> 1 channel for grey files, 3 (R, G, B) otherwise.
+namespace {
+struct TiffFile {
+   const std::vector<uint8_t> &b;
+   bool be = false;
+   explicit TiffFile(const std::vector<uint8_t> &bytes) : b(bytes) {}
+   bool has(size_t o, size_t n) const { return o <= b.size() && n <= b.size() - o; }
+   uint32_t u16(size_t o) const { return be ? ((uint32_t)b[o] << 8) | b[o + 1] : ((uint32_t)b[o + 1] << 8) | b[o]; }
+   uint32_t u32(size_t o) const { return be ? (u16(o) << 16) | u16(o + 2) : (u16(o + 2) << 16) | u16(o); }
+};
+
+// values of one directory entry (types BYTE 1, SHORT 3, LONG 4) as 32-bit numbers; false: another type or out of the file
+bool tiff_values(const TiffFile &t, size_t entry, std::vector<uint32_t> &out, size_t max_count)
+{
+   const uint32_t type = t.u16(entry + 2), count = t.u32(entry + 4);
+   const size_t sz = type == 1 ? 1 : type == 3 ? 2 : type == 4 ? 4 : 0;
+   if (sz == 0 || count == 0 || count > max_count) return false;
+   size_t at = entry + 8;
+   if ((size_t)count * sz > 4) { at = t.u32(entry + 8); if (!t.has(at, (size_t)count * sz)) return false; }
+   out.resize(count);
+   for (uint32_t i = 0; i < count; i++) out[i] = sz == 1 ? t.b[at + i] : sz == 2 ? t.u16(at + 2 * i) : t.u32(at + 4 * i);
+   return true;
+}
+
+// TIFF 6.0 section 9: PackBits
+bool tiff_packbits(const uint8_t *src, size_t n, uint8_t *dst, size_t want)
+{
+   size_t i = 0, o = 0;
+   while (o < want && i < n) {
+      const int c = (int8_t)src[i++];
+      if (c >= 0) { const size_t m = (size_t)c + 1; if (i + m > n || o + m > want) return false; memcpy(dst + o, src + i, m); i += m; o += m; }
+      else if (c != -128) { const size_t m = (size_t)(1 - c); if (i >= n || o + m > want) return false; memset(dst + o, src[i++], m); o += m; }
+   }
+   return o == want;
+}
+
+// TIFF 6.0 section 13: LZW, MSB-first codes of 9..12 bits, ClearCode 256, EndOfInformation 257, "early change" of the code width
+bool tiff_lzw(const uint8_t *src, size_t n, uint8_t *dst, size_t want)
+{
+   struct Ent { uint16_t prev; uint16_t len; uint8_t first, last; };
+   std::vector<Ent> tab(4096);
+   for (int i = 0; i < 256; i++) tab[(size_t)i] = {0xffff, 1, (uint8_t)i, (uint8_t)i};
+   uint32_t acc = 0; int nbits = 0, width = 9; size_t i = 0, o = 0; int next = 258, prev = -1;
+   auto emit = [&](int code) -> bool {
+      const size_t len = tab[(size_t)code].len;
+      if (o + len > want) return false;
+      size_t at = o + len;
+      for (int c = code; c != 0xffff; c = tab[(size_t)c].prev) dst[--at] = tab[(size_t)c].last;
+      o += len;
+      return true;
+   };
+   while (o < want) {
+      while (nbits < width) { if (i >= n) return false; acc = (acc << 8) | src[i++]; nbits += 8; }
+      const int code = (int)((acc >> (nbits - width)) & ((1u << width) - 1));
+      nbits -= width;
+      if (code == 257) break;
+      if (code == 256) { next = 258; width = 9; prev = -1; continue; }
+      if (prev < 0) { if (code > 255 || !emit(code)) return false; prev = code; continue; }
+      if (code < next) {
+         if (!emit(code)) return false;
+         if (next < 4096) { tab[(size_t)next] = {(uint16_t)prev, (uint16_t)(tab[(size_t)prev].len + 1), tab[(size_t)prev].first, tab[(size_t)code].first}; next++; }
+      } else if (code == next && next < 4096) {
+         tab[(size_t)next] = {(uint16_t)prev, (uint16_t)(tab[(size_t)prev].len + 1), tab[(size_t)prev].first, tab[(size_t)prev].first};
+         next++;
+         if (!emit(code)) return false;
+      } else return false;
+      prev = code;
+      if (next == 511 && width == 9) width = 10;
+      else if (next == 1023 && width == 10) width = 11;
+      else if (next == 2047 && width == 11) width = 12;
+   }
+   return o == want;
+}
+
+int read_tiff_bytes(const std::vector<uint8_t> &bytes, uint8_t **data, int *width, int *height, int *channels)
+{
+   TiffFile t(bytes);
+   if (bytes.size() < 8) return HESAFF_ERR_IO;
+   if (bytes[0] == 'M' && bytes[1] == 'M') t.be = true;
+   else if (!(bytes[0] == 'I' && bytes[1] == 'I')) return HESAFF_ERR_IO;
+   if (t.u16(2) != 42) return HESAFF_ERR_IO;   // (43: BigTIFF)
+   const size_t ifd = t.u32(4);
+   if (!t.has(ifd, 2)) return HESAFF_ERR_IO;
+   const uint32_t nent = t.u16(ifd);
+   if (!t.has(ifd + 2, (size_t)nent * 12)) return HESAFF_ERR_IO;
+   uint32_t W = 0, H = 0, comp = 1, photo = 0xffff, spp = 1, rps = 0xffffffffu, planar = 1, pred = 1, tw = 0, th = 0, fill = 1, extra = 0xffff;
+   std::vector<uint32_t> bps{1}, offs, counts, cmap, v;
+   bool tiled = false;
+   for (uint32_t e = 0; e < nent; e++) {
+      const size_t at = ifd + 2 + (size_t)e * 12;
+      const uint32_t tag = t.u16(at);
+      const bool ok = tiff_values(t, at, v, tag == 320 ? 3 * 256 : (size_t)1 << 24);
+      switch (tag) {
+         case 256: if (!ok) return HESAFF_ERR_IO; W = v[0]; break;
+         case 257: if (!ok) return HESAFF_ERR_IO; H = v[0]; break;
+         case 258: if (!ok) return HESAFF_ERR_IO; bps = v; break;
+         case 259: if (!ok) return HESAFF_ERR_IO; comp = v[0]; break;
+         case 262: if (!ok) return HESAFF_ERR_IO; photo = v[0]; break;
+         case 266: if (ok) fill = v[0]; break;
+         case 273: if (!ok) return HESAFF_ERR_IO; offs = v; break;
+         case 277: if (!ok) return HESAFF_ERR_IO; spp = v[0]; break;
+         case 278: if (ok) rps = v[0]; break;
+         case 279: if (!ok) return HESAFF_ERR_IO; counts = v; break;
+         case 284: if (ok) planar = v[0]; break;
+         case 317: if (ok) pred = v[0]; break;
+         case 320: if (!ok) return HESAFF_ERR_IO; cmap = v; break;
+         case 322: if (!ok) return HESAFF_ERR_IO; tw = v[0]; tiled = true; break;
+         case 323: if (!ok) return HESAFF_ERR_IO; th = v[0]; break;
+         case 324: if (!ok) return HESAFF_ERR_IO; offs = v; break;
+         case 325: if (!ok) return HESAFF_ERR_IO; counts = v; break;
+         case 338: if (ok) extra = v[0]; break;
+         case 339: if (ok) for (uint32_t f : v) if (f != 1) return HESAFF_ERR_IO; break;   // SampleFormat: unsigned integers only
+         default: break;
+      }
+   }
+   if (W < 1 || H < 1 || W > (1u << 30) / H || spp < 1 || spp > 4 || bps.size() < 1) return HESAFF_ERR_IO;
+   const uint32_t bits = bps[0];
+   for (uint32_t q : bps) if (q != bits) return HESAFF_ERR_IO;
+   if (!(comp == 1 || comp == 5 || comp == 8 || comp == 32946 || comp == 32773) || fill != 1 || (planar != 1 && planar != 2)) return HESAFF_ERR_IO;
+   if (pred != 1 && !(pred == 2 && bits == 8)) return HESAFF_ERR_IO;
+   bool grey = false;
+   if (photo == 0 || photo == 1) { if (spp != 1 || !(bits == 1 || bits == 2 || bits == 4 || bits == 8)) return HESAFF_ERR_IO; grey = true; }
+   else if (photo == 3) { if (spp != 1 || bits != 8 || cmap.size() != 3 * 256) return HESAFF_ERR_IO; }
+   else if (photo == 2) { if (!(spp == 3 || spp == 4) || bits != 8) return HESAFF_ERR_IO; }
+   else return HESAFF_ERR_IO;
+   if (planar == 2 && spp == 1) planar = 1;
+   // chunk geometry: strips are tiles as wide as the image
+   if (!tiled) { tw = W; th = std::min(rps, H); if (th == 0) return HESAFF_ERR_IO; }
+   else if (tw < 1 || th < 1 || tw > (1u << 20) || th > (1u << 20)) return HESAFF_ERR_IO;
+   const uint32_t tx = (W + tw - 1) / tw, ty = (H + th - 1) / th;
+   const size_t planes = planar == 2 ? spp : 1, spc = planar == 2 ? 1 : spp;   // samples per pixel inside one chunk
+   const size_t nchunks = (size_t)tx * ty * planes;
+   if (offs.size() != nchunks || counts.size() != nchunks) return HESAFF_ERR_IO;
+   const size_t row_bytes = ((size_t)tw * spc * bits + 7) / 8;
+   if ((size_t)th > ((size_t)1 << 31) / std::max<size_t>(row_bytes, 1)) return HESAFF_ERR_IO;
+   bool cmap16 = false;
+   for (uint32_t q : cmap) if (q >= 256) cmap16 = true;   // libtiff's checkcmap: a map that stays below 256 is an 8-bit map
+   const int ch = grey ? 1 : 3;
+   uint8_t *out = (uint8_t *)malloc((size_t)W * H * ch);
+   if (!out) return HESAFF_ERR_NOMEM;
+   std::vector<uint8_t> chunk;
+   std::vector<uint8_t> rgba;   // planar files: the samples of all planes gathered per pixel
+   bool ok = true;
+   try {
+      if (planar == 2) rgba.assign((size_t)W * H * spp, 0);
+      for (size_t c = 0; ok && c < nchunks; c++) {
+         const size_t plane = c / ((size_t)tx * ty), ci = c % ((size_t)tx * ty), cx = ci % tx, cy = ci / tx;
+         const uint32_t rows = tiled ? th : std::min<uint32_t>(th, H - (uint32_t)cy * th);
+         const size_t want = row_bytes * rows;
+         chunk.resize(want);
+         if (!t.has(offs[c], counts[c])) { ok = false; break; }
+         const uint8_t *src = bytes.data() + offs[c];
+         if (comp == 1) { if (counts[c] < want) { ok = false; break; } memcpy(chunk.data(), src, want); }
+         else if (comp == 32773) ok = tiff_packbits(src, counts[c], chunk.data(), want);
+         else if (comp == 5) ok = tiff_lzw(src, counts[c], chunk.data(), want);
+         else { uLongf len = (uLongf)want; ok = uncompress(chunk.data(), &len, src, (uLong)counts[c]) == Z_OK && len == want; }
+         if (!ok) break;
+         if (pred == 2)
+            for (uint32_t r = 0; r < rows; r++) { uint8_t *q = chunk.data() + (size_t)r * row_bytes; for (size_t k = spc; k < (size_t)tw * spc; k++) q[k] = (uint8_t)(q[k] + q[k - spc]); }
+         for (uint32_t r = 0; r < rows; r++) {
+            const size_t y = (size_t)cy * th + r;
+            if (y >= H) break;
+            const uint8_t *q = chunk.data() + (size_t)r * row_bytes;
+            for (uint32_t xx = 0; xx < tw; xx++) {
+               const size_t x = (size_t)cx * tw + xx;
+               if (x >= W) break;
+               if (planar == 2) { rgba[(y * W + x) * spp + plane] = q[xx]; continue; }
+               uint8_t *o = out + (y * W + x) * ch;
+               if (grey) {
+                  uint32_t vv = bits == 8 ? q[xx] : bits == 4 ? ((q[xx >> 1] >> ((xx & 1) ? 0 : 4)) & 15) : bits == 2 ? ((q[xx >> 2] >> (6 - 2 * (xx & 3))) & 3) : ((q[xx >> 3] >> (7 - (xx & 7))) & 1);
+                  vv = bits == 8 ? vv : vv * 255 / ((1u << bits) - 1);
+                  o[0] = (uint8_t)(photo == 0 ? 255 - vv : vv);
+               } else if (photo == 3) {
+                  const uint32_t idx = q[xx];
+                  for (int k = 0; k < 3; k++) o[k] = (uint8_t)(cmap16 ? cmap[(size_t)k * 256 + idx] >> 8 : cmap[(size_t)k * 256 + idx]);
+               } else {
+                  const uint8_t *px = q + (size_t)xx * spp;
+                  if (spp == 4 && extra == 2) { const uint32_t a = px[3]; for (int k = 0; k < 3; k++) o[k] = (uint8_t)((px[k] * a + 127) / 255); }
+                  else { o[0] = px[0]; o[1] = px[1]; o[2] = px[2]; }
+               }
+            }
+         }
+      }
+      if (ok && planar == 2)
+         for (size_t i = 0; i < (size_t)W * H; i++) {
+            const uint8_t *px = rgba.data() + i * spp;
+            uint8_t *o = out + i * 3;
+            if (spp == 4 && extra == 2) { const uint32_t a = px[3]; for (int k = 0; k < 3; k++) o[k] = (uint8_t)((px[k] * a + 127) / 255); }
+            else { o[0] = px[0]; o[1] = px[1]; o[2] = px[2]; }
+         }
+   } catch (...) { free(out); throw; }
+   if (!ok) { free(out); return HESAFF_ERR_IO; }
+   *data = out; *width = (int)W; *height = (int)H; *channels = ch;
+   return HESAFF_OK;
+}
+} // namespace
+
+int hesaff_read_tiff(const char *path, uint8_t **data, int *width, int *height, int *channels)
+{
+   if (!path || !data || !width || !height || !channels) return HESAFF_ERR_ARG;
+   FILE *f = fopen(path, "rb");
+   if (!f) return HESAFF_ERR_IO;
+   HOSTIO_TRY
+   std::vector<uint8_t> bytes;
+   try {
+      uint8_t chunk[1 << 16];
+      for (size_t n; (n = fread(chunk, 1, sizeof chunk, f)) > 0;) bytes.insert(bytes.end(), chunk, chunk + n);
+   } catch (...) {
+      fclose(f);
+      throw;
+   }
+   fclose(f);
+   return read_tiff_bytes(bytes, data, width, height, channels);
+   HOSTIO_CATCH
+}
+
+// the imread of hesaff.cpp:137 for the formats this library decodes itself: PBM/PGM/PPM, PNG, JPEG, BMP and baseline TIFF, by magic number
 int hesaff_read_image(const char *path, uint8_t **data, int *width, int *height, int *channels)
 {
    return hesaff_read_image_alloc(path, data, width, height, channels, nullptr, nullptr);
@@ -588,6 +813,7 @@ int hesaff_read_image_alloc(const char *path, uint8_t **data, int *width, int *h
    if (c1 == 0x89 && c2 == 'P') return hesaff_read_png(path, data, width, height, channels);
    if (c1 == 0xFF && c2 == 0xD8) return hesaff_read_jpeg(path, data, width, height, channels);
    if (c1 == 'B' && c2 == 'M') return hesaff_read_bmp(path, data, width, height, channels);
+   if ((c1 == 'I' && c2 == 'I') || (c1 == 'M' && c2 == 'M')) return hesaff_read_tiff(path, data, width, height, channels);
    return HESAFF_ERR_IO;
 }
 

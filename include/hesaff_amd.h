@@ -280,10 +280,14 @@ int hesaff_read_png(const char *path, uint8_t **data, int *width, int *height, i
 int hesaff_read_jpeg(const char *path, uint8_t **data, int *width, int *height, int *channels);
 /* Windows bitmaps as OpenCV's BMP decoder delivers them at imread's default flag: 1 / 4 / 8 bits through the palette (uncompressed, RLE4, RLE8),
  * 16 bits (5-5-5, or 5-6-5 by bit fields; low bits left zero), 24 bits, 32 bits (fourth byte dropped), bottom-up or top-down, OS/2 core headers;
- * channels = 3 (R,G,B order), or 1 when the whole palette is grey.  (TIFF files, which cv::imread reads through libtiff, are not read:
- * HESAFF_ERR_IO.) */
+ * channels = 3 (R,G,B order), or 1 when the whole palette is grey. */
 int hesaff_read_bmp(const char *path, uint8_t **data, int *width, int *height, int *channels);
-/* PBM/PGM/PPM, PNG, JPEG or BMP by magic number */
+/* Baseline TIFF the way cv::imread delivers it (libtiff's RGBA interface, alpha byte dropped): bilevel / 2 / 4 / 8-bit grey (MinIsBlack,
+ * MinIsWhite), 8-bit palette, 8-bit RGB and RGB + alpha (unassociated alpha multiplied in: (v a + 127) / 255); strips or tiles, chunky or
+ * planar, both byte orders; uncompressed, PackBits, LZW, Deflate, horizontal predictor.  16-bit / float samples, YCbCr / CMYK / Lab, JPEG-
+ * or fax-compressed data and BigTIFF are refused (HESAFF_ERR_IO).  channels = 1 for grey files, 3 (R,G,B order) otherwise. */
+int hesaff_read_tiff(const char *path, uint8_t **data, int *width, int *height, int *channels);
+/* PBM/PGM/PPM, PNG, JPEG, BMP or TIFF by magic number */
 int hesaff_read_image(const char *path, uint8_t **data, int *width, int *height, int *channels);
 /* the same with the pixel buffer from the caller's allocator (only the PNM reader asks it; see hesaff_blob_alloc below):
  * hesaff_process_files reads straight into pinned host memory this way (no malloc'ed buffer, no staging copy) and recycles the

@@ -9,6 +9,8 @@ cp $G/${T}_prof/bench_under_rocprof.json profiles/${R}_bench_under_rocprof.json
 cp $G/${T}_prof/pmc_traffic_raw.json profiles/${R}_pmc_traffic.json
 cp $G/${T}_prof/pmc_traffic_raw.json profiles/pmc_traffic.json
 (echo "# Per-kernel counters, ${R} (every kernel alone on the device, batch 8; scripts/gpu_pmc2.sh, gpu_pmc_lds.sh, gpu_pmc_mem.sh)"; echo; cat $G/${T}_pmc.md; echo; cat $G/${T}_pmc_lds.md; echo; cat $G/${T}_pmc_mem.md) > profiles/${R}_pmc_kernels.md
+(echo "# Per-kernel counters on the photograph mosaics, ${R} (every kernel alone on the device, batch 8, --density photo)"; echo; cat $G/${T}_pmc2_photo.md; echo; cat $G/${T}_pmc_lds_photo.md; echo; cat $G/${T}_pmc_mem_photo.md) > profiles/${R}_pmc_kernels_photographs.md
+cp $G/stage_util_${T}.md profiles/${R}_stage_utilisation.md
 cp $G/${T}_kernels_serial.txt profiles/${R}_kernels_serial.txt
 cp $G/${T}_kernels_serial_fast2.txt profiles/${R}_kernels_serial_fast2.txt
 cp $G/${T}_kernels_serial_photo.txt profiles/${R}_kernels_serial_photographs.txt

@@ -1,5 +1,6 @@
 # usage (through gpurun): bash scripts/gpu_final.sh <tag>
-# round-end evidence, ONE pass: GPU test suite, default bench line, rocprofv3 stats + HBM traffic of the bench command, per-kernel PMC tables,
+# round-end evidence, ONE pass (needs the tuning library: `make -C hesaff_amd/csrc tuning` before the gpurun call): GPU test suite, default bench line,
+# rocprofv3 stats + HBM traffic of the bench command, per-kernel PMC tables (dense and photographs), counters of the overlapped step,
 # per-kernel serial times (parity, fast = 2, photographs), fast-mode reports, config-5 sequence tables (band noise and photograph, fast 0 / 2),
 # the file path inside 2 / 4 / 8 CPUs with per-thread CPU seconds, end-to-end thread sweep, JPEG lists (UHD and 1024x768; pixels on the device / on the host)
 cd $GRAFT_REPO_ROOT
@@ -11,6 +12,9 @@ bash scripts/gpu_profile_round.sh ${TAG}_prof > gpurun_out/${TAG}_prof.log 2>&1;
 bash scripts/gpu_pmc2.sh ${TAG} 8 > gpurun_out/${TAG}_pmc.md 2>&1; cat gpurun_out/${TAG}_pmc.md
 bash scripts/gpu_pmc_lds.sh ${TAG} 8 > gpurun_out/${TAG}_pmc_lds.md 2>&1; cat gpurun_out/${TAG}_pmc_lds.md
 bash scripts/gpu_pmc_mem.sh ${TAG} 8 > gpurun_out/${TAG}_pmc_mem.md 2>&1; cat gpurun_out/${TAG}_pmc_mem.md
+# the same three tables on the photograph mosaics (k_patch_large_rows / _finish are the second largest kernels there), and the counters of the overlapped step
+for S in pmc2 pmc_lds pmc_mem; do BENCH_EXTRA="--density photo" PMC_ROWS=14 bash scripts/gpu_$S.sh ${TAG}_photo 8 > gpurun_out/${TAG}_${S}_photo.md 2>&1; done; cat gpurun_out/${TAG}_pmc2_photo.md
+bash scripts/gpu_pmc_overlap.sh ${TAG} 256 > gpurun_out/${TAG}_pmc_overlap.log 2>&1; head -30 gpurun_out/stage_util_${TAG}.md | cut -c1-300
 bash scripts/gpu_kernels.sh ${TAG} 32 > gpurun_out/${TAG}_kernels_serial.txt 2>&1; head -30 gpurun_out/${TAG}_kernels_serial.txt
 HESAFF_FAST=2 bash scripts/gpu_kernels.sh ${TAG}_fast2 32 > gpurun_out/${TAG}_kernels_serial_fast2.txt 2>&1; head -12 gpurun_out/${TAG}_kernels_serial_fast2.txt
 BENCH_EXTRA="--density photo" bash scripts/gpu_kernels.sh ${TAG}_photo 32 > gpurun_out/${TAG}_kernels_serial_photo.txt 2>&1; head -12 gpurun_out/${TAG}_kernels_serial_photo.txt

@@ -90,5 +90,6 @@ for n in sorted(dp, key=lambda k: -dp[k]):
     print('| %s | %d | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f |' % (n[:48], cp[n], dp[n], dq[n], 1e3 * c.get('SQ_ACTIVE_INST_VALU', 0) * 4 / 1024 / (clock * 1e9) if clock else 0,
           1e3 * c.get('SQ_LDS_IDX_ACTIVE', 0) / 256 / (clock * 1e9) if clock else 0, 2 * fe.get(n, {}).get('FETCH_SIZE', 0) * 1024 / 1e9, wr.get(n, {}).get('WRITE_SIZE', 0) * 1024 / 1e9))
 PY
-find $OUT -name "*.db" -delete   # (the csv files stay: a few MB, and the table can be remade from them)
+[ -s gpurun_out/stage_util_$TAG.md ] && { find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; }
+find $OUT -name "*.db" -delete
 cat gpurun_out/stage_util_$TAG.md

@@ -869,18 +869,18 @@ def test_process_files_pipeline(tmp_path, oracle):
 
 
 def test_process_files_mixed_formats_against_the_oracle(tmp_path, oracle):
-    """One list with PGM, colour PPM, PNG, sequential and progressive JPEG and BMP files of several sizes through hesaff_process_files:
+    """One list with PGM, colour PPM, PNG, sequential and progressive JPEG, BMP and TIFF files of several sizes through hesaff_process_files:
     every output equals the oracle's text for the pixels the in-tree readers deliver (pixels == Pillow's, i.e. libjpeg / zlib)."""
     import hesaff_amd
     from PIL import Image
     from tests import _oracle
     rng = np.random.default_rng(17)
     paths = []
-    for i, (h, w) in enumerate(((150, 200), (150, 200), (131, 177), (200, 260), (150, 200), (96, 128), (150, 200), (131, 177))):
+    for i, (h, w) in enumerate(((150, 200), (150, 200), (131, 177), (200, 260), (150, 200), (96, 128), (150, 200), (131, 177), (150, 200), (96, 128))):
         g = band_noise_image(h, w, 300 + i, SMALL_BANDS)
         rgb = np.stack([g, np.roll(g, 3, 1), np.roll(g, 5, 0)], 2)
-        kind = ("pgm", "ppm", "png", "jpg", "pjpg", "gpng", "bmp", "gbmp")[i]
-        q = str(tmp_path / ("m%d.%s" % (i, {"pjpg": "jpg", "gpng": "png", "gbmp": "bmp"}.get(kind, kind))))
+        kind = ("pgm", "ppm", "png", "jpg", "pjpg", "gpng", "bmp", "gbmp", "tif", "gtif")[i]
+        q = str(tmp_path / ("m%d.%s" % (i, {"pjpg": "jpg", "gpng": "png", "gbmp": "bmp", "gtif": "tif"}.get(kind, kind))))
         if kind == "pgm":
             open(q, "wb").write(b"P5\n%d %d\n255\n" % (w, h) + g.tobytes())
         elif kind == "ppm":
@@ -893,6 +893,10 @@ def test_process_files_mixed_formats_against_the_oracle(tmp_path, oracle):
             Image.fromarray(rgb, "RGB").save(q, "BMP")
         elif kind == "gbmp":
             Image.fromarray(g, "L").save(q, "BMP")
+        elif kind == "tif":
+            Image.fromarray(rgb, "RGB").save(q, "TIFF", compression="tiff_lzw", tiffinfo={317: 2})
+        elif kind == "gtif":
+            Image.fromarray(g, "L").save(q, "TIFF", compression="tiff_adobe_deflate")
         elif kind == "jpg":
             Image.fromarray(rgb, "RGB").save(q, "JPEG", quality=88, subsampling=1)
         else:

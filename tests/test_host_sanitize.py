@@ -178,6 +178,23 @@ def test_readers_refuse_damaged_files_without_memory_errors(driver, tmp_path):
               ("b565.bmp", bmp(13, 9, 16, nrng.integers(0, 256, 28 * 9, dtype=np.uint8).tobytes(), comp=3, masks=struct.pack("<III", 0xF800, 0x7E0, 0x1F))),
               ("rle8.bmp", bmp(8, 4, 8, bytes([5, 7, 0, 3, 1, 2, 3, 0, 0, 0, 2, 9, 0, 2, 3, 1, 2, 4, 0, 0, 8, 200, 0, 1]), comp=1,
                                palette=nrng.integers(0, 256, 1024, dtype=np.uint8).tobytes()))]
+    # ... and baseline TIFF: LZW / PackBits / Deflate strips written by Pillow's libtiff, hand-made tiles, planar samples and a colour map
+    from io import BytesIO
+    from PIL import Image
+    from tests.test_host_side import _tiff_bytes
+    ramp = (np.add.outer(np.arange(40), np.arange(61)) // 3 % 256).astype(np.uint8)
+    tg = np.where(nrng.random((40, 61)) < 0.3, nrng.integers(0, 256, (40, 61)), ramp).astype(np.uint8)
+    trgb = np.stack([tg, np.roll(tg, 2, 1), 255 - tg], 2)
+    for name, arr, mode, comp, kw in (("lzw.tif", trgb, "RGB", "tiff_lzw", {"tiffinfo": {317: 2}}), ("pb.tif", tg, "L", "packbits", {}),
+                                      ("zip.tif", trgb, "RGB", "tiff_adobe_deflate", {}), ("lzw1.tif", tg, "L", "tiff_lzw", {"tiffinfo": {278: 40}})):
+        bio = BytesIO(); Image.fromarray(arr, mode).save(bio, "TIFF", compression=comp, **kw); blobs.append((name, bio.getvalue()))
+    tiles = []
+    for ty in range(0, 40, 16):
+        for tx in range(0, 61, 16):
+            t = np.zeros((16, 16, 3), np.uint8); blk = trgb[ty:ty + 16, tx:tx + 16]; t[: blk.shape[0], : blk.shape[1]] = blk; tiles.append(t.tobytes())
+    blobs += [("tiles.tif", _tiff_bytes(61, 40, 8, 2, 3, tiles, tile=(16, 16))),
+              ("planar_be.tif", _tiff_bytes(61, 40, 8, 2, 3, [trgb[y:y + 8, :, k].tobytes() for k in range(3) for y in range(0, 40, 8)], be=True, rps=8, planar=2)),
+              ("pal.tif", _tiff_bytes(61, 40, 8, 3, 1, [tg.tobytes()], cmap=[int(v) for v in nrng.integers(0, 65536, 768)]))]
     paths = []
     for f, data in blobs:
         p0 = str(tmp_path / ("intact_" + f)); open(p0, "wb").write(data); paths.append(p0)   # the intact file too

@@ -797,3 +797,125 @@ def test_read_bmp_matches_imread_semantics(tmp_path):
         q = str(tmp_path / "bad.bmp"); open(q, "wb").write(bad)
         with pytest.raises(hesaff_amd.HesaffError):
             hesaff_amd.read_image(q)
+
+
+def _tiff_bytes(w, h, bits, photo, spp, chunks, be=False, tile=None, rps=None, planar=1, cmap=None, extra=None, comp=1):
+    """A minimal TIFF writer for the reader's tests: `chunks` = the strips' / tiles' bytes in file order."""
+    import struct
+    E = ">" if be else "<"
+    ents = []
+
+    def ent(tag, typ, vals):
+        ents.append((tag, typ, list(vals)))
+    ent(256, 4, [w]); ent(257, 4, [h]); ent(258, 3, [bits] * spp); ent(259, 3, [comp]); ent(262, 3, [photo]); ent(277, 3, [spp])
+    if planar != 1:
+        ent(284, 3, [planar])
+    if extra is not None:
+        ent(338, 3, [extra])
+    if cmap is not None:
+        ent(320, 3, cmap)
+    if tile:
+        ent(322, 3, [tile[0]]); ent(323, 3, [tile[1]])
+    else:
+        ent(278, 4, [rps or h])
+    off_tag, cnt_tag = (324, 325) if tile else (273, 279)
+    ent(off_tag, 4, [0] * len(chunks)); ent(cnt_tag, 4, [len(c) for c in chunks])
+    ents.sort()
+    n = len(ents)
+    ifd_at = 8
+    extra_at = ifd_at + 2 + 12 * n + 4
+    blob = b""
+    recs = []
+    for tag, typ, vals in ents:
+        sz = {1: 1, 3: 2, 4: 4}[typ]
+        raw = b"".join(struct.pack(E + {1: "B", 3: "H", 4: "I"}[typ], v) for v in vals)
+        if len(raw) <= 4:
+            recs.append([tag, typ, len(vals), raw.ljust(4, b"\0"), None])
+        else:
+            recs.append([tag, typ, len(vals), None, len(blob)]); blob += raw + (b"\0" if len(raw) & 1 else b"")
+    data_at = extra_at + len(blob)
+    offs, at = [], data_at
+    for c in chunks:
+        offs.append(at); at += len(c)
+    for r in recs:
+        if r[0] == off_tag:
+            raw = b"".join(struct.pack(E + "I", o) for o in offs)
+            if len(raw) <= 4:
+                r[3] = raw.ljust(4, b"\0")
+            else:
+                blob = blob[: r[4]] + raw + blob[r[4] + len(raw):]
+    out = (b"MM" if be else b"II") + struct.pack(E + "HI", 42, ifd_at) + struct.pack(E + "H", n)
+    for tag, typ, cnt, inline, at_blob in recs:
+        out += struct.pack(E + "HHI", tag, typ, cnt) + (inline if inline is not None else struct.pack(E + "I", extra_at + at_blob))
+    return out + struct.pack(E + "I", 0) + blob + b"".join(chunks)
+
+
+def test_read_tiff_matches_imread_semantics(tmp_path):
+    """hesaff_read_tiff (cv::imread hesaff.cpp:137 for TIFF: libtiff's RGBA interface, alpha dropped): files written by Pillow's libtiff
+    (uncompressed, LZW with and without the horizontal predictor, PackBits, Deflate; grey, RGB, palette, bilevel, several strip heights)
+    against Pillow's decoder, and hand-made files for the rest: tiles, planar samples, big-endian, MinIsWhite, 4-bit grey, an 8-bit
+    colour map, unassociated alpha.  Unsupported and damaged files are refused."""
+    import hesaff_amd
+    from PIL import Image
+    rng = np.random.default_rng(23)
+    for H, W in ((37, 53), (64, 64), (1, 1), (300, 211)):
+        # smooth + noisy content: long LZW strings, table resets (the 300 x 211 file exceeds 4096 codes per strip), literal runs
+        ramp = (np.add.outer(np.arange(H), np.arange(W)) // 3 % 256).astype(np.uint8)
+        g = np.where(rng.random((H, W)) < 0.3, rng.integers(0, 256, (H, W)), ramp).astype(np.uint8)
+        rgb = np.stack([g, np.roll(g, 2, 1), 255 - g], 2)
+        for comp, kw in (("raw", {}), ("tiff_lzw", {}), ("tiff_lzw", {"tiffinfo": {317: 2}}), ("packbits", {}), ("tiff_adobe_deflate", {}),
+                         ("tiff_adobe_deflate", {"tiffinfo": {317: 2}}), ("tiff_lzw", {"tiffinfo": {278: 7}})):
+            for name, arr, mode in (("g", g, "L"), ("c", rgb, "RGB")):
+                q = str(tmp_path / ("%s_%s.tif" % (name, comp)))
+                Image.fromarray(arr, mode).save(q, "TIFF", compression=comp, **kw)
+                assert np.array_equal(hesaff_amd.read_image(q), arr), (H, W, comp, kw, name)
+        p = Image.fromarray(g).convert("P"); p.putpalette(list(rng.integers(0, 256, 768)))
+        q = str(tmp_path / "p.tif"); p.save(q, "TIFF", compression="tiff_lzw")
+        assert np.array_equal(hesaff_amd.read_image(q), np.asarray(Image.open(q).convert("RGB")))
+        bits = rng.integers(0, 2, (H, W), dtype=np.uint8)
+        q = str(tmp_path / "b.tif"); Image.fromarray(bits * 255).convert("1").save(q, "TIFF", compression="packbits")
+        assert np.array_equal(hesaff_amd.read_image(q), np.asarray(Image.open(q).convert("L")))
+    H, W = 19, 27
+    g = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+
+    def put(name, blob):
+        q = str(tmp_path / name); open(q, "wb").write(blob); return q
+    # tiles of 16 x 16 (padded at the right and bottom edges), little- and big-endian
+    for be in (False, True):
+        tiles = []
+        for ty in range(0, H, 16):
+            for tx in range(0, W, 16):
+                t = np.zeros((16, 16, 3), np.uint8); blk = rgb[ty:ty + 16, tx:tx + 16]; t[: blk.shape[0], : blk.shape[1]] = blk
+                tiles.append(t.tobytes())
+        assert np.array_equal(hesaff_amd.read_image(put("tiles.tif", _tiff_bytes(W, H, 8, 2, 3, tiles, be=be, tile=(16, 16)))), rgb), be
+        # strips of 5 rows, planar: all strips of R, then G, then B
+        strips = [rgb[y:y + 5, :, k].tobytes() for k in range(3) for y in range(0, H, 5)]
+        assert np.array_equal(hesaff_amd.read_image(put("planar.tif", _tiff_bytes(W, H, 8, 2, 3, strips, be=be, rps=5, planar=2))), rgb), be
+    # MinIsWhite 8 bit, 4-bit MinIsBlack (v * 255 / 15), bilevel MinIsWhite
+    assert np.array_equal(hesaff_amd.read_image(put("w.tif", _tiff_bytes(W, H, 8, 0, 1, [g.tobytes()]))), 255 - g)
+    n4 = rng.integers(0, 16, (H, W), dtype=np.uint8)
+    rows = b"".join(bytes(((int(r[i]) << 4) | (int(r[i + 1]) if i + 1 < W else 0)) for i in range(0, W, 2)) for r in n4)
+    assert np.array_equal(hesaff_amd.read_image(put("n4.tif", _tiff_bytes(W, H, 4, 1, 1, [rows]))), (n4.astype(np.int32) * 255 // 15).astype(np.uint8))
+    b1 = rng.integers(0, 2, (H, W), dtype=np.uint8)
+    rows = b"".join(np.packbits(r).tobytes() for r in b1)
+    assert np.array_equal(hesaff_amd.read_image(put("b1w.tif", _tiff_bytes(W, H, 1, 0, 1, [rows]))), (1 - b1) * 255)
+    # palette: a 16-bit colour map is reduced with >> 8, a map whose entries all stay below 256 is an 8-bit map (libtiff's checkcmap)
+    cm16 = rng.integers(0, 65536, 768); cm8 = rng.integers(0, 256, 768)
+    for cm, f in ((cm16, lambda v: v >> 8), (cm8, lambda v: v)):
+        got = hesaff_amd.read_image(put("pal.tif", _tiff_bytes(W, H, 8, 3, 1, [g.tobytes()], cmap=[int(v) for v in cm])))
+        want = np.stack([f(cm[k * 256 + g.astype(np.int64)]) for k in range(3)], 2).astype(np.uint8)
+        assert np.array_equal(got, want)
+    # RGB + alpha: unassociated alpha (ExtraSamples = 2) is multiplied in as libtiff does, associated alpha (1) is dropped
+    rgba = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+    a = rgba[:, :, 3:4].astype(np.int32)
+    assert np.array_equal(hesaff_amd.read_image(put("ua.tif", _tiff_bytes(W, H, 8, 2, 4, [rgba.tobytes()], extra=2))), ((rgba[:, :, :3].astype(np.int32) * a + 127) // 255).astype(np.uint8))
+    assert np.array_equal(hesaff_amd.read_image(put("aa.tif", _tiff_bytes(W, H, 8, 2, 4, [rgba.tobytes()], extra=1))), rgba[:, :, :3])
+    # refused: 16-bit samples, YCbCr, JPEG compression, BigTIFF, truncated data, offsets past the file, an absurd size
+    good = _tiff_bytes(W, H, 8, 1, 1, [g.tobytes()])
+    g16 = rng.integers(0, 65536, (H, W), dtype=np.uint16)
+    bad = [_tiff_bytes(W, H, 16, 1, 1, [g16.tobytes()]), _tiff_bytes(W, H, 8, 6, 3, [rgb.tobytes()]), _tiff_bytes(W, H, 8, 1, 1, [g.tobytes()], comp=7),
+           b"II+\0" + good[4:], good[: len(good) - 11], good[:40], _tiff_bytes(1 << 17, 1 << 17, 8, 1, 1, [b"\0" * 16]), b"II*\0\xff\xff\xff\x7f"]
+    for blob in bad:
+        with pytest.raises(hesaff_amd.HesaffError):
+            hesaff_amd.read_image(put("bad.tif", blob))
