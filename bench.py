@@ -388,6 +388,20 @@ def budgeted_child(cfg):
 
     cfg["phase"] = [0]
     out = {"cpus": sorted(os.sched_getaffinity(0)), "plan": hp}
+    if cfg.get("renice_runtime") is not None:
+        # The HIP runtime's helper threads at a lower priority than the pool (what `hesaff --batch` does on a CPU-starved plan): the threads that
+        # appear while the first context of the process is made are the runtime's - its event thread spins while the device works, and inside
+        # a two-CPU share that spinning otherwise takes a third of a CPU from the threads that write
+        before = set(os.listdir("/proc/self/task"))
+        with hesaff_amd.HesaffContext(hesaff_amd.default_params(), device=cfg["device"]):
+            pass
+        moved = []
+        for tid in set(os.listdir("/proc/self/task")) - before:
+            try:
+                os.setpriority(os.PRIO_PROCESS, int(tid), int(cfg["renice_runtime"])); moved.append(int(tid))
+            except OSError:
+                pass
+        out["reniced_threads"] = len(moved)
     for name, fmt in (("text", 1), ("sidecar", 2)):
         r = _timed_file_run(hesaff_amd, paths, cfg["chunk"], cfg["device"], fmt, hp["decode_threads"], hp["write_threads"], sync, threads_table=True, profiling=0)
         ext = ".hesaff.sift" if fmt == 1 else ".hesaff.bin"
@@ -402,7 +416,7 @@ def budgeted_child(cfg):
     return 0
 
 
-def budgeted_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, rank, world, sync, confine_runtime=True):
+def budgeted_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, rank, world, sync, confine_runtime=True, renice_runtime=None):
     """The file path inside ONE device's share of the host: the CPUs this job may use (affinity mask, capped by the
     cgroup quota: hesaff_host_threads) divided by BUDGET_SHARE = 8 devices, whatever `world` is; rank r's child process is pinned
     to the r-th such slice before it loads anything, takes its thread counts from the library's rule and reports CPU seconds
@@ -420,7 +434,7 @@ def budgeted_leg(hesaff_amd, host_imgs, W, H, n_files, chunk, device, rank, worl
     if rank == 0:   # what an interrupted earlier run may have left behind (the other ranks' children need seconds before they write here)
         shutil.rmtree(os.path.join(os.path.dirname(tmp), "hesaff_sync_%s" % os.environ.get("MASTER_PORT", "0")), ignore_errors=True)
     try:
-        cfg = {"dir": tmp, "n": len(paths), "chunk": chunk, "device": device, "cpus": cpus, "rank": rank, "world": world, "confine_runtime": confine_runtime,
+        cfg = {"dir": tmp, "n": len(paths), "chunk": chunk, "device": device, "cpus": cpus, "rank": rank, "world": world, "confine_runtime": confine_runtime, "renice_runtime": renice_runtime,
                "sync_dir": os.path.join(os.path.dirname(tmp), "hesaff_sync_%s" % os.environ.get("MASTER_PORT", "0"))}
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--budgeted-child", json.dumps(cfg)], capture_output=True, text=True, timeout=900)
         if r.returncode != 0 or not r.stdout.strip():
@@ -730,14 +744,15 @@ def main():
                 end_to_end["binary_sidecar"] = eb
             # the same list inside ONE device's share of the host: a child process per rank, pinned before it loads anything
             if args.budgeted:
-                def budgeted(confine_runtime):
-                    bd = budgeted_leg(hesaff_amd, host_imgs, W, H, args.e2e_images, args.e2e_chunk, local_rank, rank, world, barrier, confine_runtime)
+                def budgeted(confine_runtime, renice_runtime=None):
+                    bd = budgeted_leg(hesaff_amd, host_imgs, W, H, args.e2e_images, args.e2e_chunk, local_rank, rank, world, barrier, confine_runtime, renice_runtime)
                     legs = {}
                     for name in ("text", "sidecar"):
                         legs[name] = combine(dict(bd[name]) if name in bd else {"skipped": bd.get("skipped", "no result")})
                     return bd, legs
                 bd, legs = budgeted(True)
                 bd_u, legs_u = budgeted(False)
+                bd_n, legs_n = budgeted(True, 19)
                 if rank == 0:
                     end_to_end_budgeted = {
                         "what": "hesaff_process_files as in end_to_end, but every rank's run is a child process confined (sched_setaffinity before it "
@@ -750,7 +765,10 @@ def main():
                                 "the sidecar (17 MB) is not.  runtime_threads_unconfined: the same without the environment variable (the runtime's "
                                 "event thread then runs on CPUs outside the share: the confinement leaks by that thread)" % BUDGET_SHARE,
                         "share": bd.get("share"), "cpus_rank0": bd.get("cpus"), "plan": bd.get("plan"), "text": legs["text"], "binary_sidecar": legs["sidecar"],
-                        "runtime_threads_unconfined": {"text": legs_u["text"], "binary_sidecar": legs_u["sidecar"]}}
+                        "runtime_threads_unconfined": {"text": legs_u["text"], "binary_sidecar": legs_u["sidecar"]},
+                        "runtime_threads_niced": {"what": "confined as the first form, and the threads the HIP runtime created while the child's first context was made moved to nice 19 "
+                                                          "(below the pool's nice 10) - what `hesaff --batch` does on a CPU-starved plan: the event thread's spinning yields to the threads that write",
+                                                  "reniced_threads": bd_n.get("reniced_threads"), "text": legs_n["text"], "binary_sidecar": legs_n["sidecar"]}}
                 if world == 1:
                     end_to_end_budgeted["contexts_in_one_process"] = contexts_leg(host_imgs, W, H, args.e2e_images, args.e2e_chunk, local_rank)
 

@@ -18,9 +18,13 @@
 //       under a temporary name and renamed, so an interrupted run leaves no torn file (checkpoint / resume).
 //       --host-share K                this process may use 1/K of the host's CPUs (default 1): one of K processes on a node, e.g. one per GPU.
 //       Host threads per device context = hesaff_host_plan_for(devices x K): the library's one rule (include/hesaff_amd.h).
+//       On a CPU-starved plan (CPUs of this process <= pool threads + 1, e.g. --host-share 8 on a 16-CPU quota) the threads the HIP runtime creates
+//       while the contexts are made - its event thread spins for most of the time the device works - are moved to nice 19: inside a two-CPU share
+//       the text path then writes 217 instead of 181 images/s (profiles/r06_notes.md).  --runtime-nice 0 leaves them alone, --runtime-nice 1 forces it.
 //       --output text | bin | both    what every image gets: <image>.hesaff.sift (default), the binary sidecar
 //       <image>.hesaff.bin (the same rows unprinted, include/hesaff_amd.h: hesaff_write_bin), or both.
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -33,9 +37,32 @@
 #include <thread>
 #include <vector>
 
+#include <dirent.h>
+#include <set>
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include "hesaff.hpp"
 
 namespace {
+
+std::set<long> g_tids_at_start;   // the threads this process had before it made its first library call
+
+// the thread ids of this process (/proc/self/task)
+std::set<long> list_tids()
+{
+   std::set<long> out;
+   if (DIR *d = opendir("/proc/self/task")) {
+      while (struct dirent *e = readdir(d)) {
+         char *end = nullptr;
+         const long t = strtol(e->d_name, &end, 10);
+         if (end != e->d_name && *end == 0 && t > 0) out.insert(t);
+      }
+      closedir(d);
+   }
+   return out;
+}
 
 // "0-7", "0,2,5", "1", "all" -> device ordinals
 bool parse_devices(const char *spec, std::vector<int> &out)
@@ -68,7 +95,7 @@ bool parse_devices(const char *spec, std::vector<int> &out)
 
 // hesaff --batch: the list is cut into contiguous shards, one per device context (hesaff_shard_range); every shard runs
 // through hesaff_process_files - decode threads -> device -> writer threads, bounded memory - on its own host thread.
-int run_batch_mode(const char *list_path, const char *devices_spec, int out_format, bool dynamic, int fast, int resume, int host_share)
+int run_batch_mode(const char *list_path, const char *devices_spec, int out_format, bool dynamic, int fast, int resume, int host_share, int runtime_nice)
 {
    std::ifstream lf(list_path);
    if (!lf) { fprintf(stderr, "hesaff: cannot read list '%s'\n", list_path); return 1; }
@@ -93,7 +120,20 @@ int run_batch_mode(const char *list_path, const char *devices_spec, int out_form
    const auto t1 = std::chrono::steady_clock::now();
    const int kBlock = 256;
    std::atomic<int> next_block(0);
+   // Threads that appear while the contexts are created and that this program did not start are the HIP runtime's helpers (its event
+   // thread, which spins while the device works).  On a CPU-starved plan they go to nice 19, below the pool's nice 10: the spinning then
+   // yields to the threads that write.  `own`: the device workers' ids, complete before the first context is made (the latch below).
+   const std::set<long> &tids_before = g_tids_at_start;   // (taken in main: already hesaff_device_count starts the runtime)
+   std::mutex own_mu;
+   std::condition_variable own_cv;
+   std::set<long> own;
    auto device_worker = [&](int rank) {
+      {
+         std::unique_lock<std::mutex> lk(own_mu);
+         own.insert((long)syscall(SYS_gettid));
+         own_cv.notify_all();
+         own_cv.wait(lk, [&] { return (int)own.size() >= world; });
+      }
       int lo = 0, hi = 0;
       hesaff_shard_range(n, rank, world, &lo, &hi);
       if (!dynamic && hi <= lo) return;
@@ -108,6 +148,21 @@ int run_batch_mode(const char *list_path, const char *devices_spec, int out_form
       hesaff_host_plan hp;   // this device's share of the host: the library's one rule (include/hesaff_amd.h)
       hesaff_host_plan_for(world * host_share, &hp);
       const int wt = hp.write_threads, dt = hp.decode_threads;
+      if (runtime_nice == 1 || (runtime_nice < 0 && hp.cpus <= dt + wt + 1)) {   // this device's share of the host is no larger than its pool + the caller
+         {
+            // one tiny batch through the context first: the runtime starts its helper threads with the first launches and events, not with the context
+            std::vector<uint8_t> blank((size_t)64 * 64, 0);
+            const uint8_t *img = blank.data();
+            const int side = 64, chn = 1;
+            hesaff_result res;
+            (void)hesaff_detect_batch(ctx, 1, &img, &side, &side, &side, &chn, &res);
+         }
+         std::lock_guard<std::mutex> lk(own_mu);
+         int moved = 0;
+         for (long t : list_tids())
+            if (!tids_before.count(t) && !own.count(t) && setpriority(PRIO_PROCESS, (id_t)t, 19) == 0) moved++;   // (a refusal changes nothing)
+         if (runtime_nice == 1) fprintf(stderr, "hesaff: device %d: %d runtime helper thread(s) at nice 19\n", devices[(size_t)rank], moved);
+      }
       for (;;) {
          if (dynamic) {   // the next block of the list nobody has taken yet
             lo = next_block.fetch_add(1) * kBlock;
@@ -156,6 +211,7 @@ int run_batch_mode(const char *list_path, const char *devices_spec, int out_form
 
 int main(int argc, char **argv)
 {
+   g_tids_at_start = list_tids();
    if (hesaff_abi_version() != HESAFF_ABI_VERSION || hesaff_sizeof_params() != sizeof(hesaff_params)) {
       fprintf(stderr, "hesaff: libhesaff_amd.so has ABI version %d, this program was built for %d\n", hesaff_abi_version(), HESAFF_ABI_VERSION);
       return 1;
@@ -166,7 +222,7 @@ int main(int argc, char **argv)
    for (int i = 1; i < argc; i++) batch = batch || strcmp(argv[i], "--batch") == 0;
    if (batch) {
       const char *devices = nullptr, *list = nullptr;
-      int out_format = HESAFF_OUT_TEXT, fast = 0, host_share = 1;
+      int out_format = HESAFF_OUT_TEXT, fast = 0, host_share = 1, runtime_nice = -1;
       bool bad = false, dynamic = false;
       int resume = 0;
       for (int i = 1; i < argc && !bad; i += 2) {
@@ -176,6 +232,7 @@ int main(int argc, char **argv)
          else if (strcmp(argv[i], "--batch") == 0) list = argv[i + 1];
          else if (strcmp(argv[i], "--devices") == 0) devices = argv[i + 1];
          else if (strcmp(argv[i], "--host-share") == 0) { host_share = atoi(argv[i + 1]); bad = host_share < 1 || host_share > 1024; }
+         else if (strcmp(argv[i], "--runtime-nice") == 0) { runtime_nice = atoi(argv[i + 1]); bad = runtime_nice < 0 || runtime_nice > 1; }
          else if (strcmp(argv[i], "--fast") == 0) {
             if (strcmp(argv[i + 1], "0") == 0 || strcmp(argv[i + 1], "2") == 0) fast = atoi(argv[i + 1]);
             else bad = true;
@@ -189,8 +246,8 @@ int main(int argc, char **argv)
             else bad = true;
          } else bad = true;
       }
-      if (bad || !list) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all] [--output text|bin|both] [--schedule static|dynamic] [--fast 0|2] [--resume|--resume=strict] [--host-share K]\n"); return 1; }
-      return run_batch_mode(list, devices, out_format, dynamic, fast, resume, host_share);
+      if (bad || !list) { fprintf(stderr, "hesaff: usage: hesaff --batch <list file> [--devices 0-7|0,2|all] [--output text|bin|both] [--schedule static|dynamic] [--fast 0|2] [--resume|--resume=strict] [--host-share K] [--runtime-nice 0|1]\n"); return 1; }
+      return run_batch_mode(list, devices, out_format, dynamic, fast, resume, host_share, runtime_nice);
    }
    if (argc > 1) {
       uint8_t *data = nullptr;

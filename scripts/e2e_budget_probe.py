@@ -24,6 +24,10 @@ try:
         cfg = {"dir": tmp, "n": len(paths), "chunk": 32, "device": 0, "cpus": allowed[:k], "rank": 0, "world": 1}
         if os.environ.get("PROBE_POOL"):   # e.g. PROBE_POOL=1,2: decode and write threads instead of the rule's
             cfg["pool"] = [int(v) for v in os.environ["PROBE_POOL"].split(",")]
+        if os.environ.get("PROBE_RENICE"):   # experiment: the runtime's helper threads at this nice value (bench.py: budgeted_child)
+            cfg["renice_runtime"] = int(os.environ["PROBE_RENICE"])
+        if os.environ.get("PROBE_UNCONFINED_RUNTIME"):
+            cfg["confine_runtime"] = False
         r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "bench.py"), "--budgeted-child", json.dumps(cfg)],
                            capture_output=True, text=True, timeout=900)
         if r.returncode != 0:
