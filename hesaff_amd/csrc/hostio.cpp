@@ -729,10 +729,10 @@ int read_tiff_bytes(const std::vector<uint8_t> &bytes, uint8_t **data, int *widt
          const size_t plane = c / ((size_t)tx * ty), ci = c % ((size_t)tx * ty), cx = ci % tx, cy = ci / tx;
          const uint32_t rows = tiled ? th : std::min<uint32_t>(th, H - (uint32_t)cy * th);
          const size_t want = row_bytes * rows;
+         if (!t.has(offs[c], counts[c]) || (comp == 1 && counts[c] < want)) { ok = false; break; }   // (before the buffer is made: a header may claim gigabytes)
          chunk.resize(want);
-         if (!t.has(offs[c], counts[c])) { ok = false; break; }
          const uint8_t *src = bytes.data() + offs[c];
-         if (comp == 1) { if (counts[c] < want) { ok = false; break; } memcpy(chunk.data(), src, want); }
+         if (comp == 1) memcpy(chunk.data(), src, want);
          else if (comp == 32773) ok = tiff_packbits(src, counts[c], chunk.data(), want);
          else if (comp == 5) ok = tiff_lzw(src, counts[c], chunk.data(), want);
          else { uLongf len = (uLongf)want; ok = uncompress(chunk.data(), &len, src, (uLong)counts[c]) == Z_OK && len == want; }
