@@ -9,9 +9,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --batch $BATCH --no-cpu-baseline --no-host-path"
 timeout 900 rocprofv3 --kernel-trace --output-format csv -d $OUT/plain -o p -- $B > $OUT/plain.json 2> $OUT/plain.log
-timeout 1200 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -o p -- $B > $OUT/sq.json 2> $OUT/sq.log
+timeout 420 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -o p -- $B > $OUT/sq.json 2> $OUT/sq.log
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 1200 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -o p -- $B > $OUT/$C.json 2> $OUT/$C.log
+  timeout 420 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -o p -- $B > $OUT/$C.json 2> $OUT/$C.log
 done
 cd $GRAFT_REPO_ROOT
 python3 - $OUT $BATCH > gpurun_out/stage_util_$TAG.md <<'PY'
